@@ -1,0 +1,59 @@
+/* tsg_hip.h -- C ABI of libtsg_hip.so: MI355X (gfx950) kernels for the cross-modal matching hot
+ * path of haojc/ShufflingVideosForTSG (grounding/model).
+ *
+ * The reference has no FFI of its own: its seam is the Python nn.Module protocol.
+ * Each entry point below replaces the arithmetic of one reference forward (cited per function)
+ * and is what a ctypes / cffi binding on the reference side would bind.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers on the current HIP device, 16-byte aligned, row-major
+ *     contiguous, batch-first; the caller owns every buffer (outputs and workspaces included);
+ *     the library never allocates, frees or synchronises.
+ *   - `dtype`: TSG_F32 (0) only in this revision; TSG_BF16 (1) is reserved.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); work is only enqueued.
+ *   - return 0 on success; <0 = argument error (TSG_E_*); >0 = hipError_t from the launch.
+ *     tsg_last_error() returns a thread-local message for the last non-zero return.
+ *   - re-entrant; no global mutable state except a per-process device-property cache.
+ */
+#ifndef TSG_HIP_H
+#define TSG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSG_VERSION 1
+#define TSG_F32 0
+#define TSG_BF16 1
+
+#define TSG_E_NULL   (-1)   /* a required pointer is NULL                      */
+#define TSG_E_SHAPE  (-2)   /* non-positive or unsupported dimension           */
+#define TSG_E_ALIGN  (-3)   /* pointer / leading dimension not 16-B aligned    */
+#define TSG_E_DTYPE  (-4)   /* dtype not supported by this entry point         */
+#define TSG_E_LDS    (-5)   /* tile does not fit the 160 KiB LDS budget        */
+
+int         tsg_version(void);
+const char* tsg_last_error(void);
+
+/* ---- K1: SCDM additive cross-attention (SCDM_Attention.forward, networks/attention.py:109-121)
+ * inputs are the PROJECTED tensors: a = W_a(video)+b [B,T,H], s = W_s(sent) [B,N,H], w [H] (the
+ * [1,H] weight of self.w), sent [B,N,Ds].  Computes, without ever materialising [B,T,N,H]:
+ *   e[b,t,n] = sum_k w[k]*tanh(a[b,t,k]+s[b,n,k]);  P = softmax_n(e);  C = P @ sent.
+ * Outputs C [B,T,Ds] and P [B,T,N] (kept for the backward).  Limits: N <= 32, H%4==0, Ds%4==0,
+ * roundup(N,4)*roundup(H,256)*4 B must fit LDS (TSG_E_LDS otherwise).                           */
+int tsg_scdm_attn_fwd(const void* a, const void* s, const void* w, const void* sent,
+                      void* C, void* P, int B, int T, int N, int H, int Ds, int dtype, void* stream);
+
+/* backward of the above.  dC [B,T,Ds] -> da [B,T,H], ds [B,N,H], dw [H], dsent [B,N,Ds] (direct
+ * path through C = P@sent only; the path through s = W_s(sent) is the caller's GEMM).
+ * `de_ws` is a caller-owned workspace of B*T*N floats.  dw is fully overwritten.                */
+int tsg_scdm_attn_bwd(const void* a, const void* s, const void* w, const void* sent, const void* P,
+                      const void* dC, void* da, void* ds, void* dw, void* dsent, void* de_ws,
+                      int B, int T, int N, int H, int Ds, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSG_HIP_H */

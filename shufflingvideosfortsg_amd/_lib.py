@@ -1,0 +1,75 @@
+"""ctypes binding of libtsg_hip.so (include/tsg_hip.h).  No CPU fallback: every call needs the
+built library and device tensors, and raises otherwise."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_uint64, c_void_p
+
+import torch  # noqa: F401  (must be imported first: libtsg_hip.so reuses torch's libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtsg_hip.so")
+TSG_F32, TSG_BF16 = 0, 1
+
+_lib = None
+
+# name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/tsg_hip.h
+_P, _I = c_void_p, c_int
+_SIGNATURES = {
+    "tsg_version": [],
+    "tsg_last_error": [],
+    "tsg_scdm_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "tsg_scdm_attn_bwd": [_P] * 11 + [_I] * 6 + [_P],
+}
+_RESTYPE = {"tsg_last_error": c_char_p}
+
+
+class TsgLibraryError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and return the library; raises TsgLibraryError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TsgLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m shufflingvideosfortsg_amd.build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError here = header / library mismatch
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, c_int)
+    if lib.tsg_version() != 1:
+        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 1 expected by the Python host code")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().tsg_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t: torch.Tensor) -> int:
+    return t.data_ptr()
+
+
+def stream_of(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_device(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "shufflingvideosfortsg_amd hot-path ops run only on an MI355X through libtsg_hip.so; "
+                f"got a {t.device} tensor (there is no CPU fallback)")

@@ -1,0 +1,69 @@
+"""K1 parity on the GPU: tsg_scdm_attn_{fwd,bwd} (through the C ABI) vs the CPU oracle."""
+import pytest
+import torch
+
+from oracle import tsg_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=1e-4, rtol=1e-4)     # north-star tolerance: 1e-4 fp32
+
+
+def _run(B, T, N, H, Ds, seed=0, scale=1.0):
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn(B, T, H, generator=g) * scale).requires_grad_(True)
+    s = (torch.randn(B, N, H, generator=g) * scale).requires_grad_(True)
+    w = (torch.randn(H, generator=g) / H ** 0.5).requires_grad_(True)
+    sent = torch.randn(B, N, Ds, generator=g).requires_grad_(True)
+    gC = torch.randn(B, T, Ds, generator=g)
+    C0, P0 = O.scdm_core(a, s, w, sent)
+    C0.backward(gC)
+    ref = [x.grad.clone() for x in (a, s, w, sent)]
+    ad, sd, wd, vd = (x.detach().cuda().requires_grad_(True) for x in (a, s, w, sent))
+    C1, P1 = F.scdm_attn(ad, sd, wd, vd, return_p=True)
+    C1.backward(gC.cuda())
+    torch.cuda.synchronize()
+    torch.testing.assert_close(P1.cpu(), P0.detach(), **TOL)
+    torch.testing.assert_close(C1.detach().cpu(), C0.detach(), **TOL)
+    for got, want, name in zip((ad, sd, wd, vd), ref, "a s w sent".split()):
+        torch.testing.assert_close(got.grad.cpu(), want, atol=2e-4, rtol=1e-3, msg=lambda m, n=name: f"d{n}: {m}")
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 9, 5, 24, 24),       # tiny, H < 256, N not a multiple of 4
+    (3, 17, 20, 40, 24),     # H != Ds
+    (1, 1, 1, 8, 8),         # degenerate: one clip, one word
+    (2, 32, 15, 512, 512),   # BASELINE config 0 shape (Charades N=15, d=512)
+    (4, 64, 20, 512, 512),   # config 1 (B reduced for the CPU oracle)
+    (2, 128, 20, 1024, 1024),  # north-star tile shape (B reduced)
+    (2, 40, 25, 1024, 1024),   # ANet N=25, ragged T
+    (1, 33, 32, 260, 516),     # N = 32 max, H and Ds not multiples of 256
+])
+def test_scdm_parity(shape):
+    _run(*shape)
+
+
+def test_scdm_large_activations():
+    """|a+s| large: tanh saturates; the exp-product formulation must stay finite and exact."""
+    _run(2, 16, 8, 64, 64, seed=3, scale=12.0)
+
+
+def test_scdm_golden(golden):
+    """Same inputs/weights as the reference run captured in tests/golden/scdm_b.npz."""
+    from shufflingvideosfortsg_amd import functional as F
+    g = golden("scdm_b")
+    w = {k: v.cuda() for k, v in g.weights.items()}
+    video, sent = g.t("video").cuda(), g.t("sent").cuda().requires_grad_(True)
+    a = torch.nn.functional.linear(video, w["W_a.weight"], w["W_a.bias"])
+    s = torch.nn.functional.linear(sent, w["W_s.weight"])
+    C = F.scdm_attn(a, s, w["w.weight"].reshape(-1), sent)
+    torch.testing.assert_close(C.cpu(), g.t("C"), **TOL)
+
+
+def test_scdm_errors():
+    from shufflingvideosfortsg_amd import functional as F
+    a = torch.randn(1, 4, 8); s = torch.randn(1, 3, 8); w = torch.randn(8); v = torch.randn(1, 3, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        F.scdm_attn(a, s, w, v)
+    with pytest.raises(RuntimeError, match="N=40"):
+        F.scdm_attn(torch.randn(1, 4, 8).cuda(), torch.randn(1, 40, 8).cuda(), w.cuda(), torch.randn(1, 40, 8).cuda())
