@@ -9,7 +9,7 @@ from ctypes import c_char_p, c_float, c_int, c_uint64, c_void_p
 import torch  # noqa: F401  (must be imported first: libtsg_hip.so reuses torch's libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtsg_hip.so")
+LIB_PATH = os.environ.get("TSG_HIP_LIB", os.path.join(_HERE, "libtsg_hip.so"))   # override: developer builds
 TSG_F32, TSG_BF16 = 0, 1
 
 _lib = None

@@ -33,6 +33,7 @@
 //                dsent[n,j] = sum_t P[t,n] dC[t,j]
 //              Es for the slice lives in registers (NP*4 per lane); de / P rows are wave-uniform.
 #include "tsg_common.h"
+#include <cstdlib>
 
 namespace tsg {
 namespace {
@@ -43,6 +44,18 @@ constexpr int kFwdThreads = 512;              // forward: 8 waves share one Es t
 constexpr int kFwdWaves = kFwdThreads / kWave;
 constexpr float kClamp = 40.0f;
 
+// Timing-only ablation (developer builds with -DTSG_ABLATE: phases are skipped per bit of the env
+// var TSG_ABLATE_MASK, outputs are then wrong).  In the product build TSG_SKIP() folds to false.
+#ifdef TSG_ABLATE
+#define TSG_SKIP(bit) ((dbg & (bit)) != 0)
+static int ablate_mask() { const char* e = getenv("TSG_ABLATE_MASK"); return e ? atoi(e) : 0; }
+#else
+#define TSG_SKIP(bit) false
+static int ablate_mask() { return 0; }
+#endif
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __host__ __device__ __forceinline__ int roundup256(int x) { return (x + 255) & ~255; }
 
 __device__ __forceinline__ int wave_id() {    // wave-uniform (SGPR) wave index inside the workgroup
@@ -52,160 +65,281 @@ __device__ __forceinline__ int wave_id() {    // wave-uniform (SGPR) wave index 
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
+// One wave-level k-chunk step for R clip rows: acc[r][n] += sum_c w2[c] / (Ea[r][c]*Es[n][c] + 1).
+// The words are walked in groups of 2 with the next group's Es float4s already in flight; the
+// sched_barrier keeps hipcc from hoisting every x of the chunk ahead of the first rcp (which costs
+// 160+ VGPRs and spills).  (Calibration, tools/ubench: v_rcp_f32 ~10 cyc, v_fma_f32 ~2.8 cyc per
+// wave-instruction; v_pk_fma_f32 costs two v_fma_f32, and sharing one rcp between two elements
+// (1/x0 = x1/(x0 x1)) buys nothing, so the plain fma-rcp-fma triple is the floor: ~15.6 cyc.)
+template <int NP, int R>
+__device__ __forceinline__ void scdm_chunk_step(const float (&Ea)[R][4], const float* __restrict__ esp, int HP,
+                                                const float (&w2)[4], float (&acc)[R][NP]) {
+  constexpr int G = (R == 1) ? 4 : 2;          // words per scheduling group (~16 triples of VALU work)
+  static_assert(NP % G == 0, "word groups");
+  float4 cur[G], nxt[G];
+#pragma unroll
+  for (int u = 0; u < G; ++u) cur[u] = *reinterpret_cast<const float4*>(esp + u * HP);
+#pragma unroll
+  for (int n0 = 0; n0 < NP; n0 += G) {
+    if (n0 + G < NP) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) nxt[u] = *reinterpret_cast<const float4*>(esp + (n0 + G + u) * HP);
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const float e4[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[r][n0 + u] = fmaf(w2[c], fast_rcp(fmaf(Ea[r][c], e4[c], 1.f)), acc[r][n0 + u]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < G; ++u) cur[u] = nxt[u];
+  }
+}
+
+// Sum NP per-lane partials over the 64 lanes with the gfx950 swap instructions: v_permlane32_swap
+// folds the two wave halves of TWO values at once, v_permlane16_swap the two 16-lane rows of each
+// half, then 4 DPP steps finish inside a row.  NP values -> NP/4 registers; afterwards register j,
+// 16-lane row q holds the total for word n = 4j + {0,2,1,3}[q].   (NP is a multiple of 4.)
+template <int NP>
+__device__ __forceinline__ void wave_transpose_sum(const float (&v)[NP], float (&z)[NP / 4]) {
+  float h[NP / 2];
+#pragma unroll
+  for (int i = 0; i < NP / 2; ++i) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * i]), __float_as_uint(v[2 * i + 1]), false, false);
+    h[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#pragma unroll
+  for (int j = 0; j < NP / 4; ++j) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[2 * j]), __float_as_uint(h[2 * j + 1]), false, false);
+    float t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    t += dpp_mov<0xB1>(t);    // quad_perm [1,0,3,2]
+    t += dpp_mov<0x4E>(t);    // quad_perm [2,3,0,1]
+    t += dpp_mov<0x141>(t);   // row_half_mirror
+    t += dpp_mov<0x140>(t);   // row_mirror
+    z[j] = t;
+  }
+}
+
+__device__ __forceinline__ float xrow_max(float v) {     // max over the four 16-lane rows
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xrow_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+  return v + __shfl_xor(v, 32, 64);
+}
+
+__device__ __forceinline__ float4 exp2x4(float4 v) {     // exp(2 v), v clamped to +-kClamp
+  return make_float4(fast_exp2(clampf(v.x, -kClamp, kClamp) * k2Log2e), fast_exp2(clampf(v.y, -kClamp, kClamp) * k2Log2e),
+                     fast_exp2(clampf(v.z, -kClamp, kClamp) * k2Log2e), fast_exp2(clampf(v.w, -kClamp, kClamp) * k2Log2e));
+}
+
+// Forward kernel.  Workgroup = (batch item b, TT consecutive clips), 8 waves.  The TT rows are
+// processed as TT/SUB sub-tiles of SUB = 8R rows (R rows per wave): scores+softmax of sub-tile i+1
+// run while the C rows of sub-tile i are still draining to HBM (a CU retires stores at only ~7
+// B/clk, so an un-overlapped 128 KiB C tile costs ~8 us of store tail).  In phase 2 wave w owns a
+// fixed (column group, row slot); its sent[b,:,cols] slice stays in registers for the whole kernel.
 template <int NP, int R>
 __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
     const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w,
     const float* __restrict__ V, float* __restrict__ C, float* __restrict__ P,
-    int B, int T, int N, int H, int Ds, int TT, int tiles) {
+    int B, int T, int N, int H, int Ds, int TT, int tiles, int dbg) {
+  constexpr int SUB = kFwdWaves * R;
+  constexpr int CW = NP <= 20 ? 4 : 2;               // sentence columns per lane in phase 2 (VGPR budget)
   const int HP = roundup256(H);
   extern __shared__ __align__(16) float lds[];
-  float* Es = lds;                 // [NP][HP]
-  float* Pl = lds + NP * HP;       // [TT][NP]
+  float* Es = lds;                       // [NP][HP]
+  float* Wl = lds + NP * HP;             // [HP]   -2*w (0 beyond H: padded columns add nothing)
+  float* Pl = Wl + HP;                   // [2][SUB][NP]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int bid = xcd_remap(blockIdx.x, gridDim.x, tiles);
   const int b = bid / tiles, tile = bid % tiles;
+  const int t_tile = tile * TT;
+  const float* ab = a + (size_t)b * T * H;
 
-  // ---- prologue: Es = exp(2 s[b]) into LDS (zero padding: r = 1, harmless, masked below) ----
-  const float* sb = s + (size_t)b * N * H;
-  const int hp4 = HP / 4;
-  for (int idx = tid; idx < NP * hp4; idx += kFwdThreads) {
-    const int n = idx / hp4, k = (idx % hp4) * 4;
-    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < N && k < H) {
-      const float4 v = *reinterpret_cast<const float4*>(sb + (size_t)n * H + k);
-      e.x = fast_exp2(clampf(v.x, -kClamp, kClamp) * k2Log2e);
-      e.y = fast_exp2(clampf(v.y, -kClamp, kClamp) * k2Log2e);
-      e.z = fast_exp2(clampf(v.z, -kClamp, kClamp) * k2Log2e);
-      e.w = fast_exp2(clampf(v.w, -kClamp, kClamp) * k2Log2e);
-    }
-    *reinterpret_cast<float4*>(Es + n * HP + k) = e;
-  }
-  __syncthreads();
-
-  const int rows_per_wave = TT / kFwdWaves;
-  const int t_wave = tile * TT + wv * rows_per_wave;
-
-  // ---- phase 1: scores + softmax, R rows at a time; k swept in 256-column chunks --------------
-  for (int r0 = 0; r0 < rows_per_wave; r0 += R) {
-    const float* arow[R];
+  // A wave keeps its current clip row(s) in registers (H <= 1024: 4 float4 per lane and row) and
+  // loads the NEXT sub-tile's rows before the current score loop starts.  They are waited for right
+  // after that loop -- before this sub-tile's P / C stores are issued -- so that no wait in the
+  // steady state sits behind a store (vmcnt counts loads and stores together, in order; a wait
+  // that follows the C stores would drain them and serialise the store tail with the next loop).
+  float4 q[R][4], qn[R][4];
+  auto load_rows = [&](float4 (&dst)[R][4], int t_first) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int t = t_wave + r0 + r;
-      arow[r] = a + ((size_t)b * T + (t < T ? t : T - 1)) * H + lane * 4;
+      const int t = t_first + wv * R + r;
+      const float* row = ab + (size_t)(t < T ? t : T - 1) * H + lane * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        dst[r][i] = (i * 256 + lane * 4 < H) ? *reinterpret_cast<const float4*>(row + i * 256)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+  load_rows(q, t_tile);
+
+  // ---- prologue: Es = exp(2 s[b]) and -2w into LDS (zero padding of Es: r = 1, masked below).
+  // Up to 12 float4 per thread per round, every load issued before the first exp (the prologue is
+  // latency-, not bandwidth-bound: s[b] is 80 KiB).
+  const float* sb = s + (size_t)b * N * H;
+  const int hp4 = HP / 4, total4 = TSG_SKIP(8) ? 0 : NP * hp4;
+  constexpr int PU = 12;
+  for (int base = tid; base < total4; base += PU * kFwdThreads) {
+    float4 v[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int idx = base + u * kFwdThreads;
+      const int n = idx / hp4, k = (idx % hp4) * 4;
+      v[u] = (idx < total4 && n < N && k < H) ? *reinterpret_cast<const float4*>(sb + (size_t)n * H + k)
+                                              : make_float4(-1e30f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int idx = base + u * kFwdThreads;
+      if (idx < total4) {
+        const int n = idx / hp4, k = (idx % hp4) * 4;
+        float4 e = exp2x4(v[u]);
+        if (v[u].x == -1e30f) e = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Es + n * HP + k) = e;
+      }
+    }
+  }
+  for (int k = tid * 4; k < HP; k += 4 * kFwdThreads) {
+    float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < H) wq = *reinterpret_cast<const float4*>(w + k);
+    *reinterpret_cast<float4*>(Wl + k) = make_float4(-2.f * wq.x, -2.f * wq.y, -2.f * wq.z, -2.f * wq.w);
+  }
+
+  // phase-2 role of this wave: column group cg (64*CW columns), row slot rs of every `rslots`
+  const int cgroups = (Ds + 64 * CW - 1) / (64 * CW);
+  int cgp = 1;
+  while (cgp < cgroups && cgp < kFwdWaves) cgp <<= 1;
+  const int cg = wv % cgp, rs = wv / cgp, rslots = kFwdWaves / cgp;   // host guarantees cgroups <= 8
+  const float* Vb = V + (size_t)b * N * Ds;
+  v2f vreg[NP][CW / 2];
+  auto load_v = [&](int j) {
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+      const float* src = Vb + (size_t)(n < N ? n : 0) * Ds + (j < Ds ? j : 0);
+      if (CW == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(src);
+        vreg[n][0] = (v2f){q.x, q.y}; vreg[n][CW / 2 - 1] = (v2f){q.z, q.w};
+      } else {
+        const float2 q = *reinterpret_cast<const float2*>(src);
+        vreg[n][0] = (v2f){q.x, q.y};
+      }
+      if (n >= N) {                                    // padded words: P is 0 there, keep V finite
+#pragma unroll
+        for (int h = 0; h < CW / 2; ++h) vreg[n][h] = (v2f){0.f, 0.f};
+      }
+    }
+  };
+  const int jcol = cg * 64 * CW + lane * CW;
+  if (!TSG_SKIP(4)) load_v(jcol);
+  lds_barrier();
+
+  const int nsub = TT / SUB;
+  for (int st = 0; st < nsub; ++st) {
+    const int t0 = t_tile + st * SUB;                  // first clip of the sub-tile
+    float* Pcur = Pl + (st & 1) * SUB * NP;
+
+    // ---- phase 1: scores + softmax for this wave's R rows; k in 256-column chunks --------------
     float acc[R][NP];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int n = 0; n < NP; ++n) acc[r][n] = 0.f;
-
-    float4 av[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      av[r] = (lane * 4 < H) ? *reinterpret_cast<const float4*>(arow[r]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (st + 1 < nsub) load_rows(qn, t0 + SUB);          // flies during the score loop below
 
 #pragma unroll 1
-    for (int k0 = 0; k0 < HP; k0 += 256) {
+    for (int k0 = 0; k0 < (TSG_SKIP(1) ? 0 : HP); k0 += 256) {
       const int k = k0 + lane * 4;
-      float4 nxt[R];                                    // prefetch the next chunk of the R rows
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        nxt[r] = (k + 256 < H) ? *reinterpret_cast<const float4*>(arow[r] + k0 + 256) : make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);     // 0 beyond H: padded columns add nothing
-      if (k < H) wq = *reinterpret_cast<const float4*>(w + k);
-      const float w2[4] = {-2.f * wq.x, -2.f * wq.y, -2.f * wq.z, -2.f * wq.w};
+      const float4 wq = *reinterpret_cast<const float4*>(Wl + k);
+      const float w2[4] = {wq.x, wq.y, wq.z, wq.w};
       float Ea[R][4];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        Ea[r][0] = fast_exp2(clampf(av[r].x, -kClamp, kClamp) * k2Log2e);
-        Ea[r][1] = fast_exp2(clampf(av[r].y, -kClamp, kClamp) * k2Log2e);
-        Ea[r][2] = fast_exp2(clampf(av[r].z, -kClamp, kClamp) * k2Log2e);
-        Ea[r][3] = fast_exp2(clampf(av[r].w, -kClamp, kClamp) * k2Log2e);
+        const float4 e = exp2x4(q[r][0]);
+        Ea[r][0] = e.x; Ea[r][1] = e.y; Ea[r][2] = e.z; Ea[r][3] = e.w;
+        q[r][0] = q[r][1]; q[r][1] = q[r][2]; q[r][2] = q[r][3];   // H <= 1024: the whole row is here
       }
-      const float* esp = Es + k;
-#pragma unroll
-      for (int n = 0; n < NP; ++n) {
-        const float4 es = *reinterpret_cast<const float4*>(esp + n * HP);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          acc[r][n] = fmaf(w2[0], fast_rcp(fmaf(Ea[r][0], es.x, 1.f)), acc[r][n]);
-          acc[r][n] = fmaf(w2[1], fast_rcp(fmaf(Ea[r][1], es.y, 1.f)), acc[r][n]);
-          acc[r][n] = fmaf(w2[2], fast_rcp(fmaf(Ea[r][2], es.z, 1.f)), acc[r][n]);
-          acc[r][n] = fmaf(w2[3], fast_rcp(fmaf(Ea[r][3], es.w, 1.f)), acc[r][n]);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) av[r] = nxt[r];
+      scdm_chunk_step<NP, R>(Ea, Es + k, HP, w2, acc);
     }
+    // land the next rows now (long since arrived), ahead of this sub-tile's stores
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        asm volatile("" : "+v"(qn[r][i].x), "+v"(qn[r][i].y), "+v"(qn[r][i].z), "+v"(qn[r][i].w));
+        q[r][i] = qn[r][i];
+      }
 
+    // k-reduction + softmax over the N words, one clip row at a time
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int tl = wv * rows_per_wave + r0 + r;       // row inside the tile
-      const int t = tile * TT + tl;
+      float z[NP / 4];
+      if (TSG_SKIP(2)) {
+#pragma unroll
+        for (int j = 0; j < NP / 4; ++j) z[j] = acc[r][j];
+      } else {
+        wave_transpose_sum<NP>(acc[r], z);
+      }
+      const int q = lane >> 4;
+      const int nq = ((q & 1) << 1) | (q >> 1);         // row q holds word 4j + {0,2,1,3}[q]
       float m = -INFINITY;
 #pragma unroll
-      for (int n = 0; n < NP; ++n) {
-        acc[r][n] = wave_allsum(acc[r][n]);
-        if (n < N) m = fmaxf(m, acc[r][n]);
+      for (int j = 0; j < NP / 4; ++j) {
+        if (4 * j + nq >= N) z[j] = -INFINITY;
+        m = fmaxf(m, z[j]);
       }
+      m = xrow_max(m);
       float sum = 0.f;
 #pragma unroll
-      for (int n = 0; n < NP; ++n) {
-        acc[r][n] = (n < N) ? fast_exp2((acc[r][n] - m) * kLog2e) : 0.f;
-        sum += acc[r][n];
+      for (int j = 0; j < NP / 4; ++j) {
+        z[j] = fast_exp2((z[j] - m) * kLog2e);            // exp(-inf) = 0 for padded words
+        sum += z[j];
       }
-      const float inv = 1.f / sum;
-      float mine = 0.f;
+      const float inv = 1.f / xrow_sum(sum);
+      const int tl = wv * R + r;                        // row inside the sub-tile
+      const int t = t0 + tl;
+      if ((lane & 15) == 0) {
 #pragma unroll
-      for (int n = 0; n < NP; ++n) mine = (lane == n) ? acc[r][n] * inv : mine;
-      if (r0 + r < rows_per_wave) {
-        if (lane < NP) Pl[tl * NP + lane] = mine;
-        if (lane < N && t < T) P[((size_t)b * T + t) * N + lane] = mine;
+        for (int j = 0; j < NP / 4; ++j) {
+          const int n = 4 * j + nq;
+          const float pv = z[j] * inv;
+          Pcur[tl * NP + n] = pv;
+          if (n < N && t < T) P[((size_t)b * T + t) * N + n] = pv;
+        }
       }
     }
-  }
-  // Pl rows are written and read by the same wave only: no workgroup barrier needed, but the LDS
-  // writes must have landed before the broadcast reads below.
-  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    lds_barrier();                                       // the sub-tile's P rows are in LDS (stores keep flying)
 
-  // ---- phase 2: C[t,:] = sum_n P[t,n] * sent[b,n,:], rows blocked in registers ---------------
-  const float* Vb = V + (size_t)b * N * Ds;
-  constexpr int RC = 4;                                  // rows per register block
-  for (int j0 = 0; j0 < Ds; j0 += 256) {
-    const int j = j0 + lane * 4;
-    for (int r0 = 0; r0 < rows_per_wave; r0 += RC) {
-      float4 c[RC];
+    // ---- phase 2: C[t, cols] = sum_n P[t,n] * sent[b,n,cols] for rows rs, rs+rslots, ... ---------
+    if (!TSG_SKIP(4)) {
+      const bool jok = jcol < Ds;
+#pragma unroll 2
+      for (int tl = rs; tl < SUB; tl += rslots) {
+        const int t = t0 + tl;
+        v2f c[CW / 2];
 #pragma unroll
-      for (int r = 0; r < RC; ++r) c[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < Ds) {
+        for (int h = 0; h < CW / 2; ++h) c[h] = (v2f){0.f, 0.f};
 #pragma unroll
         for (int n4 = 0; n4 < NP; n4 += 4) {
-          float4 v[4];
+          const float4 p = *reinterpret_cast<const float4*>(Pcur + tl * NP + n4);
+          const float pp[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            v[q] = (n4 + q < N) ? *reinterpret_cast<const float4*>(Vb + (size_t)(n4 + q) * Ds + j)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int r = 0; r < RC; ++r) {
-            if (r0 + r < rows_per_wave) {
-              const float4 p = *reinterpret_cast<const float4*>(Pl + (wv * rows_per_wave + r0 + r) * NP + n4);
-              c[r].x = fmaf(p.x, v[0].x, c[r].x); c[r].y = fmaf(p.x, v[0].y, c[r].y);
-              c[r].z = fmaf(p.x, v[0].z, c[r].z); c[r].w = fmaf(p.x, v[0].w, c[r].w);
-              c[r].x = fmaf(p.y, v[1].x, c[r].x); c[r].y = fmaf(p.y, v[1].y, c[r].y);
-              c[r].z = fmaf(p.y, v[1].z, c[r].z); c[r].w = fmaf(p.y, v[1].w, c[r].w);
-              c[r].x = fmaf(p.z, v[2].x, c[r].x); c[r].y = fmaf(p.z, v[2].y, c[r].y);
-              c[r].z = fmaf(p.z, v[2].z, c[r].z); c[r].w = fmaf(p.z, v[2].w, c[r].w);
-              c[r].x = fmaf(p.w, v[3].x, c[r].x); c[r].y = fmaf(p.w, v[3].y, c[r].y);
-              c[r].z = fmaf(p.w, v[3].z, c[r].z); c[r].w = fmaf(p.w, v[3].w, c[r].w);
-            }
-          }
+            for (int h = 0; h < CW / 2; ++h)
+              c[h] = __builtin_elementwise_fma((v2f){pp[u], pp[u]}, vreg[n4 + u][h], c[h]);
         }
-#pragma unroll
-        for (int r = 0; r < RC; ++r) {
-          const int t = t_wave + r0 + r;
-          if (r0 + r < rows_per_wave && t < T)
-            *reinterpret_cast<float4*>(C + ((size_t)b * T + t) * Ds + j) = c[r];
+        if (t < T && jok) {
+          float* dst = C + ((size_t)b * T + t) * Ds + jcol;
+          if (CW == 4) *reinterpret_cast<float4*>(dst) = make_float4(c[0].x, c[0].y, c[CW / 2 - 1].x, c[CW / 2 - 1].y);
+          else *reinterpret_cast<float2*>(dst) = make_float2(c[0].x, c[0].y);
         }
       }
     }
@@ -395,12 +529,16 @@ __global__ __launch_bounds__(kThreads) void scdm_bwd_cols_kernel(
 template <int NP>
 int launch_fwd(const float* a, const float* s, const float* w, const float* V, float* C, float* P,
                int B, int T, int N, int H, int Ds, hipStream_t st) {
-  constexpr int R = 4;
-  // rows per workgroup: 32 (4 per wave) when that still gives every CU a workgroup, else 16 / 8
+  constexpr int R = 1;                       // clip rows per wave and sub-tile (sub-tile = 8R rows)
+  constexpr int SUB = kFwdWaves * R;
+  // rows per workgroup: 32 (4 sub-tiles) when that still gives every CU a workgroup, else 16 / 8
   int TT = 32;
-  while (TT > kFwdWaves && (long)B * cdiv(T, TT) < 256) TT >>= 1;
+  while (TT > SUB && (long)B * cdiv(T, TT) < 256) TT >>= 1;
   const int tiles = cdiv(T, TT);
-  const size_t lds = sizeof(float) * ((size_t)NP * roundup256(H) + (size_t)TT * NP);
+  const size_t lds = sizeof(float) * ((size_t)(NP + 1) * roundup256(H) + (size_t)2 * SUB * NP);
+  if (H > 1024 || Ds > (NP <= 20 ? 2048 : 1024))
+    return set_error(TSG_E_SHAPE, "scdm_attn_fwd: H=%d (max 1024) / Ds=%d (max %d at N=%d) not supported",
+                     H, Ds, NP <= 20 ? 2048 : 1024, N);
   if (lds > (size_t)kLdsBytes)
     return set_error(TSG_E_LDS, "scdm_attn_fwd: N=%d H=%d needs %zu B of LDS (> %d)", N, H, lds, kLdsBytes);
   auto kern = scdm_fwd_kernel<NP, R>;
@@ -410,7 +548,7 @@ int launch_fwd(const float* a, const float* s, const float* w, const float* V, f
     if (e != hipSuccess) return set_error((int)e, "scdm_attn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
     allowed = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kFwdThreads), lds, st, a, s, w, V, C, P, B, T, N, H, Ds, TT, tiles);
+  hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kFwdThreads), lds, st, a, s, w, V, C, P, B, T, N, H, Ds, TT, tiles, ablate_mask());
   return check_launch("scdm_attn_fwd");
 }
 

@@ -65,6 +65,15 @@ __device__ __forceinline__ float wave_allmax(float v) {
   return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits
+// for every global store the wave still has in flight -- exactly what a kernel that overlaps its
+// output stores with the next tile's compute must not do.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Blocks are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  Remap a linear
 // block id so that `group` consecutive logical ids (e.g. the tiles that share one batch item's
 // word features) land on ONE XCD.  Speed only -- any placement is correct.
