@@ -347,178 +347,268 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// backward, kernel 1: de[b,t,n] = P*(dP - <P,dP>),  dP[n] = <dC[t,:], sent[b,n,:]>
-// one wave per clip row; sent rows come from L2 (80 KiB per batch item).
+// backward, kernel 1: de[b,t,n] = P*(dP - <P,dP>),  dP[t,n] = <dC[t,:], sent[b,n,:]>
+// Workgroup = (b, 32 clips), 8 waves = (column group cg, row slot rs) exactly as forward phase 2:
+// the wave's sent[b,:,cols] slice stays in registers, its dC rows stream through (next row in
+// flight), each row's NP partial dots are folded with the swap reduction, and the column groups
+// meet in LDS.  sent[b] is read once per workgroup instead of once per clip row.
 // ------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(kThreads) void scdm_bwd_rows_kernel(
+__global__ __launch_bounds__(kFwdThreads) void scdm_bwd_rows_kernel(
     const float* __restrict__ V, const float* __restrict__ P, const float* __restrict__ dC,
-    float* __restrict__ de, int B, int T, int N, int Ds) {
-  const int lane = threadIdx.x & 63, wv = wave_id();
-  const long row = (long)blockIdx.x * kWaves + wv;            // = b*T + t
-  if (row >= (long)B * T) return;
-  const int b = (int)(row / T);
+    float* __restrict__ de, int B, int T, int N, int Ds, int tiles) {
+  constexpr int TT = 32;
+  constexpr int CW = NP <= 20 ? 4 : 2;
+  __shared__ float part[kFwdWaves][TT][NP + 1];          // [cg][row][n] (padded against bank conflicts)
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+  const int bid = xcd_remap(blockIdx.x, gridDim.x, tiles);
+  const int b = bid / tiles, t_tile = (bid % tiles) * TT;
+
+  const int cgroups = (Ds + 64 * CW - 1) / (64 * CW);
+  int cgp = 1;
+  while (cgp < cgroups && cgp < kFwdWaves) cgp <<= 1;
+  const int cg = wv % cgp, rs = wv / cgp, rslots = kFwdWaves / cgp;
+  const int jcol = cg * 64 * CW + lane * CW;
+  const bool jok = jcol < Ds;
   const float* Vb = V + (size_t)b * N * Ds;
-  const float* g = dC + (size_t)row * Ds;
-  float dp[NP];
-#pragma unroll
-  for (int n = 0; n < NP; ++n) dp[n] = 0.f;
-  for (int j = lane * 4; j < Ds; j += 256) {
-    const float4 gv = *reinterpret_cast<const float4*>(g + j);
-#pragma unroll
-    for (int n = 0; n < NP; ++n) {
-      if (n < N) {
-        const float4 v = *reinterpret_cast<const float4*>(Vb + (size_t)n * Ds + j);
-        dp[n] = fmaf(gv.x, v.x, fmaf(gv.y, v.y, fmaf(gv.z, v.z, fmaf(gv.w, v.w, dp[n]))));
-      }
-    }
-  }
-  const float p = (lane < N) ? P[(size_t)row * N + lane] : 0.f;
-  float mine = 0.f;
+  float vreg[NP][CW];
 #pragma unroll
   for (int n = 0; n < NP; ++n) {
-    dp[n] = wave_allsum(dp[n]);
-    mine = (lane == n) ? dp[n] : mine;
+    const float* src = Vb + (size_t)(n < N ? n : 0) * Ds + (jok ? jcol : 0);
+    if (CW == 4) {
+      const float4 q = *reinterpret_cast<const float4*>(src);
+      vreg[n][0] = q.x; vreg[n][1] = q.y; vreg[n][CW - 2] = q.z; vreg[n][CW - 1] = q.w;
+    } else {
+      const float2 q = *reinterpret_cast<const float2*>(src);
+      vreg[n][0] = q.x; vreg[n][1] = q.y;
+    }
+    if (n >= N || !jok) {
+#pragma unroll
+      for (int c = 0; c < CW; ++c) vreg[n][c] = 0.f;
+    }
   }
-  const float dot = wave_allsum(p * mine);                     // <P, dP>
-  if (lane < N) de[(size_t)row * N + lane] = p * (mine - dot);
+  auto load_g = [&](int tl, float (&g)[CW]) {
+    const int t = t_tile + tl;
+    const float* src = dC + ((size_t)b * T + (t < T ? t : T - 1)) * Ds + (jok ? jcol : 0);
+    if (CW == 4) {
+      const float4 q = *reinterpret_cast<const float4*>(src);
+      g[0] = q.x; g[1] = q.y; g[CW - 2] = q.z; g[CW - 1] = q.w;
+    } else {
+      const float2 q = *reinterpret_cast<const float2*>(src);
+      g[0] = q.x; g[1] = q.y;
+    }
+  };
+  float g[CW], gn[CW];
+  load_g(rs, g);
+  const int q4 = lane >> 4;
+  const int nq = ((q4 & 1) << 1) | (q4 >> 1);
+  for (int tl = rs; tl < TT; tl += rslots) {
+    if (tl + rslots < TT) load_g(tl + rslots, gn);
+    float dp[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) acc = fmaf(g[c], vreg[n][c], acc);
+      dp[n] = acc;
+    }
+    float z[NP / 4];
+    wave_transpose_sum<NP>(dp, z);
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int j = 0; j < NP / 4; ++j) part[cg][tl][4 * j + nq] = z[j];
+    }
+#pragma unroll
+    for (int c = 0; c < CW; ++c) g[c] = gn[c];
+  }
+  __syncthreads();
+  // 32 rows x NP words: one thread per (row, word); the softmax-Jacobian row dot via LDS
+  float* dots = &part[0][0][0];                          // reuse: after the sums are taken (2nd barrier)
+  float dpv = 0.f, pv = 0.f;
+  const int row = tid / NP, n = tid % NP;                // 512 threads cover 25 rows of NP=20 at a time
+  for (int r0 = 0; r0 < TT; r0 += kFwdThreads / NP) {
+    const int tl = r0 + row, t = t_tile + tl;
+    const bool ok = row < kFwdThreads / NP && tl < TT && t < T && n < N;
+    dpv = 0.f; pv = 0.f;
+    if (ok) {
+      for (int c = 0; c < cgp; ++c) dpv += part[c][tl][n];
+      pv = P[((size_t)b * T + t) * N + n];
+    }
+    // <P,dP> over the row: NP consecutive threads hold one row
+    __shared__ float prod[kFwdThreads];
+    prod[tid] = pv * dpv;
+    __syncthreads();
+    if (ok) {
+      float dot = 0.f;
+      const int base = tid - n;
+      for (int m = 0; m < N; ++m) dot += prod[base + m];
+      de[((size_t)b * T + t) * N + n] = pv * (dpv - dot);
+    }
+    __syncthreads();
+  }
+  (void)dots;
 }
 
 // ------------------------------------------------------------------------------------------
-// backward, kernel 2: one workgroup = (b, 256-column slice c); waves stride over the T rows.
+// backward, kernel 2: one workgroup = (b, 256-column slice c), 8 waves striding over the T rows.
+//   da[t,k] = 4 w[k] sum_n v      ds[n,k] = 4 w[k] sum_t v      dw[k] += -2 sum_{t,n} u
+//   with u = de[t,n] r,  v = u (1 - r) = de * r(1-r),  r = 1/(Ea Es + 1)
+//   dsent[n,j] = sum_t P[t,n] dC[t,j]
+// Es for the slice lives in registers (NP*4 per lane); the de / P rows are wave-uniform (scalar
+// loads); the next row's a / dC float4 and de / P row are in flight while the current one is used.
+// Cross-wave sums go through LDS in word chunks (deterministic order, no atomics except dw).
 // ------------------------------------------------------------------------------------------
+constexpr int kColThreads = 512;
+constexpr int kColWaves = kColThreads / kWave;
+constexpr int kCpl = 2;                                   // columns per lane (VGPR budget: 2*NP*kCpl accumulators)
+constexpr int kSlice = kWave * kCpl;                      // 128 columns per workgroup
+constexpr int kRedChunk = 8;                              // words per LDS reduction round: 8*8*128*4 = 32 KiB
+
+__device__ __forceinline__ float2 exp2x2(float2 v) {
+  return make_float2(fast_exp2(clampf(v.x, -kClamp, kClamp) * k2Log2e), fast_exp2(clampf(v.y, -kClamp, kClamp) * k2Log2e));
+}
+
 template <int NP>
-__global__ __launch_bounds__(kThreads) void scdm_bwd_cols_kernel(
+__device__ __forceinline__ void cols_reduce_store(float (&acc)[NP][kCpl], float* __restrict__ red, float* __restrict__ out,
+                                                  const float* __restrict__ scale, int N, int width, int col0,
+                                                  int tid, int lane, int wv) {
+  // out[n*width + col0 + c] = scale[c] * sum_waves acc[n][c];  red = [kColWaves][kRedChunk][kSlice]
+  for (int n0 = 0; n0 < NP; n0 += kRedChunk) {
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+      if (n >= n0 && n < n0 + kRedChunk)
+        *reinterpret_cast<float2*>(red + ((wv * kRedChunk + (n - n0)) * kSlice) + lane * kCpl) = make_float2(acc[n][0], acc[n][1]);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kRedChunk * kSlice; idx += kColThreads) {
+      const int nn = n0 + idx / kSlice, c = idx % kSlice;
+      if (nn < N && col0 + c < width) {
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < kColWaves; ++u) sum += red[(u * kRedChunk + (nn - n0)) * kSlice + c];
+        out[(size_t)nn * width + col0 + c] = (scale ? scale[c] : 1.f) * sum;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int NP>
+__global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
     const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w,
     const float* __restrict__ P, const float* __restrict__ dC, const float* __restrict__ de,
     float* __restrict__ da, float* __restrict__ ds, float* __restrict__ dw, float* __restrict__ dV,
     int B, int T, int N, int H, int Ds, int hslices, int slices) {
-  extern __shared__ __align__(16) float lds[];                 // [kWaves][NP][256] cross-wave reduce
+  __shared__ __align__(16) float red[kColWaves * kRedChunk * kSlice];
+  __shared__ float wscale[kSlice];
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int bid = xcd_remap(blockIdx.x, gridDim.x, slices);
   const int b = bid / slices, c = bid % slices;
-  const int k = c * 256 + lane * 4;
+  const int k = c * kSlice + lane * kCpl;
   const float* deb = de + (size_t)b * T * N;
   const float* Pb = P + (size_t)b * T * N;
 
-  // ---------------- main: da, ds, dw for hidden columns k..k+3 --------------------------------
+  // ---------------- main: da, ds, dw for hidden columns k, k+1 ---------------------------------
   if (c < hslices) {
     const bool live = k < H;
-    float es[NP][4];
+    const float* arow = a + (size_t)b * T * H + (live ? k : 0);
+    float2 av = *reinterpret_cast<const float2*>(arow + (size_t)(wv < T ? wv : 0) * H);
+    float es[NP][kCpl];
     const float* sb = s + (size_t)b * N * H;
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N && live) v = *reinterpret_cast<const float4*>(sb + (size_t)n * H + k);
-      es[n][0] = fast_exp2(clampf(v.x, -kClamp, kClamp) * k2Log2e);
-      es[n][1] = fast_exp2(clampf(v.y, -kClamp, kClamp) * k2Log2e);
-      es[n][2] = fast_exp2(clampf(v.z, -kClamp, kClamp) * k2Log2e);
-      es[n][3] = fast_exp2(clampf(v.w, -kClamp, kClamp) * k2Log2e);
+      float2 v = make_float2(0.f, 0.f);
+      if (n < N && live) v = *reinterpret_cast<const float2*>(sb + (size_t)n * H + k);
+      const float2 e = exp2x2(v);
+      es[n][0] = e.x; es[n][1] = e.y;
     }
-    float4 wv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) wv4 = *reinterpret_cast<const float4*>(w + k);
-    const float w4[4] = {4.f * wv4.x, 4.f * wv4.y, 4.f * wv4.z, 4.f * wv4.w};
-
-    float dsacc[NP][4];
-    float dwacc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < kSlice) wscale[tid] = (c * kSlice + tid < H) ? 4.f * w[c * kSlice + tid] : 0.f;
+    float dsacc[NP][kCpl], dwacc[kCpl] = {0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < NP; ++n)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dsacc[n][q] = 0.f;
+      for (int q = 0; q < kCpl; ++q) dsacc[n][q] = 0.f;
+    float dcur[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) dcur[n] = (n < N && wv < T) ? deb[(size_t)wv * N + n] : 0.f;
+    __syncthreads();
+    const float2 ws2 = *reinterpret_cast<const float2*>(wscale + lane * kCpl);
 
-    for (int t = wv; t < T; t += kWaves) {
-      float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live) av = *reinterpret_cast<const float4*>(a + ((size_t)b * T + t) * H + k);
-      const float ea[4] = {fast_exp2(clampf(av.x, -kClamp, kClamp) * k2Log2e),
-                           fast_exp2(clampf(av.y, -kClamp, kClamp) * k2Log2e),
-                           fast_exp2(clampf(av.z, -kClamp, kClamp) * k2Log2e),
-                           fast_exp2(clampf(av.w, -kClamp, kClamp) * k2Log2e)};
-      float dasum[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* der = deb + (size_t)t * N;                  // wave-uniform row -> scalar loads
+    for (int t = wv; t < T; t += kColWaves) {
+      const int tn = t + kColWaves;
+      float2 avn = make_float2(0.f, 0.f);
+      float dnext[NP];
+      if (tn < T) avn = *reinterpret_cast<const float2*>(arow + (size_t)tn * H);
+#pragma unroll
+      for (int n = 0; n < NP; ++n) dnext[n] = (n < N && tn < T) ? deb[(size_t)tn * N + n] : 0.f;
+
+      const float2 e2 = exp2x2(av);
+      const float ea[kCpl] = {e2.x, e2.y};
+      float dasum[kCpl] = {0.f, 0.f};
 #pragma unroll
       for (int n = 0; n < NP; ++n) {
-        if (n < N) {
-          const float d = der[n];
+        const float d = dcur[n];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float r = fast_rcp(fmaf(ea[q], es[n][q], 1.f));
-            const float qq = fmaf(-r, r, r);                   // r(1-r)
-            const float dq = d * qq;
-            dsacc[n][q] += dq;
-            dasum[q] += dq;
-            dwacc[q] = fmaf(d, r, dwacc[q]);
-          }
+        for (int q = 0; q < kCpl; ++q) {
+          const float r = fast_rcp(fmaf(ea[q], es[n][q], 1.f));
+          const float u = d * r;
+          const float v = fmaf(-u, r, u);
+          dsacc[n][q] += v;
+          dasum[q] += v;
+          dwacc[q] += u;
         }
       }
       if (live)
-        *reinterpret_cast<float4*>(da + ((size_t)b * T + t) * H + k) =
-            make_float4(w4[0] * dasum[0], w4[1] * dasum[1], w4[2] * dasum[2], w4[3] * dasum[3]);
+        *reinterpret_cast<float2*>(da + ((size_t)b * T + t) * H + k) = make_float2(ws2.x * dasum[0], ws2.y * dasum[1]);
+      av = avn;
+#pragma unroll
+      for (int n = 0; n < NP; ++n) dcur[n] = dnext[n];
     }
 
-    // cross-wave reduction of dsacc / dwacc through LDS
-    float* red = lds;                                          // [kWaves][NP+1][256]
-#pragma unroll
-    for (int n = 0; n < NP; ++n)
-      *reinterpret_cast<float4*>(red + ((wv * (NP + 1) + n) * 256) + lane * 4) =
-          make_float4(dsacc[n][0], dsacc[n][1], dsacc[n][2], dsacc[n][3]);
-    *reinterpret_cast<float4*>(red + ((wv * (NP + 1) + NP) * 256) + lane * 4) =
-        make_float4(dwacc[0], dwacc[1], dwacc[2], dwacc[3]);
+    cols_reduce_store<NP>(dsacc, red, ds + (size_t)b * N * H, wscale, N, H, c * kSlice, tid, lane, wv);
+    // dw: one more round through the same buffer, then one atomic per column and workgroup
+    *reinterpret_cast<float2*>(red + wv * kSlice + lane * kCpl) = make_float2(dwacc[0], dwacc[1]);
     __syncthreads();
-    // 256 threads: thread tid owns column (c*256 + tid) for every n
-    {
-      const int kk = c * 256 + tid;
-      const float wk = (kk < H) ? w[kk] : 0.f;
-      for (int n = 0; n <= NP; ++n) {
-        float acc = 0.f;
+    if (tid < kSlice && c * kSlice + tid < H) {
+      float sum = 0.f;
 #pragma unroll
-        for (int u = 0; u < kWaves; ++u) acc += red[(u * (NP + 1) + n) * 256 + tid];
-        if (kk < H) {
-          if (n < N) ds[((size_t)b * N + n) * H + kk] = 4.f * wk * acc;
-          else if (n == NP) atomicAdd(dw + kk, -2.f * acc);
-        }
-      }
+      for (int u = 0; u < kColWaves; ++u) sum += red[u * kSlice + tid];
+      atomicAdd(dw + c * kSlice + tid, -2.f * sum);
     }
     __syncthreads();
   }
 
   // ---------------- dsent[b,n,j] = sum_t P[t,n] dC[t,j] for sentence columns of slice c --------
-  {
-    const int j = c * 256 + lane * 4;
-    if (c * 256 < Ds) {
-      float dv[NP][4];
+  if (c * kSlice < Ds) {
+    const int j = c * kSlice + lane * kCpl;
+    const bool jok = j < Ds;
+    const float* grow = dC + (size_t)b * T * Ds + (jok ? j : 0);
+    float dv[NP][kCpl];
 #pragma unroll
-      for (int n = 0; n < NP; ++n)
+    for (int n = 0; n < NP; ++n)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dv[n][q] = 0.f;
-      for (int t = wv; t < T; t += kWaves) {
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < Ds) g = *reinterpret_cast<const float4*>(dC + ((size_t)b * T + t) * Ds + j);
-        const float* pr = Pb + (size_t)t * N;
+      for (int q = 0; q < kCpl; ++q) dv[n][q] = 0.f;
+    float2 g = *reinterpret_cast<const float2*>(grow + (size_t)(wv < T ? wv : 0) * Ds);
+    float pcur[NP];
 #pragma unroll
-        for (int n = 0; n < NP; ++n) {
-          if (n < N) {
-            const float p = pr[n];
-            dv[n][0] = fmaf(p, g.x, dv[n][0]); dv[n][1] = fmaf(p, g.y, dv[n][1]);
-            dv[n][2] = fmaf(p, g.z, dv[n][2]); dv[n][3] = fmaf(p, g.w, dv[n][3]);
-          }
-        }
+    for (int n = 0; n < NP; ++n) pcur[n] = (n < N && wv < T) ? Pb[(size_t)wv * N + n] : 0.f;
+    for (int t = wv; t < T; t += kColWaves) {
+      const int tn = t + kColWaves;
+      float2 gn = make_float2(0.f, 0.f);
+      float pnext[NP];
+      if (tn < T) gn = *reinterpret_cast<const float2*>(grow + (size_t)tn * Ds);
+#pragma unroll
+      for (int n = 0; n < NP; ++n) pnext[n] = (n < N && tn < T) ? Pb[(size_t)tn * N + n] : 0.f;
+      if (!jok) g = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int n = 0; n < NP; ++n) {
+        dv[n][0] = fmaf(pcur[n], g.x, dv[n][0]); dv[n][1] = fmaf(pcur[n], g.y, dv[n][1]);
       }
-      float* red = lds;
+      g = gn;
 #pragma unroll
-      for (int n = 0; n < NP; ++n)
-        *reinterpret_cast<float4*>(red + ((wv * (NP + 1) + n) * 256) + lane * 4) =
-            make_float4(dv[n][0], dv[n][1], dv[n][2], dv[n][3]);
-      __syncthreads();
-      const int jj = c * 256 + tid;
-      if (jj < Ds) {
-        for (int n = 0; n < N; ++n) {
-          float acc = 0.f;
-#pragma unroll
-          for (int u = 0; u < kWaves; ++u) acc += red[(u * (NP + 1) + n) * 256 + tid];
-          dV[((size_t)b * N + n) * Ds + jj] = acc;
-        }
-      }
+      for (int n = 0; n < NP; ++n) pcur[n] = pnext[n];
     }
+    cols_reduce_store<NP>(dv, red, dV + (size_t)b * N * Ds, nullptr, N, Ds, c * kSlice, tid, lane, wv);
   }
 }
 
@@ -556,23 +646,16 @@ template <int NP>
 int launch_bwd(const float* a, const float* s, const float* w, const float* V, const float* P,
                const float* dC, float* da, float* ds, float* dw, float* dV, float* de,
                int B, int T, int N, int H, int Ds, hipStream_t st) {
+  if (Ds > (NP <= 20 ? 2048 : 1024))
+    return set_error(TSG_E_SHAPE, "scdm_attn_bwd: Ds=%d (max %d at N=%d) not supported", Ds, NP <= 20 ? 2048 : 1024, N);
   hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * H, st);
   if (e != hipSuccess) return set_error((int)e, "scdm_attn_bwd: memset dw: %s", hipGetErrorString(e));
-  const long rows = (long)B * T;
-  hipLaunchKernelGGL(scdm_bwd_rows_kernel<NP>, dim3((unsigned)cdiv((int)rows, kWaves)), dim3(kThreads), 0, st,
-                     V, P, dC, de, B, T, N, Ds);
+  const int tiles = cdiv(T, 32);
+  hipLaunchKernelGGL(scdm_bwd_rows_kernel<NP>, dim3(B * tiles), dim3(kFwdThreads), 0, st, V, P, dC, de, B, T, N, Ds, tiles);
   int rc = check_launch("scdm_attn_bwd(rows)");
   if (rc) return rc;
-  const int hslices = cdiv(H, 256), slices = hslices > cdiv(Ds, 256) ? hslices : cdiv(Ds, 256);
-  const size_t lds = sizeof(float) * kWaves * (NP + 1) * 256;
-  auto kern = scdm_bwd_cols_kernel<NP>;
-  static thread_local bool allowed = false;
-  if (!allowed && lds > 64 * 1024) {
-    e = allow_lds(kern, lds);
-    if (e != hipSuccess) return set_error((int)e, "scdm_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    allowed = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(B * slices), dim3(kThreads), lds, st, a, s, w, P, dC, de, da, ds, dw, dV,
+  const int hslices = cdiv(H, kSlice), slices = hslices > cdiv(Ds, kSlice) ? hslices : cdiv(Ds, kSlice);
+  hipLaunchKernelGGL(scdm_bwd_cols_kernel<NP>, dim3(B * slices), dim3(kColThreads), 0, st, a, s, w, P, dC, de, da, ds, dw, dV,
                      B, T, N, H, Ds, hslices, slices);
   return check_launch("scdm_attn_bwd(cols)");
 }
