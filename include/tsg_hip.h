@@ -53,6 +53,27 @@ int tsg_scdm_attn_bwd(const void* a, const void* s, const void* w, const void* s
                       const void* dC, void* da, void* ds, void* dw, void* dsent, void* de_ws,
                       int B, int T, int N, int H, int Ds, int dtype, void* stream);
 
+/* ---- K3: boundary-score head (VideoSentenceConcat + MLP_predictor.forward,
+ * components/CrossModalInteraction.py:44-47 + components/SpanPredictor.py:71-85; GMD gate
+ * SpanGroundMatchDisc.py:86).  Start and end branches are stacked on the hidden axis: J = 2*Hm.
+ * inputs: y [B,T,J] = video @ [W1s_v | W1e_v]^T (the video half of both first Linears, no bias),
+ *         cs [B,J] = sent @ [W1s_s | W1e_s]^T (sentence half, no bias), b1 [J], w2 [J], b2 [2],
+ *         gate [B,T] or NULL (GMD: raw matching logits multiply the concatenated feature),
+ *         mask int32 [B,T] or NULL (mask_logits with -1e30, networks/attention.py:129-133).
+ *   z = gate*(y + cs) + b1;  l = w2 . tanh(z) + b2 (per branch);  p = softmax over T.
+ * outputs p_start, p_end [B,T].   Limits: J % 4 == 0, J <= 1024, T <= 8192.                   */
+int tsg_boundary_score_fwd(const void* y, const void* cs, const void* b1, const void* w2, const void* b2,
+                           const void* gate, const int32_t* mask, void* p_start, void* p_end,
+                           int B, int T, int Hm, int dtype, void* stream);
+
+/* backward.  dp_start/dp_end [B,T] -> dy [B,T,J], dcs [B,J], per-sample partial sums db1_part [B,J],
+ * dw2_part [B,J], db2_part [B,2] (the caller adds them over B), dgate [B,T] (may be NULL).       */
+int tsg_boundary_score_bwd(const void* y, const void* cs, const void* b1, const void* w2, const void* gate,
+                           const int32_t* mask, const void* p_start, const void* p_end,
+                           const void* dp_start, const void* dp_end, void* dy, void* dcs, void* db1_part,
+                           void* dw2_part, void* db2_part, void* dgate, int B, int T, int Hm, int dtype,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,8 @@ _SIGNATURES = {
     "tsg_last_error": [],
     "tsg_scdm_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsg_scdm_attn_bwd": [_P] * 11 + [_I] * 6 + [_P],
+    "tsg_boundary_score_fwd": [_P] * 9 + [_I] * 4 + [_P],
+    "tsg_boundary_score_bwd": [_P] * 16 + [_I] * 4 + [_P],
 }
 _RESTYPE = {"tsg_last_error": c_char_p}
 

@@ -1,0 +1,285 @@
+// K3 -- boundary-score head for gfx950: the part of VideoSentenceConcat + MLP_predictor
+// (reference grounding/model/components/CrossModalInteraction.py:44-47, SpanPredictor.py:71-85,
+// gate from SpanGroundMatchDisc.py:86) that follows the video-half GEMM.
+//
+// The reference concatenates [video_t | sent] (a [B,T,Dv+Ds] tensor) and runs two Linear(Dv+Ds,Hm).
+// Split W1 = [W1v | W1s]: the sentence half is a per-sample row cs[b] = W1s sent[b] (T-invariant),
+// so   z[b,t,:] = g[b,t] * (y[b,t,:] + cs[b,:]) + b1,   y = W1v video   (g = 1 without the GMD gate)
+//      l[b,t]   = w2 . tanh(z) + b2 ;  mask_logits ;  p = softmax_t(l)
+// with the start and end branches stacked along the hidden axis (J = 2*Hm columns: [start | end]).
+// The concat tensor never exists.
+//
+// One workgroup per batch item; a wave owns clip rows, lanes own hidden columns (coalesced float4
+// rows of y), the two dot products are wave reductions, the T-softmax runs out of LDS.
+// HBM-bound: reads y once (T*J*4 B per pair), writes 2T probabilities.
+#include "tsg_common.h"
+
+namespace tsg {
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / kWave;
+constexpr int kMaxJ4 = 4;            // J <= 64 lanes * 4 * kMaxJ4 = 1024 hidden columns (2*Hm)
+
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+__device__ __forceinline__ float tanh_fast(float x) {        // 1 - 2/(exp(2x)+1), exact to ~2 ulp
+  const float e = fast_exp2(clampf(x, -44.f, 44.f) * k2Log2e);
+  return 1.f - 2.f * fast_rcp(e + 1.f);
+}
+
+// mask_logits (attention.py:129-133): l*m + (-1e30)*(1-m), m cast to float
+__device__ __forceinline__ float mask_logit(float l, float m) { return l * m + (-1e30f) * (1.f - m); }
+
+// block-wide softmax over T values held in LDS (in place); returns nothing, all threads take part
+__device__ void block_softmax(float* v, int T, float* scratch) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+  float m = -INFINITY;
+  for (int t = tid; t < T; t += kThreads) m = fmaxf(m, v[t]);
+  m = wave_allmax(m);
+  if (lane == 0) scratch[wv] = m;
+  __syncthreads();
+  m = scratch[0];
+#pragma unroll
+  for (int u = 1; u < kWaves; ++u) m = fmaxf(m, scratch[u]);
+  __syncthreads();
+  float s = 0.f;
+  for (int t = tid; t < T; t += kThreads) {
+    const float e = __expf(v[t] - m);
+    v[t] = e;
+    s += e;
+  }
+  s = wave_allsum(s);
+  if (lane == 0) scratch[wv] = s;
+  __syncthreads();
+  s = 0.f;
+#pragma unroll
+  for (int u = 0; u < kWaves; ++u) s += scratch[u];
+  const float inv = 1.f / s;
+  for (int t = tid; t < T; t += kThreads) v[t] *= inv;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void boundary_fwd_kernel(
+    const float* __restrict__ y, const float* __restrict__ cs, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ gate,
+    const int* __restrict__ mask, float* __restrict__ ps, float* __restrict__ pe, int B, int T, int Hm) {
+  extern __shared__ float lds[];                 // [2][T] logits + scratch
+  float* ls = lds; float* le = lds + T; float* scratch = lds + 2 * T;
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), b = blockIdx.x;
+  const int J = 2 * Hm;
+  float c[kMaxJ4][4], bb[kMaxJ4][4], ww[kMaxJ4][4];
+#pragma unroll
+  for (int i = 0; i < kMaxJ4; ++i) {
+    const int j = i * 256 + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = j + q < J;
+      c[i][q] = ok ? cs[(size_t)b * J + j + q] : 0.f;
+      bb[i][q] = ok ? b1[j + q] : 0.f;
+      ww[i][q] = ok ? w2[j + q] : 0.f;
+    }
+  }
+  const float b2s = b2[0], b2e = b2[1];
+  for (int t = wv; t < T; t += kWaves) {
+    const float g = gate ? gate[(size_t)b * T + t] : 1.f;
+    const float* yr = y + ((size_t)b * T + t) * J;
+    float as = 0.f, ae = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxJ4; ++i) {
+      const int j = i * 256 + lane * 4;
+      if (j < J) {                                 // J % 4 == 0 (checked on the host)
+        const float4 v = *reinterpret_cast<const float4*>(yr + j);
+        const float yv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float u = tanh_fast(fmaf(g, yv[q] + c[i][q], bb[i][q]));
+          if (j + q < Hm) as = fmaf(ww[i][q], u, as); else ae = fmaf(ww[i][q], u, ae);
+        }
+      }
+    }
+    as = wave_allsum(as); ae = wave_allsum(ae);
+    if (lane == 0) {
+      float l0 = as + b2s, l1 = ae + b2e;
+      if (mask) { const float m = (float)mask[(size_t)b * T + t]; l0 = mask_logit(l0, m); l1 = mask_logit(l1, m); }
+      ls[t] = l0; le[t] = l1;
+    }
+  }
+  __syncthreads();
+  block_softmax(ls, T, scratch);
+  block_softmax(le, T, scratch);
+  for (int t = tid; t < T; t += kThreads) {
+    ps[(size_t)b * T + t] = ls[t];
+    pe[(size_t)b * T + t] = le[t];
+  }
+}
+
+// backward.  dl' = p*(dp - <p,dp>);  dl = dl'*m;  dz = dl*w2*(1-u^2);  dy = g*dz;
+// dcs[b,:] = sum_t g*dz;  db1p[b,:] = sum_t dz;  dw2p[b,:] = sum_t dl*u;  db2p[b,0:2] = sum_t dl;
+// dgate[b,t] = sum_j dz*(y+cs).   (per-sample partials: the host sums db1p/dw2p/db2p over B)
+__global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
+    const float* __restrict__ y, const float* __restrict__ cs, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ gate, const int* __restrict__ mask,
+    const float* __restrict__ ps, const float* __restrict__ pe, const float* __restrict__ dps,
+    const float* __restrict__ dpe, float* __restrict__ dy, float* __restrict__ dcs, float* __restrict__ db1p,
+    float* __restrict__ dw2p, float* __restrict__ db2p, float* __restrict__ dgate, int B, int T, int Hm) {
+  extern __shared__ float lds[];                 // [2][T] dl + [kWaves] scratch + [kWaves][3][J] reduce
+  const int J = 2 * Hm;
+  float* dls = lds; float* dle = lds + T; float* scratch = lds + 2 * T; float* red = scratch + 2 * kWaves;
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), b = blockIdx.x;
+
+  // softmax Jacobian rows: dot = <p, dp> over T
+  float d0 = 0.f, d1 = 0.f;
+  for (int t = tid; t < T; t += kThreads) {
+    d0 = fmaf(ps[(size_t)b * T + t], dps[(size_t)b * T + t], d0);
+    d1 = fmaf(pe[(size_t)b * T + t], dpe[(size_t)b * T + t], d1);
+  }
+  d0 = wave_allsum(d0); d1 = wave_allsum(d1);
+  if (lane == 0) { scratch[wv] = d0; scratch[kWaves + wv] = d1; }
+  __syncthreads();
+  d0 = 0.f; d1 = 0.f;
+#pragma unroll
+  for (int u = 0; u < kWaves; ++u) { d0 += scratch[u]; d1 += scratch[kWaves + u]; }
+  float sb0 = 0.f, sb1 = 0.f;
+  for (int t = tid; t < T; t += kThreads) {
+    const float m = mask ? (float)mask[(size_t)b * T + t] : 1.f;
+    const float a0 = ps[(size_t)b * T + t] * (dps[(size_t)b * T + t] - d0) * m;
+    const float a1 = pe[(size_t)b * T + t] * (dpe[(size_t)b * T + t] - d1) * m;
+    dls[t] = a0; dle[t] = a1; sb0 += a0; sb1 += a1;
+  }
+  sb0 = wave_allsum(sb0); sb1 = wave_allsum(sb1);
+  __syncthreads();
+  if (lane == 0) { scratch[wv] = sb0; scratch[kWaves + wv] = sb1; }
+  __syncthreads();
+  if (tid == 0) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int u = 0; u < kWaves; ++u) { s0 += scratch[u]; s1 += scratch[kWaves + u]; }
+    db2p[(size_t)b * 2] = s0; db2p[(size_t)b * 2 + 1] = s1;
+  }
+
+  float c[kMaxJ4][4], bb[kMaxJ4][4], ww[kMaxJ4][4];
+  float acs[kMaxJ4][4], ab1[kMaxJ4][4], aw2[kMaxJ4][4];
+#pragma unroll
+  for (int i = 0; i < kMaxJ4; ++i) {
+    const int j = i * 256 + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = j + q < J;
+      c[i][q] = ok ? cs[(size_t)b * J + j + q] : 0.f;
+      bb[i][q] = ok ? b1[j + q] : 0.f;
+      ww[i][q] = ok ? w2[j + q] : 0.f;
+      acs[i][q] = 0.f; ab1[i][q] = 0.f; aw2[i][q] = 0.f;
+    }
+  }
+  for (int t = wv; t < T; t += kWaves) {
+    const float g = gate ? gate[(size_t)b * T + t] : 1.f;
+    const float dl0 = dls[t], dl1 = dle[t];
+    const float* yr = y + ((size_t)b * T + t) * J;
+    float* dyr = dy + ((size_t)b * T + t) * J;
+    float dg = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxJ4; ++i) {
+      const int j = i * 256 + lane * 4;
+      if (j < J) {
+        const float4 v = *reinterpret_cast<const float4*>(yr + j);
+        const float yv[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float pre = yv[q] + c[i][q];
+          const float u = tanh_fast(fmaf(g, pre, bb[i][q]));
+          const float dl = (j + q < Hm) ? dl0 : dl1;
+          const float dz = dl * ww[i][q] * (1.f - u * u);
+          o[q] = g * dz;
+          acs[i][q] += o[q];
+          ab1[i][q] += dz;
+          aw2[i][q] = fmaf(dl, u, aw2[i][q]);
+          dg = fmaf(dz, pre, dg);
+        }
+        *reinterpret_cast<float4*>(dyr + j) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    if (dgate) {
+      dg = wave_allsum(dg);
+      if (lane == 0) dgate[(size_t)b * T + t] = dg;
+    }
+  }
+  // cross-wave sums of the three per-column accumulators
+#pragma unroll
+  for (int i = 0; i < kMaxJ4; ++i) {
+    const int j = i * 256 + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (j + q < J) {
+        red[(wv * 3 + 0) * J + j + q] = acs[i][q];
+        red[(wv * 3 + 1) * J + j + q] = ab1[i][q];
+        red[(wv * 3 + 2) * J + j + q] = aw2[i][q];
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 3 * J; idx += kThreads) {
+    const int which = idx / J, j = idx % J;
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < kWaves; ++u) s += red[(u * 3 + which) * J + j];
+    float* dst = which == 0 ? dcs : (which == 1 ? db1p : dw2p);
+    dst[(size_t)b * J + j] = s;
+  }
+}
+
+int check(const char* fn, int B, int T, int Hm, int dtype) {
+  if (dtype != TSG_F32) return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (fp32 only)", fn, dtype);
+  if (B <= 0 || T <= 0 || Hm <= 0) return set_error(TSG_E_SHAPE, "%s: non-positive dimension B=%d T=%d Hm=%d", fn, B, T, Hm);
+  if ((2 * Hm) % 4 || 2 * Hm > 256 * kMaxJ4)
+    return set_error(TSG_E_SHAPE, "%s: 2*Hm=%d must be a multiple of 4 and <= %d", fn, 2 * Hm, 256 * kMaxJ4);
+  if (T > 8192) return set_error(TSG_E_SHAPE, "%s: T=%d > 8192 not supported", fn, T);
+  return 0;
+}
+
+}  // namespace
+}  // namespace tsg
+
+using namespace tsg;
+
+extern "C" int tsg_boundary_score_fwd(const void* y, const void* cs, const void* b1, const void* w2, const void* b2,
+                                      const void* gate, const int32_t* mask, void* p_start, void* p_end,
+                                      int B, int T, int Hm, int dtype, void* stream) {
+  const char* fn = "tsg_boundary_score_fwd";
+  for (const void* p : {y, cs, b1, w2, b2, (const void*)p_start, (const void*)p_end})
+    if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+  if (!aligned16(y)) return set_error(TSG_E_ALIGN, "%s: y is not 16-byte aligned", fn);
+  int rc = check(fn, B, T, Hm, dtype);
+  if (rc) return rc;
+  const size_t lds = sizeof(float) * (2 * (size_t)T + 2 * kWaves);
+  hipLaunchKernelGGL(boundary_fwd_kernel, dim3(B), dim3(kThreads), lds, static_cast<hipStream_t>(stream),
+                     (const float*)y, (const float*)cs, (const float*)b1, (const float*)w2, (const float*)b2,
+                     (const float*)gate, mask, (float*)p_start, (float*)p_end, B, T, Hm);
+  return check_launch(fn);
+}
+
+extern "C" int tsg_boundary_score_bwd(const void* y, const void* cs, const void* b1, const void* w2, const void* gate,
+                                      const int32_t* mask, const void* p_start, const void* p_end,
+                                      const void* dp_start, const void* dp_end, void* dy, void* dcs, void* db1_part,
+                                      void* dw2_part, void* db2_part, void* dgate, int B, int T, int Hm, int dtype,
+                                      void* stream) {
+  const char* fn = "tsg_boundary_score_bwd";
+  for (const void* p : {y, cs, b1, w2, p_start, p_end, dp_start, dp_end, (const void*)dy, (const void*)dcs,
+                        (const void*)db1_part, (const void*)dw2_part, (const void*)db2_part})
+    if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+  if (!aligned16(y) || !aligned16(dy)) return set_error(TSG_E_ALIGN, "%s: y/dy not 16-byte aligned", fn);
+  int rc = check(fn, B, T, Hm, dtype);
+  if (rc) return rc;
+  const size_t lds = sizeof(float) * (2 * (size_t)T + 2 * kWaves + (size_t)kWaves * 3 * 2 * Hm);
+  if (lds > (size_t)kLdsBytes) return set_error(TSG_E_LDS, "%s: needs %zu B of LDS", fn, lds);
+  auto kern = boundary_bwd_kernel;
+  if (lds > 64 * 1024) {
+    hipError_t e = allow_lds(kern, lds);
+    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), lds, static_cast<hipStream_t>(stream), (const float*)y,
+                     (const float*)cs, (const float*)b1, (const float*)w2, (const float*)gate, mask,
+                     (const float*)p_start, (const float*)p_end, (const float*)dp_start, (const float*)dp_end,
+                     (float*)dy, (float*)dcs, (float*)db1_part, (float*)dw2_part, (float*)db2_part, (float*)dgate, B, T, Hm);
+  return check_launch(fn);
+}

@@ -56,3 +56,56 @@ def scdm_attn(a, s, w, sent, return_p: bool = False):
     """Fused SCDM additive cross-attention on projected inputs (see include/tsg_hip.h, K1)."""
     C, P = _ScdmAttn.apply(a, s, w, sent)
     return (C, P) if return_p else C
+
+
+class _BoundaryScore(torch.autograd.Function):
+    """K3: (y=[B,T,2Hm], cs=[B,2Hm], b1=[2Hm], w2=[2Hm], b2=[2], gate=[B,T]|None, mask=[B,T] int|None)
+    -> (p_start, p_end) [B,T]."""
+
+    @staticmethod
+    def forward(ctx, y, cs, b1, w2, b2, gate, mask):
+        require_device(y, cs, b1, w2, b2, gate, mask)
+        y, cs, b1, w2, b2 = _f32c(y), _f32c(cs), _f32c(b1), _f32c(w2), _f32c(b2)
+        B, T, J = y.shape
+        if J % 2 or cs.shape != (B, J) or b1.numel() != J or w2.numel() != J or b2.numel() != 2:
+            raise ValueError(f"boundary_score: shape mismatch y{tuple(y.shape)} cs{tuple(cs.shape)}")
+        gate_c = _f32c(gate) if gate is not None else None
+        mask_c = mask.to(torch.int32).contiguous() if mask is not None else None
+        ps = torch.empty(B, T, device=y.device, dtype=torch.float32)
+        pe = torch.empty_like(ps)
+        check(load().tsg_boundary_score_fwd(ptr(y), ptr(cs), ptr(b1), ptr(w2), ptr(b2),
+                                            ptr(gate_c) if gate_c is not None else None,
+                                            ptr(mask_c) if mask_c is not None else None,
+                                            ptr(ps), ptr(pe), B, T, J // 2, TSG_F32, stream_of(y)),
+              "tsg_boundary_score_fwd")
+        ctx.save_for_backward(y, cs, b1, w2, ps, pe, *( [gate_c] if gate_c is not None else []), *([mask_c] if mask_c is not None else []))
+        ctx.has_gate, ctx.has_mask = gate_c is not None, mask_c is not None
+        return ps, pe
+
+    @staticmethod
+    def backward(ctx, dps, dpe):
+        saved = list(ctx.saved_tensors)
+        y, cs, b1, w2, ps, pe = saved[:6]
+        rest = saved[6:]
+        gate = rest.pop(0) if ctx.has_gate else None
+        mask = rest.pop(0) if ctx.has_mask else None
+        B, T, J = y.shape
+        dps = _f32c(dps) if dps is not None else torch.zeros_like(ps)
+        dpe = _f32c(dpe) if dpe is not None else torch.zeros_like(pe)
+        dy = torch.empty_like(y); dcs = torch.empty_like(cs)
+        db1p = torch.empty(B, J, device=y.device, dtype=torch.float32)
+        dw2p = torch.empty_like(db1p)
+        db2p = torch.empty(B, 2, device=y.device, dtype=torch.float32)
+        dgate = torch.empty(B, T, device=y.device, dtype=torch.float32) if gate is not None else None
+        check(load().tsg_boundary_score_bwd(ptr(y), ptr(cs), ptr(b1), ptr(w2),
+                                            ptr(gate) if gate is not None else None,
+                                            ptr(mask) if mask is not None else None,
+                                            ptr(ps), ptr(pe), ptr(dps), ptr(dpe), ptr(dy), ptr(dcs), ptr(db1p),
+                                            ptr(dw2p), ptr(db2p), ptr(dgate) if dgate is not None else None,
+                                            B, T, J // 2, TSG_F32, stream_of(y)), "tsg_boundary_score_bwd")
+        return dy, dcs, db1p.sum(0), dw2p.sum(0), db2p.sum(0), dgate, None
+
+
+def boundary_score(y, cs, b1, w2, b2, gate=None, mask=None):
+    """Fused boundary head after the video-half GEMM (see include/tsg_hip.h, K3)."""
+    return _BoundaryScore.apply(y, cs, b1, w2, b2, gate, mask)
