@@ -74,6 +74,24 @@ int tsg_boundary_score_bwd(const void* y, const void* cs, const void* b1, const 
                            void* dw2_part, void* db2_part, void* dgate, int B, int T, int Hm, int dtype,
                            void* stream);
 
+/* ---- K2: multi-head dot-product attention between the wq/wk/wv projections and wo
+ * (Attention.forward networks/attention.py:45-55, MultiHead.forward / A_forward :71-97).
+ * Q [B,Tq,d_key], K [B,Tk,d_key], V [B,Tk,d_value] are split into n_heads chunks of the last axis;
+ *   A_h = (Qh Kh^T - 1e10*triu(1) if causal) / scale;  S_h = softmax(A_h);  O = cat_h(S_h Vh).
+ * `scale` is the DIVISOR: the reference passes sqrt(d_key) of the full width (attention.py:41,61).
+ * Outputs O [B,Tq,d_value], lse [B,n_heads,Tq] (kept for the backward) and, when non-NULL, the
+ * A_forward side outputs A_sum = sum_h A_h and S_sum = sum_h S_h, both [B,Tq,Tk].
+ * p_drop must be 0 (attention dropout is not implemented; seed/offset are reserved for it).
+ * Limits: head widths multiples of 4, d_value/n_heads <= 512; causal needs Tq == Tk.          */
+int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O, void* A_sum, void* S_sum, void* lse,
+                int B, int Tq, int Tk, int d_key, int d_value, int n_heads, float scale, int causal,
+                float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream);
+
+/* backward: dO [B,Tq,d_value] -> dQ, dK, dV (fully overwritten; no atomics, deterministic).    */
+int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* lse,
+                void* dQ, void* dK, void* dV, int B, int Tq, int Tk, int d_key, int d_value, int n_heads,
+                float scale, int causal, float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

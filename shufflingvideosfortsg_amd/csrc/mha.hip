@@ -1,0 +1,410 @@
+// K2 -- fused multi-head dot-product attention for gfx950, with the exact semantics of the
+// reference's MultiHead / Attention (grounding/model/networks/attention.py:39-97) between its
+// wq/wk/wv projections and wo:
+//     Qh,Kh,Vh = chunk(n_heads);  A_h = (Qh Kh^T - 1e10*triu(1) [causal]) / scale;
+//     S_h = softmax(A_h);  O = cat_h(S_h Vh);  side outputs  sum_h A_h  and  sum_h S_h (A_forward).
+// `scale` is passed in by the caller: the reference divides by sqrt(d_key) of the FULL model width,
+// not of the head -- nothing in here assumes sqrt(d_head).
+//
+// Forward: workgroup = (batch b, 32-query tile), 256 threads, heads processed one after another.
+// Per head the Q tile, a 32-key K block and the matching V block are staged in LDS in 128-channel
+// chunks (rows padded by 4 floats: the b128 reads below are conflict-free); thread (r = tid/8,
+// s = tid%8) owns query row r: scores for keys {s, s+8, s+16, s+24} of the block, then output
+// channels {4s + 32j}.  Softmax is online over key blocks (flash-style running max / sum in
+// registers, 8-lane DPP reductions); the [Tq,Tk] score matrix only exists if the caller asks for
+// the A_forward side outputs.  LSE per (b, head, query) is kept for the backward.
+//
+// Backward: workgroup = (b, head): every dK/dV/dQ element of that head is produced by exactly one
+// workgroup -- no atomics, bitwise reproducible.  For each 32-key block the dK/dV accumulators live
+// in registers while the query tiles stream through LDS; P is recomputed from LSE.
+#include "tsg_common.h"
+
+namespace tsg {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int TQ = 32;          // queries per tile
+constexpr int KB = 32;          // keys per block
+constexpr int CC = 128;         // channels per LDS chunk
+constexpr int LS = CC + 4;      // padded LDS row stride (floats)
+constexpr int PS = KB + 4;      // padded stride of the P / dS tiles
+constexpr int MAXVC = 4;        // head width of V <= MAXVC*CC = 512
+constexpr float kNegBig = -3.0e38f;
+
+// reduce over the 8 consecutive lanes that share one query row
+__device__ __forceinline__ float sum8(float v) {
+  v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v);
+  return v;
+}
+__device__ __forceinline__ float max8(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v)); v = fmaxf(v, dpp_mov<0x141>(v));
+  return v;
+}
+
+// stage rows [row0, row0+32) x channels [c0, c0+CC) of a [rows_total, ld] matrix into LDS (zero fill)
+__device__ __forceinline__ void stage_tile(float* __restrict__ dst, const float* __restrict__ src, int row0,
+                                           int rows_total, int ld, int c0, int cend) {
+  for (int idx = threadIdx.x; idx < 32 * (CC / 4); idx += kThreads) {
+    const int r = idx / (CC / 4), c = (idx % (CC / 4)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < rows_total && c0 + c < cend) v = *reinterpret_cast<const float4*>(src + (size_t)(row0 + r) * ld + c0 + c);
+    *reinterpret_cast<float4*>(dst + r * LS + c) = v;
+  }
+}
+
+// s[j] += <X[r][:], Y[sub + 8j][:]> over one staged channel chunk
+__device__ __forceinline__ void dot_rows(const float* __restrict__ Xs, const float* __restrict__ Ys, int r, int sub,
+                                         float (&s)[4]) {
+#pragma unroll 4
+  for (int c = 0; c < CC; c += 4) {
+    const float4 x = *reinterpret_cast<const float4*>(Xs + r * LS + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 y = *reinterpret_cast<const float4*>(Ys + (sub + 8 * j) * LS + c);
+      s[j] = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, s[j]))));
+    }
+  }
+}
+
+// raw dot products of the tile -> scaled, causally shifted scores a[j] for keys k0 + sub + 8j
+__device__ __forceinline__ void finish_scores(float (&a)[4], int q, int k0, int sub, int Tk, float inv_scale,
+                                              int causal) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = k0 + sub + 8 * j;
+    float v = a[j];
+    if (causal && key > q) v -= 1e10f;          // attention.py:47-51: subtracted BEFORE the division
+    v *= inv_scale;
+    a[j] = (key < Tk) ? v : kNegBig;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void mha_fwd_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    float* __restrict__ O, float* __restrict__ Asum, float* __restrict__ Ssum, float* __restrict__ LSE,
+    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int qtiles) {
+  __shared__ __align__(16) float Qs[TQ * LS];
+  __shared__ __align__(16) float Ks[KB * LS];      // K chunk, then reused for the V chunk
+  __shared__ __align__(16) float Ps[TQ * PS];
+  const int tid = threadIdx.x, r = tid >> 3, sub = tid & 7;
+  const int b = blockIdx.x / qtiles, q0 = (blockIdx.x % qtiles) * TQ;
+  const int q = q0 + r;
+  const int dh = dk / H, dvh = dv / H;
+  const float* Qb = Q + (size_t)b * Tq * dk;
+  const float* Kb = K + (size_t)b * Tk * dk;
+  const float* Vb = V + (size_t)b * Tk * dv;
+  const int vchunks = (dvh + CC - 1) / CC;
+
+  for (int hd = 0; hd < H; ++hd) {
+    float m_run = kNegBig, l_run = 0.f;
+    float4 o[MAXVC][4];
+#pragma unroll
+    for (int vc = 0; vc < MAXVC; ++vc)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[vc][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int pass = 0; pass < (Ssum ? 2 : 1); ++pass) {
+      // pass 0: online softmax + PV.  pass 1 (only for the A_forward side output): the final
+      // probabilities exp(a - lse) need the complete row sum, so the scores are recomputed.
+      const float lse = (pass == 1) ? m_run + __logf(l_run) : 0.f;
+      for (int k0 = 0; k0 < Tk; k0 += KB) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < dh; c0 += CC) {
+          __syncthreads();
+          stage_tile(Qs, Qb + hd * dh, q0, Tq, dk, c0, dh);
+          stage_tile(Ks, Kb + hd * dh, k0, Tk, dk, c0, dh);
+          __syncthreads();
+          dot_rows(Qs, Ks, r, sub, a);
+        }
+        finish_scores(a, q, k0, sub, Tk, inv_scale, causal);
+        if (pass == 1) {
+          if (q < Tq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int key = k0 + sub + 8 * j;
+              if (key < Tk) Ssum[((size_t)b * Tq + q) * Tk + key] += __expf(a[j] - lse);
+            }
+          }
+          continue;
+        }
+        if (Asum && q < Tq) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int key = k0 + sub + 8 * j;
+            if (key < Tk) Asum[((size_t)b * Tq + q) * Tk + key] += a[j];
+          }
+        }
+        const float m_new = fmaxf(m_run, max8(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]))));
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p = (a[j] > kNegBig) ? __expf(a[j] - m_new) : 0.f;
+          Ps[r * PS + sub + 8 * j] = p;
+          psum += p;
+        }
+        l_run = l_run * alpha + sum8(psum);
+        m_run = m_new;
+#pragma unroll
+        for (int vc = 0; vc < MAXVC; ++vc)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[vc][j].x *= alpha; o[vc][j].y *= alpha; o[vc][j].z *= alpha; o[vc][j].w *= alpha;
+          }
+#pragma unroll
+        for (int vc = 0; vc < MAXVC; ++vc) {
+          if (vc < vchunks) {
+            __syncthreads();
+            stage_tile(Ks, Vb + hd * dvh, k0, Tk, dv, vc * CC, dvh);
+            __syncthreads();
+#pragma unroll 2
+            for (int n4 = 0; n4 < KB; n4 += 4) {
+              const float4 p4 = *reinterpret_cast<const float4*>(Ps + r * PS + n4);
+              const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const float4 v = *reinterpret_cast<const float4*>(Ks + (n4 + u) * LS + sub * 4 + 32 * j);
+                  o[vc][j].x = fmaf(pp[u], v.x, o[vc][j].x); o[vc][j].y = fmaf(pp[u], v.y, o[vc][j].y);
+                  o[vc][j].z = fmaf(pp[u], v.z, o[vc][j].z); o[vc][j].w = fmaf(pp[u], v.w, o[vc][j].w);
+                }
+            }
+          }
+        }
+      }
+    }
+    if (q < Tq) {
+      const float inv = 1.f / l_run;
+#pragma unroll
+      for (int vc = 0; vc < MAXVC; ++vc)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = vc * CC + sub * 4 + 32 * j;
+          if (vc < vchunks && c < dvh)
+            *reinterpret_cast<float4*>(O + ((size_t)b * Tq + q) * dv + hd * dvh + c) =
+                make_float4(o[vc][j].x * inv, o[vc][j].y * inv, o[vc][j].z * inv, o[vc][j].w * inv);
+        }
+      if (sub == 0) LSE[((size_t)b * H + hd) * Tq + q] = m_run + __logf(l_run);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: workgroup = (b, head).
+//   D[q]    = <dO[q,:], O[q,:]> (head channels)          P = exp(a - LSE)
+//   dV[n,:] = sum_q P[q,n] dO[q,:]       dP[q,n] = <dO[q,:], V[n,:]>       dS = P (dP - D) / scale
+//   dK[n,:] = sum_q dS[q,n] Q[q,:]       dQ[q,:] = sum_n dS[q,n] K[n,:]
+// (the causal shift is a constant, so it only enters through P.)
+// Key blocks outermost: dK/dV of the block accumulate in registers (thread (n = tid/8, s) owns
+// channels {4s + 32j} of key n) across the query tiles; dQ is accumulated in global memory by the
+// same thread across key blocks.  Head widths up to 128 per chunk pass; wider heads loop chunks.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void mha_bwd_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ LSE,
+    float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
+    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal) {
+  __shared__ __align__(16) float Xs[TQ * LS];      // Q or dO tile chunk
+  __shared__ __align__(16) float Ys[KB * LS];      // K or V block chunk
+  __shared__ __align__(16) float Ps[TQ * PS];      // P tile   [q][n]
+  __shared__ __align__(16) float Ss[TQ * PS];      // dS tile  [q][n]
+  __shared__ float Dq[TQ];
+  const int tid = threadIdx.x, r = tid >> 3, sub = tid & 7;
+  const int b = blockIdx.x / H, hd = blockIdx.x % H;
+  const int dh = dk / H, dvh = dv / H;
+  const float* Qb = Q + (size_t)b * Tq * dk + hd * dh;
+  const float* Kb = K + (size_t)b * Tk * dk + hd * dh;
+  const float* Vb = V + (size_t)b * Tk * dv + hd * dvh;
+  const float* Ob = O + (size_t)b * Tq * dv + hd * dvh;
+  const float* dOb = dO + (size_t)b * Tq * dv + hd * dvh;
+  float* dQb = dQ + (size_t)b * Tq * dk + hd * dh;
+  float* dKb = dK + (size_t)b * Tk * dk + hd * dh;
+  float* dVb = dV + (size_t)b * Tk * dv + hd * dvh;
+  const float* lse = LSE + ((size_t)b * H + hd) * Tq;
+  const int kchunks = (dh + CC - 1) / CC, vchunks = (dvh + CC - 1) / CC;
+
+  for (int k0 = 0; k0 < Tk; k0 += KB) {
+    // channel chunks of the dK / dV accumulators are handled one at a time (registers), which
+    // re-runs the score computation per chunk; heads are <= 128 wide in every config of interest.
+    const int nchunks = kchunks > vchunks ? kchunks : vchunks;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      float4 dk_acc[4], dv_acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dk_acc[j] = make_float4(0.f, 0.f, 0.f, 0.f); dv_acc[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+      for (int q0 = 0; q0 < Tq; q0 += TQ) {
+        const int q = q0 + r;
+        // ---- scores a[q][n] and dP[q][n] for the tile (thread (r,sub): keys sub+8j) ----
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f}, dpart = 0.f;
+        for (int c0 = 0; c0 < dh; c0 += CC) {
+          __syncthreads();
+          stage_tile(Xs, Qb, q0, Tq, dk, c0, dh);
+          stage_tile(Ys, Kb, k0, Tk, dk, c0, dh);
+          __syncthreads();
+          dot_rows(Xs, Ys, r, sub, a);
+        }
+        for (int c0 = 0; c0 < dvh; c0 += CC) {
+          __syncthreads();
+          stage_tile(Xs, dOb, q0, Tq, dv, c0, dvh);
+          stage_tile(Ys, Vb, k0, Tk, dv, c0, dvh);
+          __syncthreads();
+          dot_rows(Xs, Ys, r, sub, dp);
+          // D[q] partial: this thread's 1/8 of the chunk's channels
+          if (q < Tq) {
+            for (int c = sub * 4; c < CC && c0 + c < dvh; c += 32) {
+              const float4 g = *reinterpret_cast<const float4*>(Xs + r * LS + c);
+              const float4 ov = *reinterpret_cast<const float4*>(Ob + (size_t)q * dv + c0 + c);
+              dpart = fmaf(g.x, ov.x, fmaf(g.y, ov.y, fmaf(g.z, ov.z, fmaf(g.w, ov.w, dpart))));
+            }
+          }
+        }
+        const float Drow = sum8(dpart);
+        finish_scores(a, q, k0, sub, Tk, inv_scale, causal);
+        const float l = (q < Tq) ? lse[q] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p = (a[j] > kNegBig && q < Tq) ? __expf(a[j] - l) : 0.f;
+          Ps[r * PS + sub + 8 * j] = p;
+          Ss[r * PS + sub + 8 * j] = p * (dp[j] - Drow) * inv_scale;
+        }
+        __syncthreads();
+
+        // ---- dQ[q, chunk ch] += sum_n dS[q][n] K[n][chunk]  (thread (r,sub): channels 4sub+32j) ----
+        if (ch < kchunks) {
+          __syncthreads();
+          stage_tile(Ys, Kb, k0, Tk, dk, ch * CC, dh);
+          __syncthreads();
+          float4 dq[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int n4 = 0; n4 < KB; n4 += 4) {
+            const float4 s4 = *reinterpret_cast<const float4*>(Ss + r * PS + n4);
+            const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float4 kv = *reinterpret_cast<const float4*>(Ys + (n4 + u) * LS + sub * 4 + 32 * j);
+                dq[j].x = fmaf(ss[u], kv.x, dq[j].x); dq[j].y = fmaf(ss[u], kv.y, dq[j].y);
+                dq[j].z = fmaf(ss[u], kv.z, dq[j].z); dq[j].w = fmaf(ss[u], kv.w, dq[j].w);
+              }
+          }
+          if (q < Tq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int c = ch * CC + sub * 4 + 32 * j;
+              if (c < dh) {
+                float4* dst = reinterpret_cast<float4*>(dQb + (size_t)q * dk + c);
+                float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 > 0) cur = *dst;                    // same thread wrote it in the previous key block
+                *dst = make_float4(cur.x + dq[j].x, cur.y + dq[j].y, cur.z + dq[j].z, cur.w + dq[j].w);
+              }
+            }
+          }
+        }
+
+        // ---- dK[n, chunk] += sum_q dS[q][n] Q[q][chunk];  dV[n, chunk] += sum_q P[q][n] dO[q][chunk]
+        //      thread (n = r, sub): channels 4sub+32j of key k0+n.  The tiles are read column-wise:
+        //      Ss[q*PS + n] -- 8 lanes share n, rows differ by PS=36 floats: conflict-free. ----
+        if (ch < kchunks) {
+          __syncthreads();
+          stage_tile(Xs, Qb, q0, Tq, dk, ch * CC, dh);
+          __syncthreads();
+          for (int qq = 0; qq < TQ; ++qq) {
+            const float sv = Ss[qq * PS + r];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float4 x = *reinterpret_cast<const float4*>(Xs + qq * LS + sub * 4 + 32 * j);
+              dk_acc[j].x = fmaf(sv, x.x, dk_acc[j].x); dk_acc[j].y = fmaf(sv, x.y, dk_acc[j].y);
+              dk_acc[j].z = fmaf(sv, x.z, dk_acc[j].z); dk_acc[j].w = fmaf(sv, x.w, dk_acc[j].w);
+            }
+          }
+        }
+        if (ch < vchunks) {
+          __syncthreads();
+          stage_tile(Xs, dOb, q0, Tq, dv, ch * CC, dvh);
+          __syncthreads();
+          for (int qq = 0; qq < TQ; ++qq) {
+            const float pv = Ps[qq * PS + r];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float4 x = *reinterpret_cast<const float4*>(Xs + qq * LS + sub * 4 + 32 * j);
+              dv_acc[j].x = fmaf(pv, x.x, dv_acc[j].x); dv_acc[j].y = fmaf(pv, x.y, dv_acc[j].y);
+              dv_acc[j].z = fmaf(pv, x.z, dv_acc[j].z); dv_acc[j].w = fmaf(pv, x.w, dv_acc[j].w);
+            }
+          }
+        }
+      }
+      const int key = k0 + r;
+      if (key < Tk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = ch * CC + sub * 4 + 32 * j;
+          if (ch < kchunks && c < dh) *reinterpret_cast<float4*>(dKb + (size_t)key * dk + c) = dk_acc[j];
+          if (ch < vchunks && c < dvh) *reinterpret_cast<float4*>(dVb + (size_t)key * dv + c) = dv_acc[j];
+        }
+      }
+    }
+  }
+  (void)Dq;
+}
+
+int check(const char* fn, int B, int Tq, int Tk, int dk, int dv, int H, int dtype) {
+  if (dtype != TSG_F32) return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (fp32 only)", fn, dtype);
+  if (B <= 0 || Tq <= 0 || Tk <= 0 || dk <= 0 || dv <= 0 || H <= 0)
+    return set_error(TSG_E_SHAPE, "%s: non-positive dimension B=%d Tq=%d Tk=%d dk=%d dv=%d heads=%d", fn, B, Tq, Tk, dk, dv, H);
+  if (dk % H || dv % H) return set_error(TSG_E_SHAPE, "%s: d_key=%d / d_value=%d not divisible by n_heads=%d", fn, dk, dv, H);
+  if ((dk / H) % 4 || (dv / H) % 4)
+    return set_error(TSG_E_ALIGN, "%s: head widths %d / %d must be multiples of 4", fn, dk / H, dv / H);
+  if (dv / H > MAXVC * CC) return set_error(TSG_E_SHAPE, "%s: value head width %d > %d not supported", fn, dv / H, MAXVC * CC);
+  return 0;
+}
+
+}  // namespace
+}  // namespace tsg
+
+using namespace tsg;
+
+extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O, void* A_sum, void* S_sum, void* lse,
+                           int B, int Tq, int Tk, int d_key, int d_value, int n_heads, float scale, int causal,
+                           float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream) {
+  const char* fn = "tsg_mha_fwd";
+  for (const void* p : {Q, K, V, (const void*)O, (const void*)lse}) {
+    if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+    if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
+  }
+  int rc = check(fn, B, Tq, Tk, d_key, d_value, n_heads, dtype);
+  if (rc) return rc;
+  if (p_drop != 0.f) return set_error(TSG_E_SHAPE, "%s: attention dropout p=%g not supported (eval / p=0 only)", fn, p_drop);
+  if (!(scale > 0.f)) return set_error(TSG_E_SHAPE, "%s: scale must be positive", fn);
+  (void)seed; (void)offset;
+  auto st = static_cast<hipStream_t>(stream);
+  const size_t map_bytes = sizeof(float) * (size_t)B * Tq * Tk;
+  if (A_sum) { hipError_t e = hipMemsetAsync(A_sum, 0, map_bytes, st); if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e)); }
+  if (S_sum) { hipError_t e = hipMemsetAsync(S_sum, 0, map_bytes, st); if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e)); }
+  const int qtiles = cdiv(Tq, TQ);
+  hipLaunchKernelGGL(mha_fwd_kernel, dim3(B * qtiles), dim3(kThreads), 0, st, (const float*)Q, (const float*)K,
+                     (const float*)V, (float*)O, (float*)A_sum, (float*)S_sum, (float*)lse, B, Tq, Tk, d_key, d_value,
+                     n_heads, 1.f / scale, causal, qtiles);
+  return check_launch(fn);
+}
+
+extern "C" int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* lse,
+                           void* dQ, void* dK, void* dV, int B, int Tq, int Tk, int d_key, int d_value, int n_heads,
+                           float scale, int causal, float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream) {
+  const char* fn = "tsg_mha_bwd";
+  for (const void* p : {Q, K, V, O, dO, lse, (const void*)dQ, (const void*)dK, (const void*)dV}) {
+    if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+    if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
+  }
+  int rc = check(fn, B, Tq, Tk, d_key, d_value, n_heads, dtype);
+  if (rc) return rc;
+  if (p_drop != 0.f) return set_error(TSG_E_SHAPE, "%s: attention dropout p=%g not supported (eval / p=0 only)", fn, p_drop);
+  (void)seed; (void)offset;
+  hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * n_heads), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                     (const float*)Q, (const float*)K, (const float*)V, (const float*)O, (const float*)dO,
+                     (const float*)lse, (float*)dQ, (float*)dK, (float*)dV, B, Tq, Tk, d_key, d_value, n_heads,
+                     1.f / scale, causal);
+  return check_launch(fn);
+}

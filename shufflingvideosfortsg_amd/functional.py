@@ -109,3 +109,52 @@ class _BoundaryScore(torch.autograd.Function):
 def boundary_score(y, cs, b1, w2, b2, gate=None, mask=None):
     """Fused boundary head after the video-half GEMM (see include/tsg_hip.h, K3)."""
     return _BoundaryScore.apply(y, cs, b1, w2, b2, gate, mask)
+
+
+class _MHA(torch.autograd.Function):
+    """K2: (Q=[B,Tq,dk], K=[B,Tk,dk], V=[B,Tk,dv]) -> (O=[B,Tq,dv], A_sum, S_sum) with the reference's
+    chunked heads and caller-provided scale divisor."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, n_heads, scale, causal, want_maps):
+        require_device(Q, K, V)
+        Q, K, V = _f32c(Q), _f32c(K), _f32c(V)
+        B, Tq, dk = Q.shape
+        _, Tk, dv = V.shape
+        if K.shape != (B, Tk, dk):
+            raise ValueError(f"mha: shape mismatch Q{tuple(Q.shape)} K{tuple(K.shape)} V{tuple(V.shape)}")
+        if causal and Tq != Tk:
+            raise ValueError("mha: causal attention needs Tq == Tk (the reference subtracts a [Tk,Tk] triangle)")
+        O = torch.empty(B, Tq, dv, device=Q.device, dtype=torch.float32)
+        lse = torch.empty(B, n_heads, Tq, device=Q.device, dtype=torch.float32)
+        A = torch.empty(B, Tq, Tk, device=Q.device, dtype=torch.float32) if want_maps else None
+        S = torch.empty(B, Tq, Tk, device=Q.device, dtype=torch.float32) if want_maps else None
+        check(load().tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(A) if want_maps else None,
+                                 ptr(S) if want_maps else None, ptr(lse), B, Tq, Tk, dk, dv, int(n_heads),
+                                 float(scale), int(bool(causal)), 0.0, 0, 0, TSG_F32, stream_of(Q)), "tsg_mha_fwd")
+        ctx.save_for_backward(Q, K, V, O, lse)
+        ctx.cfg = (int(n_heads), float(scale), int(bool(causal)))
+        if want_maps:
+            ctx.mark_non_differentiable(A, S)
+            return O, A, S
+        return O, None, None
+
+    @staticmethod
+    def backward(ctx, dO, _dA, _dS):
+        Q, K, V, O, lse = ctx.saved_tensors
+        n_heads, scale, causal = ctx.cfg
+        dO = _f32c(dO)
+        B, Tq, dk = Q.shape
+        _, Tk, dv = V.shape
+        dQ = torch.empty_like(Q); dK = torch.empty_like(K); dV = torch.empty_like(V)
+        check(load().tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(dO), ptr(lse), ptr(dQ), ptr(dK), ptr(dV),
+                                 B, Tq, Tk, dk, dv, n_heads, scale, causal, 0.0, 0, 0, TSG_F32, stream_of(Q)),
+              "tsg_mha_bwd")
+        return dQ, dK, dV, None, None, None, None
+
+
+def mha(Q, K, V, n_heads, scale, causal=False, return_maps=False):
+    """Fused multi-head attention on projected inputs (see include/tsg_hip.h, K2).
+    Returns O, or (O, A_sum, S_sum) with ``return_maps``."""
+    O, A, S = _MHA.apply(Q, K, V, n_heads, scale, causal, return_maps)
+    return (O, A, S) if return_maps else O
