@@ -1,0 +1,107 @@
+"""Model construction and the train / eval step of the grounding path, with the step semantics of the
+reference drivers (grounding/train_baseline.py, train.py, test_baseline.py) but none of their CLI,
+logging or checkpoint-directory plumbing.
+
+  * ``default_params`` / ``make_settings`` reproduce the argparse defaults and the four setting dicts
+    the reference packs for its model constructors (train.py:50-91).
+  * ``baseline_step`` / ``gmd_step``: forward -> losses (train_baseline.py:120-134, train.py:142-165)
+    -> backward; the optimiser is ``Adam(lr 1e-3, weight_decay 1e-4, eps 1e-6)`` (train.py:367-384).
+  * ``evaluate``: forward under no_grad -> ``span_pred`` -> the reference's submits-JSON schema
+    (test_baseline.py:86-137), scored by ``IoU_eval.retrieval_eval``.
+"""
+from __future__ import annotations
+
+import copy
+import logging
+from typing import Dict, Iterable
+
+import torch
+
+from . import loss as L
+from .model import GMD, Baseline
+from .model.networks.attention import masked_softmax
+
+LOG = logging.getLogger("tsg")
+
+
+def default_params(**over) -> Dict:
+    p = dict(video_encoder="query_aware_encoder", video_feature_dim=1024, video_rnn_hiddendim=256,
+             video_rnn_layers=2, video_rnn_cell="lstm", mask=False, dropout=0.5, video_len=128,
+             sent_encoder="rnn", sent_rnn_hiddendim=256, sent_rnn_layers=2, sent_rnn_cell="lstm", sent_len=20,
+             crossmodal="vs", predictor="mlp", span_hidden_dim=128, mlp_hidden_dim=256,
+             m_cross="concat", m_temp="none", m_pred="mlp", m_pred_activ="relu", m_pred_hidden=1024,
+             loss_m1_lambda=1.0, loss_m2_lambda=1.0, loss_disc_lambda=1.0, lr=1e-3, weight_decay=1e-4)
+    p.update(over)
+    return p
+
+
+def make_settings(params: Dict):
+    """The four constructor dicts (train.py:50-91)."""
+    video = dict(name=params["video_encoder"], input_dim=params["video_feature_dim"],
+                 rnn_hidden_dim=params["video_rnn_hiddendim"], rnn_layers=params["video_rnn_layers"],
+                 rnn_cell=params["video_rnn_cell"], mask=params["mask"], drop_out=params["dropout"],
+                 T=params["video_len"], nblocks=2)
+    sent = dict(name=params["sent_encoder"], input_dim=300, rnn_hidden_dim=params["sent_rnn_hiddendim"],
+                rnn_layers=params["sent_rnn_layers"], rnn_cell=params["sent_rnn_cell"], drop_out=params["dropout"])
+    ground = dict(cross_name=params["crossmodal"], name=params["predictor"],
+                  lstm_hidden_dim=params["span_hidden_dim"], mlp_hidden_dim=params["mlp_hidden_dim"])
+    match = dict(cross=dict(name=params["m_cross"]),
+                 temporal=dict(name=params["m_temp"], hidden_dim=256, layers=2, dropout=params["dropout"]),
+                 predict=dict(name=params["m_pred"], activation=params["m_pred_activ"], hidden_dim=params["m_pred_hidden"]))
+    return video, sent, ground, match
+
+
+def build_model(kind: str, params: Dict, logger=LOG) -> torch.nn.Module:
+    cls = {"qave": Baseline, "baseline": Baseline, "gmd": GMD}[kind.lower()]
+    return cls(*copy.deepcopy(make_settings(params)), logger, params["dropout"])
+
+
+def make_optimizer(model, params):
+    return torch.optim.Adam(model.parameters(), lr=params["lr"], weight_decay=params["weight_decay"], eps=1e-6)
+
+
+def baseline_step(model, batch):
+    """forward + span_ground_loss of one QAVE batch (train_baseline.py:120-134) -> (loss, span_prob)."""
+    out = model(batch["video"], batch["query"], batch["video_mask"], batch["query_mask"])
+    return L.span_ground_loss(out["start"], out["end"], batch["gt"]["framestps"]), out
+
+
+def gmd_step(model, batch, params):
+    """forward + the four GMD losses (train.py:131-165) -> (loss, parts, span_prob)."""
+    gt, pgt = batch["gt"], batch["pseudo_gt"]
+    span, om, pm, od, pd = model(batch["query"], batch["query_mask"], batch["video"], batch["video_mask"],
+                                 batch["pseudo_video"], batch["video_mask"],
+                                 gt["temporal_labels"], gt["fore_masks"], gt["back_masks"],
+                                 pgt["temporal_labels"], pgt["fore_masks"], pgt["back_masks"])
+    lg = L.span_ground_loss(span["start"], span["end"], gt["framestps"])
+    l1 = params["loss_m1_lambda"] * (L.BCE_loss(om, gt["temporal_labels"], batch["video_mask"])
+                                     + L.BCE_loss(pm, pgt["temporal_labels"], batch["video_mask"]))
+    l2 = params["loss_m2_lambda"] * L.matching_KL_divergence(masked_softmax(om, gt["temporal_labels"]),
+                                                             masked_softmax(pm, pgt["temporal_labels"]),
+                                                             gt["framestps"], pgt["framestps"])
+    ld = L.temporal_order_discrimination_loss(od, pd)
+    return lg + l1 + l2 + params["loss_disc_lambda"] * ld, (lg, l1, l2, ld), span
+
+
+@torch.no_grad()
+def evaluate(model, batches: Iterable[Dict], params: Dict = None) -> Dict:
+    """-> submits dict {'version','results','external_data','params'} (test_baseline.py:86-137).
+    Each batch may carry 'sentences', 'vids', 'durations' lists; predicted 'seconds' are frame indices
+    (frame2sec is the identity for raw features, charades.py:275-279)."""
+    model.eval()
+    sub = {"version": "V0", "results": {}, "external_data": {"used": True, "details": "provided i3D feature"},
+           "params": params or {}}
+    for bi, batch in enumerate(batches):
+        fwd = model.eval_forward if isinstance(model, GMD) else model
+        out = fwd(batch["video"], batch["query"], batch["video_mask"], batch["query_mask"])
+        pred, score = L.span_pred(out["start"], out["end"])
+        pred, score = pred.float().cpu().numpy(), score.cpu().numpy()
+        B = pred.shape[0]
+        ts = batch["gt"]["timestps"].cpu().numpy()
+        for i in range(B):
+            vid = batch.get("vids", [f"b{bi}"] * B)[i]
+            sub["results"].setdefault(vid, []).append({
+                "sentence": batch.get("sentences", [""] * B)[i], "timestamp": pred[i].tolist(),
+                "gt_timestamp": ts[i].tolist(), "score": float(score[i]),
+                "video_duration": float(batch.get("durations", [0.0] * B)[i])})
+    return sub

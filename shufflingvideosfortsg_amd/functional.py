@@ -24,7 +24,7 @@ class _ScdmAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, s, w, sent):
         require_device(a, s, w, sent)
-        a, s, w, sent = _f32c(a), _f32c(s), _f32c(w.reshape(-1)), _f32c(sent)
+        a, s, w, sent = _f32c(a), _f32c(s), _f32c(w), _f32c(sent)
         B, T, H = a.shape
         _, N, Ds = sent.shape
         if s.shape != (B, N, H) or w.numel() != H:
@@ -54,7 +54,7 @@ class _ScdmAttn(torch.autograd.Function):
 
 def scdm_attn(a, s, w, sent, return_p: bool = False):
     """Fused SCDM additive cross-attention on projected inputs (see include/tsg_hip.h, K1)."""
-    C, P = _ScdmAttn.apply(a, s, w, sent)
+    C, P = _ScdmAttn.apply(a, s, w.reshape(-1), sent)      # [1,H] Linear weight or [H]: autograd undoes the view
     return (C, P) if return_p else C
 
 

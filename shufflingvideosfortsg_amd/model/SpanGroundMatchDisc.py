@@ -1,0 +1,61 @@
+"""GMD: QAVE + cross-modal matching gate + temporal-order discriminator, trained on (original video,
+shuffled pseudo video) pairs (reference grounding/model/SpanGroundMatchDisc.py).  Same constructor
+protocol, parameter names and ``forward`` (12 tensors -> 5-tuple) / ``eval_forward`` signatures.
+The raw matching logits gate the fused feature (SpanGroundMatchDisc.py:86); here the gate goes
+straight into the boundary kernel (K3), the gated concat is never built."""
+import torch.nn as nn
+
+from .components import (CrossModalInteraction, SentenceEncoder, SpanPredictor, TemporalOrderDiscriminator,
+                         VideoEncoder)
+from .components.DistributionAlign import VideoTextSemanticMatch
+
+
+class GMD(nn.Module):
+    def __init__(self, video_seq_set, sent_seq_set, grounding_set, matching_set, logger, drop_out):
+        super().__init__()
+        self.sentence_encoder = SentenceEncoder.select_sent_encoder(sent_seq_set['name'], logger)(sent_seq_set, logger)
+        self.textual_dim = self.sentence_encoder.textual_dim
+
+        video_seq_set['query_dim'] = self.textual_dim
+        self.video_encoder = VideoEncoder.select_video_encoder(video_seq_set['name'], logger)(video_seq_set, logger)
+        self.visual_dim = self.video_encoder.visual_dim
+        self.video_if_mask = video_seq_set['mask']
+
+        self.CMI = CrossModalInteraction.select_CMI(grounding_set['cross_name'], logger)(self.visual_dim, self.textual_dim)
+        self.cross_dim = self.CMI.cross_dim()
+        self.span_predictor = SpanPredictor.SpanPredictor_Boundary(self.cross_dim, grounding_set, drop_out=drop_out, logger=logger)
+
+        matching_set['cross']['video_dim'] = self.visual_dim
+        matching_set['cross']['query_dim'] = self.textual_dim
+        self.csmm = VideoTextSemanticMatch(matching_set['cross'], matching_set['temporal'], matching_set['predict'])
+        self.matching_dim = self.csmm.temporal_dim
+
+        tod = TemporalOrderDiscriminator.select_temporal_order_discriminator('moment_pooling', logger)
+        self.tod = tod(self.visual_dim, logger)
+        self._fused_head = isinstance(self.CMI, CrossModalInteraction.VideoSentenceConcat)
+
+    def _span(self, frame_feat, word_feat, sent_embed, gate, video_mask):
+        mask = video_mask if self.video_if_mask else None
+        if self._fused_head:
+            s, e = self.span_predictor.forward_split(frame_feat, sent_embed, gate, mask)
+        else:
+            s, e = self.span_predictor(gate.unsqueeze(dim=2) * self.CMI(frame_feat, word_feat, sent_embed), v_mask=mask)
+        return {'start': s, 'end': e}
+
+    def forward(self, query_feat, query_mask, ori_video_feat, ori_video_mask, pseudo_video_feat, pseudo_video_mask,
+                ori_temporal_mask, ori_fore_mask, ori_back_mask, pseudo_temporal_mask, pseudo_fore_mask, pseudo_back_mask):
+        word_feat, sent_embed = self.sentence_encoder(query_feat)
+        ori_frame_feat = self.video_encoder(ori_video_feat, word_feat)
+        pseudo_frame_feat = self.video_encoder(pseudo_video_feat, word_feat)
+        ori_match, _ = self.csmm(ori_frame_feat, sent_embed, ori_video_mask)
+        pseudo_match, _ = self.csmm(pseudo_frame_feat, sent_embed, pseudo_video_mask)
+        span_prob = self._span(ori_frame_feat, word_feat, sent_embed, ori_match, ori_video_mask)
+        ori_disc = self.tod(ori_frame_feat, ori_temporal_mask, ori_fore_mask, ori_back_mask)
+        pseudo_disc = self.tod(pseudo_frame_feat, pseudo_temporal_mask, pseudo_fore_mask, pseudo_back_mask)
+        return span_prob, ori_match, pseudo_match, ori_disc, pseudo_disc
+
+    def eval_forward(self, video_feat, query_feat, video_mask=None, sent_mask=None):
+        word_feat, sent_embed = self.sentence_encoder(query_feat)
+        frame_feat = self.video_encoder(video_feat, word_feat)
+        match, _ = self.csmm(frame_feat, sent_embed, video_mask)
+        return self._span(frame_feat, word_feat, sent_embed, match, video_mask)

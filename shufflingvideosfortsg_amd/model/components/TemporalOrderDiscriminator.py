@@ -1,0 +1,31 @@
+"""Temporal-order discriminator (reference components/TemporalOrderDiscriminator.py), GMD only:
+masked means over the target / fore / back clip ranges -> small MLPs -> 2-way logits
+(original vs shuffled video).  Training-only auxiliary head; torch ops."""
+import torch
+import torch.nn as nn
+
+from ..networks.attention import mask_logits
+
+
+def select_temporal_order_discriminator(name, logger):
+    if name.lower() in ['moment_pooling', 'mp']:
+        return MomentPooling
+    logger.error('error temporal order discriminator name: %s (must be \'moment_pooling\')', name)
+    raise ValueError(name)
+
+
+class MomentPooling(nn.Module):
+    def __init__(self, visual_dim, logger, *args):
+        super().__init__()
+        self.foreback_context = nn.Sequential(nn.Linear(visual_dim * 2, visual_dim), nn.ReLU(inplace=True))
+        self.dropout = nn.Dropout(p=0.5)
+        self.fc_classifier_domain_video = nn.Sequential(nn.Linear(visual_dim * 3, 2))
+
+    def average_mask(self, feat, mask):
+        return torch.sum(mask_logits(feat, mask, mask_value=0.0), dim=1) / (torch.sum(mask, dim=1, keepdim=True) + 1e-6)
+
+    def forward(self, feat, target_mask, fore_mask, back_mask):
+        tgt = self.average_mask(feat, target_mask)
+        fore = self.foreback_context(torch.cat((self.average_mask(feat, fore_mask), tgt), -1))
+        back = self.foreback_context(torch.cat((tgt, self.average_mask(feat, back_mask)), -1))
+        return self.fc_classifier_domain_video(self.dropout(torch.cat((tgt, fore, back), -1)))

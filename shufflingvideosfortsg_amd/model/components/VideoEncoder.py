@@ -1,0 +1,86 @@
+"""Query-aware video encoder (QAVE), reference components/VideoEncoder.py.
+
+``rnn_recalibration_layer``: BiLSTM -> SCDM cross-attention (fused HIP kernel K1) -> channel gate
+``rnn_out * sigmoid(sent_linear(C))``.  ``QueryAwareEncoder``: two chained blocks sharing the word
+features, then LayerNorm.  Parameter names match the reference (``blocks.{i}.attention.W_s.weight`` ...).
+"""
+import torch
+import torch.nn as nn
+
+from ..networks.RNN import BiLSTM
+from ..networks.attention import SCDM_Attention
+
+
+def select_video_encoder(name, logger):
+    name = name.lower()
+    if name in ['rnn', 'r']:
+        return RNNEncoder
+    if name in ['query_aware_encoder', 'qae', 'qave']:
+        return QueryAwareEncoder
+    logger.error('error video encoder name: %s (must be \'rnn\' or \'qae\')', name)
+    raise ValueError(name)
+
+
+class RNNEncoder(nn.Module):
+    """Plain BiLSTM + LayerNorm alternative (no query information)."""
+
+    def __init__(self, video_seq_set, logger, *args):
+        super().__init__()
+        hidden_dim = video_seq_set['rnn_hidden_dim']
+        self.rnn_cell = BiLSTM(video_seq_set['input_dim'], hidden_dim, video_seq_set['rnn_layers'], video_seq_set['drop_out'])
+        self.visual_dim = hidden_dim * 2
+        self.video_layernorm = nn.LayerNorm(hidden_dim * 2)
+
+    def forward(self, input, *args):
+        video_encoding, _, _ = self.rnn_cell(input)
+        return self.video_layernorm(video_encoding)
+
+
+class rnn_recalibration_layer(nn.Module):
+    def __init__(self, input_dim, sent_dim, hidden_dim, n_layers, ca_activ, drop_out, logger):
+        super().__init__()
+        self.ca_activ = ca_activ
+        self.rnn_cell = BiLSTM(input_dim, hidden_dim, n_layers, drop_out)
+        self.visual_dim = hidden_dim * 2
+        self.attention = SCDM_Attention(self.visual_dim, sent_dim)
+        self.sent_linear = nn.Linear(sent_dim, self.visual_dim)
+
+    def forward(self, video_feat, word_feat):
+        rnn_output, _, _ = self.rnn_cell(video_feat)
+        C = self.attention(rnn_output, word_feat)
+        channel_attn = self.sent_linear(C)
+        if self.ca_activ in ['sigmoid']:
+            channel_attn = torch.sigmoid(channel_attn)
+        elif self.ca_activ in ['relu']:
+            channel_attn = torch.relu(channel_attn)
+        elif self.ca_activ in ['tanh']:
+            channel_attn = torch.tanh(channel_attn)
+        return rnn_output * channel_attn
+
+
+class QueryAwareEncoder(nn.Module):
+    def __init__(self, video_seq_set, logger, *args):
+        super().__init__()
+        hidden_dim = video_seq_set['rnn_hidden_dim']
+        self.nblocks = video_seq_set['nblocks']
+        input_dim = video_seq_set['input_dim']
+        self.blocks = nn.ModuleList()
+        for _ in range(self.nblocks):
+            self.blocks.append(rnn_recalibration_layer(input_dim, video_seq_set['query_dim'], hidden_dim,
+                                                       video_seq_set['rnn_layers'], 'sigmoid',
+                                                       video_seq_set['drop_out'], logger))
+            input_dim = hidden_dim * 2
+        self.visual_dim = hidden_dim * 2
+        self.norm = nn.LayerNorm(self.visual_dim)
+
+    def forward(self, video_feat, query_feat, *args):
+        if not isinstance(query_feat, list):
+            queries = [query_feat] * self.nblocks
+        elif len(query_feat) < self.nblocks:
+            queries = query_feat + [query_feat[-1]] * (self.nblocks - len(query_feat))
+        else:
+            queries = query_feat
+        x = video_feat
+        for blk, q in zip(self.blocks, queries):
+            x = blk(x, q)
+        return self.norm(x)

@@ -1,0 +1,74 @@
+"""The C-ABI library: builds, loads, exports exactly what include/tsg_hip.h declares, and rejects
+bad arguments before touching a device (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from shufflingvideosfortsg_amd import _lib, build
+    build.build()                         # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "tsg_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_exports_match_header(lib):
+    from shufflingvideosfortsg_amd import _lib
+    want = declared_symbols()
+    assert want == _lib.exported_symbols(), "ctypes signature table and header disagree"
+    for name in want:
+        assert hasattr(lib, name), f"{name} declared in tsg_hip.h but not exported by libtsg_hip.so"
+    assert lib.tsg_version() == 1
+
+
+def test_argument_errors_without_gpu(lib):
+    from shufflingvideosfortsg_amd._lib import TSG_F32
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    p = (p + 15) & ~15
+    # NULL pointer
+    assert lib.tsg_scdm_attn_fwd(None, p, p, p, p, p, 1, 1, 1, 4, 4, TSG_F32, None) == -1
+    assert b"NULL" in lib.tsg_last_error()
+    # bad shapes / dtype / alignment
+    assert lib.tsg_scdm_attn_fwd(p, p, p, p, p, p, 1, 1, 33, 4, 4, TSG_F32, None) == -2      # N > 32
+    assert lib.tsg_scdm_attn_fwd(p, p, p, p, p, p, 1, 1, 1, 6, 4, TSG_F32, None) == -3       # H % 4
+    assert lib.tsg_scdm_attn_fwd(p, p, p, p, p, p, 1, 1, 1, 4, 4, 7, None) == -4             # dtype
+    assert lib.tsg_scdm_attn_fwd(p + 4, p, p, p, p, p, 1, 1, 1, 4, 4, TSG_F32, None) == -3   # misaligned
+    assert lib.tsg_mha_fwd(p, p, p, p, None, None, p, 1, 4, 4, 8, 8, 3, 1.0, 0, 0.0, 0, 0, TSG_F32, None) == -2  # 8 % 3
+    assert lib.tsg_mha_fwd(p, p, p, p, None, None, p, 1, 4, 4, 8, 8, 2, 1.0, 0, 0.5, 0, 0, TSG_F32, None) == -2  # dropout
+    assert lib.tsg_boundary_score_fwd(p, p, p, p, p, None, None, p, p, 1, 4, 3, TSG_F32, None) == -2             # 2*Hm % 4
+
+
+def test_no_cpu_fallback():
+    """Hot-path ops and modules refuse CPU tensors instead of silently computing elsewhere."""
+    from shufflingvideosfortsg_amd import functional as F
+    from shufflingvideosfortsg_amd.model.networks.attention import SCDM_Attention, MultiHead
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        F.scdm_attn(torch.randn(1, 4, 8), torch.randn(1, 3, 8), torch.randn(8), torch.randn(1, 3, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SCDM_Attention(8, 8)(torch.randn(1, 4, 8), torch.randn(1, 3, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        MultiHead(8, 8, 2, 0.0)(torch.randn(1, 4, 8), torch.randn(1, 4, 8), torch.randn(1, 4, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        F.boundary_score(torch.randn(1, 4, 8), torch.randn(1, 8), torch.randn(8), torch.randn(8), torch.randn(2))
+
+
+def test_product_does_not_import_oracle():
+    """oracle/ is test infrastructure: nothing under the package may reference it."""
+    pkg = os.path.join(ROOT, "shufflingvideosfortsg_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                assert "oracle" not in txt.replace("test oracle", ""), f"{f} mentions the oracle"

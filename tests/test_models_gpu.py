@@ -1,0 +1,232 @@
+"""Module / model parity on the GPU against golden vectors captured from the real reference
+(tests/golden, oracle/make_golden.py) and against the CPU oracle at larger shapes."""
+import logging
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tsg_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=1e-4, rtol=1e-4)          # north-star: boundary scores within 1e-4 fp32
+LOG = logging.getLogger("t")
+
+
+def _sets(in_dim, h, mlp_h, match_h, mask=False, drop=0.0):
+    video = dict(name="query_aware_encoder", input_dim=in_dim, rnn_hidden_dim=h, rnn_layers=2, rnn_cell="lstm",
+                 mask=mask, drop_out=drop, T=16, nblocks=2)
+    sent = dict(name="rnn", input_dim=300, rnn_hidden_dim=h, rnn_layers=2, rnn_cell="lstm", drop_out=drop)
+    ground = dict(cross_name="vs", name="mlp", lstm_hidden_dim=16, mlp_hidden_dim=mlp_h)
+    match = dict(cross=dict(name="concat"), temporal=dict(name="none", hidden_dim=256, layers=2, dropout=drop),
+                 predict=dict(name="mlp", activation="relu", hidden_dim=match_h))
+    return video, sent, ground, match
+
+
+def _check_grads(model, want, atol=2e-4, rtol=2e-3):
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        torch.testing.assert_close(p.grad.cpu(), want[k], atol=atol, rtol=rtol, msg=lambda m, k=k: f"grad {k}: {m}")
+
+
+def test_scdm_module_golden(golden):
+    from shufflingvideosfortsg_amd.model.networks.attention import SCDM_Attention
+    for tag, (Dv, Ds, H) in {"a": (24, 24, None), "b": (40, 24, 32), "c": (8, 8, None)}.items():
+        g = golden("scdm_" + tag)
+        m = SCDM_Attention(Dv, Ds, H)
+        m.load_state_dict(g.weights)
+        m.cuda()
+        v = g.t("video").cuda().requires_grad_(True); s = g.t("sent").cuda().requires_grad_(True)
+        C = m(v, s)
+        torch.testing.assert_close(C.cpu(), g.t("C"), **TOL)
+        C.backward(g.t("gC").cuda())
+        torch.testing.assert_close(v.grad.cpu(), g.t("gvideo"), atol=2e-4, rtol=2e-3)
+        torch.testing.assert_close(s.grad.cpu(), g.t("gsent"), atol=2e-4, rtol=2e-3)
+        _check_grads(m, g.wgrads)
+
+
+@pytest.mark.parametrize("tag", ["cross", "self", "causal", "onehead"])
+def test_multihead_module_golden(golden, tag):
+    from shufflingvideosfortsg_amd.model.networks.attention import MultiHead
+    g = golden("mha_" + tag)
+    d = g.a["q"].shape[-1]
+    m = MultiHead(d, d, int(g.a["n_heads"]), 0.0, bool(g.a["causal"]))
+    m.load_state_dict(g.weights)
+    m.cuda().eval()
+    q = g.t("q").cuda().requires_grad_(True)
+    if tag in ("self", "causal"):
+        k = v = q
+    else:
+        k = g.t("k").cuda().requires_grad_(True); v = g.t("v").cuda().requires_grad_(True)
+    out = m(q, k, v)
+    torch.testing.assert_close(out.cpu(), g.t("out"), **TOL)
+    out.backward(g.t("g").cuda())
+    torch.testing.assert_close(q.grad.cpu(), g.t("gq"), atol=2e-4, rtol=2e-3)
+    if tag not in ("self", "causal"):
+        torch.testing.assert_close(k.grad.cpu(), g.t("gk"), atol=2e-4, rtol=2e-3)
+        torch.testing.assert_close(v.grad.cpu(), g.t("gv"), atol=2e-4, rtol=2e-3)
+    _check_grads(m, g.wgrads)
+    out2 = m.A_forward(q.detach(), k.detach(), v.detach())
+    torch.testing.assert_close(out2.cpu(), g.t("out"), **TOL)
+    torch.testing.assert_close(m.A_softmax.cpu(), g.t("A_softmax"), **TOL)
+    torch.testing.assert_close(m.A.cpu(), g.t("A"), atol=1e-3, rtol=1e-5)
+
+
+def test_attention_module_golden(golden):
+    from shufflingvideosfortsg_amd.model.networks.attention import Attention
+    g = golden("attention_causal")
+    a = Attention(16, 0.0, True).cuda().eval()
+    o, A, S = a(g.t("q").cuda(), g.t("k").cuda(), g.t("v").cuda())
+    torch.testing.assert_close(o.cpu(), g.t("out"), **TOL)
+    torch.testing.assert_close(S.cpu(), g.t("S"), **TOL)
+    torch.testing.assert_close(A.cpu(), g.t("A"), atol=1e-3, rtol=1e-5)
+    a.train(); a.dropout.p = 0.5
+    with pytest.raises(RuntimeError, match="dropout"):
+        a(g.t("q").cuda(), g.t("k").cuda(), g.t("v").cuda())
+
+
+@pytest.mark.parametrize("tag", ["nomask", "mask"])
+def test_mlp_predictor_module_golden(golden, tag):
+    from shufflingvideosfortsg_amd.model.components.SpanPredictor import MLP_predictor
+    g = golden("mlp_" + tag)
+    m = MLP_predictor(40, 16)
+    m.load_state_dict(g.weights)
+    m.cuda()
+    x = g.t("x").cuda().requires_grad_(True)
+    s, e = m(x, g.t("mask").cuda() if tag == "mask" else None)
+    torch.testing.assert_close(s.cpu(), g.t("start"), **TOL)
+    torch.testing.assert_close(e.cpu(), g.t("end"), **TOL)
+    (s * g.t("gs").cuda() + e * g.t("ge").cuda()).sum().backward()
+    torch.testing.assert_close(x.grad.cpu(), g.t("gx"), atol=2e-4, rtol=2e-3)
+    _check_grads(m, g.wgrads)
+
+
+@pytest.mark.parametrize("tag", ["pe", "nope"])
+def test_self_attention_predictor_golden(golden, tag):
+    from shufflingvideosfortsg_amd.model.components.SpanPredictor import Self_Attention_predictor
+    g = golden("selfattn_pred_" + tag)
+    m = Self_Attention_predictor(16, int(g.a["n_heads"]), tag == "pe", 0.0)
+    m.load_state_dict(g.weights)
+    m.cuda().eval()
+    x = g.t("x").cuda().requires_grad_(True)
+    s, e = m(x)
+    torch.testing.assert_close(s.cpu(), g.t("start"), **TOL)
+    torch.testing.assert_close(e.cpu(), g.t("end"), **TOL)
+    (s * g.t("gs").cuda() + e * g.t("ge").cuda()).sum().backward()
+    torch.testing.assert_close(x.grad.cpu(), g.t("gx"), atol=2e-4, rtol=2e-3)
+    _check_grads(m, g.wgrads)
+
+
+def test_query_aware_encoder_golden(golden):
+    from shufflingvideosfortsg_amd.model.components.VideoEncoder import QueryAwareEncoder
+    g = golden("qave")
+    vs = _sets(20, 8, 12, 16)[0]; vs["query_dim"] = 16
+    m = QueryAwareEncoder(vs, LOG)
+    m.load_state_dict(g.weights)
+    m.cuda().train()          # MIOpen's LSTM backward needs training mode; every dropout here is p=0
+    v = g.t("video").cuda().requires_grad_(True); w = g.t("word").cuda().requires_grad_(True)
+    o = m(v, w)
+    torch.testing.assert_close(o.cpu(), g.t("out"), **TOL)
+    o.backward(g.t("g").cuda())
+    torch.testing.assert_close(v.grad.cpu(), g.t("gvideo"), atol=2e-4, rtol=2e-3)
+    torch.testing.assert_close(w.grad.cpu(), g.t("gword"), atol=2e-4, rtol=2e-3)
+    _check_grads(m, g.wgrads)
+
+
+@pytest.mark.parametrize("tag", ["nomask", "mask"])
+def test_baseline_golden(golden, tag):
+    """Full QAVE forward + span_ground_loss + backward: outputs, loss, decoded spans, every parameter
+    gradient equal to the reference's."""
+    from shufflingvideosfortsg_amd import loss as L
+    from shufflingvideosfortsg_amd.model import Baseline
+    g = golden("baseline_" + tag)
+    m = Baseline(*_sets(24, 8, 12, 16, tag == "mask"), LOG, 0.0)
+    m.load_state_dict(g.weights)
+    m.cuda().train()          # (MIOpen LSTM backward; dropout p=0)
+    out = m(g.t("video").cuda(), g.t("query").cuda(), g.t("vmask").cuda(), None)
+    torch.testing.assert_close(out["start"].cpu(), g.t("start"), **TOL)
+    torch.testing.assert_close(out["end"].cpu(), g.t("end"), **TOL)
+    loss = L.span_ground_loss(out["start"], out["end"], g.a["framestps"])
+    torch.testing.assert_close(loss.cpu(), g.t("loss"), **TOL)
+    loss.backward()
+    _check_grads(m, g.wgrads)
+    pred, score = L.span_pred(out["start"].detach(), out["end"].detach())
+    assert torch.equal(pred.cpu(), g.t("pred"))
+    torch.testing.assert_close(score.cpu(), g.t("score"), **TOL)
+
+
+def test_gmd_golden(golden):
+    """Full GMD train step (original + shuffled video, four losses) and eval_forward vs the reference."""
+    from shufflingvideosfortsg_amd import engine
+    from shufflingvideosfortsg_amd.model import GMD
+    g = golden("gmd")
+    m = GMD(*_sets(24, 8, 12, 16), LOG, 0.0)
+    m.load_state_dict(g.weights)
+    m.cuda().train()         # (MIOpen LSTM backward) with MomentPooling's fixed p=0.5 dropout switched off,
+    m.tod.dropout.p = 0.0    # as in the captured reference run (eval mode there)
+    c = lambda k: g.t(k).cuda()
+    batch = {"video": c("video"), "pseudo_video": c("pvideo"), "query": c("query"), "video_mask": c("vmask"),
+             "query_mask": None,
+             "gt": {"framestps": g.a["framestps"].tolist(), "temporal_labels": c("ot"), "fore_masks": c("of"), "back_masks": c("ob")},
+             "pseudo_gt": {"framestps": g.a["pframestps"].tolist(), "temporal_labels": c("pt"), "fore_masks": c("pf"), "back_masks": c("pb")}}
+    loss, (lg, l1, l2, ld), span = engine.gmd_step(m, batch, engine.default_params())
+    for got, key in ((span["start"], "start"), (span["end"], "end"), (lg, "lg"), (l1, "l1"), (l2, "l2"), (ld, "ld"), (loss, "loss")):
+        torch.testing.assert_close(got.detach().cpu(), g.t(key), **TOL, msg=lambda m_, key=key: f"{key}: {m_}")
+    loss.backward()
+    _check_grads(m, g.wgrads, atol=3e-4, rtol=3e-3)
+    m.eval()
+    with torch.no_grad():
+        ev = m.eval_forward(c("video"), c("query"), c("vmask"), None)
+    torch.testing.assert_close(ev["start"].cpu(), g.t("eval_start"), **TOL)
+    torch.testing.assert_close(ev["end"].cpu(), g.t("eval_end"), **TOL)
+
+
+def test_config0_plumbing(golden):
+    """BASELINE config 0: QAVE d=512, B=2, T=32, N=15, real Charades-CD sentences (GloVe rows), seeded
+    i3d stand-in, weights from the SAME seed as the reference run (default init, construction order):
+    boundary scores within 1e-4, identical decoded spans, and the eval -> submits -> scorer plumbing."""
+    from shufflingvideosfortsg_amd import IoU_eval, engine
+    g = golden("config0")
+    torch.manual_seed(0)
+    m = engine.build_model("qave", engine.default_params()).cuda().eval()
+    gen = torch.Generator().manual_seed(int(g.a["video_seed"]))
+    video = torch.randn(2, 32, 1024, generator=gen).cuda()
+    batch = {"video": video, "query": g.t("query").cuda(), "video_mask": torch.ones(2, 32, dtype=torch.int32).cuda(),
+             "query_mask": None, "gt": {"timestps": torch.tensor([[3.0, 9.0], [0.0, 31.0]])},
+             "sentences": [str(s) for s in g.a["sentences"]], "vids": ["A", "B"], "durations": [30.0, 31.0]}
+    with torch.no_grad():
+        out = m(batch["video"], batch["query"], batch["video_mask"], None)
+    torch.testing.assert_close(out["start"].cpu(), g.t("start"), **TOL)
+    torch.testing.assert_close(out["end"].cpu(), g.t("end"), **TOL)
+    sub = engine.evaluate(m, [batch])
+    got = np.array([sub["results"]["A"][0]["timestamp"], sub["results"]["B"][0]["timestamp"]])
+    np.testing.assert_array_equal(got, g.a["pred"].astype(np.float64))
+    miou, recall = IoU_eval.retrieval_eval(sub, verbose=False)
+    want = O.retrieval_eval(g.a["pred"], np.array([[3.0, 9.0], [0.0, 31.0]]))
+    assert (miou, recall) == want
+
+
+def test_full_size_properties():
+    """BASELINE full size [B=64,T=128,N=20,d=1024]: size-independent properties of K1, plus an exact
+    oracle check on two batch items."""
+    from shufflingvideosfortsg_amd import functional as F
+    B, T, N, d = 64, 128, 20, 1024
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(B, T, d, generator=g); s = torch.randn(B, N, d, generator=g)
+    w = torch.randn(d, generator=g) / d ** 0.5; sent = torch.randn(B, N, d, generator=g)
+    a[1] = a[0]; s[1] = s[0]; sent[1] = sent[0]                      # duplicated pair
+    ad, sd, wd, vd = (x.cuda().requires_grad_(True) for x in (a, s, w, sent))
+    C, P = F.scdm_attn(ad, sd, wd, vd, return_p=True)
+    assert torch.isfinite(C).all()
+    torch.testing.assert_close(P.sum(-1), torch.ones(B, T, device="cuda"), atol=1e-5, rtol=0)   # softmax rows
+    assert (C.detach() <= vd.detach().max(1, keepdim=True).values + 1e-5).all()               # convex combination
+    assert (C.detach() >= vd.detach().min(1, keepdim=True).values - 1e-5).all()
+    assert torch.equal(C[0], C[1]) and torch.equal(P[0], P[1])                                # batch independence
+    gC = torch.randn(B, T, d, generator=g).cuda()
+    g1 = torch.autograd.grad(C, (ad, sd, wd, vd), gC, retain_graph=True)
+    g2 = torch.autograd.grad(C, (ad, sd, wd, vd), 2 * gC)
+    for x, y in zip(g1, g2):                                                                 # backward is linear in dC
+        torch.testing.assert_close(2 * x, y, atol=1e-5, rtol=1e-4)
+    C0, P0 = O.scdm_core(a[:2], s[:2], w, sent[:2])
+    torch.testing.assert_close(C[:2].detach().cpu(), C0, **TOL)
+    torch.testing.assert_close(P[:2].detach().cpu(), P0, **TOL)
