@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the cross-modal matching hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+One "step" = one full training step of the grounding model over one synthetic batch of B=64
+clip-query pairs per GPU at [T_clip=128, T_word=20, d=1024] (BASELINE.json metric shape), fp32:
+forward -> losses -> backward -> gradient all-reduce (RCCL, N>1) -> Adam.  Default model = GMD, the
+shuffling framework's train step (original + shuffled video, BASELINE config 2); ``--model qave`` runs
+the QAVE baseline step.  Inputs are generated on the host and made resident in HBM before the timed
+region.  Weak scaling: per-GPU batch fixed, `value` = pairs of ALL ranks / max-over-ranks time.
+
+The one JSON line also carries
+  roofline     : the cross-attention kernel (K1 forward, tsg_scdm_attn_fwd): algorithmic bytes per
+                 launch / its mean duration measured with events on the launch stream INSIDE the timed
+                 steps, against the 8 TB/s HBM3E peak;
+  kernels      : the same for the other hot-path kernels (informational);
+  cpu_baseline : the CPU oracle (oracle/tsg_oracle.py, a port of the reference's op graph) running
+                 the same step on a bounded sample of the same workload on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from shufflingvideosfortsg_amd import data, engine, functional  # noqa: E402
+from shufflingvideosfortsg_amd.dp import FlatGradAllReduce      # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+_T0 = time.time()
+
+
+def log(msg):
+    """progress on stderr (stdout carries exactly one JSON line)"""
+    if int(os.environ.get("RANK", 0)) == 0:
+        print(f"[bench {time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def alg_bytes(kind, B, T, N, d, Hm=256, e=4):
+    """Algorithmic HBM bytes per launch (SURVEY.md 8d / DESIGN.md)."""
+    if kind == "scdm_fwd":
+        return B * ((2 * T + 2 * N) * d * e + T * N * e)
+    if kind == "scdm_bwd":
+        return B * ((3 * T + 4 * N) * d * e + T * N * e)
+    if kind == "boundary_fwd":
+        return B * (T * 2 * Hm * e + 2 * T * e)
+    if kind == "boundary_bwd":
+        return B * (2 * T * 2 * Hm * e + 4 * T * e)
+    raise KeyError(kind)
+
+
+def cpu_baseline(kind, params, T, N, sample_B):
+    """The CPU oracle on the same step, bounded sample (about 10-30 s of CPU work)."""
+    from oracle import tsg_oracle as O
+    torch.manual_seed(0)
+    model = engine.build_model(kind, params)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+
+    def step(B):
+        b = data.synthetic_batch(B, T, N, pair=(kind == "gmd"))
+        if kind == "gmd":
+            g, pg = b["gt"], b["pseudo_gt"]
+            out = O.gmd_forward(sd, b["query"], b["video"], b["video_mask"], b["pseudo_video"], b["video_mask"],
+                                g["temporal_labels"], g["fore_masks"], g["back_masks"],
+                                pg["temporal_labels"], pg["fore_masks"], pg["back_masks"])
+            loss, _ = O.gmd_losses(out, b["video_mask"], b["video_mask"], g, pg)
+        else:
+            out = O.baseline_forward(sd, b["video"], b["query"], b["video_mask"])
+            loss = O.span_ground_loss(out["start"], out["end"], b["gt"]["framestps"])
+        loss.backward()
+    # The oracle's LSTM is a Python loop of small GEMMs: more than ~16 intra-op threads only adds
+    # fork/join overhead (with all 256 host threads of the GPU box one step takes many minutes).
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    log(f"cpu baseline: oracle {kind} step on {cores} threads")
+    step(1)                                   # warm-up
+    t0 = time.time()
+    done = 0
+    while done < sample_B and time.time() - t0 < 20.0:     # bounded: at most ~30 s of CPU work
+        step(2)
+        done += 2
+    dt = time.time() - t0
+    log(f"cpu baseline: {done} pairs in {dt:.1f} s")
+    return {"value": round(done / dt, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{done // 2} {kind.upper()} train steps (fwd+losses+bwd, fp32) of 2 pairs at T={T},N={N},"
+                      f"d={2 * params['video_rnn_hiddendim']} by oracle/tsg_oracle.py on {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="gmd", choices=["gmd", "qave"])
+    ap.add_argument("--B", type=int, default=64, help="clip-query pairs per GPU")
+    ap.add_argument("--T", type=int, default=128)
+    ap.add_argument("--N", type=int, default=20)
+    ap.add_argument("--d", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=8, help="pairs in the CPU-baseline sample (0 = skip)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    params = engine.default_params(video_rnn_hiddendim=a.d // 2, sent_rnn_hiddendim=a.d // 2,
+                                   video_len=a.T, sent_len=a.N)
+    torch.manual_seed(0)
+    log(f"building {a.model} (d={a.d}) on {torch.cuda.get_device_name(local)}")
+    model = engine.build_model(a.model, params).to(dev).train()
+    dp = FlatGradAllReduce(model)
+    opt = engine.make_optimizer(model, params)
+    batch = data.synthetic_batch(a.B, a.T, a.N, seed=1234 + rank, pair=(a.model == "gmd"), device=dev)
+
+    def step():
+        dp.zero_grad()
+        if a.model == "gmd":
+            loss, _, _ = engine.gmd_step(model, batch, params)
+        else:
+            loss, _ = engine.baseline_step(model, batch)
+        loss.backward()
+        dp.finish()
+        opt.step()
+        return loss
+
+    log("batch resident; warm-up")
+    for i in range(a.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    functional.kernel_timer.enable()          # event pairs around every hot-path kernel launch
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    functional.kernel_timer.disable()
+    log(f"timed {a.steps} steps in {dt:.3f} s")
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if not torch.isfinite(loss):
+        raise SystemExit("non-finite loss in the timed region")
+
+    if rank == 0:
+        kt = functional.kernel_timer.summary()          # name -> (mean us, launches)
+        H = a.d
+        kern = {}
+        for name, (us, n) in sorted(kt.items()):
+            key = {"tsg_scdm_attn_fwd": "scdm_fwd", "tsg_scdm_attn_bwd": "scdm_bwd",
+                   "tsg_boundary_score_fwd": "boundary_fwd", "tsg_boundary_score_bwd": "boundary_bwd"}.get(name)
+            entry = {"mean_us": round(us, 2), "launches": n}
+            if key:
+                by = alg_bytes(key, a.B, a.T, a.N, H)
+                entry.update(alg_bytes=by, achieved_GBs=round(by / us / 1e3, 1), frac=round(by / us / 1e3 / HBM_PEAK_GBS, 4))
+            kern[name] = entry
+        k1 = kern.get("tsg_scdm_attn_fwd", {})
+        roof = {"kernel": "scdm_fwd_kernel (tsg_scdm_attn_fwd)", "bound": "hbm",
+                "achieved": k1.get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": k1.get("frac"), "traffic": None,
+                "alg_bytes_per_launch": k1.get("alg_bytes"), "mean_launch_us": k1.get("mean_us"),
+                "launches_timed": k1.get("launches")}
+        out = {"metric": "clip-query pairs/sec fwd+bwd at B=64,T=128,d=1024", "value": round(a.B * world * a.steps / dt, 2),
+               "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{a.model}_train_step: fwd+losses+bwd+grad-allreduce+Adam, "
+                                      f"B={a.B}/GPU,T_clip={a.T},T_word={a.N},d={a.d}, i3d width 1024, GloVe 300",
+                          "global_batch": a.B * world, "parallelism": f"dp{world}", "grad_bytes": dp.grad_bytes},
+               "roofline": roof, "kernels": kern,
+               "cpu_baseline": cpu_baseline(a.model, params, a.T, a.N, a.cpu_sample) if (a.cpu_sample > 0 and world == 1) else None}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

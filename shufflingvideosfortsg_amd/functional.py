@@ -12,6 +12,49 @@ from . import _lib
 from ._lib import TSG_F32, check, load, ptr, require_device, stream_of
 
 
+class _KernelTimer:
+    """Optional per-launch timing of the C-ABI calls: an event pair on the launch stream around each
+    call (bench.py reads the means).  Disabled by default: no events, no overhead."""
+
+    def __init__(self):
+        self.on = False
+        self.records = []
+
+    def enable(self):
+        self.on, self.records = True, []
+
+    def disable(self):
+        self.on = False
+
+    def summary(self):
+        """name -> (mean microseconds, launches); synchronises on the recorded events."""
+        acc = {}
+        for name, e0, e1 in self.records:
+            e1.synchronize()
+            tot, n = acc.get(name, (0.0, 0))
+            acc[name] = (tot + e0.elapsed_time(e1) * 1e3, n + 1)
+        return {k: (tot / n, n) for k, (tot, n) in acc.items()}
+
+
+kernel_timer = _KernelTimer()
+
+
+def _call(name: str, like: torch.Tensor, *args) -> None:
+    """Invoke one C-ABI entry point on ``like``'s current stream and raise on a non-zero return."""
+    fn = getattr(load(), name)
+    st = stream_of(like)
+    if kernel_timer.on:
+        stream = torch.cuda.current_stream(like.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        rc = fn(*args, st)
+        e1.record(stream)
+        kernel_timer.records.append((name, e0, e1))
+    else:
+        rc = fn(*args, st)
+    check(rc, name)
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise TypeError(f"fp32 tensor expected, got {t.dtype}")
@@ -31,8 +74,8 @@ class _ScdmAttn(torch.autograd.Function):
             raise ValueError(f"scdm_attn: shape mismatch a{tuple(a.shape)} s{tuple(s.shape)} w{tuple(w.shape)} sent{tuple(sent.shape)}")
         C = torch.empty(B, T, Ds, device=a.device, dtype=torch.float32)
         P = torch.empty(B, T, N, device=a.device, dtype=torch.float32)
-        check(load().tsg_scdm_attn_fwd(ptr(a), ptr(s), ptr(w), ptr(sent), ptr(C), ptr(P),
-                                       B, T, N, H, Ds, TSG_F32, stream_of(a)), "tsg_scdm_attn_fwd")
+        _call("tsg_scdm_attn_fwd", a, ptr(a), ptr(s), ptr(w), ptr(sent), ptr(C), ptr(P),
+                                       B, T, N, H, Ds, TSG_F32)
         ctx.save_for_backward(a, s, w, sent, P)
         ctx.mark_non_differentiable(P)
         return C, P
@@ -46,9 +89,8 @@ class _ScdmAttn(torch.autograd.Function):
         da = torch.empty_like(a); ds = torch.empty_like(s)
         dw = torch.empty_like(w); dsent = torch.empty_like(sent)
         de = torch.empty(B, T, N, device=a.device, dtype=torch.float32)
-        check(load().tsg_scdm_attn_bwd(ptr(a), ptr(s), ptr(w), ptr(sent), ptr(P), ptr(dC), ptr(da), ptr(ds),
-                                       ptr(dw), ptr(dsent), ptr(de), B, T, N, H, Ds, TSG_F32, stream_of(a)),
-              "tsg_scdm_attn_bwd")
+        _call("tsg_scdm_attn_bwd", a, ptr(a), ptr(s), ptr(w), ptr(sent), ptr(P), ptr(dC), ptr(da), ptr(ds),
+                                       ptr(dw), ptr(dsent), ptr(de), B, T, N, H, Ds, TSG_F32)
         return da, ds, dw, dsent
 
 
@@ -73,11 +115,10 @@ class _BoundaryScore(torch.autograd.Function):
         mask_c = mask.to(torch.int32).contiguous() if mask is not None else None
         ps = torch.empty(B, T, device=y.device, dtype=torch.float32)
         pe = torch.empty_like(ps)
-        check(load().tsg_boundary_score_fwd(ptr(y), ptr(cs), ptr(b1), ptr(w2), ptr(b2),
+        _call("tsg_boundary_score_fwd", y, ptr(y), ptr(cs), ptr(b1), ptr(w2), ptr(b2),
                                             ptr(gate_c) if gate_c is not None else None,
                                             ptr(mask_c) if mask_c is not None else None,
-                                            ptr(ps), ptr(pe), B, T, J // 2, TSG_F32, stream_of(y)),
-              "tsg_boundary_score_fwd")
+                                            ptr(ps), ptr(pe), B, T, J // 2, TSG_F32)
         ctx.save_for_backward(y, cs, b1, w2, ps, pe, *( [gate_c] if gate_c is not None else []), *([mask_c] if mask_c is not None else []))
         ctx.has_gate, ctx.has_mask = gate_c is not None, mask_c is not None
         return ps, pe
@@ -97,12 +138,12 @@ class _BoundaryScore(torch.autograd.Function):
         dw2p = torch.empty_like(db1p)
         db2p = torch.empty(B, 2, device=y.device, dtype=torch.float32)
         dgate = torch.empty(B, T, device=y.device, dtype=torch.float32) if gate is not None else None
-        check(load().tsg_boundary_score_bwd(ptr(y), ptr(cs), ptr(b1), ptr(w2),
+        _call("tsg_boundary_score_bwd", y, ptr(y), ptr(cs), ptr(b1), ptr(w2),
                                             ptr(gate) if gate is not None else None,
                                             ptr(mask) if mask is not None else None,
                                             ptr(ps), ptr(pe), ptr(dps), ptr(dpe), ptr(dy), ptr(dcs), ptr(db1p),
                                             ptr(dw2p), ptr(db2p), ptr(dgate) if dgate is not None else None,
-                                            B, T, J // 2, TSG_F32, stream_of(y)), "tsg_boundary_score_bwd")
+                                            B, T, J // 2, TSG_F32)
         return dy, dcs, db1p.sum(0), dw2p.sum(0), db2p.sum(0), dgate, None
 
 
@@ -129,9 +170,9 @@ class _MHA(torch.autograd.Function):
         lse = torch.empty(B, n_heads, Tq, device=Q.device, dtype=torch.float32)
         A = torch.empty(B, Tq, Tk, device=Q.device, dtype=torch.float32) if want_maps else None
         S = torch.empty(B, Tq, Tk, device=Q.device, dtype=torch.float32) if want_maps else None
-        check(load().tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(A) if want_maps else None,
+        _call("tsg_mha_fwd", Q, ptr(Q), ptr(K), ptr(V), ptr(O), ptr(A) if want_maps else None,
                                  ptr(S) if want_maps else None, ptr(lse), B, Tq, Tk, dk, dv, int(n_heads),
-                                 float(scale), int(bool(causal)), 0.0, 0, 0, TSG_F32, stream_of(Q)), "tsg_mha_fwd")
+                                 float(scale), int(bool(causal)), 0.0, 0, 0, TSG_F32)
         ctx.save_for_backward(Q, K, V, O, lse)
         ctx.cfg = (int(n_heads), float(scale), int(bool(causal)))
         if want_maps:
@@ -147,9 +188,8 @@ class _MHA(torch.autograd.Function):
         B, Tq, dk = Q.shape
         _, Tk, dv = V.shape
         dQ = torch.empty_like(Q); dK = torch.empty_like(K); dV = torch.empty_like(V)
-        check(load().tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(dO), ptr(lse), ptr(dQ), ptr(dK), ptr(dV),
-                                 B, Tq, Tk, dk, dv, n_heads, scale, causal, 0.0, 0, 0, TSG_F32, stream_of(Q)),
-              "tsg_mha_bwd")
+        _call("tsg_mha_bwd", Q, ptr(Q), ptr(K), ptr(V), ptr(O), ptr(dO), ptr(lse), ptr(dQ), ptr(dK), ptr(dV),
+                                 B, Tq, Tk, dk, dv, n_heads, scale, causal, 0.0, 0, 0, TSG_F32)
         return dQ, dK, dV, None, None, None, None
 
 
