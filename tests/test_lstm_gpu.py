@@ -1,0 +1,71 @@
+"""BiLSTM recurrence kernels (csrc/lstm.hip) vs the CPU oracle's explicit cell recurrence and the
+golden vectors captured from the reference's nn.LSTM."""
+import pytest
+import torch
+
+from oracle import tsg_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=1e-4, rtol=1e-4)
+
+
+def _params(I, h, layers, g):
+    p = {}
+    for k in range(layers):
+        for suf in ("", "_reverse"):
+            inp = I if k == 0 else 2 * h
+            p[f"lstm.weight_ih_l{k}{suf}"] = torch.randn(4 * h, inp, generator=g) / inp ** 0.5
+            p[f"lstm.weight_hh_l{k}{suf}"] = torch.randn(4 * h, h, generator=g) / h ** 0.5
+            p[f"lstm.bias_ih_l{k}{suf}"] = torch.randn(4 * h, generator=g) * 0.1
+            p[f"lstm.bias_hh_l{k}{suf}"] = torch.randn(4 * h, generator=g) * 0.1
+    return p
+
+
+@pytest.mark.parametrize("B,T,I,h", [
+    (3, 7, 12, 8),           # golden-like tiny
+    (2, 1, 8, 4),            # single step
+    (5, 20, 300, 256),       # sentence encoder shape (N=20 words, GloVe 300)
+    (4, 32, 1024, 256),      # video block 0, config 0
+    (130, 9, 64, 36),        # batch > one 128-row pass, h not a multiple of 16 / 64
+    (2, 128, 1024, 512),     # north-star video shape (B reduced)
+])
+def test_bilstm_parity(B, T, I, h):
+    from shufflingvideosfortsg_amd.model.networks.RNN import BiLSTM
+    g = torch.Generator().manual_seed(9)
+    p = {k: v.requires_grad_(True) for k, v in _params(I, h, 2, g).items()}
+    x = torch.randn(B, T, I, generator=g, requires_grad=True)
+    go = torch.randn(B, T, 2 * h, generator=g); gh = torch.randn(4, B, h, generator=g)
+    out0, hn0, cn0 = O.bilstm(x, p, 2)
+    ((out0 * go).sum() + (hn0 * gh).sum()).backward()
+    m = BiLSTM(I, h, 2, 0.0)
+    m.load_state_dict({k: v.detach() for k, v in p.items()})
+    m.cuda().train()
+    assert m.backend == "hip"
+    xd = x.detach().cuda().requires_grad_(True)
+    out1, hn1, cn1 = m(xd)
+    ((out1 * go.cuda()).sum() + (hn1 * gh.cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out1.detach().cpu(), out0.detach(), **TOL)
+    torch.testing.assert_close(hn1.detach().cpu(), hn0.detach(), **TOL)
+    torch.testing.assert_close(cn1.detach().cpu(), cn0.detach(), **TOL)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, atol=3e-4, rtol=2e-3)
+    for k, v in m.named_parameters():
+        torch.testing.assert_close(v.grad.cpu(), p[k].grad, atol=5e-4, rtol=3e-3, msg=lambda s, k=k: f"{k}: {s}")
+
+
+def test_bilstm_golden(golden):
+    from shufflingvideosfortsg_amd.model.networks.RNN import BiLSTM
+    g = golden("bilstm")
+    m = BiLSTM(12, 8, 2, 0.5)
+    m.load_state_dict(g.weights)
+    m.cuda().train()
+    m.lstm.dropout = 0.0               # the golden run was eval mode
+    x = g.t("x").cuda().requires_grad_(True)
+    out, hn, cn = m(x)
+    torch.testing.assert_close(out.detach().cpu(), g.t("out"), **TOL)
+    torch.testing.assert_close(hn.detach().cpu(), g.t("hn"), **TOL)
+    torch.testing.assert_close(cn.detach().cpu(), g.t("cn"), **TOL)
+    ((out * g.t("g").cuda()).sum() + (hn * g.t("gh").cuda()).sum()).backward()
+    torch.testing.assert_close(x.grad.cpu(), g.t("gx"), atol=2e-4, rtol=2e-3)
+    for k, v in m.named_parameters():
+        torch.testing.assert_close(v.grad.cpu(), g.wgrads[k], atol=2e-4, rtol=2e-3, msg=lambda s, k=k: f"{k}: {s}")
