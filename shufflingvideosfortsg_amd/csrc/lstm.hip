@@ -27,8 +27,10 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;       // 8 waves x 16 batch rows = 128 rows per pass
-constexpr int KC = 64;                          // h_{t-1} columns per LDS chunk
-constexpr int HS = KC + 4;                      // chunk row stride (floats), = 4 mod 64
+constexpr int KC = 32;                          // h_{t-1} columns per LDS chunk
+constexpr int HS = KC + 4;                      // chunk row stride (floats), = 4 mod 32: conflict-free b64 reads
+constexpr int NBUF = 6;                         // LDS ring depth
+constexpr int PF = 4;                           // chunks in flight (global -> registers) ahead of the MFMAs
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.f + fast_exp2(-x * kLog2e)); }
@@ -39,13 +41,16 @@ __device__ __forceinline__ float tanh_f(float x) {
 
 // ---------------------------------------------------------------------------------------------
 // forward step.  grid = 2 * ceil(h/4).  tt = time index of this step for direction d.
+// Latency, not bandwidth, bounds a step: everything the step needs is requested up front (W_hh
+// rows, the first PF chunks of h_{t-1}, the Gx / c_{t-1} operands of the cell update) and the K
+// loop keeps PF chunks in flight through a 6-deep LDS ring.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
     const float* __restrict__ Gx, const float* __restrict__ Whh, float* __restrict__ out,
     float* __restrict__ R, float* __restrict__ Cs, int B, int T, int h, int step, int WS) {
   extern __shared__ __align__(16) float lds[];
   float* Wl = lds;                              // [16][WS]   rows (u,g) -> W_hh[d][g*h + u0+u][:]
-  float* Hl = lds + 16 * WS;                    // [2][128][HS]
+  float* Hl = lds + 16 * WS;                    // [NBUF][128][HS]
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int uslices = (h + 3) / 4;
   const int d = blockIdx.x / uslices, u0 = (blockIdx.x % uslices) * 4;
@@ -53,66 +58,80 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
   const int tp = d == 0 ? tt - 1 : tt + 1;      // time index of h_{t-1}
   const bool first = step == 0;
   const int jb = lane & 15, ku = lane >> 4;     // batch row within the tile / unit (and k phase)
-
-  if (!first) {
-    const float* Wd = Whh + (size_t)d * 4 * h * h;
-    const int wc4 = (WS - 4) / 4;                // padded row length (multiple of 64 columns) in float4
-    for (int idx = tid; idx < 16 * wc4; idx += kThreads) {
-      const int row = idx / wc4, k = (idx % wc4) * 4;
-      const int u = row >> 2, g = row & 3;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero beyond h: the MFMA loop runs over whole chunks
-      if (u0 + u < h && k < h) v = *reinterpret_cast<const float4*>(Wd + (size_t)(g * h + u0 + u) * h + k);
-      *reinterpret_cast<float4*>(Wl + row * WS + k) = v;
-    }
-  }
+  const int nchunks = (h + KC - 1) / KC;
+  // chunk loader: 128 rows x 32 cols = 1024 float4, 2 per thread
+  const int lr = tid >> 3, lc = (tid & 7) * 4;  // row / column of this thread's float4 (second one: row + 64)
 
   for (int b0 = 0; b0 < B; b0 += 128) {
+    const int b = b0 + wv * 16 + jb, u = u0 + ku;
+    const bool live = b < B && u < h;
+    // cell-update operands: requested now, used after the MFMAs
+    float gx[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (live) {
+      const float* g = Gx + (((size_t)b * T + tt) * 2 + d) * 4 * h + u;
+      gx[0] = g[0]; gx[1] = g[h]; gx[2] = g[2 * h]; gx[3] = g[3 * h];
+      if (!first) cprev = Cs[(((size_t)tp * 2 + d) * B + b) * h + u];
+    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (!first) {
-      const int nchunks = (h + KC - 1) / KC;
-      // chunk loader: 128 rows x 64 cols = 2048 float4, 4 per thread
-      float4 stage[4];
-      auto gload = [&](int c) {
+      float4 stage[PF][2];
+      auto gload = [&](int c, float4 (&st)[2]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int idx = tid + q * kThreads;
-          const int r = idx >> 4, k = c * KC + (idx & 15) * 4;
-          stage[q] = (b0 + r < B && k < h) ? *reinterpret_cast<const float4*>(out + ((size_t)(b0 + r) * T + tp) * 2 * h + d * h + k)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 2; ++q) {
+          const int r = lr + 64 * q, k = c * KC + lc;
+          st[q] = (b0 + r < B && k < h) ? *reinterpret_cast<const float4*>(out + ((size_t)(b0 + r) * T + tp) * 2 * h + d * h + k)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       };
-      auto lstore = [&](int buf) {
+      auto lstore = [&](int buf, const float4 (&st)[2]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int idx = tid + q * kThreads;
-          *reinterpret_cast<float4*>(Hl + (buf * 128 + (idx >> 4)) * HS + (idx & 15) * 4) = stage[q];
-        }
+        for (int q = 0; q < 2; ++q)
+          *reinterpret_cast<float4*>(Hl + (buf * 128 + lr + 64 * q) * HS + lc) = st[q];
       };
-      gload(0);
-      lstore(0);
+#pragma unroll
+      for (int i = 0; i < PF; ++i)
+        if (i < nchunks) gload(i, stage[i]);
+      if (b0 == 0) {                              // W_hh rows of this workgroup's 4 units (once per launch)
+        const float* Wd = Whh + (size_t)d * 4 * h * h;
+        const int wc4 = (WS - 4) / 4;             // padded row length (multiple of 64 columns) in float4
+        for (int idx = tid; idx < 16 * wc4; idx += kThreads) {
+          const int row = idx / wc4, k = (idx % wc4) * 4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero beyond h: the MFMA loop runs over whole chunks
+          if (u0 + (row >> 2) < h && k < h) v = *reinterpret_cast<const float4*>(Wd + (size_t)((row & 3) * h + u0 + (row >> 2)) * h + k);
+          *reinterpret_cast<float4*>(Wl + row * WS + k) = v;
+        }
+      }
+      lstore(0, stage[0]);
       __syncthreads();
-      for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) gload(c + 1);
-        const float* hrow = Hl + ((c & 1) * 128 + wv * 16 + jb) * HS + 2 * ku;
-        const float* wrow = Wl + jb * WS + c * KC + 2 * ku;
+      // steady state: chunk c is consumed from ring slot c % NBUF; chunk c+1 is written to its slot
+      // (its data was requested PF chunks ago); chunk c+PF is requested.  Slot reuse distance NBUF >
+      // PF + 1, so one barrier per chunk suffices.
+#pragma unroll 1
+      for (int c0 = 0; c0 < nchunks; c0 += PF) {
 #pragma unroll
-        for (int j = 0; j < KC / 8; ++j) {
-          const float2 a = *reinterpret_cast<const float2*>(wrow + 8 * j);
-          const float2 b = *reinterpret_cast<const float2*>(hrow + 8 * j);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+        for (int i = 0; i < PF; ++i) {
+          const int c = c0 + i;
+          if (c < nchunks) {
+            const float* hrow = Hl + ((c % NBUF) * 128 + wv * 16 + jb) * HS + 2 * ku;
+            const float* wrow = Wl + jb * WS + c * KC + 2 * ku;
+#pragma unroll
+            for (int j = 0; j < KC / 8; ++j) {
+              const float2 a = *reinterpret_cast<const float2*>(wrow + 8 * j);
+              const float2 bv = *reinterpret_cast<const float2*>(hrow + 8 * j);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv.x, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv.y, acc, 0, 0, 0);
+            }
+            if (c + 1 < nchunks) lstore((c + 1) % NBUF, stage[(i + 1) % PF]);
+            if (c + PF < nchunks) gload(c + PF, stage[i]);
+            __syncthreads();
+          }
         }
-        if (c + 1 < nchunks) lstore((c + 1) & 1);
-        __syncthreads();
       }
     }
     // lane-local cell update for (batch b, unit u); accumulator register g = gate (i,f,g,o)
-    const int b = b0 + wv * 16 + jb, u = u0 + ku;
-    if (b < B && u < h) {
-      const float* gx = Gx + (((size_t)b * T + tt) * 2 + d) * 4 * h + u;
-      const float pi = acc[0] + gx[0], pf = acc[1] + gx[h], pg = acc[2] + gx[2 * h], po = acc[3] + gx[3 * h];
-      const float cprev = first ? 0.f : Cs[(((size_t)tp * 2 + d) * B + b) * h + u];
-      const float gi = sigmoid_f(pi), gf = sigmoid_f(pf), gg = tanh_f(pg), go = sigmoid_f(po);
+    if (live) {
+      const float gi = sigmoid_f(acc[0] + gx[0]), gf = sigmoid_f(acc[1] + gx[1]);
+      const float gg = tanh_f(acc[2] + gx[2]), go = sigmoid_f(acc[3] + gx[3]);
       const float c = fmaf(gf, cprev, gi * gg);
       const float hv = go * tanh_f(c);
       const size_t s = (((size_t)tt * 2 + d) * B + b) * h + u;
@@ -120,7 +139,6 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
       *reinterpret_cast<float4*>(R + s * 4) = make_float4(gi, gf, gg, go);
       out[((size_t)b * T + tt) * 2 * h + d * h + u] = hv;
     }
-    if (b0 + 128 < B) __syncthreads();
   }
 }
 
@@ -131,15 +149,17 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
 constexpr int kBwdThreads = 256;                // 4 waves = 2 batch tiles x 2 halves of every K chunk
 constexpr int KCB = 64;
 constexpr int HSB = KCB + 4;
+constexpr int NBUFB = 6;
+constexpr int PFB = 4;
+constexpr int kStageRows = 32 + 16;             // one ring slot: 32 rows of dG_{t+1} + 16 rows of W_hh^T
 
 __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
     const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
     const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG, float* __restrict__ dCn,
-    int B, int T, int h, int step, int WS) {
-  extern __shared__ __align__(16) float lds[];
-  float* Wl = lds;                              // [16 units][WS]: Wl[u][col] = W_hh[d][col][u0+u] = WhhT[d][u0+u][col]
-  float* Gl = lds + 16 * WS;                    // [2][32][HSB] chunk of dG_{t+1}
-  float* Xl = Gl + 2 * 32 * HSB;                // [2 tiles][64 lanes][4] partial sums of the second K half
+    int B, int T, int h, int step) {
+  // ring slot = [48][HSB]: rows 0..31 = dG_{t+1}[b0+r][chunk], rows 32..47 = WhhT[d][u0+u][chunk].
+  // Both operands stream (PFB chunks in flight); nothing is loaded wholesale up front.
+  __shared__ __align__(16) float ring[NBUFB * kStageRows * HSB];
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int tile = wv & 1, khalf = wv >> 1;
   const int uslices = (h + 15) / 16, bslices = (B + 31) / 32;
@@ -154,52 +174,79 @@ __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
   const bool last = step == 0;                  // no recurrent gradient yet
   const int jb = lane & 15, ku = lane >> 4;
   const int K = 4 * h;
+  const int b = b0 + tile * 16 + jb;            // lane: batch b, units u0 + 4*ku + r (r = accumulator register)
+  const bool has_prev = (d == 0) ? (tt > 0) : (tt < T - 1);
+
+  // cell-backward operands of this lane's 4 (b, unit) pairs: requested now, used after the MFMAs
+  float4 g4[4]; float cc[4], cpv[4], dov[4], dcv[4]; bool ok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int u = u0 + 4 * ku + r;
+    ok[r] = khalf == 0 && b < B && u < h;
+    g4[r] = make_float4(0.f, 0.f, 0.f, 0.f); cc[r] = cpv[r] = dov[r] = dcv[r] = 0.f;
+    if (ok[r]) {
+      const size_t s = (((size_t)tt * 2 + d) * B + b) * h + u;
+      const size_t cs = ((size_t)d * B + b) * h + u;
+      g4[r] = *reinterpret_cast<const float4*>(R + s * 4);
+      cc[r] = Cs[s];
+      if (has_prev) cpv[r] = Cs[(((size_t)tp * 2 + d) * B + b) * h + u];
+      dov[r] = dOut[((size_t)b * T + tt) * 2 * h + d * h + u];
+      if (last) { if (dHn) dov[r] += dHn[cs]; } else dcv[r] = dCn[cs];
+    }
+  }
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (!last) {
     const float* Wd = WhhT + (size_t)d * h * K;
-    const int wc4 = (WS - 4) / 4;
-    for (int idx = tid; idx < 16 * wc4; idx += kBwdThreads) {
-      const int u = idx / wc4, k = (idx % wc4) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (u0 + u < h && k < K) v = *reinterpret_cast<const float4*>(Wd + (size_t)(u0 + u) * K + k);
-      *reinterpret_cast<float4*>(Wl + u * WS + k) = v;
-    }
     const int nchunks = (K + KCB - 1) / KCB;
-    float4 stage[2];
-    auto gload = [&](int c) {                   // 32 rows x 64 cols = 512 float4, 2 per thread
+    // loader: 48 rows x 64 cols = 768 float4, 3 per thread: thread -> (row = tid/16 + 16q, col = (tid%16)*4)
+    const int lr = tid >> 4, lc = (tid & 15) * 4;
+    float4 stage[PFB][3];
+    auto gload = [&](int c, float4 (&st)[3]) {
+      const int k = c * KCB + lc;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const int idx = tid + q * kBwdThreads;
-        const int r = idx >> 4, k = c * KCB + (idx & 15) * 4;
-        stage[q] = (b0 + r < B && k < K) ? *reinterpret_cast<const float4*>(dG + (((size_t)(b0 + r) * T + tn) * 2 + d) * K + k)
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int r = lr + 16 * q;
+        st[q] = (b0 + r < B && k < K) ? *reinterpret_cast<const float4*>(dG + (((size_t)(b0 + r) * T + tn) * 2 + d) * K + k)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+      st[2] = (u0 + lr < h && k < K) ? *reinterpret_cast<const float4*>(Wd + (size_t)(u0 + lr) * K + k)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const float4 (&st)[3]) {
+      float* base = ring + buf * kStageRows * HSB;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int idx = tid + q * kBwdThreads;
-        *reinterpret_cast<float4*>(Gl + (buf * 32 + (idx >> 4)) * HSB + (idx & 15) * 4) = stage[q];
-      }
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<float4*>(base + (lr + 16 * q) * HSB + lc) = st[q];
     };
-    gload(0);
-    lstore(0);
+#pragma unroll
+    for (int i = 0; i < PFB; ++i)
+      if (i < nchunks) gload(i, stage[i]);
+    lstore(0, stage[0]);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-      if (c + 1 < nchunks) gload(c + 1);
-      const float* grow = Gl + ((c & 1) * 32 + tile * 16 + jb) * HSB + 2 * ku + khalf * (KCB / 2);
-      const float* wrow = Wl + jb * WS + c * KCB + 2 * ku + khalf * (KCB / 2);
+#pragma unroll 1
+    for (int c0 = 0; c0 < nchunks; c0 += PFB) {
 #pragma unroll
-      for (int j = 0; j < KCB / 16; ++j) {
-        const float2 a = *reinterpret_cast<const float2*>(wrow + 8 * j);
-        const float2 b = *reinterpret_cast<const float2*>(grow + 8 * j);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+      for (int i = 0; i < PFB; ++i) {
+        const int c = c0 + i;
+        if (c < nchunks) {
+          const float* base = ring + (c % NBUFB) * kStageRows * HSB;
+          const float* grow = base + (tile * 16 + jb) * HSB + 2 * ku + khalf * (KCB / 2);
+          const float* wrow = base + (32 + jb) * HSB + 2 * ku + khalf * (KCB / 2);
+#pragma unroll
+          for (int j = 0; j < KCB / 16; ++j) {
+            const float2 a = *reinterpret_cast<const float2*>(wrow + 8 * j);
+            const float2 bv = *reinterpret_cast<const float2*>(grow + 8 * j);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv.y, acc, 0, 0, 0);
+          }
+          if (c + 1 < nchunks) lstore((c + 1) % NBUFB, stage[(i + 1) % PFB]);
+          if (c + PFB < nchunks) gload(c + PFB, stage[i]);
+          __syncthreads();
+        }
       }
-      if (c + 1 < nchunks) lstore((c + 1) & 1);
-      __syncthreads();
     }
+    // fold the two K halves (the ring is free now)
+    float* Xl = ring;
     if (khalf == 1) *reinterpret_cast<float4*>(Xl + (tile * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     __syncthreads();
     if (khalf == 0) {
@@ -207,35 +254,22 @@ __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
       acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
     }
   }
-  // lane: batch b = b0 + tile*16 + jb, units u0 + 4*ku + r (r = accumulator register)
-  const int b = b0 + tile * 16 + jb;
   if (khalf == 0 && b < B) {
     float dgate[4][4];                           // [unit r][gate]
-    bool ok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int u = u0 + 4 * ku + r;
-      ok[r] = u < h;
 #pragma unroll
       for (int g = 0; g < 4; ++g) dgate[r][g] = 0.f;
       if (!ok[r]) continue;
-      const size_t s = (((size_t)tt * 2 + d) * B + b) * h + u;
-      const float4 g4 = *reinterpret_cast<const float4*>(R + s * 4);
-      const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
-      const float c = Cs[s];
-      const bool has_prev = (d == 0) ? (tt > 0) : (tt < T - 1);
-      const float cprev = has_prev ? Cs[(((size_t)tp * 2 + d) * B + b) * h + u] : 0.f;
-      const float tc = tanh_f(c);
-      float dh = dOut[((size_t)b * T + tt) * 2 * h + d * h + u] + acc[r];
-      const size_t cs = ((size_t)d * B + b) * h + u;
-      float dc = 0.f;
-      if (last) { if (dHn) dh += dHn[cs]; } else dc = dCn[cs];
-      dc = fmaf(dh * go, 1.f - tc * tc, dc);
+      const float gi = g4[r].x, gf = g4[r].y, gg = g4[r].z, go = g4[r].w;
+      const float tc = tanh_f(cc[r]);
+      const float dh = dov[r] + acc[r];
+      const float dc = fmaf(dh * go, 1.f - tc * tc, dcv[r]);
       dgate[r][0] = dc * gg * gi * (1.f - gi);
-      dgate[r][1] = dc * cprev * gf * (1.f - gf);
+      dgate[r][1] = dc * cpv[r] * gf * (1.f - gf);
       dgate[r][2] = dc * gi * (1.f - gg * gg);
       dgate[r][3] = dh * tc * go * (1.f - go);
-      dCn[cs] = dc * gf;
+      dCn[((size_t)d * B + b) * h + u0 + 4 * ku + r] = dc * gf;
     }
     float* dst = dG + (((size_t)b * T + tt) * 2 + d) * K + u0 + 4 * ku;
 #pragma unroll
@@ -272,7 +306,7 @@ extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R,
   int rc = lstm_check(fn, B, T, h, dtype);
   if (rc) return rc;
   const int WS = roundup(h, 64) + 4;                     // = 4 mod 64
-  const size_t lds = sizeof(float) * ((size_t)16 * WS + 2 * 128 * HS);
+  const size_t lds = sizeof(float) * ((size_t)16 * WS + (size_t)NBUF * 128 * HS);
   if (lds > (size_t)kLdsBytes) return set_error(TSG_E_LDS, "%s: h=%d needs %zu B of LDS", fn, h, lds);
   auto kern = lstm_fwd_step_kernel;
   hipError_t e = allow_lds(kern, lds);
@@ -294,16 +328,11 @@ extern "C" int tsg_lstm_bwd(const void* WhhT, const void* R, const void* Cs, con
   }
   int rc = lstm_check(fn, B, T, h, dtype);
   if (rc) return rc;
-  const int WS = roundup(4 * h, 64) + 4;
-  const size_t lds = sizeof(float) * ((size_t)16 * WS + 2 * 32 * HSB + 2 * 64 * 4);
-  if (lds > (size_t)kLdsBytes) return set_error(TSG_E_LDS, "%s: h=%d needs %zu B of LDS", fn, h, lds);
   auto kern = lstm_bwd_step_kernel;
-  hipError_t e = allow_lds(kern, lds);
-  if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
   auto st = static_cast<hipStream_t>(stream);
   const int grid = 2 * cdiv(h, 16) * cdiv(B, 32);
   for (int step = 0; step < T; ++step)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), lds, st, (const float*)WhhT, (const float*)R, (const float*)Cs,
-                       (const float*)dOut, (const float*)dHn, (float*)dG, (float*)dC_ws, B, T, h, step, WS);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), 0, st, (const float*)WhhT, (const float*)R, (const float*)Cs,
+                       (const float*)dOut, (const float*)dHn, (float*)dG, (float*)dC_ws, B, T, h, step);
   return check_launch(fn);
 }

@@ -3,6 +3,7 @@ shuffled pseudo video) pairs (reference grounding/model/SpanGroundMatchDisc.py).
 protocol, parameter names and ``forward`` (12 tensors -> 5-tuple) / ``eval_forward`` signatures.
 The raw matching logits gate the fused feature (SpanGroundMatchDisc.py:86); here the gate goes
 straight into the boundary kernel (K3), the gated concat is never built."""
+import torch
 import torch.nn as nn
 
 from .components import (CrossModalInteraction, SentenceEncoder, SpanPredictor, TemporalOrderDiscriminator,
@@ -45,8 +46,11 @@ class GMD(nn.Module):
     def forward(self, query_feat, query_mask, ori_video_feat, ori_video_mask, pseudo_video_feat, pseudo_video_mask,
                 ori_temporal_mask, ori_fore_mask, ori_back_mask, pseudo_temporal_mask, pseudo_fore_mask, pseudo_back_mask):
         word_feat, sent_embed = self.sentence_encoder(query_feat)
-        ori_frame_feat = self.video_encoder(ori_video_feat, word_feat)
-        pseudo_frame_feat = self.video_encoder(pseudo_video_feat, word_feat)
+        # the original and the shuffled video go through the shared-weight encoder as ONE batch of 2B
+        # (every op in it is per-sample): half as many sequential LSTM steps, twice the rows per launch
+        B = ori_video_feat.size(0)
+        both = self.video_encoder(torch.cat([ori_video_feat, pseudo_video_feat], 0), torch.cat([word_feat, word_feat], 0))
+        ori_frame_feat, pseudo_frame_feat = both[:B], both[B:]
         ori_match, _ = self.csmm(ori_frame_feat, sent_embed, ori_video_mask)
         pseudo_match, _ = self.csmm(pseudo_frame_feat, sent_embed, pseudo_video_mask)
         span_prob = self._span(ori_frame_feat, word_feat, sent_embed, ori_match, ori_video_mask)
