@@ -58,6 +58,19 @@ def alg_bytes(kind, B, T, N, d, Hm=256, e=4):
     raise KeyError(kind)
 
 
+def pmc_traffic(kernel, B, T, N, d):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    profiles/r1/k1_pmc_traffic.json); None when no pass exists for this shape."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1", "k1_pmc_traffic.json")) as f:
+            j = json.load(f)
+        if j["shape"] == {"B": B, "T": T, "N": N, "d": d, "dtype": "f32"}:
+            return j["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(kind, params, T, N, sample_B):
     """The CPU oracle on the same step, bounded sample (about 10-30 s of CPU work)."""
     from oracle import tsg_oracle as O
@@ -179,7 +192,7 @@ def main():
         k1 = kern.get("tsg_scdm_attn_fwd", {})
         roof = {"kernel": "scdm_fwd_kernel (tsg_scdm_attn_fwd)", "bound": "hbm",
                 "achieved": k1.get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": k1.get("frac"), "traffic": None,
+                "frac": k1.get("frac"), "traffic": pmc_traffic("scdm_fwd_kernel", a.B, a.T, a.N, a.d),
                 "alg_bytes_per_launch": k1.get("alg_bytes"), "mean_launch_us": k1.get("mean_us"),
                 "launches_timed": k1.get("launches")}
         out = {"metric": "clip-query pairs/sec fwd+bwd at B=64,T=128,d=1024", "value": round(a.B * world * a.steps / dt, 2),
