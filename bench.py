@@ -58,6 +58,41 @@ def alg_bytes(kind, B, T, N, d, Hm=256, e=4):
     raise KeyError(kind)
 
 
+def micro_kernels(B, T, N, d, heads=8, iters=20):
+    """Stand-alone launches of the hot-path kernels the train step does not exercise (K2 = the
+    multi-head attention of MultiHead / Self_Attention_predictor) at the bench shape, timed with
+    event pairs on the launch stream.  Outside the timed region; informational."""
+    import math
+    from shufflingvideosfortsg_amd import functional as F
+    dev = "cuda"
+    out = {}
+
+    def run(name, fn, nbytes):
+        for _ in range(3):
+            fn()
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(iters):
+            fn()
+        e1.record(st); e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        out[name] = {"mean_us": round(us, 2), "launches": iters, "alg_bytes": nbytes,
+                     "achieved_GBs": round(nbytes / us / 1e3, 1), "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+    e = 4
+    for tag, Tk in (("cross", N), ("self", T)):
+        Q = torch.randn(B, T, d, device=dev, requires_grad=True)
+        K = torch.randn(B, Tk, d, device=dev, requires_grad=True)
+        V = torch.randn(B, Tk, d, device=dev, requires_grad=True)
+        g = torch.randn(B, T, d, device=dev)
+        with torch.no_grad():
+            run(f"tsg_mha_fwd[{tag}]", lambda: F.mha(Q, K, V, heads, math.sqrt(d)), B * (2 * T + 2 * Tk) * d * e)
+        o = F.mha(Q, K, V, heads, math.sqrt(d))
+        run(f"tsg_mha_bwd[{tag}]", lambda: torch.autograd.grad(o, (Q, K, V), g, retain_graph=True),
+            B * (4 * T + 4 * Tk) * d * e)          # read Q,K,V,O,dO ; write dQ,dK,dV
+    return out
+
+
 def pmc_traffic(kernel, B, T, N, d):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
     profiles/r1/k1_pmc_traffic.json); None when no pass exists for this shape."""
@@ -119,6 +154,7 @@ def main():
     ap.add_argument("--N", type=int, default=20)
     ap.add_argument("--d", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-micro", action="store_true", help="skip the stand-alone K2 launches")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
@@ -178,21 +214,31 @@ def main():
         raise SystemExit("non-finite loss in the timed region")
 
     if rank == 0:
-        kt = functional.kernel_timer.summary()          # name -> (mean us, launches)
-        H = a.d
+        kt = functional.kernel_timer.summary()          # (name, dims) -> (mean us, launches)
         kern = {}
-        for name, (us, n) in sorted(kt.items()):
+        for (name, dims), (us, n) in sorted(kt.items()):
+            entry = {"mean_us": round(us, 2), "launches": n, "dims": list(dims)}
             key = {"tsg_scdm_attn_fwd": "scdm_fwd", "tsg_scdm_attn_bwd": "scdm_bwd",
                    "tsg_boundary_score_fwd": "boundary_fwd", "tsg_boundary_score_bwd": "boundary_bwd"}.get(name)
-            entry = {"mean_us": round(us, 2), "launches": n}
-            if key:
-                by = alg_bytes(key, a.B, a.T, a.N, H)
+            if key and key.startswith("scdm"):            # dims = (B, T, N, H, Ds, dtype)
+                by = alg_bytes(key, dims[0], dims[1], dims[2], dims[3])
+            elif key:                                     # dims = (B, T, Hm, dtype)
+                by = alg_bytes(key, dims[0], dims[1], 0, 0, Hm=dims[2])
+            else:
+                by = None
+            if by:
                 entry.update(alg_bytes=by, achieved_GBs=round(by / us / 1e3, 1), frac=round(by / us / 1e3 / HBM_PEAK_GBS, 4))
-            kern[name] = entry
-        k1 = kern.get("tsg_scdm_attn_fwd", {})
+            kern[f"{name}{list(dims[:-1])}"] = entry
+        if not a.no_micro:
+            log("stand-alone K2 launches")
+            kern.update(micro_kernels(a.B, a.T, a.N, a.d))
+        k1 = max((v for k, v in kern.items() if k.startswith("tsg_scdm_attn_fwd[")), key=lambda v: v["launches"], default={})
+        k1B = (k1.get("dims") or [a.B])[0]
+        tr = pmc_traffic("scdm_fwd_kernel", 64, a.T, a.N, a.d)       # PMC pass was taken at B=64; bytes scale with B
         roof = {"kernel": "scdm_fwd_kernel (tsg_scdm_attn_fwd)", "bound": "hbm",
                 "achieved": k1.get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": k1.get("frac"), "traffic": pmc_traffic("scdm_fwd_kernel", a.B, a.T, a.N, a.d),
+                "frac": k1.get("frac"), "traffic": int(tr * k1B / 64) if tr else None,
+                "pairs_per_launch": k1B,
                 "alg_bytes_per_launch": k1.get("alg_bytes"), "mean_launch_us": k1.get("mean_us"),
                 "launches_timed": k1.get("launches")}
         out = {"metric": "clip-query pairs/sec fwd+bwd at B=64,T=128,d=1024", "value": round(a.B * world * a.steps / dt, 2),

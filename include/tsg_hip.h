@@ -67,12 +67,13 @@ int tsg_boundary_score_fwd(const void* y, const void* cs, const void* b1, const 
                            int B, int T, int Hm, int dtype, void* stream);
 
 /* backward.  dp_start/dp_end [B,T] -> dy [B,T,J], dcs [B,J], per-sample partial sums db1_part [B,J],
- * dw2_part [B,J], db2_part [B,2] (the caller adds them over B), dgate [B,T] (may be NULL).       */
+ * dw2_part [B,J], db2_part [B,2] (the caller adds them over B), dgate [B,T] (may be NULL).
+ * dl_ws: caller-owned workspace of 2*B*T floats.                                                 */
 int tsg_boundary_score_bwd(const void* y, const void* cs, const void* b1, const void* w2, const void* gate,
                            const int32_t* mask, const void* p_start, const void* p_end,
                            const void* dp_start, const void* dp_end, void* dy, void* dcs, void* db1_part,
-                           void* dw2_part, void* db2_part, void* dgate, int B, int T, int Hm, int dtype,
-                           void* stream);
+                           void* dw2_part, void* db2_part, void* dgate, void* dl_ws, int B, int T, int Hm,
+                           int dtype, void* stream);
 
 /* ---- K2: multi-head dot-product attention between the wq/wk/wv projections and wo
  * (Attention.forward networks/attention.py:45-55, MultiHead.forward / A_forward :71-97).

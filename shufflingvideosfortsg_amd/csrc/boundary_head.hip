@@ -9,8 +9,9 @@
 // with the start and end branches stacked along the hidden axis (J = 2*Hm columns: [start | end]).
 // The concat tensor never exists.
 //
-// One workgroup per batch item; a wave owns clip rows, lanes own hidden columns (coalesced float4
-// rows of y), the two dot products are wave reductions, the T-softmax runs out of LDS.
+// Workgroup = (batch item, 32 clips) so that [64,128] still covers the chip; a wave owns 4 clip rows
+// (all requested up front), lanes own hidden columns (coalesced float4 rows of y), the two dot
+// products are wave reductions; a second tiny kernel does the T-softmax in LDS.
 // HBM-bound: reads y once (T*J*4 B per pair), writes 2T probabilities.
 #include "tsg_common.h"
 
@@ -60,14 +61,28 @@ __device__ void block_softmax(float* v, int T, float* scratch) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kThreads) void boundary_fwd_kernel(
+// ---- forward, kernel 1: raw (masked) logits.  grid = B * ceil(T/TR): 32 clip rows per workgroup so
+// that a [64,128] problem still covers all 256 CUs; each wave owns 4 rows and requests all of them
+// before the first tanh (the kernel is latency-bound otherwise: one 2 KiB row per iteration).
+constexpr int TR = 32;                 // rows per workgroup
+constexpr int RW = TR / kWaves;        // rows per wave
+
+__global__ __launch_bounds__(kThreads) void boundary_logits_kernel(
     const float* __restrict__ y, const float* __restrict__ cs, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ gate,
-    const int* __restrict__ mask, float* __restrict__ ps, float* __restrict__ pe, int B, int T, int Hm) {
-  extern __shared__ float lds[];                 // [2][T] logits + scratch
-  float* ls = lds; float* le = lds + T; float* scratch = lds + 2 * T;
-  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), b = blockIdx.x;
+    const int* __restrict__ mask, float* __restrict__ ls, float* __restrict__ le, int B, int T, int Hm, int tiles) {
+  const int lane = threadIdx.x & 63, wv = wave_id();
+  const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * TR + wv * RW;
   const int J = 2 * Hm;
+  float4 yv[RW][kMaxJ4];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int i = 0; i < kMaxJ4; ++i) {
+      const int j = i * 256 + lane * 4;
+      yv[r][i] = (t0 + r < T && j < J) ? *reinterpret_cast<const float4*>(y + ((size_t)b * T + t0 + r) * J + j)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   float c[kMaxJ4][4], bb[kMaxJ4][4], ww[kMaxJ4][4];
 #pragma unroll
   for (int i = 0; i < kMaxJ4; ++i) {
@@ -81,54 +96,50 @@ __global__ __launch_bounds__(kThreads) void boundary_fwd_kernel(
     }
   }
   const float b2s = b2[0], b2e = b2[1];
-  for (int t = wv; t < T; t += kWaves) {
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int t = t0 + r;
+    if (t >= T) break;
     const float g = gate ? gate[(size_t)b * T + t] : 1.f;
-    const float* yr = y + ((size_t)b * T + t) * J;
     float as = 0.f, ae = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxJ4; ++i) {
       const int j = i * 256 + lane * 4;
-      if (j < J) {                                 // J % 4 == 0 (checked on the host)
-        const float4 v = *reinterpret_cast<const float4*>(yr + j);
-        const float yv[4] = {v.x, v.y, v.z, v.w};
+      const float v4[4] = {yv[r][i].x, yv[r][i].y, yv[r][i].z, yv[r][i].w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float u = tanh_fast(fmaf(g, yv[q] + c[i][q], bb[i][q]));
-          if (j + q < Hm) as = fmaf(ww[i][q], u, as); else ae = fmaf(ww[i][q], u, ae);
-        }
+      for (int q = 0; q < 4; ++q) {
+        const float u = tanh_fast(fmaf(g, v4[q] + c[i][q], bb[i][q]));     // ww = 0 beyond J
+        if (j + q < Hm) as = fmaf(ww[i][q], u, as); else ae = fmaf(ww[i][q], u, ae);
       }
     }
     as = wave_allsum(as); ae = wave_allsum(ae);
     if (lane == 0) {
       float l0 = as + b2s, l1 = ae + b2e;
       if (mask) { const float m = (float)mask[(size_t)b * T + t]; l0 = mask_logit(l0, m); l1 = mask_logit(l1, m); }
-      ls[t] = l0; le[t] = l1;
+      ls[(size_t)b * T + t] = l0; le[(size_t)b * T + t] = l1;
     }
-  }
-  __syncthreads();
-  block_softmax(ls, T, scratch);
-  block_softmax(le, T, scratch);
-  for (int t = tid; t < T; t += kThreads) {
-    ps[(size_t)b * T + t] = ls[t];
-    pe[(size_t)b * T + t] = le[t];
   }
 }
 
-// backward.  dl' = p*(dp - <p,dp>);  dl = dl'*m;  dz = dl*w2*(1-u^2);  dy = g*dz;
-// dcs[b,:] = sum_t g*dz;  db1p[b,:] = sum_t dz;  dw2p[b,:] = sum_t dl*u;  db2p[b,0:2] = sum_t dl;
-// dgate[b,t] = sum_j dz*(y+cs).   (per-sample partials: the host sums db1p/dw2p/db2p over B)
-__global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
-    const float* __restrict__ y, const float* __restrict__ cs, const float* __restrict__ b1,
-    const float* __restrict__ w2, const float* __restrict__ gate, const int* __restrict__ mask,
-    const float* __restrict__ ps, const float* __restrict__ pe, const float* __restrict__ dps,
-    const float* __restrict__ dpe, float* __restrict__ dy, float* __restrict__ dcs, float* __restrict__ db1p,
-    float* __restrict__ dw2p, float* __restrict__ db2p, float* __restrict__ dgate, int B, int T, int Hm) {
-  extern __shared__ float lds[];                 // [2][T] dl + [kWaves] scratch + [kWaves][3][J] reduce
-  const int J = 2 * Hm;
-  float* dls = lds; float* dle = lds + T; float* scratch = lds + 2 * T; float* red = scratch + 2 * kWaves;
-  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), b = blockIdx.x;
+// ---- forward, kernel 2: softmax over T, in place (grid = B) ----
+__global__ __launch_bounds__(kThreads) void boundary_softmax_kernel(float* __restrict__ ps, float* __restrict__ pe, int T) {
+  extern __shared__ float lds[];
+  float* ls = lds; float* le = lds + T; float* scratch = lds + 2 * T;
+  const int b = blockIdx.x;
+  for (int t = threadIdx.x; t < T; t += kThreads) { ls[t] = ps[(size_t)b * T + t]; le[t] = pe[(size_t)b * T + t]; }
+  __syncthreads();
+  block_softmax(ls, T, scratch);
+  block_softmax(le, T, scratch);
+  for (int t = threadIdx.x; t < T; t += kThreads) { ps[(size_t)b * T + t] = ls[t]; pe[(size_t)b * T + t] = le[t]; }
+}
 
-  // softmax Jacobian rows: dot = <p, dp> over T
+// ---- backward, kernel 1 (grid = B): dl = p*(dp - <p,dp>)*m into the workspace, db2 partials ----
+__global__ __launch_bounds__(kThreads) void boundary_dl_kernel(
+    const int* __restrict__ mask, const float* __restrict__ ps, const float* __restrict__ pe,
+    const float* __restrict__ dps, const float* __restrict__ dpe, float* __restrict__ dl, float* __restrict__ db2p,
+    int B, int T) {
+  __shared__ float scratch[2 * kWaves];
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), b = blockIdx.x;
   float d0 = 0.f, d1 = 0.f;
   for (int t = tid; t < T; t += kThreads) {
     d0 = fmaf(ps[(size_t)b * T + t], dps[(size_t)b * T + t], d0);
@@ -140,15 +151,16 @@ __global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
   d0 = 0.f; d1 = 0.f;
 #pragma unroll
   for (int u = 0; u < kWaves; ++u) { d0 += scratch[u]; d1 += scratch[kWaves + u]; }
+  __syncthreads();
   float sb0 = 0.f, sb1 = 0.f;
   for (int t = tid; t < T; t += kThreads) {
     const float m = mask ? (float)mask[(size_t)b * T + t] : 1.f;
     const float a0 = ps[(size_t)b * T + t] * (dps[(size_t)b * T + t] - d0) * m;
     const float a1 = pe[(size_t)b * T + t] * (dpe[(size_t)b * T + t] - d1) * m;
-    dls[t] = a0; dle[t] = a1; sb0 += a0; sb1 += a1;
+    dl[((size_t)b * T + t) * 2] = a0; dl[((size_t)b * T + t) * 2 + 1] = a1;
+    sb0 += a0; sb1 += a1;
   }
   sb0 = wave_allsum(sb0); sb1 = wave_allsum(sb1);
-  __syncthreads();
   if (lane == 0) { scratch[wv] = sb0; scratch[kWaves + wv] = sb1; }
   __syncthreads();
   if (tid == 0) {
@@ -156,7 +168,29 @@ __global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
     for (int u = 0; u < kWaves; ++u) { s0 += scratch[u]; s1 += scratch[kWaves + u]; }
     db2p[(size_t)b * 2] = s0; db2p[(size_t)b * 2 + 1] = s1;
   }
+}
 
+// ---- backward, kernel 2 (grid = B * ceil(T/TR)):  dz = dl*w2*(1-u^2);  dy = g*dz;
+// dcs[b,:] += sum_t g*dz;  db1p[b,:] += sum_t dz;  dw2p[b,:] += sum_t dl*u  (atomics: ceil(T/32) adders
+// per address, buffers zeroed by the host);  dgate[b,t] = sum_j dz*(y+cs). ----
+__global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
+    const float* __restrict__ y, const float* __restrict__ cs, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ gate, const float* __restrict__ dl,
+    float* __restrict__ dy, float* __restrict__ dcs, float* __restrict__ db1p,
+    float* __restrict__ dw2p, float* __restrict__ dgate, int B, int T, int Hm, int tiles) {
+  extern __shared__ float red[];                 // [kWaves][3][J]
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+  const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * TR + wv * RW;
+  const int J = 2 * Hm;
+  float4 yv[RW][kMaxJ4];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int i = 0; i < kMaxJ4; ++i) {
+      const int j = i * 256 + lane * 4;
+      yv[r][i] = (t0 + r < T && j < J) ? *reinterpret_cast<const float4*>(y + ((size_t)b * T + t0 + r) * J + j)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   float c[kMaxJ4][4], bb[kMaxJ4][4], ww[kMaxJ4][4];
   float acs[kMaxJ4][4], ab1[kMaxJ4][4], aw2[kMaxJ4][4];
 #pragma unroll
@@ -171,29 +205,30 @@ __global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
       acs[i][q] = 0.f; ab1[i][q] = 0.f; aw2[i][q] = 0.f;
     }
   }
-  for (int t = wv; t < T; t += kWaves) {
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int t = t0 + r;
+    if (t >= T) break;
     const float g = gate ? gate[(size_t)b * T + t] : 1.f;
-    const float dl0 = dls[t], dl1 = dle[t];
-    const float* yr = y + ((size_t)b * T + t) * J;
+    const float dl0 = dl[((size_t)b * T + t) * 2], dl1 = dl[((size_t)b * T + t) * 2 + 1];
     float* dyr = dy + ((size_t)b * T + t) * J;
     float dg = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxJ4; ++i) {
       const int j = i * 256 + lane * 4;
       if (j < J) {
-        const float4 v = *reinterpret_cast<const float4*>(yr + j);
-        const float yv[4] = {v.x, v.y, v.z, v.w};
+        const float v4[4] = {yv[r][i].x, yv[r][i].y, yv[r][i].z, yv[r][i].w};
         float o[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float pre = yv[q] + c[i][q];
+          const float pre = v4[q] + c[i][q];
           const float u = tanh_fast(fmaf(g, pre, bb[i][q]));
-          const float dl = (j + q < Hm) ? dl0 : dl1;
-          const float dz = dl * ww[i][q] * (1.f - u * u);
+          const float dlv = (j + q < Hm) ? dl0 : dl1;
+          const float dz = dlv * ww[i][q] * (1.f - u * u);
           o[q] = g * dz;
           acs[i][q] += o[q];
           ab1[i][q] += dz;
-          aw2[i][q] = fmaf(dl, u, aw2[i][q]);
+          aw2[i][q] = fmaf(dlv, u, aw2[i][q]);
           dg = fmaf(dz, pre, dg);
         }
         *reinterpret_cast<float4*>(dyr + j) = make_float4(o[0], o[1], o[2], o[3]);
@@ -204,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
       if (lane == 0) dgate[(size_t)b * T + t] = dg;
     }
   }
-  // cross-wave sums of the three per-column accumulators
+  // cross-wave sums of the three per-column accumulators, then one atomic per column and workgroup
 #pragma unroll
   for (int i = 0; i < kMaxJ4; ++i) {
     const int j = i * 256 + lane * 4;
@@ -224,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
 #pragma unroll
     for (int u = 0; u < kWaves; ++u) s += red[(u * 3 + which) * J + j];
     float* dst = which == 0 ? dcs : (which == 1 ? db1p : dw2p);
-    dst[(size_t)b * J + j] = s;
+    atomicAdd(dst + (size_t)b * J + j, s);
   }
 }
 
@@ -251,35 +286,50 @@ extern "C" int tsg_boundary_score_fwd(const void* y, const void* cs, const void*
   if (!aligned16(y)) return set_error(TSG_E_ALIGN, "%s: y is not 16-byte aligned", fn);
   int rc = check(fn, B, T, Hm, dtype);
   if (rc) return rc;
-  const size_t lds = sizeof(float) * (2 * (size_t)T + 2 * kWaves);
-  hipLaunchKernelGGL(boundary_fwd_kernel, dim3(B), dim3(kThreads), lds, static_cast<hipStream_t>(stream),
+  auto st = static_cast<hipStream_t>(stream);
+  const int tiles = cdiv(T, TR);
+  hipLaunchKernelGGL(boundary_logits_kernel, dim3(B * tiles), dim3(kThreads), 0, st,
                      (const float*)y, (const float*)cs, (const float*)b1, (const float*)w2, (const float*)b2,
-                     (const float*)gate, mask, (float*)p_start, (float*)p_end, B, T, Hm);
+                     (const float*)gate, mask, (float*)p_start, (float*)p_end, B, T, Hm, tiles);
+  rc = check_launch(fn);
+  if (rc) return rc;
+  const size_t lds = sizeof(float) * (2 * (size_t)T + 2 * kWaves);
+  hipLaunchKernelGGL(boundary_softmax_kernel, dim3(B), dim3(kThreads), lds, st, (float*)p_start, (float*)p_end, T);
   return check_launch(fn);
 }
 
 extern "C" int tsg_boundary_score_bwd(const void* y, const void* cs, const void* b1, const void* w2, const void* gate,
                                       const int32_t* mask, const void* p_start, const void* p_end,
                                       const void* dp_start, const void* dp_end, void* dy, void* dcs, void* db1_part,
-                                      void* dw2_part, void* db2_part, void* dgate, int B, int T, int Hm, int dtype,
-                                      void* stream) {
+                                      void* dw2_part, void* db2_part, void* dgate, void* dl_ws, int B, int T, int Hm,
+                                      int dtype, void* stream) {
   const char* fn = "tsg_boundary_score_bwd";
   for (const void* p : {y, cs, b1, w2, p_start, p_end, dp_start, dp_end, (const void*)dy, (const void*)dcs,
-                        (const void*)db1_part, (const void*)dw2_part, (const void*)db2_part})
+                        (const void*)db1_part, (const void*)dw2_part, (const void*)db2_part, (const void*)dl_ws})
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
   if (!aligned16(y) || !aligned16(dy)) return set_error(TSG_E_ALIGN, "%s: y/dy not 16-byte aligned", fn);
   int rc = check(fn, B, T, Hm, dtype);
   if (rc) return rc;
-  const size_t lds = sizeof(float) * (2 * (size_t)T + 2 * kWaves + (size_t)kWaves * 3 * 2 * Hm);
+  auto st = static_cast<hipStream_t>(stream);
+  const size_t J = 2 * (size_t)Hm;
+  for (void* p : {dcs, db1_part, dw2_part}) {
+    hipError_t e = hipMemsetAsync(p, 0, sizeof(float) * B * J, st);
+    if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(boundary_dl_kernel, dim3(B), dim3(kThreads), 0, st, mask, (const float*)p_start, (const float*)p_end,
+                     (const float*)dp_start, (const float*)dp_end, (float*)dl_ws, (float*)db2_part, B, T);
+  rc = check_launch(fn);
+  if (rc) return rc;
+  const size_t lds = sizeof(float) * (size_t)kWaves * 3 * J;
   if (lds > (size_t)kLdsBytes) return set_error(TSG_E_LDS, "%s: needs %zu B of LDS", fn, lds);
   auto kern = boundary_bwd_kernel;
   if (lds > 64 * 1024) {
     hipError_t e = allow_lds(kern, lds);
     if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), lds, static_cast<hipStream_t>(stream), (const float*)y,
-                     (const float*)cs, (const float*)b1, (const float*)w2, (const float*)gate, mask,
-                     (const float*)p_start, (const float*)p_end, (const float*)dp_start, (const float*)dp_end,
-                     (float*)dy, (float*)dcs, (float*)db1_part, (float*)dw2_part, (float*)db2_part, (float*)dgate, B, T, Hm);
+  const int tiles = cdiv(T, TR);
+  hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kThreads), lds, st, (const float*)y, (const float*)cs, (const float*)b1,
+                     (const float*)w2, (const float*)gate, (const float*)dl_ws, (float*)dy, (float*)dcs, (float*)db1_part,
+                     (float*)dw2_part, (float*)dgate, B, T, Hm, tiles);
   return check_launch(fn);
 }

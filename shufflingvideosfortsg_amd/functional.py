@@ -27,12 +27,13 @@ class _KernelTimer:
         self.on = False
 
     def summary(self):
-        """name -> (mean microseconds, launches); synchronises on the recorded events."""
+        """(name, dims) -> (mean microseconds, launches); dims = the integer shape arguments of the
+        call.  Synchronises on the recorded events."""
         acc = {}
-        for name, e0, e1 in self.records:
+        for name, e0, e1, dims in self.records:
             e1.synchronize()
-            tot, n = acc.get(name, (0.0, 0))
-            acc[name] = (tot + e0.elapsed_time(e1) * 1e3, n + 1)
+            tot, n = acc.get((name, dims), (0.0, 0))
+            acc[(name, dims)] = (tot + e0.elapsed_time(e1) * 1e3, n + 1)
         return {k: (tot / n, n) for k, (tot, n) in acc.items()}
 
 
@@ -49,7 +50,8 @@ def _call(name: str, like: torch.Tensor, *args) -> None:
         e0.record(stream)
         rc = fn(*args, st)
         e1.record(stream)
-        kernel_timer.records.append((name, e0, e1))
+        dims = tuple(a for a in args if isinstance(a, int) and not isinstance(a, bool) and 0 <= a < (1 << 24))
+        kernel_timer.records.append((name, e0, e1, dims))
     else:
         rc = fn(*args, st)
     check(rc, name)
@@ -138,11 +140,12 @@ class _BoundaryScore(torch.autograd.Function):
         dw2p = torch.empty_like(db1p)
         db2p = torch.empty(B, 2, device=y.device, dtype=torch.float32)
         dgate = torch.empty(B, T, device=y.device, dtype=torch.float32) if gate is not None else None
+        dl = torch.empty(B, T, 2, device=y.device, dtype=torch.float32)
         _call("tsg_boundary_score_bwd", y, ptr(y), ptr(cs), ptr(b1), ptr(w2),
                                             ptr(gate) if gate is not None else None,
                                             ptr(mask) if mask is not None else None,
                                             ptr(ps), ptr(pe), ptr(dps), ptr(dpe), ptr(dy), ptr(dcs), ptr(db1p),
-                                            ptr(dw2p), ptr(db2p), ptr(dgate) if dgate is not None else None,
+                                            ptr(dw2p), ptr(db2p), ptr(dgate) if dgate is not None else None, ptr(dl),
                                             B, T, J // 2, TSG_F32)
         return dy, dcs, db1p.sum(0), dw2p.sum(0), db2p.sum(0), dgate, None
 
