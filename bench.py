@@ -58,37 +58,42 @@ def alg_bytes(kind, B, T, N, d, Hm=256, e=4):
     raise KeyError(kind)
 
 
-def micro_kernels(B, T, N, d, heads=8, iters=20):
+def micro_kernels(B, T, N, d, heads=8, iters=30):
     """Stand-alone launches of the hot-path kernels the train step does not exercise (K2 = the
-    multi-head attention of MultiHead / Self_Attention_predictor) at the bench shape, timed with
-    event pairs on the launch stream.  Outside the timed region; informational."""
+    multi-head attention of MultiHead / Self_Attention_predictor) at the bench shape: the C entry
+    points are called back to back on preallocated buffers (no Python allocation between launches, so
+    the GPU, not the host, sets the pace) and timed with one event pair on the launch stream.
+    Outside the timed region; informational."""
     import math
-    from shufflingvideosfortsg_amd import functional as F
-    dev = "cuda"
+    from shufflingvideosfortsg_amd import _lib
+    from shufflingvideosfortsg_amd._lib import TSG_F32, ptr
+    lib, dev = _lib.load(), "cuda"
+    stream = torch.cuda.current_stream()
+    st = stream.cuda_stream
     out = {}
 
     def run(name, fn, nbytes):
         for _ in range(3):
             fn()
-        st = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
+        e0.record(stream)
         for _ in range(iters):
             fn()
-        e1.record(st); e1.synchronize()
+        e1.record(stream); e1.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
         out[name] = {"mean_us": round(us, 2), "launches": iters, "alg_bytes": nbytes,
                      "achieved_GBs": round(nbytes / us / 1e3, 1), "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
-    e = 4
+    e, sc = 4, math.sqrt(d)
     for tag, Tk in (("cross", N), ("self", T)):
-        Q = torch.randn(B, T, d, device=dev, requires_grad=True)
-        K = torch.randn(B, Tk, d, device=dev, requires_grad=True)
-        V = torch.randn(B, Tk, d, device=dev, requires_grad=True)
-        g = torch.randn(B, T, d, device=dev)
-        with torch.no_grad():
-            run(f"tsg_mha_fwd[{tag}]", lambda: F.mha(Q, K, V, heads, math.sqrt(d)), B * (2 * T + 2 * Tk) * d * e)
-        o = F.mha(Q, K, V, heads, math.sqrt(d))
-        run(f"tsg_mha_bwd[{tag}]", lambda: torch.autograd.grad(o, (Q, K, V), g, retain_graph=True),
+        Q = torch.randn(B, T, d, device=dev); K = torch.randn(B, Tk, d, device=dev); V = torch.randn(B, Tk, d, device=dev)
+        O = torch.empty(B, T, d, device=dev); lse = torch.empty(B, heads, T, device=dev); g = torch.randn(B, T, d, device=dev)
+        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+        run(f"tsg_mha_fwd[{tag}: {B},{T},{Tk},{d},h{heads}]",
+            lambda: lib.tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), None, None, ptr(lse), B, T, Tk, d, d, heads, sc, 0, 0.0, 0, 0, TSG_F32, st),
+            B * (2 * T + 2 * Tk) * d * e)
+        run(f"tsg_mha_bwd[{tag}: {B},{T},{Tk},{d},h{heads}]",
+            lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), B, T, Tk, d, d,
+                                    heads, sc, 0, 0.0, 0, 0, TSG_F32, st),
             B * (4 * T + 4 * Tk) * d * e)          # read Q,K,V,O,dO ; write dQ,dK,dV
     return out
 

@@ -191,6 +191,187 @@ __global__ __launch_bounds__(kThreads) void mha_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// forward, MFMA path (head widths <= 128, no side outputs): fp32 v_mfma_f32_32x32x2_f32.
+// Workgroup = (b, head, 128 queries), 4 waves x 32 queries.  Per 32-key block the K_h / V_h rows are
+// staged once in LDS and shared by the four waves; each wave keeps its Q_h rows as MFMA B-operand
+// fragments in registers.  The scores are computed TRANSPOSED, S^T = K_h Q_h^T, so that a lane owns
+// one query (column) and 16 of the 32 keys (rows) in its accumulator registers: the softmax over keys
+// is in-register plus one exchange with lane^32, the running rescale of O is lane-local, and the
+// P^T accumulator registers are, unchanged, the B operand of the second product O^T = V_h^T P^T
+// (register r pairs keys rho(r), rho(r)+4 -- the MFMA k-order is simply permuted to match).
+// ------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMfmaThreads = 256;
+constexpr int QB = 128;           // queries per workgroup
+constexpr int DHMAX = 128;        // max head width on this path
+
+__device__ __forceinline__ float xhalf_max(float v) {   // combine lane l with lane l^32
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Batched tile staging: every thread first REQUESTS its NV float4 (rows x cols4 float4 per row, zero fill
+// outside the matrix), then writes them to LDS -- one round trip instead of NV dependent ones.
+template <int NV>
+struct TileStage {
+  float4 v[NV];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int ld, int row0, int rows_total, int rows,
+                                       int cols, int cols4) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = threadIdx.x + i * kMfmaThreads;
+      const int r = idx / cols4, c = (idx % cols4) * 4;
+      v[i] = (r < rows && row0 + r < rows_total && c < cols) ? *reinterpret_cast<const float4*>(src + (size_t)(row0 + r) * ld + c)
+                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // 8-byte stores: row strides of the A-operand tiles are only 8-byte aligned (stride = 2 mod 64 floats)
+  __device__ __forceinline__ void store(float* __restrict__ dst, int stride, int rows, int cols4) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = threadIdx.x + i * kMfmaThreads;
+      const int r = idx / cols4, c = (idx % cols4) * 4;
+      if (r < rows && c + 4 <= stride) {                 // the padded row (zeros beyond the head width)
+        *reinterpret_cast<float2*>(dst + r * stride + c) = make_float2(v[i].x, v[i].y);
+        *reinterpret_cast<float2*>(dst + r * stride + c + 2) = make_float2(v[i].z, v[i].w);
+      }
+    }
+  }
+};
+
+__global__ __launch_bounds__(kMfmaThreads) void mha_fwd_mfma_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    float* __restrict__ O, float* __restrict__ LSE,
+    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int qblocks, int KS, int VS) {
+  extern __shared__ __align__(16) float lds[];
+  float* Kl = lds;                         // [32][KS]   KS = roundup(dh,64)+2  (conflict-free b64 A reads)
+  float* Vl = lds + 32 * KS;               // [32][VS]   VS = roundup(dvh,32)+4, zero beyond dvh
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hd = blockIdx.x % H;
+  const int qb = (blockIdx.x / H) % qblocks, b = blockIdx.x / (H * qblocks);
+  const int dh = dk / H, dvh = dv / H;
+  const int jq = lane & 31, kk = lane >> 5;
+  const int q = qb * QB + wv * 32 + jq;    // this lane's query
+  const float* Qb = Q + (size_t)b * Tq * dk + hd * dh;
+  const float* Kb = K + (size_t)b * Tk * dk + hd * dh;
+  const float* Vb = V + (size_t)b * Tk * dv + hd * dvh;
+  const int nsteps = (dh + 3) / 4;         // MFMA pairs over the head channels
+  const int ctiles = (dvh + 31) / 32;
+
+  // Q fragments: B operand of S^T = K Q^T.  Staged through LDS (rows are read coalesced) once.
+  float2 qf[DHMAX / 4];
+  {
+    float* Ql = lds;                       // [128][KS] -- fits: 128*130*4 = 66.6 KB <= allocated (see host)
+    TileStage<QB * (DHMAX / 4) / kMfmaThreads> qs;       // 16 float4 per thread at dh = 128
+    qs.load(Qb, dk, qb * QB, Tq, QB, dh, DHMAX / 4);
+    qs.store(Ql, KS, QB, DHMAX / 4);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < DHMAX / 4; ++s)
+      qf[s] = (s < nsteps && 4 * s + 2 * kk < dh) ? *reinterpret_cast<const float2*>(Ql + (wv * 32 + jq) * KS + 4 * s + 2 * kk)
+                                                  : make_float2(0.f, 0.f);
+    __syncthreads();
+  }
+
+  f32x16 o[DHMAX / 32];
+#pragma unroll
+  for (int ct = 0; ct < DHMAX / 32; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+  float m_run = kNegBig, l_run = 0.f;
+
+  // K_h / V_h rows of a 32-key block: 4 float4 per thread each; the NEXT block is requested while the
+  // current one is in the MFMAs (zero fill beyond Tk / head width)
+  TileStage<32 * (DHMAX / 4) / kMfmaThreads> ks, vs;
+  ks.load(Kb, dk, 0, Tk, 32, dh, DHMAX / 4);
+  vs.load(Vb, dv, 0, Tk, 32, dvh, DHMAX / 4);
+  for (int k0 = 0; k0 < Tk; k0 += 32) {
+    ks.store(Kl, KS, 32, DHMAX / 4);
+    vs.store(Vl, VS, 32, DHMAX / 4);
+    __syncthreads();
+    if (k0 + 32 < Tk) {
+      ks.load(Kb, dk, k0 + 32, Tk, 32, dh, DHMAX / 4);
+      vs.load(Vb, dv, k0 + 32, Tk, 32, dvh, DHMAX / 4);
+    }
+
+    // S^T tile: rows = keys (rho(r) + 4*kk), column = this lane's query
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    const float* krow = Kl + jq * KS + 2 * kk;            // A operand: K[key = lane&31][channel pair]
+#pragma unroll
+    for (int s = 0; s < DHMAX / 4; ++s) {
+      if (s < nsteps) {                                   // wave-uniform
+        const float2 a = *reinterpret_cast<const float2*>(krow + 4 * s);
+        st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[s].x, st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[s].y, st, 0, 0, 0);
+      }
+    }
+    float mb = kNegBig;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      float v = st[r];
+      if (causal && key > q) v -= 1e10f;
+      v *= inv_scale;
+      v = (key < Tk) ? v : kNegBig;
+      st[r] = v;
+      mb = fmaxf(mb, v);
+    }
+    const float m_new = fmaxf(m_run, xhalf_max(mb));
+    const float alpha = __expf(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = (st[r] > kNegBig) ? __expf(st[r] - m_new) : 0.f;
+      st[r] = p;
+      ps += p;
+    }
+    l_run = l_run * alpha + xhalf_sum(ps);
+    m_run = m_new;
+    // O^T += V^T P^T : A operand V[key = rho(r) + 4*kk][channel = ct*32 + lane&31], B operand = st[r]
+#pragma unroll
+    for (int ct = 0; ct < DHMAX / 32; ++ct) {
+      if (ct < ctiles) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float a = Vl[((r & 3) + 8 * (r >> 2) + 4 * kk) * VS + ct * 32 + jq];
+          o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, st[r], o[ct], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: O[q][c] = o / l ; transpose through LDS for coalesced row stores
+  float* Ol = lds;                                       // [128][VS]
+  const float inv = 1.f / l_run;
+#pragma unroll
+  for (int ct = 0; ct < DHMAX / 32; ++ct)
+    if (ct < ctiles) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (c < dvh) Ol[(wv * 32 + jq) * VS + c] = o[ct][r] * inv;
+      }
+    }
+  if (kk == 0 && q < Tq) LSE[((size_t)b * H + hd) * Tq + q] = m_run + __logf(l_run);
+  __syncthreads();
+  for (int idx = tid; idx < QB * (dvh / 4); idx += kMfmaThreads) {
+    const int r = idx / (dvh / 4), c = (idx % (dvh / 4)) * 4;
+    const int qq = qb * QB + r;
+    if (qq < Tq)
+      *reinterpret_cast<float4*>(O + ((size_t)b * Tq + qq) * dv + hd * dvh + c) = *reinterpret_cast<const float4*>(Ol + r * VS + c);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward: workgroup = (b, head).
 //   D[q]    = <dO[q,:], O[q,:]> (head channels)          P = exp(a - LSE)
 //   dV[n,:] = sum_q P[q,n] dO[q,:]       dP[q,n] = <dO[q,:], V[n,:]>       dS = P (dP - D) / scale
@@ -383,6 +564,23 @@ extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O,
   const size_t map_bytes = sizeof(float) * (size_t)B * Tq * Tk;
   if (A_sum) { hipError_t e = hipMemsetAsync(A_sum, 0, map_bytes, st); if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e)); }
   if (S_sum) { hipError_t e = hipMemsetAsync(S_sum, 0, map_bytes, st); if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e)); }
+  const int dh = d_key / n_heads, dvh = d_value / n_heads;
+  if (!A_sum && !S_sum && dh <= DHMAX && dvh <= DHMAX) {            // MFMA path
+    const int KS = roundup(dh, 64) + 2, VS = roundup(dvh, 32) + 4, qblocks = cdiv(Tq, QB);
+    size_t lds = sizeof(float) * (size_t)32 * (KS + VS);
+    const size_t qstage = sizeof(float) * (size_t)QB * KS, ostage = sizeof(float) * (size_t)QB * VS;
+    if (qstage > lds) lds = qstage;
+    if (ostage > lds) lds = ostage;
+    auto kern = mha_fwd_mfma_kernel;
+    if (lds > 64 * 1024) {
+      hipError_t e = allow_lds(kern, lds);
+      if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3(B * qblocks * n_heads), dim3(kMfmaThreads), lds, st, (const float*)Q, (const float*)K,
+                       (const float*)V, (float*)O, (float*)lse, B, Tq, Tk, d_key, d_value, n_heads, 1.f / scale, causal,
+                       qblocks, KS, VS);
+    return check_launch(fn);
+  }
   const int qtiles = cdiv(Tq, TQ);
   hipLaunchKernelGGL(mha_fwd_kernel, dim3(B * qtiles), dim3(kThreads), 0, st, (const float*)Q, (const float*)K,
                      (const float*)V, (float*)O, (float*)A_sum, (float*)S_sum, (float*)lse, B, Tq, Tk, d_key, d_value,
