@@ -87,12 +87,12 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
     for tag, Tk in (("cross", N), ("self", T)):
         Q = torch.randn(B, T, d, device=dev); K = torch.randn(B, Tk, d, device=dev); V = torch.randn(B, Tk, d, device=dev)
         O = torch.empty(B, T, d, device=dev); lse = torch.empty(B, heads, T, device=dev); g = torch.randn(B, T, d, device=dev)
-        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+        dQ, dK, dV, dlt = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V), torch.empty_like(lse)
         run(f"tsg_mha_fwd[{tag}: {B},{T},{Tk},{d},h{heads}]",
             lambda: lib.tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), None, None, ptr(lse), B, T, Tk, d, d, heads, sc, 0, 0.0, 0, 0, TSG_F32, st),
             B * (2 * T + 2 * Tk) * d * e)
         run(f"tsg_mha_bwd[{tag}: {B},{T},{Tk},{d},h{heads}]",
-            lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), B, T, Tk, d, d,
+            lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d,
                                     heads, sc, 0, 0.0, 0, 0, TSG_F32, st),
             B * (4 * T + 4 * Tk) * d * e)          # read Q,K,V,O,dO ; write dQ,dK,dV
     return out

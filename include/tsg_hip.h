@@ -88,10 +88,12 @@ int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O, void* A_su
                 int B, int Tq, int Tk, int d_key, int d_value, int n_heads, float scale, int causal,
                 float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream);
 
-/* backward: dO [B,Tq,d_value] -> dQ, dK, dV (fully overwritten; no atomics, deterministic).    */
+/* backward: dO [B,Tq,d_value] -> dQ, dK, dV (fully overwritten; no atomics, deterministic).
+ * delta_ws: caller-owned workspace of B*n_heads*Tq floats (NULL selects the slower non-MFMA kernel). */
 int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* lse,
-                void* dQ, void* dK, void* dV, int B, int Tq, int Tk, int d_key, int d_value, int n_heads,
-                float scale, int causal, float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream);
+                void* dQ, void* dK, void* dV, void* delta_ws, int B, int Tq, int Tk, int d_key, int d_value,
+                int n_heads, float scale, int causal, float p_drop, uint64_t seed, uint64_t offset, int dtype,
+                void* stream);
 
 /* ---- Adjacent glue: bidirectional LSTM recurrence (BiLSTM.forward networks/RNN.py:34-48 = one layer of
  * nn.LSTM(batch_first, bidirectional), zero initial state).  The caller computes the input projections of

@@ -531,6 +531,180 @@ __global__ __launch_bounds__(kThreads) void mha_bwd_kernel(
   (void)Dq;
 }
 
+// ------------------------------------------------------------------------------------------
+// backward, MFMA path (head widths <= 128).  Workgroup = (b, head), 4 waves; wave w owns channel
+// tile w (32 channels) of every product.  Orientation "key on the lane": S = Q K^T and dP = dO V^T
+// are computed with the key as the MFMA column, so their accumulators (rows = queries) are directly
+// the B operands of  dV^T = dO^T P  and  dK^T = Q^T dS  (sums over queries); only dS crosses LDS once,
+// as the A operand of dQ = dS K (sum over keys).  The 128-channel contraction of S / dP is split over
+// the four waves (32 channels each) and folded through LDS.  delta[q] = <dO[q], O[q]> (head channels)
+// comes from a small pre-pass.  Key blocks outermost: dK^T / dV^T accumulate in registers across
+// the query tiles; dQ is accumulated in global memory by its owner wave across key blocks.
+// No atomics: every output element has exactly one writer.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mha_bwd_delta_kernel(const float* __restrict__ O, const float* __restrict__ dO,
+                                                            float* __restrict__ delta, int B, int Tq, int dv, int H) {
+  // one wave per (b, q): lanes stride the dv channels; heads are contiguous channel ranges
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wv;
+  if (row >= (long)B * Tq) return;
+  const int b = (int)(row / Tq), q = (int)(row % Tq), dvh = dv / H;
+  const float* o = O + (size_t)row * dv; const float* g = dO + (size_t)row * dv;
+  for (int hd = 0; hd < H; ++hd) {
+    float acc = 0.f;
+    for (int c = lane * 4; c < dvh; c += 256) {
+      const float4 x = *reinterpret_cast<const float4*>(o + hd * dvh + c);
+      const float4 y = *reinterpret_cast<const float4*>(g + hd * dvh + c);
+      acc = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, acc))));
+    }
+    acc = wave_allsum(acc);
+    if (lane == 0) delta[((size_t)b * H + hd) * Tq + q] = acc;
+  }
+}
+
+__device__ __forceinline__ int rho(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
+
+__global__ __launch_bounds__(kMfmaThreads) void mha_bwd_mfma_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ delta,
+    float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
+    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int KS, int VS2) {
+  // LDS: Kl [32][KS], Vl [32][VS2], Ql [32][KS], Gl (dO) [32][VS2]  (strides = 2 mod 64: b64 A/B reads),
+  //      X [2][4 waves][16][64] partial S / dP, dSl [32][66], lsel [32], dl [32]
+  extern __shared__ __align__(16) float lds[];
+  float* Kl = lds; float* Vl = Kl + 32 * KS; float* Ql = Vl + 32 * VS2; float* Gl = Ql + 32 * KS;
+  float* X = Gl + 32 * VS2; float* dSl = X + 2 * 4 * 16 * 64; float* lsel = dSl + 32 * 66; float* dl = lsel + 32;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / H, hd = blockIdx.x % H;
+  const int dh = dk / H, dvh = dv / H;
+  const int jl = lane & 31, kk = lane >> 5;
+  const float* Qb = Q + (size_t)b * Tq * dk + hd * dh;
+  const float* Kb = K + (size_t)b * Tk * dk + hd * dh;
+  const float* Vb = V + (size_t)b * Tk * dv + hd * dvh;
+  const float* Gb = dO + (size_t)b * Tq * dv + hd * dvh;
+  float* dQb = dQ + (size_t)b * Tq * dk + hd * dh;
+  float* dKb = dK + (size_t)b * Tk * dk + hd * dh;
+  float* dVb = dV + (size_t)b * Tk * dv + hd * dvh;
+  const float* lse = LSE + ((size_t)b * H + hd) * Tq;
+  const float* dlt = delta + ((size_t)b * H + hd) * Tq;
+  const int c0 = wv * 32;                                  // this wave's channel tile
+  const bool has_k = c0 < dh, has_v = c0 < dvh;
+  const int ks_steps = has_k ? ((dh - c0 < 32 ? dh - c0 : 32) + 3) / 4 : 0;   // paired MFMA steps over my channels
+  const int vs_steps = has_v ? ((dvh - c0 < 32 ? dvh - c0 : 32) + 3) / 4 : 0;
+
+  TileStage<32 * (DHMAX / 4) / kMfmaThreads> t0, t1;
+  for (int k0 = 0; k0 < Tk; k0 += 32) {
+    __syncthreads();
+    t0.load(Kb, dk, k0, Tk, 32, dh, DHMAX / 4); t1.load(Vb, dv, k0, Tk, 32, dvh, DHMAX / 4);
+    t0.store(Kl, KS, 32, DHMAX / 4); t1.store(Vl, VS2, 32, DHMAX / 4);
+    f32x16 dkt, dvt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[r] = 0.f; dvt[r] = 0.f; }
+
+    for (int q0 = 0; q0 < Tq; q0 += 32) {
+      __syncthreads();                                     // previous tile's readers are done
+      t0.load(Qb, dk, q0, Tq, 32, dh, DHMAX / 4); t1.load(Gb, dv, q0, Tq, 32, dvh, DHMAX / 4);
+      t0.store(Ql, KS, 32, DHMAX / 4); t1.store(Gl, VS2, 32, DHMAX / 4);
+      if (tid < 32) { lsel[tid] = (q0 + tid < Tq) ? lse[q0 + tid] : 0.f; dl[tid] = (q0 + tid < Tq) ? dlt[q0 + tid] : 0.f; }
+      __syncthreads();
+
+      // partial S = Q K^T and dP = dO V^T over this wave's 32 channels (A: rows = queries, B: cols = keys)
+      f32x16 sp, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sp[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        if (s < ks_steps) {
+          const float2 a = *reinterpret_cast<const float2*>(Ql + jl * KS + c0 + 4 * s + 2 * kk);
+          const float2 bb = *reinterpret_cast<const float2*>(Kl + jl * KS + c0 + 4 * s + 2 * kk);
+          sp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, sp, 0, 0, 0);
+          sp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, sp, 0, 0, 0);
+        }
+        if (s < vs_steps) {
+          const float2 a = *reinterpret_cast<const float2*>(Gl + jl * VS2 + c0 + 4 * s + 2 * kk);
+          const float2 bb = *reinterpret_cast<const float2*>(Vl + jl * VS2 + c0 + 4 * s + 2 * kk);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, dp, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, dp, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { X[((0 * 4 + wv) * 16 + r) * 64 + lane] = sp[r]; X[((1 * 4 + wv) * 16 + r) * 64 + lane] = dp[r]; }
+      __syncthreads();
+      // full S, dP (every wave), then P and dS in the accumulator layout: row q = rho(r,kk), col key = jl
+      f32x16 pm, ds;
+      const int key = k0 + jl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sv = 0.f, dpv = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sv += X[((0 * 4 + u) * 16 + r) * 64 + lane]; dpv += X[((1 * 4 + u) * 16 + r) * 64 + lane]; }
+        const int ql = rho(r, kk), q = q0 + ql;
+        if (causal && key > q) sv -= 1e10f;
+        sv *= inv_scale;
+        const float p = (key < Tk && q < Tq) ? __expf(sv - lsel[ql]) : 0.f;
+        pm[r] = p;
+        ds[r] = p * (dpv - dl[ql]) * inv_scale;
+      }
+      if (wv == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dSl[rho(r, kk) * 66 + jl] = ds[r];
+      }
+      __syncthreads();
+
+      // dV^T[c][key] += dO^T[c][q] P[q][key];  dK^T[c][key] += Q^T[c][q] dS[q][key]   (sum over the 32 queries)
+      if (has_v) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dvt = __builtin_amdgcn_mfma_f32_32x32x2f32(Gl[rho(r, kk) * VS2 + c0 + jl], pm[r], dvt, 0, 0, 0);
+      }
+      if (has_k) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dkt = __builtin_amdgcn_mfma_f32_32x32x2f32(Ql[rho(r, kk) * KS + c0 + jl], ds[r], dkt, 0, 0, 0);
+        // dQ[q][c] (+)= dS[q][key] K[key][c]: A = dS rows from LDS, B = K[key pair][my channel]
+        f32x16 dq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const float2 a = *reinterpret_cast<const float2*>(dSl + jl * 66 + 4 * s + 2 * kk);
+          dq = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, Kl[(4 * s + 2 * kk) * KS + c0 + jl], dq, 0, 0, 0);
+          dq = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, Kl[(4 * s + 2 * kk + 1) * KS + c0 + jl], dq, 0, 0, 0);
+        }
+        if (c0 + jl < dh) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int q = q0 + rho(r, kk);
+            if (q < Tq) {
+              float* dst = dQb + (size_t)q * dk + c0 + jl;
+              *dst = (k0 > 0 ? *dst : 0.f) + dq[r];       // same lane wrote it for the previous key block
+            }
+          }
+        }
+      }
+    }
+    // dK / dV rows of this key block: accumulators are [channel rows][key on lane] -> transpose through LDS
+    __syncthreads();
+    float* Tl = Ql;                                        // [32 keys][KS] and Gl as [32][VS2]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (has_k) Ql[jl * KS + c0 + rho(r, kk)] = dkt[r];
+      if (has_v) Gl[jl * VS2 + c0 + rho(r, kk)] = dvt[r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * (dh / 4); idx += kMfmaThreads) {
+      const int r = idx / (dh / 4), c = (idx % (dh / 4)) * 4;
+      if (k0 + r < Tk)
+        *reinterpret_cast<float4*>(dKb + (size_t)(k0 + r) * dk + c) = make_float4(Tl[r * KS + c], Tl[r * KS + c + 1], Tl[r * KS + c + 2], Tl[r * KS + c + 3]);
+    }
+    for (int idx = tid; idx < 32 * (dvh / 4); idx += kMfmaThreads) {
+      const int r = idx / (dvh / 4), c = (idx % (dvh / 4)) * 4;
+      if (k0 + r < Tk)
+        *reinterpret_cast<float4*>(dVb + (size_t)(k0 + r) * dv + c) = make_float4(Gl[r * VS2 + c], Gl[r * VS2 + c + 1], Gl[r * VS2 + c + 2], Gl[r * VS2 + c + 3]);
+    }
+  }
+}
+
 int check(const char* fn, int B, int Tq, int Tk, int dk, int dv, int H, int dtype) {
   if (dtype != TSG_F32) return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (fp32 only)", fn, dtype);
   if (B <= 0 || Tq <= 0 || Tk <= 0 || dk <= 0 || dv <= 0 || H <= 0)
@@ -589,8 +763,9 @@ extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O,
 }
 
 extern "C" int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* lse,
-                           void* dQ, void* dK, void* dV, int B, int Tq, int Tk, int d_key, int d_value, int n_heads,
-                           float scale, int causal, float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream) {
+                           void* dQ, void* dK, void* dV, void* delta_ws, int B, int Tq, int Tk, int d_key, int d_value,
+                           int n_heads, float scale, int causal, float p_drop, uint64_t seed, uint64_t offset, int dtype,
+                           void* stream) {
   const char* fn = "tsg_mha_bwd";
   for (const void* p : {Q, K, V, O, dO, lse, (const void*)dQ, (const void*)dK, (const void*)dV}) {
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
@@ -600,6 +775,25 @@ extern "C" int tsg_mha_bwd(const void* Q, const void* K, const void* V, const vo
   if (rc) return rc;
   if (p_drop != 0.f) return set_error(TSG_E_SHAPE, "%s: attention dropout p=%g not supported (eval / p=0 only)", fn, p_drop);
   (void)seed; (void)offset;
+  const int dh = d_key / n_heads, dvh = d_value / n_heads;
+  if (delta_ws && dh <= DHMAX && dvh <= DHMAX) {                    // MFMA path
+    auto st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mha_bwd_delta_kernel, dim3(cdiv(B * Tq, 4)), dim3(256), 0, st, (const float*)O, (const float*)dO,
+                       (float*)delta_ws, B, Tq, d_value, n_heads);
+    rc = check_launch(fn);
+    if (rc) return rc;
+    const int KS = roundup(dh, 64) + 2, VS2 = roundup(dvh, 64) + 2;
+    const size_t lds = sizeof(float) * ((size_t)64 * (KS + VS2) + 2 * 4 * 16 * 64 + 32 * 66 + 64);
+    auto kern = mha_bwd_mfma_kernel;
+    if (lds > 64 * 1024) {
+      hipError_t e = allow_lds(kern, lds);
+      if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3(B * n_heads), dim3(kMfmaThreads), lds, st, (const float*)Q, (const float*)K, (const float*)V,
+                       (const float*)dO, (const float*)lse, (const float*)delta_ws, (float*)dQ, (float*)dK, (float*)dV,
+                       B, Tq, Tk, d_key, d_value, n_heads, 1.f / scale, causal, KS, VS2);
+    return check_launch(fn);
+  }
   hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * n_heads), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                      (const float*)Q, (const float*)K, (const float*)V, (const float*)O, (const float*)dO,
                      (const float*)lse, (float*)dQ, (float*)dK, (float*)dV, B, Tq, Tk, d_key, d_value, n_heads,

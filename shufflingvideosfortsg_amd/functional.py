@@ -191,7 +191,8 @@ class _MHA(torch.autograd.Function):
         B, Tq, dk = Q.shape
         _, Tk, dv = V.shape
         dQ = torch.empty_like(Q); dK = torch.empty_like(K); dV = torch.empty_like(V)
-        _call("tsg_mha_bwd", Q, ptr(Q), ptr(K), ptr(V), ptr(O), ptr(dO), ptr(lse), ptr(dQ), ptr(dK), ptr(dV),
+        delta = torch.empty_like(lse)
+        _call("tsg_mha_bwd", Q, ptr(Q), ptr(K), ptr(V), ptr(O), ptr(dO), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(delta),
                                  B, Tq, Tk, dk, dv, n_heads, scale, causal, 0.0, 0, 0, TSG_F32)
         return dQ, dK, dV, None, None, None, None
 
