@@ -96,16 +96,17 @@ int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, cons
                 void* stream);
 
 /* ---- Adjacent glue: bidirectional LSTM recurrence (BiLSTM.forward networks/RNN.py:34-48 = one layer of
- * nn.LSTM(batch_first, bidirectional), zero initial state).  The caller computes the input projections of
- * all steps and both directions with one GEMM:  Gx [B,T,2,4h] = X W_ih^T + b_ih + b_hh  (gate order i,f,g,o).
+ * nn.LSTM(bidirectional), zero initial state).  Sequence tensors are TIME-MAJOR here.  The caller computes
+ * the input projections of all steps and both directions with one GEMM:
+ *   Gx [T,B,2,4h] = X W_ih^T + b_ih + b_hh  (gate order i,f,g,o).
  * tsg_lstm_fwd runs the T sequential steps (one launch per step covering both directions):
- *   Whh [2,4h,h];  out [B,T,2h] (forward half | reverse half);  saved for backward: R [T,2,B,h,4]
+ *   Whh [2,4h,h];  out [T,B,2h] (forward half | reverse half);  saved for backward: R [T,2,B,h,4]
  *   (activated gates) and Cs [T,2,B,h] (cell states).  Limits: h % 4 == 0.                             */
 int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs,
                  int B, int T, int h, int dtype, void* stream);
 
-/* backward of the recurrence: dOut [B,T,2h] (+ optional dHn [2,B,h] added at each direction's last step)
- * -> dG [B,T,2,4h] = dL/d(pre-activation gates); the caller derives dX, dW_ih, dW_hh, db from it with
+/* backward of the recurrence: dOut [T,B,2h] (+ optional dHn [2,B,h] added at each direction's last step)
+ * -> dG [T,B,2,4h] = dL/d(pre-activation gates); the caller derives dX, dW_ih, dW_hh, db from it with
  * GEMMs.  WhhT [2,h,4h] is W_hh transposed per direction; dC_ws is a [2,B,h] float workspace.          */
 int tsg_lstm_bwd(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
                  void* dG, void* dC_ws, int B, int T, int h, int dtype, void* stream);

@@ -16,8 +16,11 @@
 //
 // Backward mirrors it: workgroup = (direction, 16 hidden units, 32 batch rows), W_hh passed transposed;
 //     dh_t = dOut_t + dG_{t+1} W_hh   (MFMA, K = 4h), then the lane-local cell backward writes
-// dG_t [B,T,2,4h] (consumed by the next step and, afterwards, by the caller's weight-gradient GEMMs).
+// dG_t [T,B,2,4h] (consumed by the next step and, afterwards, by the caller's weight-gradient GEMMs).
 //
+// All sequence tensors are TIME-MAJOR (Gx [T,B,2,4h], out [T,B,2h], dOut, dG): one step touches one
+// contiguous slab.  (Batch-first layouts put the rows of a step 0.5-2 MiB apart -- 128 pages per
+// workgroup and step -- and the step time was dominated by address-translation misses.)
 // Saved for backward (caller-owned): R [T][2][B][h][4] activated gates, Cs [T][2][B][h] cell states.
 #include "tsg_common.h"
 
@@ -27,9 +30,9 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;       // 8 waves x 16 batch rows = 128 rows per pass
-constexpr int KC = 32;                          // h_{t-1} columns per LDS chunk
+constexpr int KC = 32;                          // operand columns per LDS chunk
 constexpr int HS = KC + 4;                      // chunk row stride (floats), = 4 mod 32: conflict-free b64 reads
-constexpr int NBUF = 6;                         // LDS ring depth
+constexpr int NBUF = 6;                         // per-wave LDS ring depth
 constexpr int PF = 4;                           // chunks in flight (global -> registers) ahead of the MFMAs
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
@@ -41,17 +44,18 @@ __device__ __forceinline__ float tanh_f(float x) {
 
 // ---------------------------------------------------------------------------------------------
 // forward step.  grid = 2 * ceil(h/4).  tt = time index of this step for direction d.
-// Latency, not bandwidth, bounds a step: everything the step needs is requested up front (W_hh
-// rows, the first PF chunks of h_{t-1}, the Gx / c_{t-1} operands of the cell update) and the K
-// loop keeps PF chunks in flight through a 6-deep LDS ring.
+// A step is latency-bound (few KB per wave, ~100 MFMAs): everything is requested up front, the W_hh
+// rows are staged with ONE batched round trip and one barrier, and after that the waves never meet
+// again -- each wave streams the h_{t-1} rows of ITS 16 batch items through a private LDS ring
+// (PF chunks in flight), so the K loop has no workgroup barrier.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
     const float* __restrict__ Gx, const float* __restrict__ Whh, float* __restrict__ out,
     float* __restrict__ R, float* __restrict__ Cs, int B, int T, int h, int step, int WS) {
   extern __shared__ __align__(16) float lds[];
   float* Wl = lds;                              // [16][WS]   rows (u,g) -> W_hh[d][g*h + u0+u][:]
-  float* Hl = lds + 16 * WS;                    // [NBUF][128][HS]
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+  float* Hl = lds + 16 * WS + wv * (NBUF * 16 * HS);   // this wave's ring: [NBUF][16][HS]
   const int uslices = (h + 3) / 4;
   const int d = blockIdx.x / uslices, u0 = (blockIdx.x % uslices) * 4;
   const int tt = d == 0 ? step : T - 1 - step;
@@ -59,60 +63,68 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
   const bool first = step == 0;
   const int jb = lane & 15, ku = lane >> 4;     // batch row within the tile / unit (and k phase)
   const int nchunks = (h + KC - 1) / KC;
-  // chunk loader: 128 rows x 32 cols = 1024 float4, 2 per thread
-  const int lr = tid >> 3, lc = (tid & 7) * 4;  // row / column of this thread's float4 (second one: row + 64)
+  const int lr = lane >> 3, lc = (lane & 7) * 4;  // chunk loader: 16 rows x 8 float4; lane -> rows lr, lr+8
+
+  if (!first) {                                 // W_hh rows of this workgroup's 4 units: one batched round trip
+    const float* Wd = Whh + (size_t)d * 4 * h * h;
+    const int wc4 = (WS - 4) / 4;               // padded row length (multiple of 64 columns) in float4
+    constexpr int WB = 5;                       // 16 rows * 129 float4 (h = 512) / 512 threads, rounded up
+    for (int base = tid; base < 16 * wc4; base += WB * kThreads) {
+      float4 v[WB];
+#pragma unroll
+      for (int i = 0; i < WB; ++i) {
+        const int idx = base + i * kThreads, row = idx / wc4, k = (idx % wc4) * 4;
+        v[i] = (idx < 16 * wc4 && u0 + (row >> 2) < h && k < h)
+                   ? *reinterpret_cast<const float4*>(Wd + (size_t)((row & 3) * h + u0 + (row >> 2)) * h + k)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);   // zero beyond h: the MFMA loop runs over whole chunks
+      }
+#pragma unroll
+      for (int i = 0; i < WB; ++i) {
+        const int idx = base + i * kThreads;
+        if (idx < 16 * wc4) *reinterpret_cast<float4*>(Wl + (idx / wc4) * WS + (idx % wc4) * 4) = v[i];
+      }
+    }
+  }
 
   for (int b0 = 0; b0 < B; b0 += 128) {
-    const int b = b0 + wv * 16 + jb, u = u0 + ku;
+    const int bt = b0 + wv * 16;                 // first batch row of this wave's tile
+    const int b = bt + jb, u = u0 + ku;
     const bool live = b < B && u < h;
     // cell-update operands: requested now, used after the MFMAs
     float gx[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
     if (live) {
-      const float* g = Gx + (((size_t)b * T + tt) * 2 + d) * 4 * h + u;
+      const float* g = Gx + (((size_t)tt * B + b) * 2 + d) * 4 * h + u;
       gx[0] = g[0]; gx[1] = g[h]; gx[2] = g[2 * h]; gx[3] = g[3 * h];
       if (!first) cprev = Cs[(((size_t)tp * 2 + d) * B + b) * h + u];
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (!first) {
+    if (!first && bt < B) {                      // wave-uniform
       float4 stage[PF][2];
       auto gload = [&](int c, float4 (&st)[2]) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const int r = lr + 64 * q, k = c * KC + lc;
-          st[q] = (b0 + r < B && k < h) ? *reinterpret_cast<const float4*>(out + ((size_t)(b0 + r) * T + tp) * 2 * h + d * h + k)
+          const int r = lr + 8 * q, k = c * KC + lc;
+          st[q] = (bt + r < B && k < h) ? *reinterpret_cast<const float4*>(out + ((size_t)tp * B + bt + r) * 2 * h + d * h + k)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       };
       auto lstore = [&](int buf, const float4 (&st)[2]) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          *reinterpret_cast<float4*>(Hl + (buf * 128 + lr + 64 * q) * HS + lc) = st[q];
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<float4*>(Hl + (buf * 16 + lr + 8 * q) * HS + lc) = st[q];
       };
 #pragma unroll
       for (int i = 0; i < PF; ++i)
         if (i < nchunks) gload(i, stage[i]);
-      if (b0 == 0) {                              // W_hh rows of this workgroup's 4 units (once per launch)
-        const float* Wd = Whh + (size_t)d * 4 * h * h;
-        const int wc4 = (WS - 4) / 4;             // padded row length (multiple of 64 columns) in float4
-        for (int idx = tid; idx < 16 * wc4; idx += kThreads) {
-          const int row = idx / wc4, k = (idx % wc4) * 4;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero beyond h: the MFMA loop runs over whole chunks
-          if (u0 + (row >> 2) < h && k < h) v = *reinterpret_cast<const float4*>(Wd + (size_t)((row & 3) * h + u0 + (row >> 2)) * h + k);
-          *reinterpret_cast<float4*>(Wl + row * WS + k) = v;
-        }
-      }
       lstore(0, stage[0]);
-      __syncthreads();
-      // steady state: chunk c is consumed from ring slot c % NBUF; chunk c+1 is written to its slot
-      // (its data was requested PF chunks ago); chunk c+PF is requested.  Slot reuse distance NBUF >
-      // PF + 1, so one barrier per chunk suffices.
+      if (b0 == 0) __syncthreads();              // W_hh rows visible (the only workgroup barrier)
 #pragma unroll 1
       for (int c0 = 0; c0 < nchunks; c0 += PF) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
           const int c = c0 + i;
           if (c < nchunks) {
-            const float* hrow = Hl + ((c % NBUF) * 128 + wv * 16 + jb) * HS + 2 * ku;
+            __builtin_amdgcn_wave_barrier();
+            const float* hrow = Hl + ((c % NBUF) * 16 + jb) * HS + 2 * ku;
             const float* wrow = Wl + jb * WS + c * KC + 2 * ku;
 #pragma unroll
             for (int j = 0; j < KC / 8; ++j) {
@@ -123,10 +135,11 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
             }
             if (c + 1 < nchunks) lstore((c + 1) % NBUF, stage[(i + 1) % PF]);
             if (c + PF < nchunks) gload(c + PF, stage[i]);
-            __syncthreads();
           }
         }
       }
+    } else if (!first && b0 == 0) {
+      __syncthreads();                           // idle waves still take part in the W barrier
     }
     // lane-local cell update for (batch b, unit u); accumulator register g = gate (i,f,g,o)
     if (live) {
@@ -137,31 +150,30 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
       const size_t s = (((size_t)tt * 2 + d) * B + b) * h + u;
       Cs[s] = c;
       *reinterpret_cast<float4*>(R + s * 4) = make_float4(gi, gf, gg, go);
-      out[((size_t)b * T + tt) * 2 * h + d * h + u] = hv;
+      out[((size_t)tt * B + b) * 2 * h + d * h + u] = hv;
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward step.  grid = 2 * ceil(h/16) * ceil(B/32); 128 threads (2 waves x 16 batch rows).
-// dG layout [B,T,2,4h].  dCn [2][B][h] carries dL/dc across steps (in/out).
+// backward step.  grid = 2 * ceil(h/16) * ceil(B/32); 256 threads = 4 waves = the four quarters of
+// the K = 4h contraction; each wave carries BOTH 16-row batch tiles of the workgroup (two independent
+// MFMA chains) and streams its own operands -- 32 rows of dG_{t+1} and 16 rows of W_hh^T, its K
+// quarter only -- through a private LDS ring, so the K loop has no workgroup barrier; the four
+// partial sums meet once in LDS.   dG layout [T,B,2,4h].  dCn [2][B][h] carries dL/dc across steps.
 // ---------------------------------------------------------------------------------------------
-constexpr int kBwdThreads = 256;                // 4 waves = 2 batch tiles x 2 halves of every K chunk
-constexpr int KCB = 64;
-constexpr int HSB = KCB + 4;
-constexpr int NBUFB = 6;
-constexpr int PFB = 4;
+constexpr int kBwdThreads = 256;
+constexpr int NBUFB = 5;
+constexpr int PFB = 3;
 constexpr int kStageRows = 32 + 16;             // one ring slot: 32 rows of dG_{t+1} + 16 rows of W_hh^T
 
 __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
     const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
     const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG, float* __restrict__ dCn,
     int B, int T, int h, int step) {
-  // ring slot = [48][HSB]: rows 0..31 = dG_{t+1}[b0+r][chunk], rows 32..47 = WhhT[d][u0+u][chunk].
-  // Both operands stream (PFB chunks in flight); nothing is loaded wholesale up front.
-  __shared__ __align__(16) float ring[NBUFB * kStageRows * HSB];
-  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
-  const int tile = wv & 1, khalf = wv >> 1;
+  __shared__ __align__(16) float ring_all[4 * NBUFB * kStageRows * HS];
+  const int tid = threadIdx.x, lane = tid & 63, kq = wave_id();
+  float* ring = ring_all + kq * (NBUFB * kStageRows * HS);
   const int uslices = (h + 15) / 16, bslices = (B + 31) / 32;
   const int d = blockIdx.x / (uslices * bslices);
   const int rem = blockIdx.x % (uslices * bslices);
@@ -174,112 +186,123 @@ __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
   const bool last = step == 0;                  // no recurrent gradient yet
   const int jb = lane & 15, ku = lane >> 4;
   const int K = 4 * h;
-  const int b = b0 + tile * 16 + jb;            // lane: batch b, units u0 + 4*ku + r (r = accumulator register)
   const bool has_prev = (d == 0) ? (tt > 0) : (tt < T - 1);
+  // after the fold, wave kq finishes rows: tile = kq & 1, units u0 + 4*ku + r for r in {2*(kq>>1), +1}
+  const int tile = kq & 1, rsel = (kq >> 1) * 2;
+  const int b = b0 + tile * 16 + jb;
 
-  // cell-backward operands of this lane's 4 (b, unit) pairs: requested now, used after the MFMAs
-  float4 g4[4]; float cc[4], cpv[4], dov[4], dcv[4]; bool ok[4];
+  // cell-backward operands of this lane's 2 (b, unit) pairs: requested now, used after the MFMAs
+  float4 g4[2]; float cc[2], cpv[2], dov[2], dcv[2]; bool ok[2];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int u = u0 + 4 * ku + r;
-    ok[r] = khalf == 0 && b < B && u < h;
-    g4[r] = make_float4(0.f, 0.f, 0.f, 0.f); cc[r] = cpv[r] = dov[r] = dcv[r] = 0.f;
-    if (ok[r]) {
+  for (int i = 0; i < 2; ++i) {
+    const int u = u0 + 4 * ku + rsel + i;
+    ok[i] = b < B && u < h;
+    g4[i] = make_float4(0.f, 0.f, 0.f, 0.f); cc[i] = cpv[i] = dov[i] = dcv[i] = 0.f;
+    if (ok[i]) {
       const size_t s = (((size_t)tt * 2 + d) * B + b) * h + u;
       const size_t cs = ((size_t)d * B + b) * h + u;
-      g4[r] = *reinterpret_cast<const float4*>(R + s * 4);
-      cc[r] = Cs[s];
-      if (has_prev) cpv[r] = Cs[(((size_t)tp * 2 + d) * B + b) * h + u];
-      dov[r] = dOut[((size_t)b * T + tt) * 2 * h + d * h + u];
-      if (last) { if (dHn) dov[r] += dHn[cs]; } else dcv[r] = dCn[cs];
+      g4[i] = *reinterpret_cast<const float4*>(R + s * 4);
+      cc[i] = Cs[s];
+      if (has_prev) cpv[i] = Cs[(((size_t)tp * 2 + d) * B + b) * h + u];
+      dov[i] = dOut[((size_t)tt * B + b) * 2 * h + d * h + u];
+      if (last) { if (dHn) dov[i] += dHn[cs]; } else dcv[i] = dCn[cs];
     }
   }
 
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};      // batch tile 0 / 1
   if (!last) {
     const float* Wd = WhhT + (size_t)d * h * K;
-    const int nchunks = (K + KCB - 1) / KCB;
-    // loader: 48 rows x 64 cols = 768 float4, 3 per thread: thread -> (row = tid/16 + 16q, col = (tid%16)*4)
-    const int lr = tid >> 4, lc = (tid & 15) * 4;
-    float4 stage[PFB][3];
-    auto gload = [&](int c, float4 (&st)[3]) {
-      const int k = c * KCB + lc;
+    const int kchunks = (K + KC - 1) / KC;
+    const int per = (kchunks + 3) / 4, cbeg = kq * per, cend = (cbeg + per < kchunks) ? cbeg + per : kchunks;
+    const int lr = lane >> 3, lc = (lane & 7) * 4;           // 8 rows x 8 float4 per pass; 6 passes = 48 rows
+    float4 stage[PFB][6];
+    auto gload = [&](int c, float4 (&st)[6]) {
+      const int k = c * KC + lc;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int r = lr + 16 * q;
-        st[q] = (b0 + r < B && k < K) ? *reinterpret_cast<const float4*>(dG + (((size_t)(b0 + r) * T + tn) * 2 + d) * K + k)
+      for (int q = 0; q < 4; ++q) {
+        const int r = lr + 8 * q;
+        st[q] = (b0 + r < B && k < K) ? *reinterpret_cast<const float4*>(dG + (((size_t)tn * B + b0 + r) * 2 + d) * K + k)
                                       : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      st[2] = (u0 + lr < h && k < K) ? *reinterpret_cast<const float4*>(Wd + (size_t)(u0 + lr) * K + k)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto lstore = [&](int buf, const float4 (&st)[3]) {
-      float* base = ring + buf * kStageRows * HSB;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<float4*>(base + (lr + 16 * q) * HSB + lc) = st[q];
+      for (int q = 0; q < 2; ++q) {
+        const int r = lr + 8 * q;
+        st[4 + q] = (u0 + r < h && k < K) ? *reinterpret_cast<const float4*>(Wd + (size_t)(u0 + r) * K + k)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto lstore = [&](int buf, const float4 (&st)[6]) {
+      float* base = ring + buf * kStageRows * HS;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) *reinterpret_cast<float4*>(base + (lr + 8 * q) * HS + lc) = st[q];
     };
 #pragma unroll
     for (int i = 0; i < PFB; ++i)
-      if (i < nchunks) gload(i, stage[i]);
-    lstore(0, stage[0]);
-    __syncthreads();
+      if (cbeg + i < cend) gload(cbeg + i, stage[i]);
+    if (cbeg < cend) lstore(0, stage[0]);
 #pragma unroll 1
-    for (int c0 = 0; c0 < nchunks; c0 += PFB) {
+    for (int c0 = cbeg; c0 < cend; c0 += PFB) {
 #pragma unroll
       for (int i = 0; i < PFB; ++i) {
         const int c = c0 + i;
-        if (c < nchunks) {
-          const float* base = ring + (c % NBUFB) * kStageRows * HSB;
-          const float* grow = base + (tile * 16 + jb) * HSB + 2 * ku + khalf * (KCB / 2);
-          const float* wrow = base + (32 + jb) * HSB + 2 * ku + khalf * (KCB / 2);
+        if (c < cend) {
+          __builtin_amdgcn_wave_barrier();
+          const float* base = ring + ((c - cbeg) % NBUFB) * kStageRows * HS;
+          const float* g0 = base + jb * HS + 2 * ku;
+          const float* g1 = base + (16 + jb) * HS + 2 * ku;
+          const float* wrow = base + (32 + jb) * HS + 2 * ku;
 #pragma unroll
-          for (int j = 0; j < KCB / 16; ++j) {
+          for (int j = 0; j < KC / 8; ++j) {
             const float2 a = *reinterpret_cast<const float2*>(wrow + 8 * j);
-            const float2 bv = *reinterpret_cast<const float2*>(grow + 8 * j);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv.y, acc, 0, 0, 0);
+            const float2 x0 = *reinterpret_cast<const float2*>(g0 + 8 * j);
+            const float2 x1 = *reinterpret_cast<const float2*>(g1 + 8 * j);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x1.y, acc1, 0, 0, 0);
           }
-          if (c + 1 < nchunks) lstore((c + 1) % NBUFB, stage[(i + 1) % PFB]);
-          if (c + PFB < nchunks) gload(c + PFB, stage[i]);
-          __syncthreads();
+          if (c + 1 < cend) lstore((c + 1 - cbeg) % NBUFB, stage[(i + 1) % PFB]);
+          if (c + PFB < cend) gload(c + PFB, stage[i]);
         }
       }
     }
-    // fold the two K halves (the ring is free now)
-    float* Xl = ring;
-    if (khalf == 1) *reinterpret_cast<float4*>(Xl + (tile * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    // fold the four K quarters: Xl[kq][tile][lane][4]; wave kq then finishes (tile kq&1, registers rsel, rsel+1)
     __syncthreads();
-    if (khalf == 0) {
-      const float4 o = *reinterpret_cast<const float4*>(Xl + (tile * 64 + lane) * 4);
-      acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
+    float* Xl = ring_all;
+    *reinterpret_cast<float4*>(Xl + ((kq * 2 + 0) * 64 + lane) * 4) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+    *reinterpret_cast<float4*>(Xl + ((kq * 2 + 1) * 64 + lane) * 4) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+    __syncthreads();
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s0 += Xl[((q * 2 + tile) * 64 + lane) * 4 + rsel];
+      s1 += Xl[((q * 2 + tile) * 64 + lane) * 4 + rsel + 1];
     }
+    acc0[0] = s0; acc0[1] = s1;
   }
-  if (khalf == 0 && b < B) {
-    float dgate[4][4];                           // [unit r][gate]
+  if (b < B) {
+    const float rec[2] = {last ? 0.f : acc0[0], last ? 0.f : acc0[1]};
+    float dgate[2][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) dgate[r][g] = 0.f;
-      if (!ok[r]) continue;
-      const float gi = g4[r].x, gf = g4[r].y, gg = g4[r].z, go = g4[r].w;
-      const float tc = tanh_f(cc[r]);
-      const float dh = dov[r] + acc[r];
-      const float dc = fmaf(dh * go, 1.f - tc * tc, dcv[r]);
-      dgate[r][0] = dc * gg * gi * (1.f - gi);
-      dgate[r][1] = dc * cpv[r] * gf * (1.f - gf);
-      dgate[r][2] = dc * gi * (1.f - gg * gg);
-      dgate[r][3] = dh * tc * go * (1.f - go);
-      dCn[((size_t)d * B + b) * h + u0 + 4 * ku + r] = dc * gf;
+      for (int g = 0; g < 4; ++g) dgate[i][g] = 0.f;
+      if (!ok[i]) continue;
+      const float gi = g4[i].x, gf = g4[i].y, gg = g4[i].z, go = g4[i].w;
+      const float tc = tanh_f(cc[i]);
+      const float dh = dov[i] + rec[i];
+      const float dc = fmaf(dh * go, 1.f - tc * tc, dcv[i]);
+      dgate[i][0] = dc * gg * gi * (1.f - gi);
+      dgate[i][1] = dc * cpv[i] * gf * (1.f - gf);
+      dgate[i][2] = dc * gi * (1.f - gg * gg);
+      dgate[i][3] = dh * tc * go * (1.f - go);
+      dCn[((size_t)d * B + b) * h + u0 + 4 * ku + rsel + i] = dc * gf;
     }
-    float* dst = dG + (((size_t)b * T + tt) * 2 + d) * K + u0 + 4 * ku;
+    float* dst = dG + (((size_t)tt * B + b) * 2 + d) * K + u0 + 4 * ku + rsel;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      if (ok[3]) {
-        *reinterpret_cast<float4*>(dst + g * h) = make_float4(dgate[0][g], dgate[1][g], dgate[2][g], dgate[3][g]);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (ok[r]) dst[g * h + r] = dgate[r][g];
-      }
+      if (ok[1]) *reinterpret_cast<float2*>(dst + g * h) = make_float2(dgate[0][g], dgate[1][g]);
+      else if (ok[0]) dst[g * h] = dgate[0][g];
     }
   }
 }
@@ -306,7 +329,7 @@ extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R,
   int rc = lstm_check(fn, B, T, h, dtype);
   if (rc) return rc;
   const int WS = roundup(h, 64) + 4;                     // = 4 mod 64
-  const size_t lds = sizeof(float) * ((size_t)16 * WS + (size_t)NBUF * 128 * HS);
+  const size_t lds = sizeof(float) * ((size_t)16 * WS + (size_t)kWaves * NBUF * 16 * HS);
   if (lds > (size_t)kLdsBytes) return set_error(TSG_E_LDS, "%s: h=%d needs %zu B of LDS", fn, h, lds);
   auto kern = lstm_fwd_step_kernel;
   hipError_t e = allow_lds(kern, lds);

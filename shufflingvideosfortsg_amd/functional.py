@@ -205,20 +205,20 @@ def mha(Q, K, V, n_heads, scale, causal=False, return_maps=False):
 
 
 class _BiLSTMLayer(torch.autograd.Function):
-    """One bidirectional LSTM layer from zero state.  x [B,T,I]; W_ih [8h,I] (forward rows, then reverse),
-    bias [8h] (b_ih + b_hh), W_hh [2,4h,h]  ->  out [B,T,2h].  The two input GEMMs and the three
+    """One bidirectional LSTM layer from zero state, TIME-MAJOR.  x [T,B,I]; W_ih [8h,I] (forward rows,
+    then reverse), bias [8h] (b_ih + b_hh), W_hh [2,4h,h]  ->  out [T,B,2h].  The input GEMM and the
     weight-gradient GEMMs are library GEMMs (rocBLAS via torch); the recurrence is libtsg_hip.so."""
 
     @staticmethod
     def forward(ctx, x, W_ih, bias, W_hh):
         require_device(x, W_ih, bias, W_hh)
         x, W_ih, bias, W_hh = _f32c(x), _f32c(W_ih), _f32c(bias), _f32c(W_hh)
-        B, T, I = x.shape
+        T, B, I = x.shape
         h = W_hh.shape[2]
         if W_ih.shape != (8 * h, I) or W_hh.shape != (2, 4 * h, h) or bias.numel() != 8 * h:
             raise ValueError(f"bilstm: shape mismatch x{tuple(x.shape)} W_ih{tuple(W_ih.shape)} W_hh{tuple(W_hh.shape)}")
-        Gx = torch.addmm(bias, x.view(B * T, I), W_ih.t()).view(B, T, 2, 4 * h)
-        out = torch.empty(B, T, 2 * h, device=x.device, dtype=torch.float32)
+        Gx = torch.addmm(bias, x.view(T * B, I), W_ih.t())                  # [T,B,2,4h]
+        out = torch.empty(T, B, 2 * h, device=x.device, dtype=torch.float32)
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=torch.float32)
         Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
         _call("tsg_lstm_fwd", x, ptr(Gx), ptr(W_hh), ptr(out), ptr(R), ptr(Cs), B, T, h, TSG_F32)
@@ -229,25 +229,25 @@ class _BiLSTMLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dOut, _dCs):
         x, W_ih, W_hh, out, R, Cs = ctx.saved_tensors
-        B, T, I = x.shape
+        T, B, I = x.shape
         h = W_hh.shape[2]
         dOut = _f32c(dOut)
         WhhT = W_hh.transpose(1, 2).contiguous()
-        dG = torch.empty(B, T, 2, 4 * h, device=x.device, dtype=torch.float32)
+        dG = torch.empty(T, B, 2, 4 * h, device=x.device, dtype=torch.float32)
         dC = torch.empty(2, B, h, device=x.device, dtype=torch.float32)
         _call("tsg_lstm_bwd", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC), B, T, h, TSG_F32)
-        dGf = dG.view(B * T, 8 * h)
-        dx = (dGf @ W_ih).view(B, T, I) if ctx.needs_input_grad[0] else None
-        dW_ih = dGf.t() @ x.view(B * T, I)
+        dGf = dG.view(T * B, 8 * h)
+        dx = (dGf @ W_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
+        dW_ih = dGf.t() @ x.view(T * B, I)
         dbias = dGf.sum(0)
-        zero = out.new_zeros(B, 1, h)
-        hprev_f = torch.cat([zero, out[:, :-1, :h]], 1).reshape(B * T, h)        # h_{t-1} of the forward direction
-        hprev_r = torch.cat([out[:, 1:, h:], zero], 1).reshape(B * T, h)         # h_{t+1} feeds the reverse direction
-        dW_hh = torch.stack([dG[:, :, 0].reshape(B * T, 4 * h).t() @ hprev_f,
-                             dG[:, :, 1].reshape(B * T, 4 * h).t() @ hprev_r])
+        zero = out.new_zeros(1, B, h)
+        hprev_f = torch.cat([zero, out[:-1, :, :h]], 0).reshape(T * B, h)        # h_{t-1} of the forward direction
+        hprev_r = torch.cat([out[1:, :, h:], zero], 0).reshape(T * B, h)         # h_{t+1} feeds the reverse direction
+        dW_hh = torch.stack([dG[:, :, 0].reshape(T * B, 4 * h).t() @ hprev_f,
+                             dG[:, :, 1].reshape(T * B, 4 * h).t() @ hprev_r])
         return dx, dW_ih, dbias, dW_hh
 
 
-def bilstm_layer(x, W_ih, bias, W_hh):
-    """-> (out [B,T,2h], Cs [T,2,B,h] cell states, not differentiable).  See include/tsg_hip.h."""
-    return _BiLSTMLayer.apply(x, W_ih, bias, W_hh)
+def bilstm_layer(x_tm, W_ih, bias, W_hh):
+    """Time-major layer: x_tm [T,B,I] -> (out [T,B,2h], Cs [T,2,B,h] cell states, not differentiable)."""
+    return _BiLSTMLayer.apply(x_tm, W_ih, bias, W_hh)

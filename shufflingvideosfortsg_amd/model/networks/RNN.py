@@ -23,7 +23,7 @@ class BiLSTM(nn.Module):
 
     def _hip_forward(self, x):
         L, p = self.lstm, self.lstm.dropout
-        inp, hn, cn = x, [], []
+        inp, hn, cn = x.transpose(0, 1).contiguous(), [], []          # time-major inside (see csrc/lstm.hip)
         for k in range(self.num_layers):
             g = lambda n: getattr(L, f"{n}_l{k}")
             gr = lambda n: getattr(L, f"{n}_l{k}_reverse")
@@ -32,10 +32,10 @@ class BiLSTM(nn.Module):
             W_hh = torch.stack([g("weight_hh"), gr("weight_hh")])
             out, Cs = TF.bilstm_layer(inp, W_ih, bias, W_hh)
             h = self.hidden_size
-            hn += [out[:, -1, :h], out[:, 0, h:]]
+            hn += [out[-1, :, :h], out[0, :, h:]]
             cn += [Cs[-1, 0], Cs[0, 1]]
             inp = F.dropout(out, p, self.training) if (p > 0 and k + 1 < self.num_layers) else out
-        return out, torch.stack(hn, 0), torch.stack(cn, 0)
+        return out.transpose(0, 1).contiguous(), torch.stack(hn, 0), torch.stack(cn, 0)
 
     def forward(self, x, h0=None, c0=None):
         """-> (out [B,L,2h], hn [2*layers,B,h], cn); zero initial state on x's device (the reference

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Per-step time of the LSTM recurrence kernels (developer tool)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from shufflingvideosfortsg_amd import _lib
+from shufflingvideosfortsg_amd._lib import ptr, TSG_F32
+B, T, h = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (128, 128, 512)))
+lib = _lib.load(); dev = "cuda"; stream = torch.cuda.current_stream(); st = stream.cuda_stream
+Gx = torch.randn(T, B, 2, 4 * h, device=dev) * 0.5; W = torch.randn(2, 4 * h, h, device=dev) / h ** 0.5
+out = torch.empty(T, B, 2 * h, device=dev); R = torch.empty(T, 2, B, h, 4, device=dev); Cs = torch.empty(T, 2, B, h, device=dev)
+dOut = torch.randn(T, B, 2 * h, device=dev); WT = W.transpose(1, 2).contiguous()
+dG = torch.empty(T, B, 2, 4 * h, device=dev); dC = torch.empty(2, B, h, device=dev)
+def t(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(n): fn()
+    e1.record(stream); e1.synchronize()
+    return e0.elapsed_time(e1) / n
+f = t(lambda: lib.tsg_lstm_fwd(ptr(Gx), ptr(W), ptr(out), ptr(R), ptr(Cs), B, T, h, TSG_F32, st))
+b = t(lambda: lib.tsg_lstm_bwd(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC), B, T, h, TSG_F32, st))
+print(f"B={B} T={T} h={h}: fwd {f*1e3/T:.2f} us/step ({f:.2f} ms), bwd {b*1e3/T:.2f} us/step ({b:.2f} ms)")
