@@ -53,6 +53,24 @@ int tsg_scdm_attn_bwd(const void* a, const void* s, const void* w, const void* s
                       const void* dC, void* da, void* ds, void* dw, void* dsent, void* de_ws,
                       int B, int T, int N, int H, int Ds, int dtype, void* stream);
 
+/* ---- K1g: SCDM attention fused with the channel gate of rnn_recalibration_layer.forward
+ * (components/VideoEncoder.py:61-74):  out = r * sigmoid(sent_linear(C)),  C = P @ sent.
+ * Because sent_linear(P sent) = P (sent W_l^T) + b_l, the caller passes VW = sent @ W_l^T [B,N,Ds] (a
+ * [B*N,d]x[d,d] GEMM instead of the reference's [B*T,d]x[d,d] one) and the kernel's epilogue applies
+ * bias, sigmoid and the gate: C is never materialised.  r [B,T,Ds] is the BiLSTM output being gated
+ * (video_dim == Ds here), gbias [Ds].  Same limits as tsg_scdm_attn_fwd.                        */
+int tsg_scdm_gate_fwd(const void* a, const void* s, const void* w, const void* VW, const void* gbias,
+                      const void* r, void* out, void* P, int B, int T, int N, int H, int Ds, int dtype,
+                      void* stream);
+
+/* backward: dout [B,T,Ds] -> da, ds, dw (as tsg_scdm_attn_bwd), dVW [B,N,Ds], dgbias [Ds], dr [B,T,Ds]
+ * (gate path only: the path through a = W_a(r) is the caller's).  Workspaces: de_ws B*T*N floats,
+ * dG_ws B*T*Ds floats.                                                                          */
+int tsg_scdm_gate_bwd(const void* a, const void* s, const void* w, const void* VW, const void* gbias,
+                      const void* r, const void* P, const void* dout, void* da, void* ds, void* dw,
+                      void* dVW, void* dgbias, void* dr, void* de_ws, void* dG_ws,
+                      int B, int T, int N, int H, int Ds, int dtype, void* stream);
+
 /* ---- K3: boundary-score head (VideoSentenceConcat + MLP_predictor.forward,
  * components/CrossModalInteraction.py:44-47 + components/SpanPredictor.py:71-85; GMD gate
  * SpanGroundMatchDisc.py:86).  Start and end branches are stacked on the hidden axis: J = 2*Hm.

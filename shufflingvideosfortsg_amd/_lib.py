@@ -21,6 +21,8 @@ _SIGNATURES = {
     "tsg_last_error": [],
     "tsg_scdm_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsg_scdm_attn_bwd": [_P] * 11 + [_I] * 6 + [_P],
+    "tsg_scdm_gate_fwd": [_P] * 8 + [_I] * 6 + [_P],
+    "tsg_scdm_gate_bwd": [_P] * 16 + [_I] * 6 + [_P],
     "tsg_boundary_score_fwd": [_P] * 9 + [_I] * 4 + [_P],
     "tsg_boundary_score_bwd": [_P] * 17 + [_I] * 4 + [_P],
     "tsg_mha_fwd": [_P] * 7 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],

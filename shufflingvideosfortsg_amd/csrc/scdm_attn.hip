@@ -143,10 +143,15 @@ __device__ __forceinline__ float4 exp2x4(float4 v) {     // exp(2 v), v clamped 
 // run while the C rows of sub-tile i are still draining to HBM (a CU retires stores at only ~7
 // B/clk, so an un-overlapped 128 KiB C tile costs ~8 us of store tail).  In phase 2 wave w owns a
 // fixed (column group, row slot); its sent[b,:,cols] slice stays in registers for the whole kernel.
-template <int NP, int R>
+// GATE = true is the fused tail of rnn_recalibration_layer (components/VideoEncoder.py:65-72):
+//   out = r * sigmoid(sent_linear(C)) with sent_linear(P sent) = P (sent W^T) + bias, so V is the
+//   pre-multiplied VW = sent W^T [B,N,Ds], and the epilogue applies bias, sigmoid and the gate:
+//   C itself, the [B*T,d]x[d,d] GEMM on it and three elementwise passes never happen.
+template <int NP, int R, bool GATE>
 __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
     const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w,
     const float* __restrict__ V, float* __restrict__ C, float* __restrict__ P,
+    const float* __restrict__ gr, const float* __restrict__ gbias,
     int B, int T, int N, int H, int Ds, int TT, int tiles, int dbg) {
   constexpr int SUB = kFwdWaves * R;
   constexpr int CW = NP <= 20 ? 4 : 2;               // sentence columns per lane in phase 2 (VGPR budget)
@@ -239,6 +244,27 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
   };
   const int jcol = cg * 64 * CW + lane * CW;
   if (!TSG_SKIP(4)) load_v(jcol);
+  // GATE: bias of this lane's columns, and the r rows of the current sub-tile's phase-2 rows (requested
+  // before the score loop, landed with the next a rows -- i.e. ahead of this sub-tile's stores)
+  float gb[CW], rgv[SUB][CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) gb[c] = (GATE && jcol + c < Ds) ? gbias[jcol + c] : 0.f;
+  auto load_r = [&](int t_first) {
+#pragma unroll
+    for (int i = 0; i < SUB; ++i) {
+      const int tl = rs + i * rslots, t = t_first + tl;
+      if (tl < SUB) {
+        const float* src = gr + ((size_t)b * T + (t < T ? t : T - 1)) * Ds + (jcol < Ds ? jcol : 0);
+        if (CW == 4) {
+          const float4 q4 = *reinterpret_cast<const float4*>(src);
+          rgv[i][0] = q4.x; rgv[i][1] = q4.y; rgv[i][CW - 2] = q4.z; rgv[i][CW - 1] = q4.w;
+        } else {
+          const float2 q2 = *reinterpret_cast<const float2*>(src);
+          rgv[i][0] = q2.x; rgv[i][1] = q2.y;
+        }
+      }
+    }
+  };
   lds_barrier();
 
   const int nsub = TT / SUB;
@@ -253,6 +279,7 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
 #pragma unroll
       for (int n = 0; n < NP; ++n) acc[r][n] = 0.f;
     if (st + 1 < nsub) load_rows(qn, t0 + SUB);          // flies during the score loop below
+    if (GATE) load_r(t0);
 
 #pragma unroll 1
     for (int k0 = 0; k0 < (TSG_SKIP(1) ? 0 : HP); k0 += 256) {
@@ -276,6 +303,12 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
         asm volatile("" : "+v"(qn[r][i].x), "+v"(qn[r][i].y), "+v"(qn[r][i].z), "+v"(qn[r][i].w));
         q[r][i] = qn[r][i];
       }
+    if (GATE) {
+#pragma unroll
+      for (int i = 0; i < SUB; ++i)
+#pragma unroll
+        for (int c = 0; c < CW; ++c) asm volatile("" : "+v"(rgv[i][c]));
+    }
 
     // k-reduction + softmax over the N words, one clip row at a time
 #pragma unroll
@@ -320,8 +353,7 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
     // ---- phase 2: C[t, cols] = sum_n P[t,n] * sent[b,n,cols] for rows rs, rs+rslots, ... ---------
     if (!TSG_SKIP(4)) {
       const bool jok = jcol < Ds;
-#pragma unroll 2
-      for (int tl = rs; tl < SUB; tl += rslots) {
+      auto row = [&](int tl, const float (&rr)[CW]) {
         const int t = t0 + tl;
         v2f c[CW / 2];
 #pragma unroll
@@ -336,11 +368,28 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
             for (int h = 0; h < CW / 2; ++h)
               c[h] = __builtin_elementwise_fma((v2f){pp[u], pp[u]}, vreg[n4 + u][h], c[h]);
         }
+        float o[CW];
+#pragma unroll
+        for (int h = 0; h < CW / 2; ++h) { o[2 * h] = c[h].x; o[2 * h + 1] = c[h].y; }
+        if (GATE) {
+#pragma unroll
+          for (int cc = 0; cc < CW; ++cc)
+            o[cc] = rr[cc] * fast_rcp(1.f + fast_exp2(-(o[cc] + gb[cc]) * kLog2e));      // r * sigmoid(G)
+        }
         if (t < T && jok) {
           float* dst = C + ((size_t)b * T + t) * Ds + jcol;
-          if (CW == 4) *reinterpret_cast<float4*>(dst) = make_float4(c[0].x, c[0].y, c[CW / 2 - 1].x, c[CW / 2 - 1].y);
-          else *reinterpret_cast<float2*>(dst) = make_float2(c[0].x, c[0].y);
+          if (CW == 4) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[CW - 2], o[CW - 1]);
+          else *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
         }
+      };
+      if (GATE) {
+#pragma unroll
+        for (int i = 0; i < SUB; ++i)
+          if (rs + i * rslots < SUB) row(rs + i * rslots, rgv[i]);
+      } else {
+        const float none[CW] = {};
+#pragma unroll 2
+        for (int tl = rs; tl < SUB; tl += rslots) row(tl, none);
       }
     }
   }
@@ -353,10 +402,14 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
 // flight), each row's NP partial dots are folded with the swap reduction, and the column groups
 // meet in LDS.  sent[b] is read once per workgroup instead of once per clip row.
 // ------------------------------------------------------------------------------------------
-template <int NP>
+// GATE: dC is replaced by dout (gradient of out = r * sigmoid(G), G = P VW + bias); the kernel recomputes
+// G from the VW slice in registers, writes dr = dout*sigmoid(G) and dG = dout*r*sigmoid'(G) (the latter is
+// what the dot products below and the column kernel consume in place of dC).
+template <int NP, bool GATE>
 __global__ __launch_bounds__(kFwdThreads) void scdm_bwd_rows_kernel(
     const float* __restrict__ V, const float* __restrict__ P, const float* __restrict__ dC,
-    float* __restrict__ de, int B, int T, int N, int Ds, int tiles) {
+    float* __restrict__ de, const float* __restrict__ gr, const float* __restrict__ gbias,
+    float* __restrict__ dGout, float* __restrict__ drout, int B, int T, int N, int Ds, int tiles) {
   constexpr int TT = 32;
   constexpr int CW = NP <= 20 ? 4 : 2;
   __shared__ float part[kFwdWaves][TT][NP + 1];          // [cg][row][n] (padded against bank conflicts)
@@ -398,12 +451,59 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_bwd_rows_kernel(
       g[0] = q.x; g[1] = q.y;
     }
   };
-  float g[CW], gn[CW];
+  auto load_r = [&](int tl, float (&g)[CW]) {
+    const int t = t_tile + tl;
+    const float* src = gr + ((size_t)b * T + (t < T ? t : T - 1)) * Ds + (jok ? jcol : 0);
+    if (CW == 4) {
+      const float4 q = *reinterpret_cast<const float4*>(src);
+      g[0] = q.x; g[1] = q.y; g[CW - 2] = q.z; g[CW - 1] = q.w;
+    } else {
+      const float2 q = *reinterpret_cast<const float2*>(src);
+      g[0] = q.x; g[1] = q.y;
+    }
+  };
+  float gb[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) gb[c] = (GATE && jcol + c < Ds) ? gbias[jcol + c] : 0.f;
+  float g[CW], gn[CW], rr[CW] = {}, rn[CW] = {};
   load_g(rs, g);
+  if (GATE) load_r(rs, rr);
   const int q4 = lane >> 4;
   const int nq = ((q4 & 1) << 1) | (q4 >> 1);
   for (int tl = rs; tl < TT; tl += rslots) {
-    if (tl + rslots < TT) load_g(tl + rslots, gn);
+    if (tl + rslots < TT) { load_g(tl + rslots, gn); if (GATE) load_r(tl + rslots, rn); }
+    if (GATE) {
+      const int t = t_tile + tl;
+      const float* prow = P + ((size_t)b * T + (t < T ? t : T - 1)) * N;     // wave-uniform row
+      float G[CW];
+#pragma unroll
+      for (int c = 0; c < CW; ++c) G[c] = gb[c];
+#pragma unroll
+      for (int n = 0; n < NP; ++n) {
+        if (n < N) {
+          const float pn = prow[n];
+#pragma unroll
+          for (int c = 0; c < CW; ++c) G[c] = fmaf(pn, vreg[n][c], G[c]);
+        }
+      }
+      float dr[CW];
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        const float sg = fast_rcp(1.f + fast_exp2(-G[c] * kLog2e));
+        dr[c] = g[c] * sg;
+        g[c] = g[c] * rr[c] * sg * (1.f - sg);           // dG: from here on "dC"
+      }
+      if (t < T && jok) {
+        float* d0 = dGout + ((size_t)b * T + t) * Ds + jcol; float* d1 = drout + ((size_t)b * T + t) * Ds + jcol;
+        if (CW == 4) {
+          *reinterpret_cast<float4*>(d0) = make_float4(g[0], g[1], g[CW - 2], g[CW - 1]);
+          *reinterpret_cast<float4*>(d1) = make_float4(dr[0], dr[1], dr[CW - 2], dr[CW - 1]);
+        } else {
+          *reinterpret_cast<float2*>(d0) = make_float2(g[0], g[1]);
+          *reinterpret_cast<float2*>(d1) = make_float2(dr[0], dr[1]);
+        }
+      }
+    }
     float dp[NP];
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
@@ -419,7 +519,7 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_bwd_rows_kernel(
       for (int j = 0; j < NP / 4; ++j) part[cg][tl][4 * j + nq] = z[j];
     }
 #pragma unroll
-    for (int c = 0; c < CW; ++c) g[c] = gn[c];
+    for (int c = 0; c < CW; ++c) { g[c] = gn[c]; rr[c] = rn[c]; }
   }
   __syncthreads();
   // 32 rows x NP words: one thread per (row, word); the softmax-Jacobian row dot via LDS
@@ -498,7 +598,7 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
     const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w,
     const float* __restrict__ P, const float* __restrict__ dC, const float* __restrict__ de,
     float* __restrict__ da, float* __restrict__ ds, float* __restrict__ dw, float* __restrict__ dV,
-    int B, int T, int N, int H, int Ds, int hslices, int slices) {
+    float* __restrict__ dbias, int B, int T, int N, int H, int Ds, int hslices, int slices) {
   __shared__ __align__(16) float red[kColWaves * kRedChunk * kSlice];
   __shared__ float wscale[kSlice];
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
@@ -589,6 +689,8 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
 #pragma unroll
       for (int q = 0; q < kCpl; ++q) dv[n][q] = 0.f;
     float2 g = *reinterpret_cast<const float2*>(grow + (size_t)(wv < T ? wv : 0) * Ds);
+    if (wv >= T) g = make_float2(0.f, 0.f);
+    float gsum[kCpl] = {0.f, 0.f};                          // column sums of dC (= d bias of the fused gate)
     float pcur[NP];
 #pragma unroll
     for (int n = 0; n < NP; ++n) pcur[n] = (n < N && wv < T) ? Pb[(size_t)wv * N + n] : 0.f;
@@ -600,6 +702,7 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
 #pragma unroll
       for (int n = 0; n < NP; ++n) pnext[n] = (n < N && tn < T) ? Pb[(size_t)tn * N + n] : 0.f;
       if (!jok) g = make_float2(0.f, 0.f);
+      gsum[0] += g.x; gsum[1] += g.y;
 #pragma unroll
       for (int n = 0; n < NP; ++n) {
         dv[n][0] = fmaf(pcur[n], g.x, dv[n][0]); dv[n][1] = fmaf(pcur[n], g.y, dv[n][1]);
@@ -609,6 +712,16 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
       for (int n = 0; n < NP; ++n) pcur[n] = pnext[n];
     }
     cols_reduce_store<NP>(dv, red, dV + (size_t)b * N * Ds, nullptr, N, Ds, c * kSlice, tid, lane, wv);
+    if (dbias) {
+      *reinterpret_cast<float2*>(red + wv * kSlice + lane * kCpl) = make_float2(gsum[0], gsum[1]);
+      __syncthreads();
+      if (tid < kSlice && c * kSlice + tid < Ds) {
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < kColWaves; ++u) sum += red[u * kSlice + tid];
+        atomicAdd(dbias + c * kSlice + tid, sum);
+      }
+    }
   }
 }
 
@@ -616,9 +729,9 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
 
-template <int NP>
+template <int NP, bool GATE>
 int launch_fwd(const float* a, const float* s, const float* w, const float* V, float* C, float* P,
-               int B, int T, int N, int H, int Ds, hipStream_t st) {
+               const float* gr, const float* gbias, int B, int T, int N, int H, int Ds, hipStream_t st) {
   constexpr int R = 1;                       // clip rows per wave and sub-tile (sub-tile = 8R rows)
   constexpr int SUB = kFwdWaves * R;
   // rows per workgroup: 32 (4 sub-tiles) when that still gives every CU a workgroup, else 16 / 8
@@ -631,32 +744,36 @@ int launch_fwd(const float* a, const float* s, const float* w, const float* V, f
                      H, Ds, NP <= 20 ? 2048 : 1024, N);
   if (lds > (size_t)kLdsBytes)
     return set_error(TSG_E_LDS, "scdm_attn_fwd: N=%d H=%d needs %zu B of LDS (> %d)", N, H, lds, kLdsBytes);
-  auto kern = scdm_fwd_kernel<NP, R>;
-  static thread_local size_t allowed = 0;     // per NP instantiation
+  auto kern = scdm_fwd_kernel<NP, R, GATE>;
+  static thread_local size_t allowed = 0;     // per instantiation
   if (lds > allowed) {
     hipError_t e = allow_lds(kern, lds);
     if (e != hipSuccess) return set_error((int)e, "scdm_attn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
     allowed = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kFwdThreads), lds, st, a, s, w, V, C, P, B, T, N, H, Ds, TT, tiles, ablate_mask());
+  hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kFwdThreads), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
   return check_launch("scdm_attn_fwd");
 }
 
-template <int NP>
+// GATE: V = VW, dC = dout; extra outputs dbias [Ds], dr [B,T,Ds]; dG_ws [B,T,Ds] workspace.
+template <int NP, bool GATE>
 int launch_bwd(const float* a, const float* s, const float* w, const float* V, const float* P,
                const float* dC, float* da, float* ds, float* dw, float* dV, float* de,
+               const float* gr, const float* gbias, float* dbias, float* dr, float* dG_ws,
                int B, int T, int N, int H, int Ds, hipStream_t st) {
   if (Ds > (NP <= 20 ? 2048 : 1024))
     return set_error(TSG_E_SHAPE, "scdm_attn_bwd: Ds=%d (max %d at N=%d) not supported", Ds, NP <= 20 ? 2048 : 1024, N);
   hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * H, st);
-  if (e != hipSuccess) return set_error((int)e, "scdm_attn_bwd: memset dw: %s", hipGetErrorString(e));
+  if (e == hipSuccess && GATE) e = hipMemsetAsync(dbias, 0, sizeof(float) * Ds, st);
+  if (e != hipSuccess) return set_error((int)e, "scdm_attn_bwd: memset: %s", hipGetErrorString(e));
   const int tiles = cdiv(T, 32);
-  hipLaunchKernelGGL(scdm_bwd_rows_kernel<NP>, dim3(B * tiles), dim3(kFwdThreads), 0, st, V, P, dC, de, B, T, N, Ds, tiles);
+  hipLaunchKernelGGL((scdm_bwd_rows_kernel<NP, GATE>), dim3(B * tiles), dim3(kFwdThreads), 0, st, V, P, dC, de, gr, gbias,
+                     dG_ws, dr, B, T, N, Ds, tiles);
   int rc = check_launch("scdm_attn_bwd(rows)");
   if (rc) return rc;
   const int hslices = cdiv(H, kSlice), slices = hslices > cdiv(Ds, kSlice) ? hslices : cdiv(Ds, kSlice);
-  hipLaunchKernelGGL(scdm_bwd_cols_kernel<NP>, dim3(B * slices), dim3(kColThreads), 0, st, a, s, w, P, dC, de, da, ds, dw, dV,
-                     B, T, N, H, Ds, hslices, slices);
+  hipLaunchKernelGGL(scdm_bwd_cols_kernel<NP>, dim3(B * slices), dim3(kColThreads), 0, st, a, s, w, P, GATE ? dG_ws : dC, de,
+                     da, ds, dw, dV, GATE ? dbias : nullptr, B, T, N, H, Ds, hslices, slices);
   return check_launch("scdm_attn_bwd(cols)");
 }
 
@@ -696,8 +813,8 @@ extern "C" int tsg_scdm_attn_fwd(const void* a, const void* s, const void* w, co
   if (rc) return rc;
   const int np = roundup(N, 4);
   auto st = static_cast<hipStream_t>(stream);
-  TSG_DISPATCH_NP(np, (launch_fwd<NP>((const float*)a, (const float*)s, (const float*)w,
-                                            (const float*)sent, (float*)C, (float*)P, B, T, N, H, Ds, st)));
+  TSG_DISPATCH_NP(np, (launch_fwd<NP, false>((const float*)a, (const float*)s, (const float*)w, (const float*)sent,
+                                             (float*)C, (float*)P, nullptr, nullptr, B, T, N, H, Ds, st)));
 }
 
 extern "C" int tsg_scdm_attn_bwd(const void* a, const void* s, const void* w, const void* sent,
@@ -707,7 +824,34 @@ extern "C" int tsg_scdm_attn_bwd(const void* a, const void* s, const void* w, co
   if (rc) return rc;
   const int np = roundup(N, 4);
   auto st = static_cast<hipStream_t>(stream);
-  TSG_DISPATCH_NP(np, (launch_bwd<NP>((const float*)a, (const float*)s, (const float*)w, (const float*)sent,
-                                      (const float*)P, (const float*)dC, (float*)da, (float*)ds, (float*)dw,
-                                      (float*)dsent, (float*)de_ws, B, T, N, H, Ds, st)));
+  TSG_DISPATCH_NP(np, (launch_bwd<NP, false>((const float*)a, (const float*)s, (const float*)w, (const float*)sent,
+                                             (const float*)P, (const float*)dC, (float*)da, (float*)ds, (float*)dw,
+                                             (float*)dsent, (float*)de_ws, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                             B, T, N, H, Ds, st)));
+}
+
+extern "C" int tsg_scdm_gate_fwd(const void* a, const void* s, const void* w, const void* VW, const void* gbias,
+                                 const void* r, void* out, void* P, int B, int T, int N, int H, int Ds, int dtype,
+                                 void* stream) {
+  int rc = check_common("tsg_scdm_gate_fwd", {a, s, w, VW, gbias, r, out, P}, B, T, N, H, Ds, dtype);
+  if (rc) return rc;
+  const int np = roundup(N, 4);
+  auto st = static_cast<hipStream_t>(stream);
+  TSG_DISPATCH_NP(np, (launch_fwd<NP, true>((const float*)a, (const float*)s, (const float*)w, (const float*)VW,
+                                            (float*)out, (float*)P, (const float*)r, (const float*)gbias, B, T, N, H, Ds, st)));
+}
+
+extern "C" int tsg_scdm_gate_bwd(const void* a, const void* s, const void* w, const void* VW, const void* gbias,
+                                 const void* r, const void* P, const void* dout, void* da, void* ds, void* dw,
+                                 void* dVW, void* dgbias, void* dr, void* de_ws, void* dG_ws,
+                                 int B, int T, int N, int H, int Ds, int dtype, void* stream) {
+  int rc = check_common("tsg_scdm_gate_bwd", {a, s, w, VW, gbias, r, P, dout, da, ds, dw, dVW, dgbias, dr, de_ws, dG_ws},
+                        B, T, N, H, Ds, dtype);
+  if (rc) return rc;
+  const int np = roundup(N, 4);
+  auto st = static_cast<hipStream_t>(stream);
+  TSG_DISPATCH_NP(np, (launch_bwd<NP, true>((const float*)a, (const float*)s, (const float*)w, (const float*)VW,
+                                            (const float*)P, (const float*)dout, (float*)da, (float*)ds, (float*)dw,
+                                            (float*)dVW, (float*)de_ws, (const float*)r, (const float*)gbias,
+                                            (float*)dgbias, (float*)dr, (float*)dG_ws, B, T, N, H, Ds, st)));
 }

@@ -102,6 +102,44 @@ def scdm_attn(a, s, w, sent, return_p: bool = False):
     return (C, P) if return_p else C
 
 
+class _ScdmGate(torch.autograd.Function):
+    """K1g: (a, s, w, VW=[B,N,Ds], gbias=[Ds], r=[B,T,Ds]) -> out = r * sigmoid(P @ VW + gbias)."""
+
+    @staticmethod
+    def forward(ctx, a, s, w, VW, gbias, r):
+        require_device(a, s, w, VW, gbias, r)
+        a, s, w, VW, gbias, r = _f32c(a), _f32c(s), _f32c(w), _f32c(VW), _f32c(gbias), _f32c(r)
+        B, T, H = a.shape
+        _, N, Ds = VW.shape
+        if s.shape != (B, N, H) or w.numel() != H or r.shape != (B, T, Ds) or gbias.numel() != Ds:
+            raise ValueError(f"scdm_gate: shape mismatch a{tuple(a.shape)} s{tuple(s.shape)} VW{tuple(VW.shape)} r{tuple(r.shape)}")
+        out = torch.empty(B, T, Ds, device=a.device, dtype=torch.float32)
+        P = torch.empty(B, T, N, device=a.device, dtype=torch.float32)
+        _call("tsg_scdm_gate_fwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(r), ptr(out), ptr(P),
+              B, T, N, H, Ds, TSG_F32)
+        ctx.save_for_backward(a, s, w, VW, gbias, r, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, s, w, VW, gbias, r, P = ctx.saved_tensors
+        dout = _f32c(dout)
+        B, T, H = a.shape
+        _, N, Ds = VW.shape
+        da = torch.empty_like(a); ds = torch.empty_like(s); dw = torch.empty_like(w)
+        dVW = torch.empty_like(VW); dgb = torch.empty_like(gbias); dr = torch.empty_like(r)
+        de = torch.empty(B, T, N, device=a.device, dtype=torch.float32)
+        dG = torch.empty(B, T, Ds, device=a.device, dtype=torch.float32)
+        _call("tsg_scdm_gate_bwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(r), ptr(P), ptr(dout),
+              ptr(da), ptr(ds), ptr(dw), ptr(dVW), ptr(dgb), ptr(dr), ptr(de), ptr(dG), B, T, N, H, Ds, TSG_F32)
+        return da, ds, dw, dVW, dgb, dr
+
+
+def scdm_gate(a, s, w, VW, gbias, r):
+    """SCDM attention fused with the recalibration gate (see include/tsg_hip.h, K1g)."""
+    return _ScdmGate.apply(a, s, w.reshape(-1), VW, gbias, r)
+
+
 class _BoundaryScore(torch.autograd.Function):
     """K3: (y=[B,T,2Hm], cs=[B,2Hm], b1=[2Hm], w2=[2Hm], b2=[2], gate=[B,T]|None, mask=[B,T] int|None)
     -> (p_start, p_end) [B,T]."""

@@ -6,7 +6,9 @@ features, then LayerNorm.  Parameter names match the reference (``blocks.{i}.att
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from ... import functional as TF
 from ..networks.RNN import BiLSTM
 from ..networks.attention import SCDM_Attention
 
@@ -47,6 +49,12 @@ class rnn_recalibration_layer(nn.Module):
 
     def forward(self, video_feat, word_feat):
         rnn_output, _, _ = self.rnn_cell(video_feat)
+        att = self.attention
+        if self.ca_activ in ['sigmoid'] and type(att) is SCDM_Attention and word_feat.size(-1) == self.sent_linear.in_features:
+            # fused tail: sent_linear(P @ words) = P @ (words W_l^T) + b_l, so the Linear runs on the N word rows
+            # instead of the T clip rows and bias / sigmoid / gate are the attention kernel's epilogue
+            VW = F.linear(word_feat, self.sent_linear.weight)
+            return TF.scdm_gate(att.W_a(rnn_output), att.W_s(word_feat), att.w.weight, VW, self.sent_linear.bias, rnn_output)
         C = self.attention(rnn_output, word_feat)
         channel_attn = self.sent_linear(C)
         if self.ca_activ in ['sigmoid']:

@@ -67,3 +67,31 @@ def test_scdm_errors():
         F.scdm_attn(a, s, w, v)
     with pytest.raises(RuntimeError, match="N=40"):
         F.scdm_attn(torch.randn(1, 4, 8).cuda(), torch.randn(1, 40, 8).cuda(), w.cuda(), torch.randn(1, 40, 8).cuda())
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 5, 24), (3, 17, 20, 40), (2, 32, 15, 512), (2, 128, 20, 1024), (2, 40, 25, 1024), (1, 33, 32, 260)])
+def test_scdm_gate_parity(shape):
+    """K1g (attention + sent_linear + sigmoid gate fused, sent_linear reassociated onto the word rows)
+    vs the oracle's un-fused tail of rnn_recalibration_layer."""
+    from shufflingvideosfortsg_amd import functional as F
+    lin = torch.nn.functional.linear
+    B, T, N, d = shape
+    g = torch.Generator().manual_seed(4)
+    r = torch.randn(B, T, d, generator=g, requires_grad=True)          # BiLSTM output
+    word = torch.randn(B, N, d, generator=g, requires_grad=True)
+    p = {k: (torch.randn(*sh, generator=g) / d ** 0.5).requires_grad_(True) for k, sh in
+         dict(Ws=(d, d), Wa=(d, d), ba=(d,), w=(1, d), Wl=(d, d), bl=(d,)).items()}
+    gout = torch.randn(B, T, d, generator=g)
+    C = O.scdm_attention(r, word, p["Ws"], p["Wa"], p["ba"], p["w"])
+    out0 = r * torch.sigmoid(lin(C, p["Wl"], p["bl"]))
+    out0.backward(gout)
+    leaves = [r, word] + list(p.values())
+    ref = [t.grad.clone() for t in leaves]
+    rd, wd = r.detach().cuda().requires_grad_(True), word.detach().cuda().requires_grad_(True)
+    pd = {k: v.detach().cuda().requires_grad_(True) for k, v in p.items()}
+    out1 = F.scdm_gate(lin(rd, pd["Wa"], pd["ba"]), lin(wd, pd["Ws"]), pd["w"], lin(wd, pd["Wl"]), pd["bl"], rd)
+    out1.backward(gout.cuda())
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out1.detach().cpu(), out0.detach(), **TOL)
+    for got, want, name in zip([rd, wd] + list(pd.values()), ref, ["r", "word"] + list(p.keys())):
+        torch.testing.assert_close(got.grad.cpu(), want, atol=3e-4, rtol=2e-3, msg=lambda m, n=name: f"d{n}: {m}")
