@@ -51,6 +51,10 @@ def alg_bytes(kind, B, T, N, d, Hm=256, e=4):
         return B * ((2 * T + 2 * N) * d * e + T * N * e)
     if kind == "scdm_bwd":
         return B * ((3 * T + 4 * N) * d * e + T * N * e)
+    if kind == "scdm_gate_fwd":          # reads a, r (2T), s, VW (2N); writes out (T), P
+        return B * ((3 * T + 2 * N) * d * e + T * N * e)
+    if kind == "scdm_gate_bwd":          # reads a, r, dout (3T), s, VW (2N), P; writes da, dr (2T), ds, dVW (2N)
+        return B * ((5 * T + 4 * N) * d * e + T * N * e)
     if kind == "boundary_fwd":
         return B * (T * 2 * Hm * e + 2 * T * e)
     if kind == "boundary_bwd":
@@ -84,6 +88,16 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
         out[name] = {"mean_us": round(us, 2), "launches": iters, "alg_bytes": nbytes,
                      "achieved_GBs": round(nbytes / us / 1e3, 1), "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
     e, sc = 4, math.sqrt(d)
+    # K1 without the gate epilogue (the SCDM_Attention module on its own)
+    A = torch.randn(B, T, d, device=dev); S = torch.randn(B, N, d, device=dev); w = torch.randn(d, device=dev) / sc
+    V = torch.randn(B, N, d, device=dev); C = torch.empty(B, T, d, device=dev); P = torch.empty(B, T, N, device=dev)
+    dC = torch.randn(B, T, d, device=dev); da, ds, dw, dV = torch.empty_like(A), torch.empty_like(S), torch.empty_like(w), torch.empty_like(V)
+    de = torch.empty(B, T, N, device=dev)
+    run(f"tsg_scdm_attn_fwd[alone: {B},{T},{N},{d}]",
+        lambda: lib.tsg_scdm_attn_fwd(ptr(A), ptr(S), ptr(w), ptr(V), ptr(C), ptr(P), B, T, N, d, d, TSG_F32, st), alg_bytes("scdm_fwd", B, T, N, d))
+    run(f"tsg_scdm_attn_bwd[alone: {B},{T},{N},{d}]",
+        lambda: lib.tsg_scdm_attn_bwd(ptr(A), ptr(S), ptr(w), ptr(V), ptr(P), ptr(dC), ptr(da), ptr(ds), ptr(dw), ptr(dV), ptr(de),
+                                      B, T, N, d, d, TSG_F32, st), alg_bytes("scdm_bwd", B, T, N, d))
     for tag, Tk in (("cross", N), ("self", T)):
         Q = torch.randn(B, T, d, device=dev); K = torch.randn(B, Tk, d, device=dev); V = torch.randn(B, Tk, d, device=dev)
         O = torch.empty(B, T, d, device=dev); lse = torch.empty(B, heads, T, device=dev); g = torch.randn(B, T, d, device=dev)
@@ -224,6 +238,7 @@ def main():
         for (name, dims), (us, n) in sorted(kt.items()):
             entry = {"mean_us": round(us, 2), "launches": n, "dims": list(dims)}
             key = {"tsg_scdm_attn_fwd": "scdm_fwd", "tsg_scdm_attn_bwd": "scdm_bwd",
+                   "tsg_scdm_gate_fwd": "scdm_gate_fwd", "tsg_scdm_gate_bwd": "scdm_gate_bwd",
                    "tsg_boundary_score_fwd": "boundary_fwd", "tsg_boundary_score_bwd": "boundary_bwd"}.get(name)
             if key and key.startswith("scdm"):            # dims = (B, T, N, H, Ds, dtype)
                 by = alg_bytes(key, dims[0], dims[1], dims[2], dims[3])
@@ -235,12 +250,16 @@ def main():
                 entry.update(alg_bytes=by, achieved_GBs=round(by / us / 1e3, 1), frac=round(by / us / 1e3 / HBM_PEAK_GBS, 4))
             kern[f"{name}{list(dims[:-1])}"] = entry
         if not a.no_micro:
-            log("stand-alone K2 launches")
+            log("stand-alone K1 / K2 launches")
             kern.update(micro_kernels(a.B, a.T, a.N, a.d))
-        k1 = max((v for k, v in kern.items() if k.startswith("tsg_scdm_attn_fwd[")), key=lambda v: v["launches"], default={})
+        # the cross-attention kernel as the train step launches it: scdm_fwd_kernel with the gate epilogue
+        # (tsg_scdm_gate_fwd) when the recalibration layer is fused, else the plain tsg_scdm_attn_fwd
+        cands = [(k, v) for k, v in kern.items() if k.startswith(("tsg_scdm_gate_fwd[", "tsg_scdm_attn_fwd[")) and "dims" in v]
+        k1name, k1 = max(cands, key=lambda kv: kv[1]["launches"], default=("", {}))
+        gate = k1name.startswith("tsg_scdm_gate_fwd")
         k1B = (k1.get("dims") or [a.B])[0]
-        tr = pmc_traffic("scdm_fwd_kernel", 64, a.T, a.N, a.d)       # PMC pass was taken at B=64; bytes scale with B
-        roof = {"kernel": "scdm_fwd_kernel (tsg_scdm_attn_fwd)", "bound": "hbm",
+        tr = pmc_traffic("scdm_fwd_kernel[gate]" if gate else "scdm_fwd_kernel", 64, a.T, a.N, a.d)   # PMC pass at B=64; bytes scale with B
+        roof = {"kernel": "scdm_fwd_kernel<GATE=%s> (%s)" % ("true" if gate else "false", k1name.split("[")[0]), "bound": "hbm",
                 "achieved": k1.get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": k1.get("frac"), "traffic": int(tr * k1B / 64) if tr else None,
                 "pairs_per_launch": k1B,
