@@ -593,6 +593,9 @@ __device__ __forceinline__ void cols_reduce_store(float (&acc)[NP][kCpl], float*
   }
 }
 
+constexpr int kColTB = 256;                               // clip rows per LDS block of de / P
+constexpr int kColPF = 4;                                 // rows in flight per wave
+
 template <int NP>
 __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
     const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w,
@@ -601,18 +604,26 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
     float* __restrict__ dbias, int B, int T, int N, int H, int Ds, int hslices, int slices) {
   __shared__ __align__(16) float red[kColWaves * kRedChunk * kSlice];
   __shared__ float wscale[kSlice];
+  extern __shared__ __align__(16) float rowsl[];          // [min(T,256)][NP]: de rows, later P rows (zero padded)
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int bid = xcd_remap(blockIdx.x, gridDim.x, slices);
   const int b = bid / slices, c = bid % slices;
   const int k = c * kSlice + lane * kCpl;
-  const float* deb = de + (size_t)b * T * N;
-  const float* Pb = P + (size_t)b * T * N;
+  // A wave owns rows wv, wv+8, ... of each 256-row block and keeps kColPF of its rows' operands in
+  // flight: a row's compute (~0.5 us) is far shorter than a memory round trip, one-row-ahead starves it.
+  auto stage_rows = [&](const float* __restrict__ src, int tb0, int tbn) {   // [tbn][N] -> LDS [tbn][NP]
+    __syncthreads();
+    for (int idx = tid; idx < tbn * NP; idx += kColThreads) {
+      const int r = idx / NP, n = idx % NP;
+      rowsl[idx] = (n < N) ? src[((size_t)b * T + tb0 + r) * N + n] : 0.f;
+    }
+    __syncthreads();
+  };
 
   // ---------------- main: da, ds, dw for hidden columns k, k+1 ---------------------------------
   if (c < hslices) {
     const bool live = k < H;
     const float* arow = a + (size_t)b * T * H + (live ? k : 0);
-    float2 av = *reinterpret_cast<const float2*>(arow + (size_t)(wv < T ? wv : 0) * H);
     float es[NP][kCpl];
     const float* sb = s + (size_t)b * N * H;
 #pragma unroll
@@ -628,41 +639,51 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
     for (int n = 0; n < NP; ++n)
 #pragma unroll
       for (int q = 0; q < kCpl; ++q) dsacc[n][q] = 0.f;
-    float dcur[NP];
-#pragma unroll
-    for (int n = 0; n < NP; ++n) dcur[n] = (n < N && wv < T) ? deb[(size_t)wv * N + n] : 0.f;
-    __syncthreads();
-    const float2 ws2 = *reinterpret_cast<const float2*>(wscale + lane * kCpl);
+    float2 ws2 = make_float2(0.f, 0.f);
 
-    for (int t = wv; t < T; t += kColWaves) {
-      const int tn = t + kColWaves;
-      float2 avn = make_float2(0.f, 0.f);
-      float dnext[NP];
-      if (tn < T) avn = *reinterpret_cast<const float2*>(arow + (size_t)tn * H);
+    for (int tb0 = 0; tb0 < T; tb0 += kColTB) {
+      const int tbn = (T - tb0 < kColTB) ? T - tb0 : kColTB;
+      float2 ring[kColPF];
 #pragma unroll
-      for (int n = 0; n < NP; ++n) dnext[n] = (n < N && tn < T) ? deb[(size_t)tn * N + n] : 0.f;
-
-      const float2 e2 = exp2x2(av);
-      const float ea[kCpl] = {e2.x, e2.y};
-      float dasum[kCpl] = {0.f, 0.f};
+      for (int u = 0; u < kColPF; ++u) {
+        const int tl = wv + kColWaves * u;
+        ring[u] = (tl < tbn) ? *reinterpret_cast<const float2*>(arow + (size_t)(tb0 + tl) * H) : make_float2(0.f, 0.f);
+      }
+      stage_rows(de, tb0, tbn);
+      ws2 = *reinterpret_cast<const float2*>(wscale + lane * kCpl);
+#pragma unroll 1
+      for (int tl0 = wv; tl0 < tbn; tl0 += kColWaves * kColPF) {
 #pragma unroll
-      for (int n = 0; n < NP; ++n) {
-        const float d = dcur[n];
+        for (int u = 0; u < kColPF; ++u) {
+          const int tl = tl0 + kColWaves * u;
+          if (tl < tbn) {                                   // wave-uniform
+            const float2 av = ring[u];
+            const int tnx = tl + kColWaves * kColPF;
+            if (tnx < tbn) ring[u] = *reinterpret_cast<const float2*>(arow + (size_t)(tb0 + tnx) * H);
+            const float2 e2 = exp2x2(av);
+            const float ea[kCpl] = {e2.x, e2.y};
+            float dasum[kCpl] = {0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < kCpl; ++q) {
-          const float r = fast_rcp(fmaf(ea[q], es[n][q], 1.f));
-          const float u = d * r;
-          const float v = fmaf(-u, r, u);
-          dsacc[n][q] += v;
-          dasum[q] += v;
-          dwacc[q] += u;
+            for (int n4 = 0; n4 < NP; n4 += 4) {
+              const float4 d4 = *reinterpret_cast<const float4*>(rowsl + tl * NP + n4);   // broadcast
+              const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < kCpl; ++q) {
+                  const float r = fast_rcp(fmaf(ea[q], es[n4 + j][q], 1.f));
+                  const float u2 = dd[j] * r;
+                  const float v = fmaf(-u2, r, u2);
+                  dsacc[n4 + j][q] += v;
+                  dasum[q] += v;
+                  dwacc[q] += u2;
+                }
+            }
+            if (live)
+              *reinterpret_cast<float2*>(da + ((size_t)b * T + tb0 + tl) * H + k) = make_float2(ws2.x * dasum[0], ws2.y * dasum[1]);
+          }
         }
       }
-      if (live)
-        *reinterpret_cast<float2*>(da + ((size_t)b * T + t) * H + k) = make_float2(ws2.x * dasum[0], ws2.y * dasum[1]);
-      av = avn;
-#pragma unroll
-      for (int n = 0; n < NP; ++n) dcur[n] = dnext[n];
     }
 
     cols_reduce_store<NP>(dsacc, red, ds + (size_t)b * N * H, wscale, N, H, c * kSlice, tid, lane, wv);
@@ -688,28 +709,38 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
     for (int n = 0; n < NP; ++n)
 #pragma unroll
       for (int q = 0; q < kCpl; ++q) dv[n][q] = 0.f;
-    float2 g = *reinterpret_cast<const float2*>(grow + (size_t)(wv < T ? wv : 0) * Ds);
-    if (wv >= T) g = make_float2(0.f, 0.f);
     float gsum[kCpl] = {0.f, 0.f};                          // column sums of dC (= d bias of the fused gate)
-    float pcur[NP];
+    for (int tb0 = 0; tb0 < T; tb0 += kColTB) {
+      const int tbn = (T - tb0 < kColTB) ? T - tb0 : kColTB;
+      float2 ring[kColPF];
 #pragma unroll
-    for (int n = 0; n < NP; ++n) pcur[n] = (n < N && wv < T) ? Pb[(size_t)wv * N + n] : 0.f;
-    for (int t = wv; t < T; t += kColWaves) {
-      const int tn = t + kColWaves;
-      float2 gn = make_float2(0.f, 0.f);
-      float pnext[NP];
-      if (tn < T) gn = *reinterpret_cast<const float2*>(grow + (size_t)tn * Ds);
-#pragma unroll
-      for (int n = 0; n < NP; ++n) pnext[n] = (n < N && tn < T) ? Pb[(size_t)tn * N + n] : 0.f;
-      if (!jok) g = make_float2(0.f, 0.f);
-      gsum[0] += g.x; gsum[1] += g.y;
-#pragma unroll
-      for (int n = 0; n < NP; ++n) {
-        dv[n][0] = fmaf(pcur[n], g.x, dv[n][0]); dv[n][1] = fmaf(pcur[n], g.y, dv[n][1]);
+      for (int u = 0; u < kColPF; ++u) {
+        const int tl = wv + kColWaves * u;
+        ring[u] = (tl < tbn && jok) ? *reinterpret_cast<const float2*>(grow + (size_t)(tb0 + tl) * Ds) : make_float2(0.f, 0.f);
       }
-      g = gn;
+      stage_rows(P, tb0, tbn);
+#pragma unroll 1
+      for (int tl0 = wv; tl0 < tbn; tl0 += kColWaves * kColPF) {
 #pragma unroll
-      for (int n = 0; n < NP; ++n) pcur[n] = pnext[n];
+        for (int u = 0; u < kColPF; ++u) {
+          const int tl = tl0 + kColWaves * u;
+          if (tl < tbn) {
+            const float2 g = ring[u];
+            const int tnx = tl + kColWaves * kColPF;
+            if (tnx < tbn && jok) ring[u] = *reinterpret_cast<const float2*>(grow + (size_t)(tb0 + tnx) * Ds);
+            gsum[0] += g.x; gsum[1] += g.y;
+#pragma unroll
+            for (int n4 = 0; n4 < NP; n4 += 4) {
+              const float4 p4 = *reinterpret_cast<const float4*>(rowsl + tl * NP + n4);
+              const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+              for (int jn = 0; jn < 4; ++jn) {
+                dv[n4 + jn][0] = fmaf(pp[jn], g.x, dv[n4 + jn][0]); dv[n4 + jn][1] = fmaf(pp[jn], g.y, dv[n4 + jn][1]);
+              }
+            }
+          }
+        }
+      }
     }
     cols_reduce_store<NP>(dv, red, dV + (size_t)b * N * Ds, nullptr, N, Ds, c * kSlice, tid, lane, wv);
     if (dbias) {
@@ -772,7 +803,8 @@ int launch_bwd(const float* a, const float* s, const float* w, const float* V, c
   int rc = check_launch("scdm_attn_bwd(rows)");
   if (rc) return rc;
   const int hslices = cdiv(H, kSlice), slices = hslices > cdiv(Ds, kSlice) ? hslices : cdiv(Ds, kSlice);
-  hipLaunchKernelGGL(scdm_bwd_cols_kernel<NP>, dim3(B * slices), dim3(kColThreads), 0, st, a, s, w, P, GATE ? dG_ws : dC, de,
+  const size_t rows_lds = sizeof(float) * (size_t)(T < kColTB ? T : kColTB) * NP;
+  hipLaunchKernelGGL(scdm_bwd_cols_kernel<NP>, dim3(B * slices), dim3(kColThreads), rows_lds, st, a, s, w, P, GATE ? dG_ws : dC, de,
                      da, ds, dw, dV, GATE ? dbias : nullptr, B, T, N, H, Ds, hslices, slices);
   return check_launch("scdm_attn_bwd(cols)");
 }
