@@ -23,6 +23,7 @@
 // workgroup and step -- and the step time was dominated by address-translation misses.)
 // Saved for backward (caller-owned): R [T][2][B][h][4] activated gates, Cs [T][2][B][h] cell states.
 #include "tsg_common.h"
+#include <cstdlib>
 
 namespace tsg {
 namespace {
@@ -32,8 +33,8 @@ constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;       // 8 waves x 16 batch rows = 128 rows per pass
 constexpr int KC = 32;                          // operand columns per LDS chunk
 constexpr int HS = KC + 4;                      // chunk row stride (floats), = 4 mod 32: conflict-free b64 reads
-constexpr int NBUF = 6;                         // per-wave LDS ring depth
-constexpr int PF = 4;                           // chunks in flight (global -> registers) ahead of the MFMAs
+constexpr int NBUF = 3;                         // per-wave LDS ring depth (chunks wait in registers, not in LDS)
+constexpr int PF = 4;                           // chunks in flight (global -> registers); 16 (= all of K at h=512) measured no faster
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.f + fast_exp2(-x * kLog2e)); }
@@ -307,6 +308,129 @@ __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// forward, PERSISTENT variant: one launch runs all T steps.  A per-step launch costs ~2.6 us of
+// dispatch plus a memory round trip for W_hh before the first MFMA; here the recurrent weights never
+// move.  Workgroup = (direction, 16 hidden units = 64 gate rows, 32 batch rows), 8 waves =
+// 4 A-tiles (4 units each) x 2 batch tiles.  Each wave keeps ITS A-tile of W_hh (16 gate rows x h)
+// in registers as MFMA operand fragments (h/4 VGPRs, 128 at h = 512) and its lanes keep the cell
+// state c of their (batch, unit) pair; per step only h_{t-1} (32 rows x h, 64 KiB) is fetched.
+//
+// Hand-off between workgroups.  The 32-row slab of h_t a group needs is produced by the h/16
+// workgroups with the same (direction, batch slice): they form a GROUP with one monotone arrival
+// counter.  Producer: h_t stores are write-through (`sc1`), every wave drains vmcnt, workgroup barrier,
+// one lane adds 1 to the counter (agent scope).  Consumer: one lane polls the counter with an `sc1`
+// load until it reaches members*t, workgroup barrier, then `sc1` loads of the slab (L1 bypassed; the
+// slab's lines were never read before, so no L2 copy can be stale).  Results do not depend on
+// placement; all workgroups must be co-resident (checked on the host with the occupancy query, 1
+// workgroup per CU); every spin is bounded and raises the error word instead of hanging.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPersistMaxH = 512;
+constexpr int kSpinLimit = 1 << 22;
+
+__device__ __forceinline__ f32x4 load_sc1_x4(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void store_sc1(float* p, float v) {
+  asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+
+__global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
+    const float* __restrict__ Gx, const float* __restrict__ Whh, float* __restrict__ out,
+    float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS) {
+  extern __shared__ __align__(16) float Hl[];            // [32][HLS]  h_{t-1} rows of this batch slice
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+  const int uslices = h / 16, bslices = (B + 31) / 32;
+  const int d = blockIdx.x / (uslices * bslices);
+  const int rem = blockIdx.x % (uslices * bslices);
+  const int us = rem / bslices, bs = rem % bslices;
+  const int at = wv & 3, bt = wv >> 2;
+  const int jb = lane & 15, ku = lane >> 4;
+  const int u0 = us * 16 + at * 4;                        // first unit of this wave's A-tile
+  const int b0 = bs * 32;
+  unsigned* cnt = sync + 1 + d * bslices + bs;            // sync[0] = error word
+  const unsigned members = (unsigned)uslices;
+
+  // A fragments: row i = jb -> (unit u0 + (jb>>2), gate jb&3); element pair k = 8j + 2ku, +1
+  float2 areg[kPersistMaxH / 8];
+  {
+    const float* wrow = Whh + (size_t)d * 4 * h * h + (size_t)((jb & 3) * h + u0 + (jb >> 2)) * h + 2 * ku;
+#pragma unroll
+    for (int j = 0; j < kPersistMaxH / 8; ++j)
+      areg[j] = (8 * j < h) ? *reinterpret_cast<const float2*>(wrow + 8 * j) : make_float2(0.f, 0.f);
+  }
+  const int b = b0 + bt * 16 + jb, u = u0 + ku;
+  const bool live = b < B;
+  float cprev = 0.f;
+  const int nrow4 = h / 4;                                 // float4 per h row
+
+  for (int step = 0; step < T; ++step) {
+    const int tt = d == 0 ? step : T - 1 - step;
+    const int tp = d == 0 ? tt - 1 : tt + 1;
+    float gx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      const float* g = Gx + (((size_t)tt * B + b) * 2 + d) * 4 * h + u;
+      gx[0] = g[0]; gx[1] = g[h]; gx[2] = g[2 * h]; gx[3] = g[3 * h];
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (step > 0) {
+      if (tid == 0) {                                       // wait for the group's step-1 slab
+        const unsigned want = members * (unsigned)step;
+        int spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > kSpinLimit || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // uniform: set before the barrier
+      // slab -> LDS: 32 rows x h floats, 8 float4 per thread at h = 512 (sc1: bypass the per-CU L1)
+      f32x4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
+        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (r < 32 && b0 + r < B) v[i] = load_sc1_x4(out + ((size_t)tp * B + b0 + r) * 2 * h + d * h + c4 * 4);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
+        if (r < 32) *reinterpret_cast<f32x4*>(Hl + r * HLS + c4 * 4) = v[i];
+      }
+      __syncthreads();
+      const float* hrow = Hl + (bt * 16 + jb) * HLS + 2 * ku;
+#pragma unroll
+      for (int j = 0; j < kPersistMaxH / 8; ++j) {
+        if (8 * j < h) {
+          const float2 bv = *reinterpret_cast<const float2*>(hrow + 8 * j);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[j].x, bv.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[j].y, bv.y, acc, 0, 0, 0);
+        }
+      }
+    }
+    if (live) {
+      const float gi = sigmoid_f(acc[0] + gx[0]), gf = sigmoid_f(acc[1] + gx[1]);
+      const float gg = tanh_f(acc[2] + gx[2]), go = sigmoid_f(acc[3] + gx[3]);
+      const float c = fmaf(gf, cprev, gi * gg);
+      const float hv = go * tanh_f(c);
+      cprev = c;
+      const size_t s = (((size_t)tt * 2 + d) * B + b) * h + u;
+      Cs[s] = c;
+      *reinterpret_cast<float4*>(R + s * 4) = make_float4(gi, gf, gg, go);
+      store_sc1(out + ((size_t)tt * B + b) * 2 * h + d * h + u, hv);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's stores have left
+    __syncthreads();                                        // ... and so have everyone's; the slab in LDS is free
+    if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 }  // namespace
 }  // namespace tsg
 
@@ -319,7 +443,13 @@ static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
   return 0;
 }
 
-extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs,
+static int persist_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TSG_LSTM_PERSIST"); v = e ? atoi(e) : 0; }     // opt-in: measured no faster than the step kernels
+  return v;
+}
+
+extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                             int B, int T, int h, int dtype, void* stream) {
   const char* fn = "tsg_lstm_fwd";
   for (const void* p : {Gx, Whh, (const void*)out, (const void*)R, (const void*)Cs}) {
@@ -328,13 +458,36 @@ extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R,
   }
   int rc = lstm_check(fn, B, T, h, dtype);
   if (rc) return rc;
+  auto st = static_cast<hipStream_t>(stream);
+  // persistent path: weights stationary, one launch for all T steps -- needs every workgroup resident
+  if (sync_ws && persist_enabled() && h % 16 == 0 && h <= kPersistMaxH && T > 1) {
+    const int grid = 2 * (h / 16) * cdiv(B, 32);
+    const int HLS = roundup(h, 64) + 4;
+    const size_t plds = sizeof(float) * (size_t)32 * HLS;
+    auto pk = lstm_fwd_persist_kernel;
+    static int capacity = -1;
+    if (capacity < 0) {
+      int dev = 0, cus = 0, per = 0;
+      hipError_t e1 = allow_lds(pk, sizeof(float) * 32 * (kPersistMaxH + 4));
+      if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
+      if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, kThreads, sizeof(float) * 32 * (kPersistMaxH + 4));
+      capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;      // count ONE workgroup per CU: margin against over-reporting
+    }
+    if (grid <= capacity) {
+      hipError_t e = hipMemsetAsync(sync_ws, 0, 256, st);
+      if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+      hipLaunchKernelGGL(pk, dim3(grid), dim3(kThreads), plds, st, (const float*)Gx, (const float*)Whh, (float*)out,
+                         (float*)R, (float*)Cs, (unsigned*)sync_ws, B, T, h, HLS);
+      return check_launch(fn);
+    }
+  }
   const int WS = roundup(h, 64) + 4;                     // = 4 mod 64
   const size_t lds = sizeof(float) * ((size_t)16 * WS + (size_t)kWaves * NBUF * 16 * HS);
   if (lds > (size_t)kLdsBytes) return set_error(TSG_E_LDS, "%s: h=%d needs %zu B of LDS", fn, h, lds);
   auto kern = lstm_fwd_step_kernel;
   hipError_t e = allow_lds(kern, lds);
   if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
-  auto st = static_cast<hipStream_t>(stream);
   const int grid = 2 * cdiv(h, 4);
   for (int step = 0; step < T; ++step)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, (const float*)Gx, (const float*)Whh, (float*)out,

@@ -259,7 +259,9 @@ class _BiLSTMLayer(torch.autograd.Function):
         out = torch.empty(T, B, 2 * h, device=x.device, dtype=torch.float32)
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=torch.float32)
         Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
-        _call("tsg_lstm_fwd", x, ptr(Gx), ptr(W_hh), ptr(out), ptr(R), ptr(Cs), B, T, h, TSG_F32)
+        sync = torch.empty(64, device=x.device, dtype=torch.int32)          # persistent-kernel arrival counters
+        _call("tsg_lstm_fwd", x, ptr(Gx), ptr(W_hh), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, TSG_F32)
+        ctx.lstm_sync = sync
         ctx.save_for_backward(x, W_ih, W_hh, out, R, Cs)
         ctx.mark_non_differentiable(Cs)
         return out, Cs
