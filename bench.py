@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--d", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-micro", action="store_true", help="skip the stand-alone K2 launches")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 (default, parity mode) or bf16 = library GEMMs in bf16 (fp32 accumulate); kernels stay f32")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
@@ -196,12 +198,15 @@ def main():
     opt = engine.make_optimizer(model, params)
     batch = data.synthetic_batch(a.B, a.T, a.N, seed=1234 + rank, pair=(a.model == "gmd"), device=dev)
 
+    gdt = torch.bfloat16 if a.dtype == "bf16" else None
+
     def step():
         dp.zero_grad()
-        if a.model == "gmd":
-            loss, _, _ = engine.gmd_step(model, batch, params)
-        else:
-            loss, _ = engine.baseline_step(model, batch)
+        with engine.precision(gdt):
+            if a.model == "gmd":
+                loss, _, _ = engine.gmd_step(model, batch, params)
+            else:
+                loss, _ = engine.baseline_step(model, batch)
         loss.backward()
         dp.finish()
         opt.step()
@@ -268,9 +273,10 @@ def main():
         out = {"metric": "clip-query pairs/sec fwd+bwd at B=64,T=128,d=1024", "value": round(a.B * world * a.steps / dt, 2),
                "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": f"{a.model}_train_step: fwd+losses+bwd+grad-allreduce+Adam, "
-                                      f"B={a.B}/GPU,T_clip={a.T},T_word={a.N},d={a.d}, i3d width 1024, GloVe 300",
+                                      f"B={a.B}/GPU,T_clip={a.T},T_word={a.N},d={a.d}, i3d width 1024, GloVe 300"
+                                      + ("; library GEMMs bf16 (fp32 accumulate), HIP kernels / softmax / losses f32" if a.dtype == "bf16" else ""),
                           "global_batch": a.B * world, "parallelism": f"dp{world}", "grad_bytes": dp.grad_bytes},
                "roofline": roof, "kernels": kern,
                "cpu_baseline": cpu_baseline(a.model, params, a.T, a.N, a.cpu_sample) if (a.cpu_sample > 0 and world == 1) else None}

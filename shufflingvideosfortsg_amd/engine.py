@@ -56,6 +56,18 @@ def build_model(kind: str, params: Dict, logger=LOG) -> torch.nn.Module:
     return cls(*copy.deepcopy(make_settings(params)), logger, params["dropout"])
 
 
+def precision(gemm_dtype=None):
+    """Context for one forward: ``None`` / fp32 = parity mode; ``torch.bfloat16`` = every library GEMM
+    (nn.Linear projections via autocast, the LSTM GEMMs via functional.set_gemm_dtype) takes bf16 operands
+    with fp32 accumulation while the HIP kernels, softmaxes and losses stay fp32."""
+    import contextlib
+    from . import functional as TF
+    TF.set_gemm_dtype(gemm_dtype)
+    if gemm_dtype in (None, torch.float32):
+        return contextlib.nullcontext()
+    return torch.autocast("cuda", dtype=gemm_dtype)
+
+
 def make_optimizer(model, params):
     return torch.optim.Adam(model.parameters(), lr=params["lr"], weight_decay=params["weight_decay"], eps=1e-6)
 

@@ -57,6 +57,30 @@ def _call(name: str, like: torch.Tensor, *args) -> None:
     check(rc, name)
 
 
+# Library-GEMM precision of the adjacent glue (the LSTM's input / weight-gradient GEMMs): None = fp32
+# (parity mode, default), torch.bfloat16 = bf16 operands with fp32 accumulation (BASELINE configs 2-4).
+# The hand-written kernels always compute in fp32.
+_GEMM_DTYPE = None
+
+
+def set_gemm_dtype(dtype=None):
+    global _GEMM_DTYPE
+    if dtype not in (None, torch.float32, torch.bfloat16):
+        raise ValueError("gemm dtype must be None/float32 or bfloat16")
+    _GEMM_DTYPE = None if dtype in (None, torch.float32) else dtype
+
+
+def _mm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """fp32 [M,K] @ [K,N] -> fp32, through rocBLAS/hipBLASLt in the configured GEMM precision."""
+    if _GEMM_DTYPE is None:
+        return a @ b
+    return (a.to(_GEMM_DTYPE) @ b.to(_GEMM_DTYPE)).float()
+
+
+_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)     # under autocast: fp32 in, autocast off inside
+_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise TypeError(f"fp32 tensor expected, got {t.dtype}")
@@ -67,6 +91,7 @@ class _ScdmAttn(torch.autograd.Function):
     """K1: (a=[B,T,H], s=[B,N,H], w=[H], sent=[B,N,Ds]) -> (C=[B,T,Ds], P=[B,T,N])."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, a, s, w, sent):
         require_device(a, s, w, sent)
         a, s, w, sent = _f32c(a), _f32c(s), _f32c(w), _f32c(sent)
@@ -83,6 +108,7 @@ class _ScdmAttn(torch.autograd.Function):
         return C, P
 
     @staticmethod
+    @_bwd
     def backward(ctx, dC, _dP):
         a, s, w, sent, P = ctx.saved_tensors
         dC = _f32c(dC)
@@ -106,6 +132,7 @@ class _ScdmGate(torch.autograd.Function):
     """K1g: (a, s, w, VW=[B,N,Ds], gbias=[Ds], r=[B,T,Ds]) -> out = r * sigmoid(P @ VW + gbias)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, a, s, w, VW, gbias, r):
         require_device(a, s, w, VW, gbias, r)
         a, s, w, VW, gbias, r = _f32c(a), _f32c(s), _f32c(w), _f32c(VW), _f32c(gbias), _f32c(r)
@@ -121,6 +148,7 @@ class _ScdmGate(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd
     def backward(ctx, dout):
         a, s, w, VW, gbias, r, P = ctx.saved_tensors
         dout = _f32c(dout)
@@ -145,6 +173,7 @@ class _BoundaryScore(torch.autograd.Function):
     -> (p_start, p_end) [B,T]."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, y, cs, b1, w2, b2, gate, mask):
         require_device(y, cs, b1, w2, b2, gate, mask)
         y, cs, b1, w2, b2 = _f32c(y), _f32c(cs), _f32c(b1), _f32c(w2), _f32c(b2)
@@ -164,6 +193,7 @@ class _BoundaryScore(torch.autograd.Function):
         return ps, pe
 
     @staticmethod
+    @_bwd
     def backward(ctx, dps, dpe):
         saved = list(ctx.saved_tensors)
         y, cs, b1, w2, ps, pe = saved[:6]
@@ -198,6 +228,7 @@ class _MHA(torch.autograd.Function):
     chunked heads and caller-provided scale divisor."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, Q, K, V, n_heads, scale, causal, want_maps):
         require_device(Q, K, V)
         Q, K, V = _f32c(Q), _f32c(K), _f32c(V)
@@ -222,6 +253,7 @@ class _MHA(torch.autograd.Function):
         return O, None, None
 
     @staticmethod
+    @_bwd
     def backward(ctx, dO, _dA, _dS):
         Q, K, V, O, lse = ctx.saved_tensors
         n_heads, scale, causal = ctx.cfg
@@ -248,6 +280,7 @@ class _BiLSTMLayer(torch.autograd.Function):
     weight-gradient GEMMs are library GEMMs (rocBLAS via torch); the recurrence is libtsg_hip.so."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, W_ih, bias, W_hh):
         require_device(x, W_ih, bias, W_hh)
         x, W_ih, bias, W_hh = _f32c(x), _f32c(W_ih), _f32c(bias), _f32c(W_hh)
@@ -255,7 +288,7 @@ class _BiLSTMLayer(torch.autograd.Function):
         h = W_hh.shape[2]
         if W_ih.shape != (8 * h, I) or W_hh.shape != (2, 4 * h, h) or bias.numel() != 8 * h:
             raise ValueError(f"bilstm: shape mismatch x{tuple(x.shape)} W_ih{tuple(W_ih.shape)} W_hh{tuple(W_hh.shape)}")
-        Gx = torch.addmm(bias, x.view(T * B, I), W_ih.t())                  # [T,B,2,4h]
+        Gx = _mm(x.view(T * B, I), W_ih.t()).add_(bias)                       # [T,B,2,4h]
         out = torch.empty(T, B, 2 * h, device=x.device, dtype=torch.float32)
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=torch.float32)
         Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
@@ -267,6 +300,7 @@ class _BiLSTMLayer(torch.autograd.Function):
         return out, Cs
 
     @staticmethod
+    @_bwd
     def backward(ctx, dOut, _dCs):
         x, W_ih, W_hh, out, R, Cs = ctx.saved_tensors
         T, B, I = x.shape
@@ -277,14 +311,14 @@ class _BiLSTMLayer(torch.autograd.Function):
         dC = torch.empty(2, B, h, device=x.device, dtype=torch.float32)
         _call("tsg_lstm_bwd", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC), B, T, h, TSG_F32)
         dGf = dG.view(T * B, 8 * h)
-        dx = (dGf @ W_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
-        dW_ih = dGf.t() @ x.view(T * B, I)
+        dx = _mm(dGf, W_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
+        dW_ih = _mm(dGf.t(), x.view(T * B, I))
         dbias = dGf.sum(0)
         zero = out.new_zeros(1, B, h)
         hprev_f = torch.cat([zero, out[:-1, :, :h]], 0).reshape(T * B, h)        # h_{t-1} of the forward direction
         hprev_r = torch.cat([out[1:, :, h:], zero], 0).reshape(T * B, h)         # h_{t+1} feeds the reverse direction
-        dW_hh = torch.stack([dG[:, :, 0].reshape(T * B, 4 * h).t() @ hprev_f,
-                             dG[:, :, 1].reshape(T * B, 4 * h).t() @ hprev_r])
+        dW_hh = torch.stack([_mm(dG[:, :, 0].reshape(T * B, 4 * h).t(), hprev_f),
+                             _mm(dG[:, :, 1].reshape(T * B, 4 * h).t(), hprev_r)])
         return dx, dW_ih, dbias, dW_hh
 
 

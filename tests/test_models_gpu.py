@@ -230,3 +230,26 @@ def test_full_size_properties():
     C0, P0 = O.scdm_core(a[:2], s[:2], w, sent[:2])
     torch.testing.assert_close(C[:2].detach().cpu(), C0, **TOL)
     torch.testing.assert_close(P[:2].detach().cpu(), P0, **TOL)
+
+
+def test_bf16_gemm_mode_tracks_fp32(golden):
+    """Training-precision mode (library GEMMs in bf16, kernels fp32): boundary scores stay within bf16
+    noise of the reference's fp32 result and the step is differentiable."""
+    from shufflingvideosfortsg_amd import engine
+    from shufflingvideosfortsg_amd import loss as L
+    from shufflingvideosfortsg_amd.model import Baseline
+    g = golden("baseline_nomask")
+    m = Baseline(*_sets(24, 8, 12, 16), LOG, 0.0)
+    m.load_state_dict(g.weights)
+    m.cuda().train()
+    try:
+        with engine.precision(torch.bfloat16):
+            out = m(g.t("video").cuda(), g.t("query").cuda(), g.t("vmask").cuda(), None)
+            loss = L.span_ground_loss(out["start"], out["end"], g.a["framestps"])
+        loss.backward()
+    finally:
+        engine.precision(None)
+    assert out["start"].dtype == torch.float32
+    torch.testing.assert_close(out["start"].detach().cpu(), g.t("start"), atol=2e-2, rtol=5e-2)
+    torch.testing.assert_close(loss.detach().cpu(), g.t("loss"), atol=5e-2, rtol=5e-2)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
