@@ -186,7 +186,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("TSG_FORCE_DIST") == "1"      # the latter: exercise the RCCL path on one GPU
+    if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     params = engine.default_params(video_rnn_hiddendim=a.d // 2, sent_rnn_hiddendim=a.d // 2,
@@ -218,19 +219,19 @@ def main():
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
     functional.kernel_timer.enable()          # event pairs around every hot-path kernel launch
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     functional.kernel_timer.disable()
     log(f"timed {a.steps} steps in {dt:.3f} s")
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -281,7 +282,7 @@ def main():
                "roofline": roof, "kernels": kern,
                "cpu_baseline": cpu_baseline(a.model, params, a.T, a.N, a.cpu_sample) if (a.cpu_sample > 0 and world == 1) else None}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

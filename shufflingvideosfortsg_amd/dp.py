@@ -52,7 +52,8 @@ class FlatGradAllReduce:
             self.buckets.append((start, off, count))
         self._ready = [0] * len(self.buckets)
         self._handles = []
-        self.overlap = overlap and self.world > 1
+        self._force = dist.is_initialized() and __import__("os").environ.get("TSG_FORCE_DIST") == "1"
+        self.overlap = overlap and (self.world > 1 or self._force)
         if self.overlap:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
@@ -83,7 +84,7 @@ class FlatGradAllReduce:
 
     def finish(self):
         """Complete the gradient exchange: afterwards every rank holds the mean gradient."""
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             return
         if self.overlap:
             for b, (s, e, n) in enumerate(self.buckets):   # parameters that received no gradient
