@@ -601,12 +601,18 @@ __global__ __launch_bounds__(kMfmaThreads) void mha_bwd_mfma_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dkt[r] = 0.f; dvt[r] = 0.f; }
 
+    // Q / dO tiles: the next tile's rows are requested while the current tile is in the MFMAs
+    t0.load(Qb, dk, 0, Tq, 32, dh, DHMAX / 4); t1.load(Gb, dv, 0, Tq, 32, dvh, DHMAX / 4);
+    float lse_n = (tid < 32 && tid < Tq) ? lse[tid] : 0.f, dl_n = (tid < 32 && tid < Tq) ? dlt[tid] : 0.f;
     for (int q0 = 0; q0 < Tq; q0 += 32) {
       __syncthreads();                                     // previous tile's readers are done
-      t0.load(Qb, dk, q0, Tq, 32, dh, DHMAX / 4); t1.load(Gb, dv, q0, Tq, 32, dvh, DHMAX / 4);
       t0.store(Ql, KS, 32, DHMAX / 4); t1.store(Gl, VS2, 32, DHMAX / 4);
-      if (tid < 32) { lsel[tid] = (q0 + tid < Tq) ? lse[q0 + tid] : 0.f; dl[tid] = (q0 + tid < Tq) ? dlt[q0 + tid] : 0.f; }
+      if (tid < 32) { lsel[tid] = lse_n; dl[tid] = dl_n; }
       __syncthreads();
+      if (q0 + 32 < Tq) {
+        t0.load(Qb, dk, q0 + 32, Tq, 32, dh, DHMAX / 4); t1.load(Gb, dv, q0 + 32, Tq, 32, dvh, DHMAX / 4);
+        if (tid < 32) { lse_n = (q0 + 32 + tid < Tq) ? lse[q0 + 32 + tid] : 0.f; dl_n = (q0 + 32 + tid < Tq) ? dlt[q0 + 32 + tid] : 0.f; }
+      }
 
       // partial S = Q K^T and dP = dO V^T over this wave's 32 channels (A: rows = queries, B: cols = keys)
       f32x16 sp, dp;

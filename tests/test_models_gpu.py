@@ -253,3 +253,30 @@ def test_bf16_gemm_mode_tracks_fp32(golden):
     torch.testing.assert_close(out["start"].detach().cpu(), g.t("start"), atol=2e-2, rtol=5e-2)
     torch.testing.assert_close(loss.detach().cpu(), g.t("loss"), atol=5e-2, rtol=5e-2)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_gmd_large_config_vs_oracle():
+    """ActivityNet-style shape of BASELINE configs 3/4 (T_clip=256, T_word=25 -> the 28-word kernel
+    instantiation, d=1024), batch reduced for the CPU oracle: full GMD step, default init, vs the oracle."""
+    from shufflingvideosfortsg_amd import data, engine
+    params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, dropout=0.0, video_len=256, sent_len=25)
+    torch.manual_seed(0)
+    model = engine.build_model("gmd", params)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    b = data.synthetic_batch(2, 256, 25, seed=7, pair=True)
+    g, pg = b["gt"], b["pseudo_gt"]
+    ref = O.gmd_forward(sd, b["query"], b["video"], b["video_mask"], b["pseudo_video"], b["video_mask"],
+                        g["temporal_labels"], g["fore_masks"], g["back_masks"],
+                        pg["temporal_labels"], pg["fore_masks"], pg["back_masks"])
+    ref_loss, _ = O.gmd_losses(ref, b["video_mask"], b["video_mask"], g, pg)
+    ref_loss.backward()
+    model = model.cuda().train()
+    model.tod.dropout.p = 0.0
+    d = data.synthetic_batch(2, 256, 25, seed=7, pair=True, device="cuda")
+    loss, _, span = engine.gmd_step(model, d, params)
+    loss.backward()
+    torch.testing.assert_close(span["start"].detach().cpu(), ref[0]["start"].detach(), **TOL)
+    torch.testing.assert_close(span["end"].detach().cpu(), ref[0]["end"].detach(), **TOL)
+    torch.testing.assert_close(loss.detach().cpu(), ref_loss.detach(), **TOL)
+    for k, p in model.named_parameters():
+        torch.testing.assert_close(p.grad.cpu(), sd[k].grad, atol=5e-4, rtol=5e-3, msg=lambda m, k=k: f"{k}: {m}")
