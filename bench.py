@@ -174,8 +174,9 @@ def main():
     ap.add_argument("--d", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-micro", action="store_true", help="skip the stand-alone K2 launches")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32s"],
                     help="f32 (default, parity mode) or bf16 = library GEMMs in bf16 (fp32 accumulate); kernels stay f32")
+    ap.add_argument("--no-alt", action="store_true", help="skip the side measurement in the other GEMM-operand mode")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
@@ -199,7 +200,7 @@ def main():
     opt = engine.make_optimizer(model, params)
     batch = data.synthetic_batch(a.B, a.T, a.N, seed=1234 + rank, pair=(a.model == "gmd"), device=dev)
 
-    gdt = torch.bfloat16 if a.dtype == "bf16" else None
+    gdt = {"f32": None, "bf16": torch.bfloat16, "f32s": "f32s"}[a.dtype]
 
     def step():
         dp.zero_grad()
@@ -237,6 +238,40 @@ def main():
         dt = float(t.item())
     if not torch.isfinite(loss):
         raise SystemExit("non-finite loss in the timed region")
+
+    # side measurements, outside the timed region above and never `value`: the same K steps in the other library-GEMM
+    # modes (BASELINE config 2 names bf16; the headline stays strict fp32 so that the 1e-4 parity bar applies to it)
+    MODES = {"f32": None, "bf16": torch.bfloat16, "f32s": "f32s"}
+    NOTES = {"f32": "all-f32 (rocBLAS fp32 MFMA GEMMs)",
+             "bf16": "library GEMM operands bf16, fp32 accumulate; HIP kernels, recurrent state, softmax, losses, optimizer "
+                     "f32; deviates ~1e-3 from the fp32 reference",
+             "f32s": "LSTM input/weight-gradient GEMMs as split-precision bf16 MFMA GEMMs (hi*hi+hi*lo+lo*hi, fp32 "
+                     "accumulate: fp32-GEMM-level error, passes the fp32 parity suite); everything else f32"}
+    alt = []
+    gdt_main = gdt
+    for mode in ([] if a.no_alt else [m for m in MODES if m != a.dtype]):
+        gdt = MODES[mode]
+        for _ in range(2):
+            step()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            loss2 = step()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+        alt.append({"dtype": mode, "value": round(a.B * world * a.steps / dt2, 2), "unit": "pairs/s",
+                    "ms_per_step": round(dt2 / a.steps * 1e3, 3), "finite": bool(torch.isfinite(loss2)), "note": NOTES[mode]})
+        log(f"alternate GEMM mode {mode}: {alt[-1]['ms_per_step']} ms/step")
+    gdt = gdt_main
+    functional.set_gemm_dtype(gdt_main)
 
     if rank == 0:
         kt = functional.kernel_timer.summary()          # (name, dims) -> (mean us, launches)
@@ -277,9 +312,9 @@ def main():
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": f"{a.model}_train_step: fwd+losses+bwd+grad-allreduce+Adam, "
                                       f"B={a.B}/GPU,T_clip={a.T},T_word={a.N},d={a.d}, i3d width 1024, GloVe 300"
-                                      + ("; library GEMMs bf16 (fp32 accumulate), HIP kernels / softmax / losses f32" if a.dtype == "bf16" else ""),
+                                      + ("" if a.dtype == "f32" else "; " + NOTES[a.dtype]),
                           "global_batch": a.B * world, "parallelism": f"dp{world}", "grad_bytes": dp.grad_bytes},
-               "roofline": roof, "kernels": kern,
+               "roofline": roof, "alt_gemm_modes": alt, "kernels": kern,
                "cpu_baseline": cpu_baseline(a.model, params, a.T, a.N, a.cpu_sample) if (a.cpu_sample > 0 and world == 1) else None}
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -133,6 +133,15 @@ int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, 
 int tsg_lstm_bwd(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
                  void* dG, void* dC_ws, int B, int T, int h, int dtype, void* stream);
 
+/* ---- split-precision operand preparation (optional "f32s" GEMM mode) ------------------------------------------------
+ * Not a reference function: the reference's Linears / LSTM input GEMMs (torch.nn.Linear, nn.LSTM; e.g.
+ * attention.py:104-106, RNN.py:27) run as fp32 GEMMs.  x [rows, cols] fp32 -> three bf16 planes at
+ * out[r*ld_out + p*plane_stride + c], p = 0..2: (hi, hi, lo) for the left operand, (hi, lo, hi) when
+ * right_operand != 0, hi = rne_bf16(x), lo = rne_bf16(x - hi).  One bf16 MFMA GEMM with fp32 accumulate over the
+ * 3x longer contraction then gives hi·hi + hi·lo + lo·hi (fp32-GEMM-level error).  cols % 4 == 0.                    */
+int tsg_split_bf16x3(const void* x, void* out, long long rows, long long cols, long long ld_out, long long plane_stride,
+                     int right_operand, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

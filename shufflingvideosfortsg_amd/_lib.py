@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_uint64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_uint64, c_void_p
 
 import torch  # noqa: F401  (must be imported first: libtsg_hip.so reuses torch's libamdhip64.so.7)
 
@@ -28,6 +28,7 @@ _SIGNATURES = {
     "tsg_mha_fwd": [_P] * 7 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
     "tsg_lstm_fwd": [_P] * 6 + [_I] * 4 + [_P],
     "tsg_lstm_bwd": [_P] * 7 + [_I] * 4 + [_P],
+    "tsg_split_bf16x3": [_P, _P, c_longlong, c_longlong, c_longlong, c_longlong, _I, _P],
     "tsg_mha_bwd": [_P] * 10 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
 }
 _RESTYPE = {"tsg_last_error": c_char_p}

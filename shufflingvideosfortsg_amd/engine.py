@@ -63,7 +63,7 @@ def precision(gemm_dtype=None):
     import contextlib
     from . import functional as TF
     TF.set_gemm_dtype(gemm_dtype)
-    if gemm_dtype in (None, torch.float32):
+    if gemm_dtype in (None, torch.float32, "f32s"):        # "f32s": split-precision LSTM GEMMs, everything else fp32
         return contextlib.nullcontext()
     return torch.autocast("cuda", dtype=gemm_dtype)
 

@@ -57,23 +57,54 @@ def _call(name: str, like: torch.Tensor, *args) -> None:
     check(rc, name)
 
 
-# Library-GEMM precision of the adjacent glue (the LSTM's input / weight-gradient GEMMs): None = fp32
-# (parity mode, default), torch.bfloat16 = bf16 operands with fp32 accumulation (BASELINE configs 2-4).
+# Library-GEMM precision of the adjacent glue (the LSTM's input / weight-gradient GEMMs): None = fp32 rocBLAS
+# (parity mode, default); torch.bfloat16 = bf16 operands with fp32 accumulation (BASELINE configs 2-4);
+# "f32s" = split precision: both operands as bf16 (hi, lo) planes (tsg_split_bf16x3), ONE bf16 MFMA GEMM over the
+# 3x longer contraction with fp32 accumulate = hi·hi + hi·lo + lo·hi, fp32-GEMM-level error at 2-3x its speed.
 # The hand-written kernels always compute in fp32.
 _GEMM_DTYPE = None
 
 
 def set_gemm_dtype(dtype=None):
     global _GEMM_DTYPE
-    if dtype not in (None, torch.float32, torch.bfloat16):
-        raise ValueError("gemm dtype must be None/float32 or bfloat16")
+    if dtype not in (None, torch.float32, torch.bfloat16, "f32s"):
+        raise ValueError("gemm dtype must be None/float32, bfloat16 or 'f32s'")
     _GEMM_DTYPE = None if dtype in (None, torch.float32) else dtype
+
+
+def split_bf16x3(x: torch.Tensor, k_dim: int, right: bool) -> torch.Tensor:
+    """fp32 contiguous [R,C] -> bf16 with the contraction dimension ``k_dim`` tripled: planes (hi,hi,lo) for a
+    left GEMM operand, (hi,lo,hi) for a right one (include/tsg_hip.h: tsg_split_bf16x3)."""
+    require_device(x)
+    x = _f32c(x)
+    R, C = x.shape
+    if k_dim == 1:
+        out = torch.empty(R, 3 * C, device=x.device, dtype=torch.bfloat16)
+        ld, plane = 3 * C, C
+    else:
+        out = torch.empty(3 * R, C, device=x.device, dtype=torch.bfloat16)
+        ld, plane = C, R * C
+    _call("tsg_split_bf16x3", x, ptr(x), ptr(out), R, C, ld, plane, int(right))
+    return out
+
+
+def _split_operand(m: torch.Tensor, k_dim: int, right: bool) -> torch.Tensor:
+    """Split a (possibly transposed-view) fp32 matrix without materialising the transpose."""
+    if m.is_contiguous():
+        return split_bf16x3(m, k_dim, right)
+    if m.t().is_contiguous():
+        return split_bf16x3(m.t(), 1 - k_dim, right).t()
+    return split_bf16x3(m.contiguous(), k_dim, right)
 
 
 def _mm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """fp32 [M,K] @ [K,N] -> fp32, through rocBLAS/hipBLASLt in the configured GEMM precision."""
     if _GEMM_DTYPE is None:
         return a @ b
+    if _GEMM_DTYPE == "f32s":
+        if a.shape[1] % 4 or a.shape[0] % 4 or b.shape[1] % 4:
+            return a @ b
+        return torch.mm(_split_operand(a, 1, False), _split_operand(b, 0, True), out_dtype=torch.float32)
     return (a.to(_GEMM_DTYPE) @ b.to(_GEMM_DTYPE)).float()
 
 
@@ -312,13 +343,21 @@ class _BiLSTMLayer(torch.autograd.Function):
         _call("tsg_lstm_bwd", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC), B, T, h, TSG_F32)
         dGf = dG.view(T * B, 8 * h)
         dx = _mm(dGf, W_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
-        dW_ih = _mm(dGf.t(), x.view(T * B, I))
         dbias = dGf.sum(0)
         zero = out.new_zeros(1, B, h)
         hprev_f = torch.cat([zero, out[:-1, :, :h]], 0).reshape(T * B, h)        # h_{t-1} of the forward direction
         hprev_r = torch.cat([out[1:, :, h:], zero], 0).reshape(T * B, h)         # h_{t+1} feeds the reverse direction
-        dW_hh = torch.stack([_mm(dG[:, :, 0].reshape(T * B, 4 * h).t(), hprev_f),
-                             _mm(dG[:, :, 1].reshape(T * B, 4 * h).t(), hprev_r)])
+        if _GEMM_DTYPE == "f32s" and (T * B) % 4 == 0 and h % 4 == 0 and I % 4 == 0:
+            # one split of dG along the T·B contraction serves the three weight-gradient GEMMs (column slices of the
+            # [3·T·B, 8h] planes are strided views the GEMM takes as they are)
+            S = split_bf16x3(dGf, 0, False)
+            mm3 = lambda a3, b: torch.mm(a3.t(), split_bf16x3(b, 0, True), out_dtype=torch.float32)
+            dW_ih = mm3(S, x.view(T * B, I))
+            dW_hh = torch.stack([mm3(S[:, :4 * h], hprev_f), mm3(S[:, 4 * h:], hprev_r)])
+        else:
+            dW_ih = _mm(dGf.t(), x.view(T * B, I))
+            dW_hh = torch.stack([_mm(dG[:, :, 0].reshape(T * B, 4 * h).t(), hprev_f),
+                                 _mm(dG[:, :, 1].reshape(T * B, 4 * h).t(), hprev_r)])
         return dx, dW_ih, dbias, dW_hh
 
 

@@ -155,9 +155,13 @@ def test_baseline_golden(golden, tag):
     torch.testing.assert_close(score.cpu(), g.t("score"), **TOL)
 
 
-def test_gmd_golden(golden):
-    """Full GMD train step (original + shuffled video, four losses) and eval_forward vs the reference."""
+@pytest.mark.parametrize("gemm", [None, "f32s"])
+def test_gmd_golden(golden, gemm, request):
+    """Full GMD train step (original + shuffled video, four losses) and eval_forward vs the reference; also with the
+    LSTM GEMMs in split-precision mode ("f32s"), which must meet the SAME fp32 tolerances."""
     from shufflingvideosfortsg_amd import engine
+    engine.precision(gemm)
+    request.addfinalizer(lambda: engine.precision(None))
     from shufflingvideosfortsg_amd.model import GMD
     g = golden("gmd")
     m = GMD(*_sets(24, 8, 12, 16), LOG, 0.0)
@@ -255,10 +259,14 @@ def test_bf16_gemm_mode_tracks_fp32(golden):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
 
 
-def test_gmd_large_config_vs_oracle():
+@pytest.mark.parametrize("gemm", [None, "f32s"])
+def test_gmd_large_config_vs_oracle(gemm, request):
     """ActivityNet-style shape of BASELINE configs 3/4 (T_clip=256, T_word=25 -> the 28-word kernel
-    instantiation, d=1024), batch reduced for the CPU oracle: full GMD step, default init, vs the oracle."""
+    instantiation, d=1024), batch reduced for the CPU oracle: full GMD step, default init, vs the oracle
+    (fp32 GEMMs and the split-precision "f32s" GEMM mode, same tolerances)."""
     from shufflingvideosfortsg_amd import data, engine
+    engine.precision(gemm)
+    request.addfinalizer(lambda: engine.precision(None))
     params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, dropout=0.0, video_len=256, sent_len=25)
     torch.manual_seed(0)
     model = engine.build_model("gmd", params)
