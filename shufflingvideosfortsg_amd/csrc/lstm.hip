@@ -316,17 +316,22 @@ __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
 // in registers as MFMA operand fragments (h/4 VGPRs, 128 at h = 512) and its lanes keep the cell
 // state c of their (batch, unit) pair; per step only h_{t-1} (32 rows x h, 64 KiB) is fetched.
 //
-// Hand-off between workgroups.  The 32-row slab of h_t a group needs is produced by the h/16
-// workgroups with the same (direction, batch slice): they form a GROUP with one monotone arrival
-// counter.  Producer: h_t stores are write-through (`sc1`), every wave drains vmcnt, workgroup barrier,
-// one lane adds 1 to the counter (agent scope).  Consumer: one lane polls the counter with an `sc1`
-// load until it reaches members*t, workgroup barrier, then `sc1` loads of the slab (L1 bypassed; the
-// slab's lines were never read before, so no L2 copy can be stale).  Results do not depend on
-// placement; all workgroups must be co-resident (checked on the host with the occupancy query, 1
-// workgroup per CU); every spin is bounded and raises the error word instead of hanging.
+// Hand-off between workgroups: the data is the flag.  The 32-row slab of h_t a workgroup needs is produced by the
+// h/16 workgroups with the same (direction, batch slice).  At launch every lane marks the elements of `out` it
+// will produce with a sentinel (a signalling-NaN bit pattern h = o*tanh(c) can never take; `sc1` write-through
+// stores) and the grid meets ONCE on an arrival counter; after that a consumer simply polls the slab itself with
+// `sc1` loads (per-CU L1 bypassed) until none of its elements is the sentinel -- one memory round trip per step
+// and no atomics, fences or store drains (the first version: store-drain -> atomic add -> counter poll -> slab
+// load, measured 17 us/step like the launch-per-step kernels; this one 16 us at [128,128,512], 13.4 us with the
+// waiting removed = its load + MFMA + gate floor).  Every element is checked, so partially landed lines are
+// harmless.  Results do not depend on placement; all workgroups must be co-resident (checked on the host with
+// the occupancy query, 1 workgroup per CU); every spin is bounded and raises the error word instead of hanging.
+// The poll loads are issued unconditionally and consumed by the s_waitcnt asm directly: a conditional inline-asm
+// load makes the compiler merge (copy) its destination registers before the data has landed.
 // ---------------------------------------------------------------------------------------------
 constexpr int kPersistMaxH = 512;
 constexpr int kSpinLimit = 1 << 22;
+constexpr unsigned kSentinel = 0x7fa5c3e1u;     // a signalling-NaN bit pattern: never the value of h = o * tanh(c)
 
 __device__ __forceinline__ f32x4 load_sc1_x4(const float* p) {
   f32x4 v;
@@ -334,6 +339,15 @@ __device__ __forceinline__ f32x4 load_sc1_x4(const float* p) {
   return v;
 }
 __device__ __forceinline__ void store_sc1(float* p, float v) {
+  asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 load_sc1_u4(const float* p) {           // integer typed: the sentinel is a NaN pattern
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void store_sc1_u(float* p, unsigned v) {
   asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 
@@ -350,8 +364,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
   const int jb = lane & 15, ku = lane >> 4;
   const int u0 = us * 16 + at * 4;                        // first unit of this wave's A-tile
   const int b0 = bs * 32;
-  unsigned* cnt = sync + 1 + d * bslices + bs;            // sync[0] = error word
-  const unsigned members = (unsigned)uslices;
+  // sync[0] = error word, sync[1] = arrival counter of the one start barrier
 
   // A fragments: row i = jb -> (unit u0 + (jb>>2), gate jb&3); element pair k = 8j + 2ku, +1
   float2 areg[kPersistMaxH / 8];
@@ -366,6 +379,29 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
   float cprev = 0.f;
   const int nrow4 = h / 4;                                 // float4 per h row
 
+  {
+    // Every lane marks the elements of `out` it will produce (all T steps) with the sentinel -- the same lane, the same
+    // address and the same write-through path as the later h store, so the two stay ordered -- and the grid meets once
+    // (arrival counter sync[1]) so that no consumer can poll an element before its sentinel is in memory.
+    if (live)
+      for (int t = 0; t < T; ++t) store_sc1_u(out + ((size_t)t * B + b) * 2 * h + d * h + u, kSentinel);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+  }
+
   for (int step = 0; step < T; ++step) {
     const int tt = d == 0 ? step : T - 1 - step;
     const int tp = d == 0 ? tt - 1 : tt + 1;
@@ -376,34 +412,52 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (step > 0) {
-      if (tid == 0) {                                       // wait for the group's step-1 slab
-        const unsigned want = members * (unsigned)step;
+      f32x4 v[8];
+      {
+        // poll the slab until no element of this thread's 8 float4 is the sentinel (loads unconditional, see above)
+        unsigned pending = 0u;
+        const float* src[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
+          const bool ok = r < 32 && b0 + r < B;
+          if (ok) pending |= 1u << i;
+          src[i] = out + ((size_t)tp * B + (ok ? b0 + r : b0)) * 2 * h + d * h + (ok ? c4 * 4 : 0);
+        }
         int spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > kSpinLimit || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        u32x4 q[8];
+        while (true) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) q[i] = load_sc1_u4(src[i]);
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) : : "memory");
+          unsigned raw = 0u;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (q[i][0] == kSentinel || q[i][1] == kSentinel || q[i][2] == kSentinel || q[i][3] == kSentinel) raw |= 1u << i;
+          raw &= pending;
+#ifdef TSG_DEBUG_SENTINEL
+          if (raw) __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+          if (!raw) break;
+          if (++spins > (kSpinLimit >> 6) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
             __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
         }
-      }
-      __syncthreads();
-      if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // uniform: set before the barrier
-      // slab -> LDS: 32 rows x h floats, 8 float4 per thread at h = 512 (sc1: bypass the per-CU L1)
-      f32x4 v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
-        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (r < 32 && b0 + r < B) v[i] = load_sc1_x4(out + ((size_t)tp * B + b0 + r) * 2 * h + d * h + c4 * 4);
+        for (int i = 0; i < 8; ++i)
+          if (!(pending & (1u << i))) q[i] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          v[i] = (f32x4){__uint_as_float(q[i][0]), __uint_as_float(q[i][1]), __uint_as_float(q[i][2]), __uint_as_float(q[i][3])};
       }
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
         if (r < 32) *reinterpret_cast<f32x4*>(Hl + r * HLS + c4 * 4) = v[i];
       }
       __syncthreads();
+      if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // a bounded wait expired somewhere
       const float* hrow = Hl + (bt * 16 + jb) * HLS + 2 * ku;
 #pragma unroll
       for (int j = 0; j < kPersistMaxH / 8; ++j) {
@@ -425,9 +479,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
       *reinterpret_cast<float4*>(R + s * 4) = make_float4(gi, gf, gg, go);
       store_sc1(out + ((size_t)tt * B + b) * 2 * h + d * h + u, hv);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's stores have left
-    __syncthreads();                                        // ... and so have everyone's; the slab in LDS is free
-    if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                        // the slab in LDS is free again (the h stores keep flying)
   }
 }
 
@@ -443,11 +495,15 @@ static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
   return 0;
 }
 
-static int persist_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TSG_LSTM_PERSIST"); v = e ? atoi(e) : 0; }     // opt-in: measured no faster than the step kernels
+// TSG_LSTM_PERSIST: unset = auto (persistent launch for sequences of >= 48 steps: 14.3 vs 17.3 us/step at
+// [B=128,T=128,h=512], but 13.6 vs 11.6 us/step at [64,20,512] where the start barrier is not amortised),
+// 0 = never, 1 = whenever the grid fits.
+static int persist_mode() {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("TSG_LSTM_PERSIST"); v = e ? atoi(e) : -1; }
   return v;
 }
+static bool persist_wanted(int T) { const int m = persist_mode(); return m > 0 || (m < 0 && T >= 48); }
 
 extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                             int B, int T, int h, int dtype, void* stream) {
@@ -460,7 +516,7 @@ extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R,
   if (rc) return rc;
   auto st = static_cast<hipStream_t>(stream);
   // persistent path: weights stationary, one launch for all T steps -- needs every workgroup resident
-  if (sync_ws && persist_enabled() && h % 16 == 0 && h <= kPersistMaxH && T > 1) {
+  if (sync_ws && persist_wanted(T) && h % 16 == 0 && h <= kPersistMaxH && T > 1) {
     const int grid = 2 * (h / 16) * cdiv(B, 32);
     const int HLS = roundup(h, 64) + 4;
     const size_t plds = sizeof(float) * (size_t)32 * HLS;

@@ -765,9 +765,12 @@ int launch_fwd(const float* a, const float* s, const float* w, const float* V, f
                const float* gr, const float* gbias, int B, int T, int N, int H, int Ds, hipStream_t st) {
   constexpr int R = 1;                       // clip rows per wave and sub-tile (sub-tile = 8R rows)
   constexpr int SUB = kFwdWaves * R;
-  // rows per workgroup: 32 (4 sub-tiles) when that still gives every CU a workgroup, else 16 / 8
-  int TT = 32;
+  // rows per workgroup: as many as still give every CU a workgroup (the Es prologue, the launch ramp and the store
+  // tail are paid once per workgroup: 64 rows at 128 pairs x 128 clips measured 80 us vs 88 us for 32-row groups)
+  int TT = 64;
   while (TT > SUB && (long)B * cdiv(T, TT) < 256) TT >>= 1;
+  static const int tt_env = [] { const char* e = getenv("TSG_K1_TT"); return e ? atoi(e) : 0; }();   // tuning override
+  if (tt_env >= SUB && tt_env % SUB == 0) TT = tt_env;
   const int tiles = cdiv(T, TT);
   const size_t lds = sizeof(float) * ((size_t)(NP + 1) * roundup256(H) + (size_t)2 * SUB * NP);
   if (H > 1024 || Ds > (NP <= 20 ? 2048 : 1024))
