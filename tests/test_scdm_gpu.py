@@ -26,7 +26,10 @@ def _run(B, T, N, H, Ds, seed=0, scale=1.0):
     torch.testing.assert_close(P1.cpu(), P0.detach(), **TOL)
     torch.testing.assert_close(C1.detach().cpu(), C0.detach(), **TOL)
     for got, want, name in zip((ad, sd, wd, vd), ref, "a s w sent".split()):
-        torch.testing.assert_close(got.grad.cpu(), want, atol=2e-4, rtol=1e-3, msg=lambda m, n=name: f"d{n}: {m}")
+        # absolute tolerance on the gradient's own scale: dw sums B*T*N terms (|dw| ~ 700 at 130 x 100 x 20, where the
+        # fp32 ORACLE is 1.3e-2 from float64 and the kernel 3.4e-4: tools/dw_check.py)
+        atol = 2e-4 * max(1.0, float(want.abs().max()))
+        torch.testing.assert_close(got.grad.cpu(), want, atol=atol, rtol=1e-3, msg=lambda m, n=name: f"d{n}: {m}")
 
 
 @pytest.mark.parametrize("shape", [
@@ -41,6 +44,13 @@ def _run(B, T, N, H, Ds, seed=0, scale=1.0):
 ])
 def test_scdm_parity(shape):
     _run(*shape)
+
+
+def test_scdm_full_grid_ragged_tiles():
+    """Enough pairs that the forward picks its 64-row workgroups (>= 256 tiles; 8 pipelined sub-tiles each) with a
+    ragged last tile (T = 100 = 64 + 36), and the 32-row variant (T = 40, B = 140: 280 tiles of 32)."""
+    _run(130, 100, 20, 256, 256, seed=5)
+    _run(140, 40, 15, 128, 132, seed=6)
 
 
 def test_scdm_large_activations():
@@ -69,7 +79,8 @@ def test_scdm_errors():
         F.scdm_attn(torch.randn(1, 4, 8).cuda(), torch.randn(1, 40, 8).cuda(), w.cuda(), torch.randn(1, 40, 8).cuda())
 
 
-@pytest.mark.parametrize("shape", [(2, 9, 5, 24), (3, 17, 20, 40), (2, 32, 15, 512), (2, 128, 20, 1024), (2, 40, 25, 1024), (1, 33, 32, 260)])
+@pytest.mark.parametrize("shape", [(2, 9, 5, 24), (3, 17, 20, 40), (2, 32, 15, 512), (2, 128, 20, 1024), (2, 40, 25, 1024), (1, 33, 32, 260),
+                                   (130, 100, 20, 256)])        # last: 64-row workgroups, ragged last tile
 def test_scdm_gate_parity(shape):
     """K1g (attention + sent_linear + sigmoid gate fused, sent_linear reassociated onto the word rows)
     vs the oracle's un-fused tail of rnn_recalibration_layer."""
@@ -94,4 +105,5 @@ def test_scdm_gate_parity(shape):
     torch.cuda.synchronize()
     torch.testing.assert_close(out1.detach().cpu(), out0.detach(), **TOL)
     for got, want, name in zip([rd, wd] + list(pd.values()), ref, ["r", "word"] + list(p.keys())):
-        torch.testing.assert_close(got.grad.cpu(), want, atol=3e-4, rtol=2e-3, msg=lambda m, n=name: f"d{n}: {m}")
+        atol = 3e-4 * max(1.0, float(want.abs().max()))        # on the gradient's own scale (parameter gradients sum B*T terms)
+        torch.testing.assert_close(got.grad.cpu(), want, atol=atol, rtol=2e-3, msg=lambda m, n=name: f"d{n}: {m}")
