@@ -243,7 +243,7 @@ struct TileStage {
   }
 };
 
-__global__ __launch_bounds__(kMfmaThreads) void mha_fwd_mfma_kernel(
+__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void mha_fwd_mfma_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, float* __restrict__ LSE,
     int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int qblocks, int KS, int VS) {
@@ -261,6 +261,12 @@ __global__ __launch_bounds__(kMfmaThreads) void mha_fwd_mfma_kernel(
   const float* Vb = V + (size_t)b * Tk * dv + hd * dvh;
   const int nsteps = (dh + 3) / 4;         // MFMA pairs over the head channels
   const int ctiles = (dvh + 31) / 32;
+
+  // K_h / V_h rows of a 32-key block: 4 float4 per thread each, requested first (they fly during the Q staging);
+  // inside the loop the NEXT block is requested while the current one is in the MFMAs (zero fill beyond Tk / head width)
+  TileStage<32 * (DHMAX / 4) / kMfmaThreads> ks, vs;
+  ks.load(Kb, dk, 0, Tk, 32, dh, DHMAX / 4);
+  vs.load(Vb, dv, 0, Tk, 32, dvh, DHMAX / 4);
 
   // Q fragments: B operand of S^T = K Q^T.  Staged through LDS (rows are read coalesced) once.
   float2 qf[DHMAX / 4];
@@ -284,11 +290,6 @@ __global__ __launch_bounds__(kMfmaThreads) void mha_fwd_mfma_kernel(
     for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
   float m_run = kNegBig, l_run = 0.f;
 
-  // K_h / V_h rows of a 32-key block: 4 float4 per thread each; the NEXT block is requested while the
-  // current one is in the MFMAs (zero fill beyond Tk / head width)
-  TileStage<32 * (DHMAX / 4) / kMfmaThreads> ks, vs;
-  ks.load(Kb, dk, 0, Tk, 32, dh, DHMAX / 4);
-  vs.load(Vb, dv, 0, Tk, 32, dvh, DHMAX / 4);
   for (int k0 = 0; k0 < Tk; k0 += 32) {
     ks.store(Kl, KS, 32, DHMAX / 4);
     vs.store(Vl, VS, 32, DHMAX / 4);
