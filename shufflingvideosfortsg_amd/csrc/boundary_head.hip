@@ -137,9 +137,11 @@ __global__ __launch_bounds__(kThreads) void boundary_softmax_kernel(float* __res
 __global__ __launch_bounds__(kThreads) void boundary_dl_kernel(
     const int* __restrict__ mask, const float* __restrict__ ps, const float* __restrict__ pe,
     const float* __restrict__ dps, const float* __restrict__ dpe, float* __restrict__ dl, float* __restrict__ db2p,
-    int B, int T) {
+    float* __restrict__ z0, float* __restrict__ z1, float* __restrict__ z2, int J, int B, int T) {
   __shared__ float scratch[2 * kWaves];
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), b = blockIdx.x;
+  // this batch item's rows of the three atomic accumulators of kernel 2 (instead of three memset launches)
+  for (int j = tid; j < J; j += kThreads) { z0[(size_t)b * J + j] = 0.f; z1[(size_t)b * J + j] = 0.f; z2[(size_t)b * J + j] = 0.f; }
   float d0 = 0.f, d1 = 0.f;
   for (int t = tid; t < T; t += kThreads) {
     d0 = fmaf(ps[(size_t)b * T + t], dps[(size_t)b * T + t], d0);
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void boundary_dl_kernel(
 
 // ---- backward, kernel 2 (grid = B * ceil(T/TR)):  dz = dl*w2*(1-u^2);  dy = g*dz;
 // dcs[b,:] += sum_t g*dz;  db1p[b,:] += sum_t dz;  dw2p[b,:] += sum_t dl*u  (atomics: ceil(T/32) adders
-// per address, buffers zeroed by the host);  dgate[b,t] = sum_j dz*(y+cs). ----
+// per address, buffers zeroed by kernel 1);  dgate[b,t] = sum_j dz*(y+cs). ----
 __global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
     const float* __restrict__ y, const float* __restrict__ cs, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ gate, const float* __restrict__ dl,
@@ -312,12 +314,9 @@ extern "C" int tsg_boundary_score_bwd(const void* y, const void* cs, const void*
   if (rc) return rc;
   auto st = static_cast<hipStream_t>(stream);
   const size_t J = 2 * (size_t)Hm;
-  for (void* p : {dcs, db1_part, dw2_part}) {
-    hipError_t e = hipMemsetAsync(p, 0, sizeof(float) * B * J, st);
-    if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-  }
   hipLaunchKernelGGL(boundary_dl_kernel, dim3(B), dim3(kThreads), 0, st, mask, (const float*)p_start, (const float*)p_end,
-                     (const float*)dp_start, (const float*)dp_end, (float*)dl_ws, (float*)db2_part, B, T);
+                     (const float*)dp_start, (const float*)dp_end, (float*)dl_ws, (float*)db2_part, (float*)dcs,
+                     (float*)db1_part, (float*)dw2_part, (int)J, B, T);
   rc = check_launch(fn);
   if (rc) return rc;
   const size_t lds = sizeof(float) * (size_t)kWaves * 3 * J;
