@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Launch the gate-fused K1 backward a few times (for rocprofv3 --pmc): python3 tools/k1_bwd_only.py [B] [n]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from shufflingvideosfortsg_amd import _lib
+from shufflingvideosfortsg_amd._lib import ptr, TSG_F32
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+T, N, d = 128, 20, 1024
+lib = _lib.load(); dev = "cuda"; st = torch.cuda.current_stream().cuda_stream
+A = torch.randn(B, T, d, device=dev); S = torch.randn(B, N, d, device=dev); w = torch.randn(d, device=dev) / d ** 0.5
+P = torch.softmax(torch.randn(B, T, N, device=dev), -1); VW = torch.randn(B, N, d, device=dev); gb = torch.randn(d, device=dev)
+r = torch.randn(B, T, d, device=dev); dC = torch.randn(B, T, d, device=dev)
+da = torch.empty_like(A); ds = torch.empty_like(S); dw = torch.empty_like(w); dVW = torch.empty_like(VW); dgb = torch.empty_like(gb)
+dr = torch.empty_like(r); dG = torch.empty_like(r); de = torch.empty(B, T, N, device=dev)
+for _ in range(n):
+    lib.tsg_scdm_gate_bwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(gb), ptr(r), ptr(P), ptr(dC), ptr(da), ptr(ds), ptr(dw), ptr(dVW), ptr(dgb), ptr(dr), ptr(de), ptr(dG), B, T, N, d, d, TSG_F32, st)
+torch.cuda.synchronize()
