@@ -69,7 +69,11 @@ def precision(gemm_dtype=None):
 
 
 def make_optimizer(model, params):
-    return torch.optim.Adam(model.parameters(), lr=params["lr"], weight_decay=params["weight_decay"], eps=1e-6)
+    """Adam(lr, L2 weight decay, eps=1e-6) as the reference builds it (train.py:367-371); on a GPU the single-pass
+    fused implementation of the same update (one kernel over all parameters instead of ~7 foreach passes)."""
+    ps = list(model.parameters())
+    fused = bool(ps) and all(p.is_cuda for p in ps)
+    return torch.optim.Adam(ps, lr=params["lr"], weight_decay=params["weight_decay"], eps=1e-6, fused=fused)
 
 
 def baseline_step(model, batch):

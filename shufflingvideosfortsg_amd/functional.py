@@ -344,20 +344,28 @@ class _BiLSTMLayer(torch.autograd.Function):
         dGf = dG.view(T * B, 8 * h)
         dx = _mm(dGf, W_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         dbias = dGf.sum(0)
-        zero = out.new_zeros(1, B, h)
-        hprev_f = torch.cat([zero, out[:-1, :, :h]], 0).reshape(T * B, h)        # h_{t-1} of the forward direction
-        hprev_r = torch.cat([out[1:, :, h:], zero], 0).reshape(T * B, h)         # h_{t+1} feeds the reverse direction
-        if _GEMM_DTYPE == "f32s" and (T * B) % 4 == 0 and h % 4 == 0 and I % 4 == 0:
+        # dW_hh[d] = sum_t dG_t[d]^T h_{t-1}[d]: the step whose h_{t-1} is the zero state drops out, so both operands are
+        # plain strided VIEWS (rows t=1.. of dG with rows ..T-2 of out for the forward direction, the mirror image for
+        # the reverse one) -- no shifted copy of out, no per-direction copy of dG
+        if T > 1:
+            gf, hf = dG[1:, :, 0].reshape((T - 1) * B, 4 * h), out[:-1, :, :h].reshape((T - 1) * B, h)
+            gr, hr = dG[:-1, :, 1].reshape((T - 1) * B, 4 * h), out[1:, :, h:].reshape((T - 1) * B, h)
+        if T == 1:
+            dW_ih = _mm(dGf.t(), x.view(T * B, I))
+            dW_hh = torch.zeros_like(W_hh)
+        elif _GEMM_DTYPE == "f32s" and (T * B) % 4 == 0 and h % 4 == 0 and I % 4 == 0:
             # one split of dG along the T·B contraction serves the three weight-gradient GEMMs (column slices of the
-            # [3·T·B, 8h] planes are strided views the GEMM takes as they are)
+            # [3·T·B, 8h] planes are strided views the GEMM takes as they are); the K-concatenated planes cannot be
+            # sliced in time, so here h_{t-1} is the shifted copy with its zero row
             S = split_bf16x3(dGf, 0, False)
             mm3 = lambda a3, b: torch.mm(a3.t(), split_bf16x3(b, 0, True), out_dtype=torch.float32)
+            zero = out.new_zeros(1, B, h)
             dW_ih = mm3(S, x.view(T * B, I))
-            dW_hh = torch.stack([mm3(S[:, :4 * h], hprev_f), mm3(S[:, 4 * h:], hprev_r)])
+            dW_hh = torch.stack([mm3(S[:, :4 * h], torch.cat([zero, out[:-1, :, :h]], 0).reshape(T * B, h)),
+                                 mm3(S[:, 4 * h:], torch.cat([out[1:, :, h:], zero], 0).reshape(T * B, h))])
         else:
             dW_ih = _mm(dGf.t(), x.view(T * B, I))
-            dW_hh = torch.stack([_mm(dG[:, :, 0].reshape(T * B, 4 * h).t(), hprev_f),
-                                 _mm(dG[:, :, 1].reshape(T * B, 4 * h).t(), hprev_r)])
+            dW_hh = torch.stack([_mm(gf.t(), hf), _mm(gr.t(), hr)])
         return dx, dW_ih, dbias, dW_hh
 
 
