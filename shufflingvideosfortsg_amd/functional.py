@@ -319,7 +319,10 @@ class _BiLSTMLayer(torch.autograd.Function):
         h = W_hh.shape[2]
         if W_ih.shape != (8 * h, I) or W_hh.shape != (2, 4 * h, h) or bias.numel() != 8 * h:
             raise ValueError(f"bilstm: shape mismatch x{tuple(x.shape)} W_ih{tuple(W_ih.shape)} W_hh{tuple(W_hh.shape)}")
-        Gx = _mm(x.view(T * B, I), W_ih.t()).add_(bias)                       # [T,B,2,4h]
+        if _GEMM_DTYPE is None:
+            Gx = torch.addmm(bias, x.view(T * B, I), W_ih.t())                # [T,B,2,4h]; bias in the GEMM epilogue
+        else:
+            Gx = _mm(x.view(T * B, I), W_ih.t()).add_(bias)
         out = torch.empty(T, B, 2 * h, device=x.device, dtype=torch.float32)
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=torch.float32)
         Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
