@@ -172,7 +172,7 @@ def main():
     ap.add_argument("--T", type=int, default=128)
     ap.add_argument("--N", type=int, default=20)
     ap.add_argument("--d", type=int, default=1024)
-    ap.add_argument("--cpu-sample", type=int, default=8, help="pairs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=24, help="pairs in the CPU-baseline sample (0 = skip); bounded to ~20 s")
     ap.add_argument("--no-micro", action="store_true", help="skip the stand-alone K2 launches")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32s"],
                     help="f32 (default, parity mode) or bf16 = library GEMMs in bf16 (fp32 accumulate); kernels stay f32")
