@@ -112,14 +112,18 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
     return out
 
 
-def pmc_traffic(kernel, B, T, N, d):
+def pmc_traffic(kernel, B, T, N, d, launch_B=None):
+    launch_B = launch_B or B
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
     profiles/r1/k1_pmc_traffic.json); None when no pass exists for this shape."""
     try:
         with open(os.path.join(ROOT, "profiles", "r1", "k1_pmc_traffic.json")) as f:
             j = json.load(f)
         if j["shape"] == {"B": B, "T": T, "N": N, "d": d, "dtype": "f32"}:
-            return j["kernels"][kernel]["hbm_bytes_per_launch"]
+            exact = j["kernels"].get(f"{kernel}@B{launch_B}")          # a pass at the launch's own pair count, if committed
+            if exact:
+                return exact["hbm_bytes_per_launch"]
+            return int(j["kernels"][kernel]["hbm_bytes_per_launch"] * launch_B / B)
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -299,10 +303,10 @@ def main():
         k1name, k1 = max(cands, key=lambda kv: kv[1]["launches"], default=("", {}))
         gate = k1name.startswith("tsg_scdm_gate_fwd")
         k1B = (k1.get("dims") or [a.B])[0]
-        tr = pmc_traffic("scdm_fwd_kernel[gate]" if gate else "scdm_fwd_kernel", 64, a.T, a.N, a.d)   # PMC pass at B=64; bytes scale with B
+        tr = pmc_traffic("scdm_fwd_kernel[gate]" if gate else "scdm_fwd_kernel", 64, a.T, a.N, a.d, launch_B=k1B)   # PMC passes at B=64 (+ exact ones)
         roof = {"kernel": "scdm_fwd_kernel<GATE=%s> (%s)" % ("true" if gate else "false", k1name.split("[")[0]), "bound": "hbm",
                 "achieved": k1.get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": k1.get("frac"), "traffic": int(tr * k1B / 64) if tr else None,
+                "frac": k1.get("frac"), "traffic": tr,
                 "pairs_per_launch": k1B,
                 "alg_bytes_per_launch": k1.get("alg_bytes"), "mean_launch_us": k1.get("mean_us"),
                 "launches_timed": k1.get("launches")}
