@@ -560,24 +560,40 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_bwd_rows_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr int kColThreads = 512;
 constexpr int kColWaves = kColThreads / kWave;
-constexpr int kCpl = 2;                                   // columns per lane (VGPR budget: 2*NP*kCpl accumulators)
-constexpr int kSlice = kWave * kCpl;                      // 128 columns per workgroup
+constexpr int kCplMax = 2;                                // columns per lane: 2 up to 20 words, 1 beyond (VGPR budget:
+                                                          // 2*NP*CPL accumulators; NP = 28 at CPL = 2 spilled 57 VGPRs: 428 vs 207 us)
+constexpr int kSliceMax = kWave * kCplMax;                // 128 columns per workgroup at most
 constexpr int kRedChunk = 8;                              // words per LDS reduction round: 8*8*128*4 = 32 KiB
+template <int NP> constexpr int cpl_of() { return NP <= 20 ? 2 : 1; }
+
+template <int CPL> __device__ __forceinline__ void ld_cols(const float* __restrict__ p, float (&o)[CPL]) {
+  if constexpr (CPL == 2) { const float2 t = *reinterpret_cast<const float2*>(p); o[0] = t.x; o[1] = t.y; }
+  else o[0] = *p;
+}
+template <int CPL> __device__ __forceinline__ void st_cols(float* __restrict__ p, const float (&o)[CPL]) {
+  if constexpr (CPL == 2) *reinterpret_cast<float2*>(p) = make_float2(o[0], o[1]);
+  else *p = o[0];
+}
+template <int CPL> __device__ __forceinline__ void exp2_cols(float (&v)[CPL]) {
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) v[q] = fast_exp2(clampf(v[q], -kClamp, kClamp) * k2Log2e);
+}
 
 __device__ __forceinline__ float2 exp2x2(float2 v) {
   return make_float2(fast_exp2(clampf(v.x, -kClamp, kClamp) * k2Log2e), fast_exp2(clampf(v.y, -kClamp, kClamp) * k2Log2e));
 }
 
-template <int NP>
-__device__ __forceinline__ void cols_reduce_store(float (&acc)[NP][kCpl], float* __restrict__ red, float* __restrict__ out,
+template <int NP, int CPL>
+__device__ __forceinline__ void cols_reduce_store(float (&acc)[NP][CPL], float* __restrict__ red, float* __restrict__ out,
                                                   const float* __restrict__ scale, int N, int width, int col0,
                                                   int tid, int lane, int wv) {
   // out[n*width + col0 + c] = scale[c] * sum_waves acc[n][c];  red = [kColWaves][kRedChunk][kSlice]
+  constexpr int kSlice = kWave * CPL;
   for (int n0 = 0; n0 < NP; n0 += kRedChunk) {
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
       if (n >= n0 && n < n0 + kRedChunk)
-        *reinterpret_cast<float2*>(red + ((wv * kRedChunk + (n - n0)) * kSlice) + lane * kCpl) = make_float2(acc[n][0], acc[n][1]);
+        st_cols<CPL>(red + ((wv * kRedChunk + (n - n0)) * kSlice) + lane * CPL, acc[n]);
     }
     __syncthreads();
     for (int idx = tid; idx < kRedChunk * kSlice; idx += kColThreads) {
@@ -602,13 +618,14 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
     const float* __restrict__ P, const float* __restrict__ dC, const float* __restrict__ de,
     float* __restrict__ da, float* __restrict__ ds, float* __restrict__ dw, float* __restrict__ dV,
     float* __restrict__ dbias, int B, int T, int N, int H, int Ds, int hslices, int slices) {
-  __shared__ __align__(16) float red[kColWaves * kRedChunk * kSlice];
-  __shared__ float wscale[kSlice];
+  constexpr int CPL = cpl_of<NP>(), kSlice = kWave * CPL;
+  __shared__ __align__(16) float red[kColWaves * kRedChunk * kSliceMax];
+  __shared__ float wscale[kSliceMax];
   extern __shared__ __align__(16) float rowsl[];          // [min(T,256)][NP]: de rows, later P rows (zero padded)
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int bid = xcd_remap(blockIdx.x, gridDim.x, slices);
   const int b = bid / slices, c = bid % slices;
-  const int k = c * kSlice + lane * kCpl;
+  const int k = c * kSlice + lane * CPL;
   // A wave owns rows wv, wv+8, ... of each 256-row block and keeps kColPF of its rows' operands in
   // flight: a row's compute (~0.5 us) is far shorter than a memory round trip, one-row-ahead starves it.
   auto stage_rows = [&](const float* __restrict__ src, int tb0, int tbn) {   // [tbn][N] -> LDS [tbn][NP]
@@ -624,45 +641,48 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
   if (c < hslices) {
     const bool live = k < H;
     const float* arow = a + (size_t)b * T * H + (live ? k : 0);
-    float es[NP][kCpl];
+    float es[NP][CPL];
     const float* sb = s + (size_t)b * N * H;
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
-      float2 v = make_float2(0.f, 0.f);
-      if (n < N && live) v = *reinterpret_cast<const float2*>(sb + (size_t)n * H + k);
-      const float2 e = exp2x2(v);
-      es[n][0] = e.x; es[n][1] = e.y;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) es[n][q] = 0.f;
+      if (n < N && live) ld_cols<CPL>(sb + (size_t)n * H + k, es[n]);
+      exp2_cols<CPL>(es[n]);
     }
     if (tid < kSlice) wscale[tid] = (c * kSlice + tid < H) ? 4.f * w[c * kSlice + tid] : 0.f;
-    float dsacc[NP][kCpl], dwacc[kCpl] = {0.f, 0.f};
+    float dsacc[NP][CPL], dwacc[CPL], ws2[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) { dwacc[q] = 0.f; ws2[q] = 0.f; }
 #pragma unroll
     for (int n = 0; n < NP; ++n)
 #pragma unroll
-      for (int q = 0; q < kCpl; ++q) dsacc[n][q] = 0.f;
-    float2 ws2 = make_float2(0.f, 0.f);
+      for (int q = 0; q < CPL; ++q) dsacc[n][q] = 0.f;
 
     for (int tb0 = 0; tb0 < T; tb0 += kColTB) {
       const int tbn = (T - tb0 < kColTB) ? T - tb0 : kColTB;
-      float2 ring[kColPF];
+      float ring[kColPF][CPL];
 #pragma unroll
       for (int u = 0; u < kColPF; ++u) {
         const int tl = wv + kColWaves * u;
-        ring[u] = (tl < tbn) ? *reinterpret_cast<const float2*>(arow + (size_t)(tb0 + tl) * H) : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) ring[u][q] = 0.f;
+        if (tl < tbn) ld_cols<CPL>(arow + (size_t)(tb0 + tl) * H, ring[u]);
       }
       stage_rows(de, tb0, tbn);
-      ws2 = *reinterpret_cast<const float2*>(wscale + lane * kCpl);
+      ld_cols<CPL>(wscale + lane * CPL, ws2);
 #pragma unroll 1
       for (int tl0 = wv; tl0 < tbn; tl0 += kColWaves * kColPF) {
 #pragma unroll
         for (int u = 0; u < kColPF; ++u) {
           const int tl = tl0 + kColWaves * u;
           if (tl < tbn) {                                   // wave-uniform
-            const float2 av = ring[u];
+            float ea[CPL], dasum[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) { ea[q] = ring[u][q]; dasum[q] = 0.f; }
             const int tnx = tl + kColWaves * kColPF;
-            if (tnx < tbn) ring[u] = *reinterpret_cast<const float2*>(arow + (size_t)(tb0 + tnx) * H);
-            const float2 e2 = exp2x2(av);
-            const float ea[kCpl] = {e2.x, e2.y};
-            float dasum[kCpl] = {0.f, 0.f};
+            if (tnx < tbn) ld_cols<CPL>(arow + (size_t)(tb0 + tnx) * H, ring[u]);
+            exp2_cols<CPL>(ea);
 #pragma unroll
             for (int n4 = 0; n4 < NP; n4 += 4) {
               const float4 d4 = *reinterpret_cast<const float4*>(rowsl + tl * NP + n4);   // broadcast
@@ -670,7 +690,7 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
 #pragma unroll
               for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int q = 0; q < kCpl; ++q) {
+                for (int q = 0; q < CPL; ++q) {
                   const float r = fast_rcp(fmaf(ea[q], es[n4 + j][q], 1.f));
                   const float u2 = dd[j] * r;
                   const float v = fmaf(-u2, r, u2);
@@ -679,16 +699,19 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
                   dwacc[q] += u2;
                 }
             }
-            if (live)
-              *reinterpret_cast<float2*>(da + ((size_t)b * T + tb0 + tl) * H + k) = make_float2(ws2.x * dasum[0], ws2.y * dasum[1]);
+            if (live) {
+#pragma unroll
+              for (int q = 0; q < CPL; ++q) dasum[q] *= ws2[q];
+              st_cols<CPL>(da + ((size_t)b * T + tb0 + tl) * H + k, dasum);
+            }
           }
         }
       }
     }
 
-    cols_reduce_store<NP>(dsacc, red, ds + (size_t)b * N * H, wscale, N, H, c * kSlice, tid, lane, wv);
+    cols_reduce_store<NP, CPL>(dsacc, red, ds + (size_t)b * N * H, wscale, N, H, c * kSlice, tid, lane, wv);
     // dw: one more round through the same buffer, then one atomic per column and workgroup
-    *reinterpret_cast<float2*>(red + wv * kSlice + lane * kCpl) = make_float2(dwacc[0], dwacc[1]);
+    st_cols<CPL>(red + wv * kSlice + lane * CPL, dwacc);
     __syncthreads();
     if (tid < kSlice && c * kSlice + tid < H) {
       float sum = 0.f;
@@ -701,22 +724,25 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
 
   // ---------------- dsent[b,n,j] = sum_t P[t,n] dC[t,j] for sentence columns of slice c --------
   if (c * kSlice < Ds) {
-    const int j = c * kSlice + lane * kCpl;
+    const int j = c * kSlice + lane * CPL;
     const bool jok = j < Ds;
     const float* grow = dC + (size_t)b * T * Ds + (jok ? j : 0);
-    float dv[NP][kCpl];
+    float dv[NP][CPL], gsum[CPL];                           // gsum: column sums of dC (= d bias of the fused gate)
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) gsum[q] = 0.f;
 #pragma unroll
     for (int n = 0; n < NP; ++n)
 #pragma unroll
-      for (int q = 0; q < kCpl; ++q) dv[n][q] = 0.f;
-    float gsum[kCpl] = {0.f, 0.f};                          // column sums of dC (= d bias of the fused gate)
+      for (int q = 0; q < CPL; ++q) dv[n][q] = 0.f;
     for (int tb0 = 0; tb0 < T; tb0 += kColTB) {
       const int tbn = (T - tb0 < kColTB) ? T - tb0 : kColTB;
-      float2 ring[kColPF];
+      float ring[kColPF][CPL];
 #pragma unroll
       for (int u = 0; u < kColPF; ++u) {
         const int tl = wv + kColWaves * u;
-        ring[u] = (tl < tbn && jok) ? *reinterpret_cast<const float2*>(grow + (size_t)(tb0 + tl) * Ds) : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) ring[u][q] = 0.f;
+        if (tl < tbn && jok) ld_cols<CPL>(grow + (size_t)(tb0 + tl) * Ds, ring[u]);
       }
       stage_rows(P, tb0, tbn);
 #pragma unroll 1
@@ -725,26 +751,27 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
         for (int u = 0; u < kColPF; ++u) {
           const int tl = tl0 + kColWaves * u;
           if (tl < tbn) {
-            const float2 g = ring[u];
+            float g[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) { g[q] = ring[u][q]; gsum[q] += g[q]; }
             const int tnx = tl + kColWaves * kColPF;
-            if (tnx < tbn && jok) ring[u] = *reinterpret_cast<const float2*>(grow + (size_t)(tb0 + tnx) * Ds);
-            gsum[0] += g.x; gsum[1] += g.y;
+            if (tnx < tbn && jok) ld_cols<CPL>(grow + (size_t)(tb0 + tnx) * Ds, ring[u]);
 #pragma unroll
             for (int n4 = 0; n4 < NP; n4 += 4) {
               const float4 p4 = *reinterpret_cast<const float4*>(rowsl + tl * NP + n4);
               const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
-              for (int jn = 0; jn < 4; ++jn) {
-                dv[n4 + jn][0] = fmaf(pp[jn], g.x, dv[n4 + jn][0]); dv[n4 + jn][1] = fmaf(pp[jn], g.y, dv[n4 + jn][1]);
-              }
+              for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) dv[n4 + jn][q] = fmaf(pp[jn], g[q], dv[n4 + jn][q]);
             }
           }
         }
       }
     }
-    cols_reduce_store<NP>(dv, red, dV + (size_t)b * N * Ds, nullptr, N, Ds, c * kSlice, tid, lane, wv);
+    cols_reduce_store<NP, CPL>(dv, red, dV + (size_t)b * N * Ds, nullptr, N, Ds, c * kSlice, tid, lane, wv);
     if (dbias) {
-      *reinterpret_cast<float2*>(red + wv * kSlice + lane * kCpl) = make_float2(gsum[0], gsum[1]);
+      st_cols<CPL>(red + wv * kSlice + lane * CPL, gsum);
       __syncthreads();
       if (tid < kSlice && c * kSlice + tid < Ds) {
         float sum = 0.f;
@@ -805,6 +832,7 @@ int launch_bwd(const float* a, const float* s, const float* w, const float* V, c
                      dG_ws, dr, B, T, N, Ds, tiles);
   int rc = check_launch("scdm_attn_bwd(rows)");
   if (rc) return rc;
+  constexpr int kSlice = kWave * cpl_of<NP>();
   const int hslices = cdiv(H, kSlice), slices = hslices > cdiv(Ds, kSlice) ? hslices : cdiv(Ds, kSlice);
   const size_t rows_lds = sizeof(float) * (size_t)(T < kColTB ? T : kColTB) * NP;
   hipLaunchKernelGGL(scdm_bwd_cols_kernel<NP>, dim3(B * slices), dim3(kColThreads), rows_lds, st, a, s, w, P, GATE ? dG_ws : dC, de,

@@ -6,7 +6,7 @@ import torch
 from shufflingvideosfortsg_amd import _lib
 from shufflingvideosfortsg_amd._lib import ptr, TSG_F32
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-T, N, d, n = 128, 20, 1024, 30
+T, N, d, n = 128, int(sys.argv[2]) if len(sys.argv) > 2 else 20, 1024, 30
 lib = _lib.load(); dev = "cuda"; st = torch.cuda.current_stream().cuda_stream
 A = torch.randn(B, T, d, device=dev); S = torch.randn(B, N, d, device=dev); w = torch.randn(d, device=dev) / d ** 0.5
 P = torch.softmax(torch.randn(B, T, N, device=dev), -1); VW = torch.randn(B, N, d, device=dev); gb = torch.randn(d, device=dev)

@@ -7,7 +7,7 @@ from shufflingvideosfortsg_amd import _lib
 from shufflingvideosfortsg_amd._lib import ptr, TSG_F32
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-T, N, d = 128, 20, 1024
+T, N, d = 128, int(sys.argv[3]) if len(sys.argv) > 3 else 20, 1024
 lib = _lib.load(); dev = "cuda"; st = torch.cuda.current_stream().cuda_stream
 A = torch.randn(B, T, d, device=dev); S = torch.randn(B, N, d, device=dev)
 w = torch.randn(d, device=dev) / d ** 0.5; V = torch.randn(B, N, d, device=dev)
