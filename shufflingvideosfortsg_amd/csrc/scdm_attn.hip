@@ -558,7 +558,8 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_bwd_rows_kernel(
 // loads); the next row's a / dC float4 and de / P row are in flight while the current one is used.
 // Cross-wave sums go through LDS in word chunks (deterministic order, no atomics except dw).
 // ------------------------------------------------------------------------------------------
-constexpr int kColThreads = 512;
+constexpr int kColThreads = 256;                           // two workgroups per CU at ~234 VGPRs: their serial phases (Es prologue,
+                                                          // row staging, cross-wave reductions) overlap the other one's row loop (512: 206 us, 256: 195 us gate bwd)
 constexpr int kColWaves = kColThreads / kWave;
 constexpr int kCplMax = 2;                                // columns per lane: 2 up to 20 words, 1 beyond (VGPR budget:
                                                           // 2*NP*CPL accumulators; NP = 28 at CPL = 2 spilled 57 VGPRs: 428 vs 207 us)
