@@ -100,7 +100,9 @@ int tsg_boundary_score_bwd(const void* y, const void* cs, const void* b1, const 
  * `scale` is the DIVISOR: the reference passes sqrt(d_key) of the full width (attention.py:41,61).
  * Outputs O [B,Tq,d_value], lse [B,n_heads,Tq] (kept for the backward) and, when non-NULL, the
  * A_forward side outputs A_sum = sum_h A_h and S_sum = sum_h S_h, both [B,Tq,Tk].
- * p_drop must be 0 (attention dropout is not implemented; seed/offset are reserved for it).
+ * p_drop in [0,1): attention dropout on the softmax (out = dropout(S) V, attention.py:53-54; S_sum stays un-dropped);
+ * the keep mask is a counter-based hash of (seed, offset, b, head, q, key), regenerated by the backward from the
+ * same (p_drop, seed, offset) -- nothing is stored.
  * Limits: head widths multiples of 4, d_value/n_heads <= 512; causal needs Tq == Tk.          */
 int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O, void* A_sum, void* S_sum, void* lse,
                 int B, int Tq, int Tk, int d_key, int d_value, int n_heads, float scale, int causal,

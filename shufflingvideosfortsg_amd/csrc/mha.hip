@@ -31,6 +31,21 @@ constexpr int PS = KB + 4;      // padded stride of the P / dS tiles
 constexpr int MAXVC = 4;        // head width of V <= MAXVC*CC = 512
 constexpr float kNegBig = -3.0e38f;
 
+// Attention dropout (reference: out = dropout(softmax(A)) V, attention.py:53-54; the returned A_softmax is the
+// un-dropped softmax).  Counter-based: the keep decision of element (b, head, q, key) is a hash of its index and
+// of (seed, offset), so forward and backward regenerate the same mask and nothing is stored.  thresh = p * 2^32
+// (0 = no dropout), inv_keep = 1/(1-p).
+struct DropCfg { unsigned thresh; float inv_keep; unsigned k0, k1; };
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float drop_scale(const DropCfg& dc, int b, int H, int hd, int Tq, int q, int Tk, int key) {
+  const unsigned long long idx = ((unsigned long long)((size_t)b * H + hd) * Tq + q) * Tk + key;
+  const unsigned h = mix32(mix32((unsigned)idx + dc.k0) ^ (unsigned)(idx >> 32) ^ dc.k1);
+  return h >= dc.thresh ? dc.inv_keep : 0.f;
+}
+
 // reduce over the 8 consecutive lanes that share one query row
 __device__ __forceinline__ float sum8(float v) {
   v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v);
@@ -82,7 +97,7 @@ __device__ __forceinline__ void finish_scores(float (&a)[4], int q, int k0, int 
 __global__ __launch_bounds__(kThreads) void mha_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, float* __restrict__ Asum, float* __restrict__ Ssum, float* __restrict__ LSE,
-    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int qtiles) {
+    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int qtiles, DropCfg dc) {
   __shared__ __align__(16) float Qs[TQ * LS];
   __shared__ __align__(16) float Ks[KB * LS];      // K chunk, then reused for the V chunk
   __shared__ __align__(16) float Ps[TQ * PS];
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(kThreads) void mha_fwd_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float p = (a[j] > kNegBig) ? __expf(a[j] - m_new) : 0.f;
-          Ps[r * PS + sub + 8 * j] = p;
+          Ps[r * PS + sub + 8 * j] = dc.thresh ? p * drop_scale(dc, b, H, hd, Tq, q, Tk, k0 + sub + 8 * j) : p;
           psum += p;
         }
         l_run = l_run * alpha + sum8(psum);
@@ -243,10 +258,11 @@ struct TileStage {
   }
 };
 
+template <bool DROP>
 __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void mha_fwd_mfma_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, float* __restrict__ LSE,
-    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int qblocks, int KS, int VS) {
+    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int qblocks, int KS, int VS, DropCfg dc) {
   extern __shared__ __align__(16) float lds[];
   float* Kl = lds;                         // [32][KS]   KS = roundup(dh,64)+2  (conflict-free b64 A reads)
   float* Vl = lds + 32 * KS;               // [32][VS]   VS = roundup(dvh,32)+4, zero beyond dvh
@@ -329,7 +345,7 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float p = (st[r] > kNegBig) ? __expf(st[r] - m_new) : 0.f;
-      st[r] = p;
+      st[r] = DROP ? p * drop_scale(dc, b, H, hd, Tq, q, Tk, k0 + (r & 3) + 8 * (r >> 2) + 4 * kk) : p;
       ps += p;
     }
     l_run = l_run * alpha + xhalf_sum(ps);
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(kThreads) void mha_bwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ LSE,
     float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
-    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal) {
+    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, DropCfg dc) {
   __shared__ __align__(16) float Xs[TQ * LS];      // Q or dO tile chunk
   __shared__ __align__(16) float Ys[KB * LS];      // K or V block chunk
   __shared__ __align__(16) float Ps[TQ * PS];      // P tile   [q][n]
@@ -447,8 +463,9 @@ __global__ __launch_bounds__(kThreads) void mha_bwd_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float p = (a[j] > kNegBig && q < Tq) ? __expf(a[j] - l) : 0.f;
-          Ps[r * PS + sub + 8 * j] = p;
-          Ss[r * PS + sub + 8 * j] = p * (dp[j] - Drow) * inv_scale;
+          const float mk = dc.thresh ? drop_scale(dc, b, H, hd, Tq, q, Tk, k0 + sub + 8 * j) : 1.f;
+          Ps[r * PS + sub + 8 * j] = p * mk;                               // dropped probabilities feed dV
+          Ss[r * PS + sub + 8 * j] = p * (dp[j] * mk - Drow) * inv_scale;  // D = <dO, O> already contains the mask
         }
         __syncthreads();
 
@@ -565,11 +582,12 @@ __global__ __launch_bounds__(256) void mha_bwd_delta_kernel(const float* __restr
 
 __device__ __forceinline__ int rho(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
 
+template <bool DROP>
 __global__ __launch_bounds__(kMfmaThreads) void mha_bwd_mfma_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ delta,
     float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
-    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int KS, int VS2) {
+    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int KS, int VS2, DropCfg dc) {
   // LDS: Kl [32][KS], Vl [32][VS2], Ql [32][KS], Gl (dO) [32][VS2]  (strides = 2 mod 64: b64 A/B reads),
   //      X [2][4 waves][16][64] partial S / dP, dSl [32][66], lsel [32], dl [32]
   extern __shared__ __align__(16) float lds[];
@@ -649,8 +667,9 @@ __global__ __launch_bounds__(kMfmaThreads) void mha_bwd_mfma_kernel(
         if (causal && key > q) sv -= 1e10f;
         sv *= inv_scale;
         const float p = (key < Tk && q < Tq) ? __expf(sv - lsel[ql]) : 0.f;
-        pm[r] = p;
-        ds[r] = p * (dpv - dl[ql]) * inv_scale;
+        const float mk = DROP ? drop_scale(dc, b, H, hd, Tq, q, Tk, key) : 1.f;
+        pm[r] = p * mk;
+        ds[r] = p * (dpv * mk - dl[ql]) * inv_scale;
       }
       if (wv == 0) {
 #pragma unroll
@@ -728,6 +747,16 @@ int check(const char* fn, int B, int Tq, int Tk, int dk, int dv, int H, int dtyp
 
 using namespace tsg;
 
+static int make_drop(const char* fn, float p_drop, uint64_t seed, uint64_t offset, tsg::DropCfg* dc) {
+  if (!(p_drop >= 0.f) || p_drop >= 1.f) return tsg::set_error(TSG_E_SHAPE, "%s: dropout probability %g outside [0, 1)", fn, p_drop);
+  const double t = (double)p_drop * 4294967296.0;
+  dc->thresh = p_drop > 0.f ? (unsigned)(t < 1.0 ? 1.0 : (t > 4294967295.0 ? 4294967295.0 : t)) : 0u;
+  dc->inv_keep = 1.f / (1.f - p_drop);
+  dc->k0 = (unsigned)seed ^ ((unsigned)offset * 0x9E3779B1u);
+  dc->k1 = (unsigned)(seed >> 32) ^ ((unsigned)(offset >> 32) * 0x85EBCA77u + 0x165667B1u);
+  return 0;
+}
+
 extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O, void* A_sum, void* S_sum, void* lse,
                            int B, int Tq, int Tk, int d_key, int d_value, int n_heads, float scale, int causal,
                            float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream) {
@@ -738,9 +767,10 @@ extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O,
   }
   int rc = check(fn, B, Tq, Tk, d_key, d_value, n_heads, dtype);
   if (rc) return rc;
-  if (p_drop != 0.f) return set_error(TSG_E_SHAPE, "%s: attention dropout p=%g not supported (eval / p=0 only)", fn, p_drop);
+  DropCfg dc;
+  rc = make_drop(fn, p_drop, seed, offset, &dc);
+  if (rc) return rc;
   if (!(scale > 0.f)) return set_error(TSG_E_SHAPE, "%s: scale must be positive", fn);
-  (void)seed; (void)offset;
   auto st = static_cast<hipStream_t>(stream);
   const size_t map_bytes = sizeof(float) * (size_t)B * Tq * Tk;
   if (A_sum) { hipError_t e = hipMemsetAsync(A_sum, 0, map_bytes, st); if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e)); }
@@ -752,20 +782,20 @@ extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O,
     const size_t qstage = sizeof(float) * (size_t)QB * KS, ostage = sizeof(float) * (size_t)QB * VS;
     if (qstage > lds) lds = qstage;
     if (ostage > lds) lds = ostage;
-    auto kern = mha_fwd_mfma_kernel;
+    auto kern = dc.thresh ? mha_fwd_mfma_kernel<true> : mha_fwd_mfma_kernel<false>;
     if (lds > 64 * 1024) {
       hipError_t e = allow_lds(kern, lds);
       if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
     }
     hipLaunchKernelGGL(kern, dim3(B * qblocks * n_heads), dim3(kMfmaThreads), lds, st, (const float*)Q, (const float*)K,
                        (const float*)V, (float*)O, (float*)lse, B, Tq, Tk, d_key, d_value, n_heads, 1.f / scale, causal,
-                       qblocks, KS, VS);
+                       qblocks, KS, VS, dc);
     return check_launch(fn);
   }
   const int qtiles = cdiv(Tq, TQ);
   hipLaunchKernelGGL(mha_fwd_kernel, dim3(B * qtiles), dim3(kThreads), 0, st, (const float*)Q, (const float*)K,
                      (const float*)V, (float*)O, (float*)A_sum, (float*)S_sum, (float*)lse, B, Tq, Tk, d_key, d_value,
-                     n_heads, 1.f / scale, causal, qtiles);
+                     n_heads, 1.f / scale, causal, qtiles, dc);
   return check_launch(fn);
 }
 
@@ -780,8 +810,9 @@ extern "C" int tsg_mha_bwd(const void* Q, const void* K, const void* V, const vo
   }
   int rc = check(fn, B, Tq, Tk, d_key, d_value, n_heads, dtype);
   if (rc) return rc;
-  if (p_drop != 0.f) return set_error(TSG_E_SHAPE, "%s: attention dropout p=%g not supported (eval / p=0 only)", fn, p_drop);
-  (void)seed; (void)offset;
+  DropCfg dc;
+  rc = make_drop(fn, p_drop, seed, offset, &dc);
+  if (rc) return rc;
   const int dh = d_key / n_heads, dvh = d_value / n_heads;
   if (delta_ws && dh <= DHMAX && dvh <= DHMAX) {                    // MFMA path
     auto st = static_cast<hipStream_t>(stream);
@@ -791,19 +822,19 @@ extern "C" int tsg_mha_bwd(const void* Q, const void* K, const void* V, const vo
     if (rc) return rc;
     const int KS = roundup(dh, 64) + 2, VS2 = roundup(dvh, 64) + 2;
     const size_t lds = sizeof(float) * ((size_t)64 * (KS + VS2) + 2 * 4 * 16 * 64 + 32 * 66 + 64);
-    auto kern = mha_bwd_mfma_kernel;
+    auto kern = dc.thresh ? mha_bwd_mfma_kernel<true> : mha_bwd_mfma_kernel<false>;
     if (lds > 64 * 1024) {
       hipError_t e = allow_lds(kern, lds);
       if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
     }
     hipLaunchKernelGGL(kern, dim3(B * n_heads), dim3(kMfmaThreads), lds, st, (const float*)Q, (const float*)K, (const float*)V,
                        (const float*)dO, (const float*)lse, (const float*)delta_ws, (float*)dQ, (float*)dK, (float*)dV,
-                       B, Tq, Tk, d_key, d_value, n_heads, 1.f / scale, causal, KS, VS2);
+                       B, Tq, Tk, d_key, d_value, n_heads, 1.f / scale, causal, KS, VS2, dc);
     return check_launch(fn);
   }
   hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * n_heads), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                      (const float*)Q, (const float*)K, (const float*)V, (const float*)O, (const float*)dO,
                      (const float*)lse, (float*)dQ, (float*)dK, (float*)dV, B, Tq, Tk, d_key, d_value, n_heads,
-                     1.f / scale, causal);
+                     1.f / scale, causal, dc);
   return check_launch(fn);
 }

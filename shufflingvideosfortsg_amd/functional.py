@@ -260,7 +260,7 @@ class _MHA(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, Q, K, V, n_heads, scale, causal, want_maps):
+    def forward(ctx, Q, K, V, n_heads, scale, causal, want_maps, p_drop=0.0, seed=0, offset=0):
         require_device(Q, K, V)
         Q, K, V = _f32c(Q), _f32c(K), _f32c(V)
         B, Tq, dk = Q.shape
@@ -275,9 +275,10 @@ class _MHA(torch.autograd.Function):
         S = torch.empty(B, Tq, Tk, device=Q.device, dtype=torch.float32) if want_maps else None
         _call("tsg_mha_fwd", Q, ptr(Q), ptr(K), ptr(V), ptr(O), ptr(A) if want_maps else None,
                                  ptr(S) if want_maps else None, ptr(lse), B, Tq, Tk, dk, dv, int(n_heads),
-                                 float(scale), int(bool(causal)), 0.0, 0, 0, TSG_F32)
+                                 float(scale), int(bool(causal)), float(p_drop), int(seed), int(offset), TSG_F32)
         ctx.save_for_backward(Q, K, V, O, lse)
         ctx.cfg = (int(n_heads), float(scale), int(bool(causal)))
+        ctx.drop = (float(p_drop), int(seed), int(offset))          # the backward regenerates the same mask
         if want_maps:
             ctx.mark_non_differentiable(A, S)
             return O, A, S
@@ -288,20 +289,28 @@ class _MHA(torch.autograd.Function):
     def backward(ctx, dO, _dA, _dS):
         Q, K, V, O, lse = ctx.saved_tensors
         n_heads, scale, causal = ctx.cfg
+        p_drop, seed, offset = ctx.drop
         dO = _f32c(dO)
         B, Tq, dk = Q.shape
         _, Tk, dv = V.shape
         dQ = torch.empty_like(Q); dK = torch.empty_like(K); dV = torch.empty_like(V)
         delta = torch.empty_like(lse)
         _call("tsg_mha_bwd", Q, ptr(Q), ptr(K), ptr(V), ptr(O), ptr(dO), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(delta),
-                                 B, Tq, Tk, dk, dv, n_heads, scale, causal, 0.0, 0, 0, TSG_F32)
-        return dQ, dK, dV, None, None, None, None
+                                 B, Tq, Tk, dk, dv, n_heads, scale, causal, p_drop, seed, offset, TSG_F32)
+        return dQ, dK, dV, None, None, None, None, None, None, None
 
 
-def mha(Q, K, V, n_heads, scale, causal=False, return_maps=False):
+def mha(Q, K, V, n_heads, scale, causal=False, return_maps=False, p_drop=0.0):
     """Fused multi-head attention on projected inputs (see include/tsg_hip.h, K2).
-    Returns O, or (O, A_sum, S_sum) with ``return_maps``."""
-    O, A, S = _MHA.apply(Q, K, V, n_heads, scale, causal, return_maps)
+    Returns O, or (O, A_sum, S_sum) with ``return_maps`` (S_sum is the un-dropped softmax, as in the reference).
+    ``p_drop`` > 0 applies attention dropout inside the kernel (out = dropout(softmax) V, attention.py:53-54): the mask
+    is a counter-based hash of (seed, offset, element index); seed = torch.initial_seed(), offset drawn from torch's CPU
+    generator, so ``torch.manual_seed`` makes it reproducible and every call gets a fresh mask."""
+    seed = offset = 0
+    if p_drop > 0.0:
+        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        offset = int(torch.randint(0, 2 ** 62, (1,)).item())
+    O, A, S = _MHA.apply(Q, K, V, n_heads, scale, causal, return_maps, float(p_drop), seed, offset)
     return (O, A, S) if return_maps else O
 
 

@@ -56,16 +56,14 @@ class Attention(nn.Module):
         self.dropout = nn.Dropout(drop_ratio)
         self.causal = causal
 
-    def _check_dropout(self):
-        if self.training and self.dropout.p > 0:
-            raise RuntimeError("attention dropout (p>0 in training mode) is not implemented by the HIP kernel; "
-                               "use drop_ratio=0 or .eval()")
+    def _p(self):
+        """Dropout probability in effect (training mode only); applied inside the kernel to the softmax."""
+        return float(self.dropout.p) if self.training else 0.0
 
     def forward(self, query, key, value):
-        self._check_dropout()
         if query.dim() != 3:
             raise ValueError("Attention expects [B, T, d] tensors")
-        return TF.mha(query, key, value, 1, self.scale, bool(self.causal), return_maps=True)
+        return TF.mha(query, key, value, 1, self.scale, bool(self.causal), return_maps=True, p_drop=self._p())
 
 
 class MultiHead(nn.Module):
@@ -85,9 +83,9 @@ class MultiHead(nn.Module):
         self.A_softmax = None
 
     def _core(self, query, key, value, maps):
-        self.attention._check_dropout()
         q, k, v = self.wq(query), self.wk(key), self.wv(value)
-        return TF.mha(q, k, v, self.n_heads, self.attention.scale, bool(self.attention.causal), return_maps=maps)
+        return TF.mha(q, k, v, self.n_heads, self.attention.scale, bool(self.attention.causal), return_maps=maps,
+                      p_drop=self.attention._p())
 
     def forward(self, query, key, value):
         return self.wo(self._core(query, key, value, False))

@@ -46,7 +46,7 @@ def test_argument_errors_without_gpu(lib):
     assert lib.tsg_scdm_attn_fwd(p, p, p, p, p, p, 1, 1, 1, 4, 4, 7, None) == -4             # dtype
     assert lib.tsg_scdm_attn_fwd(p + 4, p, p, p, p, p, 1, 1, 1, 4, 4, TSG_F32, None) == -3   # misaligned
     assert lib.tsg_mha_fwd(p, p, p, p, None, None, p, 1, 4, 4, 8, 8, 3, 1.0, 0, 0.0, 0, 0, TSG_F32, None) == -2  # 8 % 3
-    assert lib.tsg_mha_fwd(p, p, p, p, None, None, p, 1, 4, 4, 8, 8, 2, 1.0, 0, 0.5, 0, 0, TSG_F32, None) == -2  # dropout
+    assert lib.tsg_mha_fwd(p, p, p, p, None, None, p, 1, 4, 4, 8, 8, 2, 1.0, 0, 1.0, 0, 0, TSG_F32, None) == -2  # dropout probability outside [0,1)
     assert lib.tsg_boundary_score_fwd(p, p, p, p, p, None, None, p, p, 1, 4, 3, TSG_F32, None) == -2             # 2*Hm % 4
 
 

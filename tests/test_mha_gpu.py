@@ -73,3 +73,68 @@ def test_mha_golden(golden, tag):
     torch.testing.assert_close(lin(o, w["wo.weight"]).cpu(), g.t("out"), **TOL)
     torch.testing.assert_close(S.cpu(), g.t("A_softmax"), **TOL)
     torch.testing.assert_close(A.cpu(), g.t("A"), atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("heads", [1, 4])
+def test_attention_dropout_mask_forward_backward(heads):
+    """Attention dropout inside K2 (reference: out = dropout(softmax(A)) V, attention.py:53-54).  With V = one identity
+    block per head the output IS dropout(S), which exposes the kernel's keep mask: the kept fraction is 1-p, kept
+    entries are S/(1-p), the MFMA and the VALU kernels draw the same mask, a different offset draws a different one,
+    and the backward equals autograd through the same masked expression."""
+    from shufflingvideosfortsg_amd import functional as TF
+    torch.manual_seed(0)
+    B, Tq, Tk, dh, p = 3, 40, 32, 16, 0.3
+    dk, dv = heads * dh, heads * Tk
+    Q = torch.randn(B, Tq, dk, device="cuda"); K = torch.randn(B, Tk, dk, device="cuda")
+    Vi = torch.zeros(B, Tk, dv, device="cuda")
+    for hd in range(heads):
+        Vi[:, :, hd * Tk:(hd + 1) * Tk] = torch.eye(Tk, device="cuda")
+    scale = dk ** 0.5
+    S0 = TF._MHA.apply(Q, K, Vi, heads, scale, False, False, 0.0, 0, 0)[0]            # un-dropped softmax per head
+    Sd = TF._MHA.apply(Q, K, Vi, heads, scale, False, False, p, 1234, 77)[0]
+    M = Sd != 0
+    kept = M.float().mean().item()
+    n = M.numel()
+    assert abs(kept - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5 + 1e-3, kept
+    torch.testing.assert_close(Sd, torch.where(M, S0 / (1 - p), torch.zeros_like(S0)), atol=1e-6, rtol=1e-5)
+    Sd_valu = TF._MHA.apply(Q, K, Vi, heads, scale, False, True, p, 1234, 77)[0]      # return_maps -> VALU kernel
+    torch.testing.assert_close(Sd_valu, Sd, atol=1e-6, rtol=1e-5)
+    assert not torch.equal(TF._MHA.apply(Q, K, Vi, heads, scale, False, False, p, 1234, 78)[0] != 0, M)
+    assert torch.equal(TF._MHA.apply(Q, K, Vi, heads, scale, False, False, p, 1234, 77)[0] != 0, M)
+    # backward with a real V, against autograd through softmax * mask / (1-p)
+    V = torch.randn(B, Tk, dv, device="cuda")
+    for maps in (False, True):
+        q, k, v = (x.clone().requires_grad_(True) for x in (Q, K, V))
+        O = TF._MHA.apply(q, k, v, heads, scale, False, maps, p, 1234, 77)[0]
+        g = torch.randn_like(O)
+        O.backward(g)
+        qr, kr, vr = (x.clone().requires_grad_(True) for x in (Q, K, V))
+        outs = []
+        for hd in range(heads):
+            a = qr[..., hd * dh:(hd + 1) * dh] @ kr[..., hd * dh:(hd + 1) * dh].transpose(1, 2) / scale
+            sm = torch.softmax(a, -1) * M[..., hd * Tk:(hd + 1) * Tk].float() / (1 - p)
+            outs.append(sm @ vr[..., hd * Tk:(hd + 1) * Tk])
+        Oref = torch.cat(outs, -1)
+        Oref.backward(g)
+        torch.testing.assert_close(O.detach(), Oref.detach(), atol=1e-4, rtol=1e-4)
+        for got, want, name in ((q, qr, "dQ"), (k, kr, "dK"), (v, vr, "dV")):
+            torch.testing.assert_close(got.grad, want.grad, atol=2e-4, rtol=2e-3, msg=lambda m, n=name: f"{n}: {m}")
+
+
+def test_multihead_module_dropout_modes():
+    """MultiHead with drop_ratio > 0: training mode drops (fresh mask per call, reproducible under manual_seed),
+    eval mode does not."""
+    from shufflingvideosfortsg_amd.model.networks.attention import MultiHead
+    torch.manual_seed(1)
+    m = MultiHead(64, 64, 4, 0.5).cuda()
+    x = torch.randn(2, 24, 64, device="cuda", requires_grad=True)
+    m.eval()
+    e1, e2 = m(x, x, x), m(x, x, x)
+    assert torch.equal(e1, e2)
+    m.train()
+    torch.manual_seed(5); t1 = m(x, x, x)
+    t2 = m(x, x, x)
+    torch.manual_seed(5); t3 = m(x, x, x)
+    assert not torch.equal(t1, t2) and torch.equal(t1, t3) and not torch.allclose(t1, e1)
+    t1.sum().backward()
+    assert torch.isfinite(x.grad).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())

@@ -80,9 +80,11 @@ def test_attention_module_golden(golden):
     torch.testing.assert_close(o.cpu(), g.t("out"), **TOL)
     torch.testing.assert_close(S.cpu(), g.t("S"), **TOL)
     torch.testing.assert_close(A.cpu(), g.t("A"), atol=1e-3, rtol=1e-5)
-    a.train(); a.dropout.p = 0.5
-    with pytest.raises(RuntimeError, match="dropout"):
-        a(g.t("q").cuda(), g.t("k").cuda(), g.t("v").cuda())
+    a.train(); a.dropout.p = 0.5          # training mode: dropout on the softmax inside the kernel; A / A_softmax stay un-dropped
+    o2, A2, S2 = a(g.t("q").cuda(), g.t("k").cuda(), g.t("v").cuda())
+    torch.testing.assert_close(S2.cpu(), g.t("S"), **TOL)
+    torch.testing.assert_close(A2.cpu(), g.t("A"), atol=1e-3, rtol=1e-5)
+    assert not torch.allclose(o2.cpu(), g.t("out"), atol=1e-3)
 
 
 @pytest.mark.parametrize("tag", ["nomask", "mask"])
