@@ -45,6 +45,9 @@ def make_settings(params: Dict):
                 rnn_layers=params["sent_rnn_layers"], rnn_cell=params["sent_rnn_cell"], drop_out=params["dropout"])
     ground = dict(cross_name=params["crossmodal"], name=params["predictor"],
                   lstm_hidden_dim=params["span_hidden_dim"], mlp_hidden_dim=params["mlp_hidden_dim"])
+    if params["predictor"] in ("self_attn", "d"):       # keys SpanPredictor_Boundary reads for this head (SpanPredictor.py:36-40);
+        ground.update(attention_nheads=params.get("attention_nheads", 8),      # the reference's drivers never set them
+                      position_encoding=params.get("position_encoding", True))
     match = dict(cross=dict(name=params["m_cross"]),
                  temporal=dict(name=params["m_temp"], hidden_dim=256, layers=2, dropout=params["dropout"]),
                  predict=dict(name=params["m_pred"], activation=params["m_pred_activ"], hidden_dim=params["m_pred_hidden"]))

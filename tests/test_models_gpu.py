@@ -290,3 +290,25 @@ def test_gmd_large_config_vs_oracle(gemm, request):
     torch.testing.assert_close(loss.detach().cpu(), ref_loss.detach(), **TOL)
     for k, p in model.named_parameters():
         torch.testing.assert_close(p.grad.cpu(), sd[k].grad, atol=5e-4, rtol=5e-3, msg=lambda m, k=k: f"{k}: {m}")
+
+
+def test_baseline_with_self_attention_predictor_trains():
+    """QAVE with the temporal self-attention boundary head (`predictor='self_attn'`, dead in the reference because of
+    its `super()` bug, working here): a training step with the default dropout 0.5 (attention dropout inside K2) gives a
+    finite loss and finite gradients for every parameter, and eval mode is deterministic."""
+    from shufflingvideosfortsg_amd import data, engine
+    params = engine.default_params(predictor="self_attn", video_len=64)
+    torch.manual_seed(0)
+    m = engine.build_model("qave", params).cuda().train()
+    b = data.synthetic_batch(4, 64, 20, seed=2, device="cuda")
+    loss, out = engine.baseline_step(m, b)
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    torch.testing.assert_close(out["start"].sum(1), torch.ones(4, device="cuda"), atol=1e-4, rtol=1e-4)
+    m.eval()
+    with torch.no_grad():
+        o1 = m(b["video"], b["query"], b["video_mask"], None)["start"]
+        o2 = m(b["video"], b["query"], b["video_mask"], None)["start"]
+    assert torch.equal(o1, o2)
