@@ -180,6 +180,8 @@ def main():
     ap.add_argument("--no-micro", action="store_true", help="skip the stand-alone K2 launches")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32s"],
                     help="f32 (default, parity mode) or bf16 = library GEMMs in bf16 (fp32 accumulate); kernels stay f32")
+    ap.add_argument("--predictor", default="mlp", choices=["mlp", "self_attn"],
+                    help="boundary head: mlp (reference default, K3) or self_attn (temporal self-attention, K2 in the step)")
     ap.add_argument("--no-alt", action="store_true", help="skip the side measurement in the other GEMM-operand mode")
     a = ap.parse_args()
 
@@ -196,7 +198,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     params = engine.default_params(video_rnn_hiddendim=a.d // 2, sent_rnn_hiddendim=a.d // 2,
-                                   video_len=a.T, sent_len=a.N)
+                                   video_len=a.T, sent_len=a.N, predictor=a.predictor)
     torch.manual_seed(0)
     log(f"building {a.model} (d={a.d}) on {torch.cuda.get_device_name(local)}")
     model = engine.build_model(a.model, params).to(dev).train()
@@ -316,6 +318,7 @@ def main():
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": f"{a.model}_train_step: fwd+losses+bwd+grad-allreduce+Adam, "
                                       f"B={a.B}/GPU,T_clip={a.T},T_word={a.N},d={a.d}, i3d width 1024, GloVe 300"
+                                      + ("" if a.predictor == "mlp" else f", boundary head {a.predictor}")
                                       + ("" if a.dtype == "f32" else "; " + NOTES[a.dtype]),
                           "global_batch": a.B * world, "parallelism": f"dp{world}", "grad_bytes": dp.grad_bytes},
                "roofline": roof, "alt_gemm_modes": alt, "kernels": kern,
