@@ -51,12 +51,19 @@ class GMD(nn.Module):
         B = ori_video_feat.size(0)
         both = self.video_encoder(torch.cat([ori_video_feat, pseudo_video_feat], 0), torch.cat([word_feat, word_feat], 0))
         ori_frame_feat, pseudo_frame_feat = both[:B], both[B:]
-        ori_match, _ = self.csmm(ori_frame_feat, sent_embed, ori_video_mask)
-        pseudo_match, _ = self.csmm(pseudo_frame_feat, sent_embed, pseudo_video_mask)
+        # the matching gate and the temporal-order discriminator are per-sample too: both streams in one pass
+        cat2 = lambda a, b: None if a is None or b is None else torch.cat([a, b], 0)
+        vmask2 = cat2(ori_video_mask, pseudo_video_mask)
+        if vmask2 is not None or (ori_video_mask is None and pseudo_video_mask is None):
+            match2, _ = self.csmm(both, torch.cat([sent_embed, sent_embed], 0), vmask2)
+            ori_match, pseudo_match = match2[:B], match2[B:]
+        else:
+            ori_match, _ = self.csmm(ori_frame_feat, sent_embed, ori_video_mask)
+            pseudo_match, _ = self.csmm(pseudo_frame_feat, sent_embed, pseudo_video_mask)
         span_prob = self._span(ori_frame_feat, word_feat, sent_embed, ori_match, ori_video_mask)
-        ori_disc = self.tod(ori_frame_feat, ori_temporal_mask, ori_fore_mask, ori_back_mask)
-        pseudo_disc = self.tod(pseudo_frame_feat, pseudo_temporal_mask, pseudo_fore_mask, pseudo_back_mask)
-        return span_prob, ori_match, pseudo_match, ori_disc, pseudo_disc
+        disc2 = self.tod(both, torch.cat([ori_temporal_mask, pseudo_temporal_mask], 0),
+                         torch.cat([ori_fore_mask, pseudo_fore_mask], 0), torch.cat([ori_back_mask, pseudo_back_mask], 0))
+        return span_prob, ori_match, pseudo_match, disc2[:B], disc2[B:]
 
     def eval_forward(self, video_feat, query_feat, video_mask=None, sent_mask=None):
         word_feat, sent_embed = self.sentence_encoder(query_feat)
