@@ -135,6 +135,12 @@ int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, 
 int tsg_lstm_bwd(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
                  void* dG, void* dC_ws, int B, int T, int h, int dtype, void* stream);
 
+/* ---- dense projection GEMM on the fp32 matrix cores ("tsg_gemm_*" of SURVEY section 8b) ------------------------------
+ * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL): torch.nn.Linear's layout, i.e. the d x d projections of the path
+ * (SCDM W_a / W_s attention.py:104-106, sent_linear VideoEncoder.py:48, MultiHead wq/wk/wv/wo attention.py:63-66, the
+ * first boundary Linear SpanPredictor.py:62-67).  Exact fp32 (v_mfma_f32_32x32x2_f32).  K % 4 == 0.                 */
+int tsg_linear_fwd(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int dtype, void* stream);
+
 /* ---- split-precision operand preparation (optional "f32s" GEMM mode) ------------------------------------------------
  * Not a reference function: the reference's Linears / LSTM input GEMMs (torch.nn.Linear, nn.LSTM; e.g.
  * attention.py:104-106, RNN.py:27) run as fp32 GEMMs.  x [rows, cols] fp32 -> three bf16 planes at

@@ -314,6 +314,52 @@ def mha(Q, K, V, n_heads, scale, causal=False, return_maps=False, p_drop=0.0):
     return (O, A, S) if return_maps else O
 
 
+class _LinearHip(torch.autograd.Function):
+    """y = x W^T (+ b) through the hand-written fp32 MFMA GEMM (tsg_linear_fwd); the two backward products reuse it
+    (dx = dy W as a Linear with the transposed weight) or go to rocBLAS (dW = dy^T x: contraction over the rows)."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, x, w, b):
+        require_device(x, w)
+        x2, w = _f32c(x.reshape(-1, x.shape[-1])), _f32c(w)
+        M, K = x2.shape
+        N = w.shape[0]
+        if w.shape[1] != K or K % 4:
+            raise ValueError(f"linear_hip: x{tuple(x.shape)} w{tuple(w.shape)} (K must match and be a multiple of 4)")
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        _call("tsg_linear_fwd", x2, ptr(x2), ptr(w), ptr(_f32c(b)) if b is not None else None, ptr(y), M, N, K, TSG_F32)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias, ctx.xshape = b is not None, x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = _f32c(dy.reshape(-1, dy.shape[-1]))
+        M, K = x2.shape
+        N = w.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if N % 4 == 0:
+                wt = w.t().contiguous()                                  # [K, N]: dx = dy W = Linear(dy, W^T)
+                dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+                _call("tsg_linear_fwd", dy2, ptr(dy2), ptr(wt), None, ptr(dx), M, K, N, TSG_F32)
+            else:
+                dx = dy2 @ w
+            dx = dx.view(ctx.xshape)
+        dw = dy2.t() @ x2 if ctx.needs_input_grad[1] else None
+        db = dy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def linear_hip(x, w, b=None):
+    """torch.nn.functional.linear on the hand-written fp32 MFMA GEMM (include/tsg_hip.h: tsg_linear_fwd).  Opt-in: rocBLAS
+    is ~18 % faster at the path's shapes, so the modules keep F.linear."""
+    return _LinearHip.apply(x, w, b)
+
+
 class _BiLSTMLayer(torch.autograd.Function):
     """One bidirectional LSTM layer from zero state, TIME-MAJOR.  x [T,B,I]; W_ih [8h,I] (forward rows,
     then reverse), bias [8h] (b_ih + b_hh), W_hh [2,4h,h]  ->  out [T,B,2h].  The input GEMM and the
