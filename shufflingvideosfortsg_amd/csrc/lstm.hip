@@ -167,14 +167,15 @@ constexpr int kBwdThreads = 256;
 constexpr int NBUFB = 5;
 constexpr int PFB = 3;
 constexpr int kStageRows = 32 + 16;             // one ring slot: 32 rows of dG_{t+1} + 16 rows of W_hh^T
+constexpr int HSB = KC + 8;                     // slot row stride: = 8 mod 32 -> the 16-lane groups of a ds_read_b128 (rows x 4 k-quads) hit 64 distinct banks
 
 __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
     const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
     const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG, float* __restrict__ dCn,
     int B, int T, int h, int step) {
-  __shared__ __align__(16) float ring_all[4 * NBUFB * kStageRows * HS];
+  __shared__ __align__(16) float ring_all[4 * NBUFB * kStageRows * HSB];
   const int tid = threadIdx.x, lane = tid & 63, kq = wave_id();
-  float* ring = ring_all + kq * (NBUFB * kStageRows * HS);
+  float* ring = ring_all + kq * (NBUFB * kStageRows * HSB);
   const int uslices = (h + 15) / 16, bslices = (B + 31) / 32;
   const int d = blockIdx.x / (uslices * bslices);
   const int rem = blockIdx.x % (uslices * bslices);
@@ -233,9 +234,9 @@ __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
       }
     };
     auto lstore = [&](int buf, const float4 (&st)[6]) {
-      float* base = ring + buf * kStageRows * HS;
+      float* base = ring + buf * kStageRows * HSB;
 #pragma unroll
-      for (int q = 0; q < 6; ++q) *reinterpret_cast<float4*>(base + (lr + 8 * q) * HS + lc) = st[q];
+      for (int q = 0; q < 6; ++q) *reinterpret_cast<float4*>(base + (lr + 8 * q) * HSB + lc) = st[q];
     };
 #pragma unroll
     for (int i = 0; i < PFB; ++i)
@@ -248,19 +249,24 @@ __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
         const int c = c0 + i;
         if (c < cend) {
           __builtin_amdgcn_wave_barrier();
-          const float* base = ring + ((c - cbeg) % NBUFB) * kStageRows * HS;
-          const float* g0 = base + jb * HS + 2 * ku;
-          const float* g1 = base + (16 + jb) * HS + 2 * ku;
-          const float* wrow = base + (32 + jb) * HS + 2 * ku;
+          const float* base = ring + ((c - cbeg) % NBUFB) * kStageRows * HSB;
+          // one ds_read_b128 per row and 16 columns: lane (row jb, quad ku) holds columns 16j + 4ku .. +3 = FOUR MFMAs' worth
+          // of k (component m = k 16j + 4ku + m, the same for both operands).  Paired-k float2 reads are merged by hipcc into
+          // ds_read2_b64, which banks mod 32 in 16-lane groups: 2-way conflicts at any stride = 4 mod 32.
+          const float* g0 = base + jb * HSB + 4 * ku;
+          const float* g1 = base + (16 + jb) * HSB + 4 * ku;
+          const float* wrow = base + (32 + jb) * HSB + 4 * ku;
 #pragma unroll
-          for (int j = 0; j < KC / 8; ++j) {
-            const float2 a = *reinterpret_cast<const float2*>(wrow + 8 * j);
-            const float2 x0 = *reinterpret_cast<const float2*>(g0 + 8 * j);
-            const float2 x1 = *reinterpret_cast<const float2*>(g1 + 8 * j);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x0.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x1.y, acc1, 0, 0, 0);
+          for (int j = 0; j < KC / 16; ++j) {
+            const float4 a4 = *reinterpret_cast<const float4*>(wrow + 16 * j);
+            const float4 x4 = *reinterpret_cast<const float4*>(g0 + 16 * j);
+            const float4 y4 = *reinterpret_cast<const float4*>(g1 + 16 * j);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], xv[m], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], yv[m], acc1, 0, 0, 0);
+            }
           }
           if (c + 1 < cend) lstore((c + 1 - cbeg) % NBUFB, stage[(i + 1) % PFB]);
           if (c + PFB < cend) gload(c + PFB, stage[i]);
