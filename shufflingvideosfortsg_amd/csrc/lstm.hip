@@ -317,10 +317,11 @@ __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
 // ---------------------------------------------------------------------------------------------
 // forward, PERSISTENT variant: one launch runs all T steps.  A per-step launch costs ~2.6 us of
 // dispatch plus a memory round trip for W_hh before the first MFMA; here the recurrent weights never
-// move.  Workgroup = (direction, 16 hidden units = 64 gate rows, 32 batch rows), 8 waves =
-// 4 A-tiles (4 units each) x 2 batch tiles.  Each wave keeps ITS A-tile of W_hh (16 gate rows x h)
-// in registers as MFMA operand fragments (h/4 VGPRs, 128 at h = 512) and its lanes keep the cell
-// state c of their (batch, unit) pair; per step only h_{t-1} (32 rows x h, 64 KiB) is fetched.
+// move.  Workgroup = (direction, 32 hidden units = 128 gate rows, 16 batch rows), 8 waves = 8 A-tiles
+// (4 units each) x one batch tile.  Each wave keeps ITS A-tile of W_hh (16 gate rows x h) in registers as MFMA
+// operand fragments (h/4 VGPRs, 128 at h = 512) and its lanes keep the cell state c of their (batch, unit)
+// pair; per step only h_{t-1} of the 16 batch rows (32 KiB at h = 512) is fetched, staged in LDS (row stride
+// = 8 mod 64) and read back as ds_read_b128 B operands several reads ahead of the MFMAs that consume them.
 //
 // Hand-off between workgroups: the data is the flag.  The 32-row slab of h_t a workgroup needs is produced by the
 // h/16 workgroups with the same (direction, batch slice).  At launch every lane marks the elements of `out` it
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int kPersistMaxH = 512;
 constexpr int kSpinLimit = 1 << 22;
+constexpr int kSlabV = 16 * (kPersistMaxH / 4) / kThreads;   // float4 of the 16-row slab per thread (4 at h = 512)
 constexpr unsigned kSentinel = 0x7fa5c3e1u;     // a signalling-NaN bit pattern: never the value of h = o * tanh(c)
 
 __device__ __forceinline__ f32x4 load_sc1_x4(const float* p) {
@@ -360,27 +362,30 @@ __device__ __forceinline__ void store_sc1_u(float* p, unsigned v) {
 __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
     const float* __restrict__ Gx, const float* __restrict__ Whh, float* __restrict__ out,
     float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS) {
-  extern __shared__ __align__(16) float Hl[];            // [32][HLS]  h_{t-1} rows of this batch slice
+  extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
-  const int uslices = h / 16, bslices = (B + 31) / 32;
+  const int uslices = h / 32, bslices = (B + 15) / 16;
   const int d = blockIdx.x / (uslices * bslices);
   const int rem = blockIdx.x % (uslices * bslices);
   const int us = rem / bslices, bs = rem % bslices;
-  const int at = wv & 3, bt = wv >> 2;
+  const int at = wv;                                      // 8 waves = 8 A-tiles (32 units) x ONE 16-row batch tile: the slab a
+                                                          // workgroup fetches per step is 16 rows (32 KiB at h = 512), half of the
+                                                          // 4 x 2 arrangement's, for the same MFMA work per wave
   const int jb = lane & 15, ku = lane >> 4;
-  const int u0 = us * 16 + at * 4;                        // first unit of this wave's A-tile
-  const int b0 = bs * 32;
+  const int u0 = us * 32 + at * 4;                        // first unit of this wave's A-tile
+  const int b0 = bs * 16;
   // sync[0] = error word, sync[1] = arrival counter of the one start barrier
 
-  // A fragments: row i = jb -> (unit u0 + (jb>>2), gate jb&3); element pair k = 8j + 2ku, +1
-  float2 areg[kPersistMaxH / 8];
+  // A fragments: row i = jb -> (unit u0 + (jb>>2), gate jb&3); lane quad ku holds columns 16j + 4ku .. +3 = the k values
+  // of FOUR MFMAs (component m = k 16j + 4ku + m), matching the ds_read_b128 of the h slab below
+  f32x4 areg[kPersistMaxH / 16];
   {
-    const float* wrow = Whh + (size_t)d * 4 * h * h + (size_t)((jb & 3) * h + u0 + (jb >> 2)) * h + 2 * ku;
+    const float* wrow = Whh + (size_t)d * 4 * h * h + (size_t)((jb & 3) * h + u0 + (jb >> 2)) * h + 4 * ku;
 #pragma unroll
-    for (int j = 0; j < kPersistMaxH / 8; ++j)
-      areg[j] = (8 * j < h) ? *reinterpret_cast<const float2*>(wrow + 8 * j) : make_float2(0.f, 0.f);
+    for (int j = 0; j < kPersistMaxH / 16; ++j)
+      areg[j] = (16 * j < h) ? *reinterpret_cast<const f32x4*>(wrow + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const int b = b0 + bt * 16 + jb, u = u0 + ku;
+  const int b = b0 + jb, u = u0 + ku;
   const bool live = b < B;
   float cprev = 0.f;
   const int nrow4 = h / 4;                                 // float4 per h row
@@ -408,7 +413,16 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
     if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   }
 
+#ifdef TSG_LSTM_TIMING
+  unsigned long long tph[4] = {0, 0, 0, 0}, tm0 = 0, tm1 = 0;       // per-phase s_memtime sums of this wave (100 MHz ticks? no: shader clock)
+#define TSG_TICK(i) { tm1 = __builtin_amdgcn_s_memtime(); tph[i] += tm1 - tm0; tm0 = tm1; }
+#else
+#define TSG_TICK(i)
+#endif
   for (int step = 0; step < T; ++step) {
+#ifdef TSG_LSTM_TIMING
+    tm0 = __builtin_amdgcn_s_memtime();
+#endif
     const int tt = d == 0 ? step : T - 1 - step;
     const int tp = d == 0 ? tt - 1 : tt + 1;
     float gx[4] = {0.f, 0.f, 0.f, 0.f};
@@ -418,27 +432,30 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (step > 0) {
-      f32x4 v[8];
+      f32x4 v[kSlabV];
       {
         // poll the slab until no element of this thread's 8 float4 is the sentinel (loads unconditional, see above)
         unsigned pending = 0u;
-        const float* src[8];
+        const float* src[kSlabV];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < kSlabV; ++i) {
           const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
-          const bool ok = r < 32 && b0 + r < B;
+          const bool ok = r < 16 && b0 + r < B;
           if (ok) pending |= 1u << i;
           src[i] = out + ((size_t)tp * B + (ok ? b0 + r : b0)) * 2 * h + d * h + (ok ? c4 * 4 : 0);
         }
+        // (measured and dropped: two or three staggered copies of the poll in flight -- the extra slab traffic costs more
+        // than the shorter retry saves, 13.7 vs 11.5 us per step)
+        static_assert(kSlabV == 4, "the wait below lists 4 loads");
         int spins = 0;
-        u32x4 q[8];
+        u32x4 q[kSlabV];
         while (true) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) q[i] = load_sc1_u4(src[i]);
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) : : "memory");
+          for (int i = 0; i < kSlabV; ++i) q[i] = load_sc1_u4(src[i]);
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : : "memory");
           unsigned raw = 0u;
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+          for (int i = 0; i < kSlabV; ++i)
             if (q[i][0] == kSentinel || q[i][1] == kSentinel || q[i][2] == kSentinel || q[i][3] == kSentinel) raw |= 1u << i;
           raw &= pending;
 #ifdef TSG_DEBUG_SENTINEL
@@ -451,29 +468,47 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
           }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < kSlabV; ++i)
           if (!(pending & (1u << i))) q[i] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < kSlabV; ++i)
           v[i] = (f32x4){__uint_as_float(q[i][0]), __uint_as_float(q[i][1]), __uint_as_float(q[i][2]), __uint_as_float(q[i][3])};
       }
+      TSG_TICK(0)                                            // poll: slab complete in registers
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < kSlabV; ++i) {
         const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
-        if (r < 32) *reinterpret_cast<f32x4*>(Hl + r * HLS + c4 * 4) = v[i];
+        if (r < 16) *reinterpret_cast<f32x4*>(Hl + r * HLS + c4 * 4) = v[i];
       }
       __syncthreads();
+      TSG_TICK(1)                                            // slab in LDS, workgroup met
       if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // a bounded wait expired somewhere
-      const float* hrow = Hl + (bt * 16 + jb) * HLS + 2 * ku;
+      // B operand: one ds_read_b128 per 16 columns (row stride = 8 mod 64: conflict-free 16-lane groups), requested PFD
+      // reads ahead of the MFMAs that consume it -- issued one at a time, each read's latency (~100+ cycles) sat in
+      // front of its two MFMAs and the chain ran at 111 instead of 32-64 cycles per MFMA (s_memtime instrumentation)
+      const float* hrow = Hl + jb * HLS + 4 * ku;
+      constexpr int NJ = kPersistMaxH / 16, PFD = 4;
+      f32x4 bq[PFD], acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < kPersistMaxH / 8; ++j) {
-        if (8 * j < h) {
-          const float2 bv = *reinterpret_cast<const float2*>(hrow + 8 * j);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[j].x, bv.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[j].y, bv.y, acc, 0, 0, 0);
+      for (int j = 0; j < PFD; ++j) bq[j] = *reinterpret_cast<const f32x4*>(hrow + 16 * j);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const f32x4 bv = bq[j % PFD];
+        if (j + PFD < NJ) bq[j % PFD] = *reinterpret_cast<const f32x4*>(hrow + 16 * (j + PFD));     // columns beyond h are never
+        if (16 * j < h) {                                                                            // consumed (wave-uniform)
+#pragma unroll
+          for (int m = 0; m < 4; m += 2) {                   // two accumulator chains: a dependent MFMA waits for its predecessor
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[j][m], bv[m], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[j][m + 1], bv[m + 1], acc2, 0, 0, 0);
+          }
         }
       }
+      acc += acc2;
     }
+#ifdef TSG_LSTM_TIMING
+    asm volatile("" : "+v"(acc));
+    if (step > 0) TSG_TICK(2)                                // MFMA chain issued (and its result consumed below)
+#endif
     if (live) {
       const float gi = sigmoid_f(acc[0] + gx[0]), gf = sigmoid_f(acc[1] + gx[1]);
       const float gg = tanh_f(acc[2] + gx[2]), go = sigmoid_f(acc[3] + gx[3]);
@@ -486,7 +521,14 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
       store_sc1(out + ((size_t)tt * B + b) * 2 * h + d * h + u, hv);
     }
     __syncthreads();                                        // the slab in LDS is free again (the h stores keep flying)
+#ifdef TSG_LSTM_TIMING
+    if (step > 0) TSG_TICK(3)                                // gates, stores issued, workgroup met
+#endif
   }
+#ifdef TSG_LSTM_TIMING
+  if (blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 4; ++i) sync[8 + i] = (unsigned)(tph[i] / (unsigned long long)(T - 1));
+#endif
 }
 
 }  // namespace
@@ -522,18 +564,18 @@ extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R,
   if (rc) return rc;
   auto st = static_cast<hipStream_t>(stream);
   // persistent path: weights stationary, one launch for all T steps -- needs every workgroup resident
-  if (sync_ws && persist_wanted(T) && h % 16 == 0 && h <= kPersistMaxH && T > 1) {
-    const int grid = 2 * (h / 16) * cdiv(B, 32);
-    const int HLS = roundup(h, 64) + 4;
-    const size_t plds = sizeof(float) * (size_t)32 * HLS;
+  if (sync_ws && persist_wanted(T) && h % 32 == 0 && h <= kPersistMaxH && T > 1) {
+    const int grid = 2 * (h / 32) * cdiv(B, 16);
+    const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
+    const size_t plds = sizeof(float) * (size_t)16 * HLS;
     auto pk = lstm_fwd_persist_kernel;
     static int capacity = -1;
     if (capacity < 0) {
       int dev = 0, cus = 0, per = 0;
-      hipError_t e1 = allow_lds(pk, sizeof(float) * 32 * (kPersistMaxH + 4));
+      hipError_t e1 = allow_lds(pk, sizeof(float) * 16 * (kPersistMaxH + 8));
       if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
       if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, kThreads, sizeof(float) * 32 * (kPersistMaxH + 4));
+      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, kThreads, sizeof(float) * 16 * (kPersistMaxH + 8));
       capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;      // count ONE workgroup per CU: margin against over-reporting
     }
     if (grid <= capacity) {

@@ -73,7 +73,7 @@ def test_bilstm_golden(golden):
 
 def test_bilstm_persistent_kernel():
     """The opt-in persistent forward (TSG_LSTM_PERSIST=1: W_hh stationary in registers, consumers poll the
-    sentinel-marked h slab itself) must give the step kernels' result bit for bit and must not trip its
+    sentinel-marked h slab itself) must give the step kernels' result (same products, different k order) and must not trip its
     bounded-wait error word."""
     import subprocess, sys, os
     code = (
@@ -86,9 +86,9 @@ def test_bilstm_persistent_kernel():
         "    out=torch.empty(T,B,2*h,device='cuda'); R=torch.empty(T,2,B,h,4,device='cuda'); Cs=torch.empty(T,2,B,h,device='cuda')\n"
         "    rc=lib.tsg_lstm_fwd(ptr(Gx),ptr(W),ptr(out),ptr(R),ptr(Cs),ptr(ws) if ws is not None else None,B,T,h,TSG_F32,torch.cuda.current_stream().cuda_stream)\n"
         "    torch.cuda.synchronize(); assert rc==0\n"
-        "    if ws is not None: assert int(ws[0])==0 and int(ws[1])==2*(h//16)*((B+31)//32), ws[:6].tolist()\n"
+        "    if ws is not None: assert int(ws[0])==0 and int(ws[1])==2*(h//32)*((B+15)//16), ws[:6].tolist()\n"
         "    outs.append((out,R,Cs))\n"
-        "for a,b in zip(*outs): assert torch.equal(a,b)\n"
+        "for a,b in zip(*outs): torch.testing.assert_close(a,b,atol=1e-5,rtol=1e-5)\n"
         "print('persist ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TSG_LSTM_PERSIST="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)

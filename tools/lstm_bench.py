@@ -20,6 +20,6 @@ def t(fn, n=5):
     return e0.elapsed_time(e1) / n
 sync = torch.zeros(64, device=dev, dtype=torch.int32)
 f = t(lambda: lib.tsg_lstm_fwd(ptr(Gx), ptr(W), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, TSG_F32, st))
-print('sync word0 (error flag):', int(sync[0]), 'counters', sync[1:9].tolist())
+print('sync word0 (error flag):', int(sync[0]), 'counters', sync[1:8].tolist(), 'phase ticks', sync[8:12].tolist())
 b = t(lambda: lib.tsg_lstm_bwd(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC), B, T, h, TSG_F32, st))
 print(f"B={B} T={T} h={h}: fwd {f*1e3/T:.2f} us/step ({f:.2f} ms), bwd {b*1e3/T:.2f} us/step ({b:.2f} ms)")
