@@ -122,8 +122,8 @@ int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, cons
  * tsg_lstm_fwd runs the T sequential steps (one launch per step covering both directions):
  *   Whh [2,4h,h];  out [T,B,2h] (forward half | reverse half);  saved for backward: R [T,2,B,h,4]
  *   (activated gates) and Cs [T,2,B,h] (cell states).  Limits: h % 4 == 0.
- * sync_ws: caller-owned 256-byte workspace (may be NULL).  When given, T >= 48 (TSG_LSTM_PERSIST=0/1 in the
- *   environment: never / always), h % 16 == 0, h <= 512 and the grid fits the device, ONE persistent launch runs all T steps (W_hh stationary in
+ * sync_ws: caller-owned 256-byte workspace (may be NULL).  When given, T >= 8 (TSG_LSTM_PERSIST=0/1 in the
+ *   environment: never / always), h % 32 == 0, h <= 512 and the grid fits the device, ONE persistent launch runs all T steps (W_hh stationary in
  *   registers; workgroups hand h_t over by polling the sentinel-marked `out` slab itself); word 0 of sync_ws is
  *   non-zero afterwards if a bounded wait expired (results then invalid).  Otherwise one launch per time step.   */
 int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,

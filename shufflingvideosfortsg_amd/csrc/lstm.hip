@@ -362,7 +362,8 @@ __device__ __forceinline__ void store_sc1_u(float* p, unsigned v) {
 __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
     const float* __restrict__ Gx, const float* __restrict__ Whh, float* __restrict__ out,
     float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS) {
-  extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice
+  extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice, then Ht [16][33]
+  float* Ht = Hl + 16 * HLS;                             // this step's h tile (16 rows x 32 units), gathered for whole-line stores
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int uslices = h / 32, bslices = (B + 15) / 16;
   const int d = blockIdx.x / (uslices * bslices);
@@ -391,11 +392,14 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
   const int nrow4 = h / 4;                                 // float4 per h row
 
   {
-    // Every lane marks the elements of `out` it will produce (all T steps) with the sentinel -- the same lane, the same
+    // Every lane marks the elements of `out` it will store (all T steps) with the sentinel -- the same lane, the same
     // address and the same write-through path as the later h store, so the two stay ordered -- and the grid meets once
     // (arrival counter sync[1]) so that no consumer can poll an element before its sentinel is in memory.
-    if (live)
-      for (int t = 0; t < T; ++t) store_sc1_u(out + ((size_t)t * B + b) * 2 * h + d * h + u, kSentinel);
+    {
+      const int row = tid >> 5, col = tid & 31;              // the same whole-line pattern as the h stores of the step loop
+      if (b0 + row < B)
+        for (int t = 0; t < T; ++t) store_sc1_u(out + ((size_t)t * B + b0 + row) * 2 * h + d * h + us * 32 + col, kSentinel);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -509,18 +513,27 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
     asm volatile("" : "+v"(acc));
     if (step > 0) TSG_TICK(2)                                // MFMA chain issued (and its result consumed below)
 #endif
+    // h_t goes out first and as WHOLE 128-byte lines: the workgroup's 16 x 32 tile is gathered in LDS and every wave
+    // writes two complete rows per store instruction (write-through); the per-lane 4-byte stores of the first version
+    // put eight partial writes from eight waves on every line.  R / Cs (not on the critical path) follow.
+    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c = 0.f;
     if (live) {
-      const float gi = sigmoid_f(acc[0] + gx[0]), gf = sigmoid_f(acc[1] + gx[1]);
-      const float gg = tanh_f(acc[2] + gx[2]), go = sigmoid_f(acc[3] + gx[3]);
-      const float c = fmaf(gf, cprev, gi * gg);
-      const float hv = go * tanh_f(c);
+      gi = sigmoid_f(acc[0] + gx[0]); gf = sigmoid_f(acc[1] + gx[1]);
+      gg = tanh_f(acc[2] + gx[2]); go = sigmoid_f(acc[3] + gx[3]);
+      c = fmaf(gf, cprev, gi * gg);
       cprev = c;
+      Ht[jb * 33 + at * 4 + ku] = go * tanh_f(c);
+    }
+    __syncthreads();                                        // tile complete; the slab in LDS is free again
+    {
+      const int row = tid >> 5, col = tid & 31;
+      if (b0 + row < B) store_sc1(out + ((size_t)tt * B + b0 + row) * 2 * h + d * h + us * 32 + col, Ht[row * 33 + col]);
+    }
+    if (live) {
       const size_t s = (((size_t)tt * 2 + d) * B + b) * h + u;
       Cs[s] = c;
       *reinterpret_cast<float4*>(R + s * 4) = make_float4(gi, gf, gg, go);
-      store_sc1(out + ((size_t)tt * B + b) * 2 * h + d * h + u, hv);
     }
-    __syncthreads();                                        // the slab in LDS is free again (the h stores keep flying)
 #ifdef TSG_LSTM_TIMING
     if (step > 0) TSG_TICK(3)                                // gates, stores issued, workgroup met
 #endif
@@ -543,15 +556,14 @@ static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
   return 0;
 }
 
-// TSG_LSTM_PERSIST: unset = auto (persistent launch for sequences of >= 48 steps: 14.3 vs 17.3 us/step at
-// [B=128,T=128,h=512], but 13.6 vs 11.6 us/step at [64,20,512] where the start barrier is not amortised),
-// 0 = never, 1 = whenever the grid fits.
+// TSG_LSTM_PERSIST: unset = auto (persistent launch for sequences of >= 8 steps: 8.2 vs 17.3 us/step at
+// [B=128,T=128,h=512], 7.4 vs 11.3 us/step at [64,20,512]), 0 = never, 1 = whenever the grid fits.
 static int persist_mode() {
   static int v = -2;
   if (v == -2) { const char* e = getenv("TSG_LSTM_PERSIST"); v = e ? atoi(e) : -1; }
   return v;
 }
-static bool persist_wanted(int T) { const int m = persist_mode(); return m > 0 || (m < 0 && T >= 48); }
+static bool persist_wanted(int T) { const int m = persist_mode(); return m > 0 || (m < 0 && T >= 8); }
 
 extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                             int B, int T, int h, int dtype, void* stream) {
@@ -567,15 +579,15 @@ extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R,
   if (sync_ws && persist_wanted(T) && h % 32 == 0 && h <= kPersistMaxH && T > 1) {
     const int grid = 2 * (h / 32) * cdiv(B, 16);
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
-    const size_t plds = sizeof(float) * (size_t)16 * HLS;
+    const size_t plds = sizeof(float) * ((size_t)16 * HLS + 16 * 33);
     auto pk = lstm_fwd_persist_kernel;
     static int capacity = -1;
     if (capacity < 0) {
       int dev = 0, cus = 0, per = 0;
-      hipError_t e1 = allow_lds(pk, sizeof(float) * 16 * (kPersistMaxH + 8));
+      hipError_t e1 = allow_lds(pk, sizeof(float) * (16 * (kPersistMaxH + 8) + 16 * 33));
       if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
       if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, kThreads, sizeof(float) * 16 * (kPersistMaxH + 8));
+      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, kThreads, sizeof(float) * (16 * (kPersistMaxH + 8) + 16 * 33));
       capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;      // count ONE workgroup per CU: margin against over-reporting
     }
     if (grid <= capacity) {
