@@ -137,6 +137,15 @@ int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, 
 int tsg_lstm_bwd(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
                  void* dG, void* dC_ws, int B, int T, int h, int dtype, void* stream);
 
+/* Same result through the persistent backward kernel when the caller provides its ring workspace: ws of at least
+ * tsg_lstm_bwd_ws_bytes(B,T,h) bytes (0 = not available for this shape: h % 128 != 0 or h > 512), 16-byte aligned,
+ * contents irrelevant.  One launch runs all T steps: workgroups exchange partial dh tiles through a 4-slot ring of
+ * sentinel-marked, write-through 128-byte lines (no atomics or fences per step).  Falls back to tsg_lstm_bwd when ws is
+ * NULL / too small, the grid does not fit the device or T < 8 (TSG_LSTM_PERSIST=0/1: never / always).            */
+long long tsg_lstm_bwd_ws_bytes(int B, int T, int h);
+int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
+                    void* dG, void* dC_ws, void* ws, long long ws_bytes, int B, int T, int h, int dtype, void* stream);
+
 /* ---- dense projection GEMM on the fp32 matrix cores ("tsg_gemm_*" of SURVEY section 8b) ------------------------------
  * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL): torch.nn.Linear's layout, i.e. the d x d projections of the path
  * (SCDM W_a / W_s attention.py:104-106, sent_linear VideoEncoder.py:48, MultiHead wq/wk/wv/wo attention.py:63-66, the

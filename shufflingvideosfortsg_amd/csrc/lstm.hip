@@ -355,6 +355,9 @@ __device__ __forceinline__ u32x4 load_sc1_u4(const float* p) {           // inte
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+__device__ __forceinline__ void store_sc1_u4(float* p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void store_sc1_u(float* p, unsigned v) {
   asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
@@ -726,6 +729,187 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward, PERSISTENT variant 2 (the default when the caller provides the ring workspace): exchange dh, not dG.
+// Workgroup = (direction, 32 units, 16 batch rows) as in the forward.  Its OWN gate gradients of the step before
+// (16 rows x 128 gate columns, in LDS) are the B operand, its 128 x h slice of W_hh (registers, 128 VGPRs at h = 512)
+// the A operand of  partial_dh[16 rows][ALL h units] = dG_own W_hh[own gate rows, :]  -- no operand has to be fetched.
+// What is exchanged is the reduction: every workgroup writes its partial tile as whole 128-byte write-through lines into
+// a ring slot (one 2 KiB block per consumer), and polls the h/32 blocks addressed to it -- 32 KiB per workgroup and
+// step, like the forward's h slab and a quarter of the dG slab of variant 1.  Ring = 4 slots, slot = step % 4, and the
+// "written" mark is a generation tag instead of a sentinel: every partial value carries (step/4) % 2 in its lowest
+// mantissa bit (a perturbation of at most one ulp of a partial sum); a consumer accepts a float4 when all four tags
+// match the generation it expects, so a slot needs no re-marking between uses (re-marking with sentinel lines doubled
+// the write-through traffic: 14.1 us per step).  Consumers are never more than one step apart, so a slot's previous
+// generation has been read by everyone before its next one is written.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDLS = 128 + 8;                    // own-dG tile row stride (floats), = 8 mod 64
+constexpr int kPLS = kPersistMaxH + 8;           // partial-dh gather row stride
+constexpr int kQLS = 36;                         // polled partial sums row stride
+
+__global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
+    const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
+    const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG,
+    float* __restrict__ ring, unsigned* __restrict__ sync, int B, int T, int h) {
+  extern __shared__ __align__(16) float smem2[];
+  float* Dl = smem2;                              // [16][kDLS]  this workgroup's dG tile, local column g*32 + ul
+  float* Pl = Dl + 16 * kDLS;                     // [16][kPLS]  partial dh of all h units, gathered for whole-line stores
+  float* Ql = Pl + 16 * kPLS;                     // [4][16][kQLS] sums of the polled blocks per producer group
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+  const int nus = h / 32, bslices = (B + 15) / 16, TW = h / 128;      // TW = 16-unit tiles per wave = float4 per thread
+  const int d = blockIdx.x / (nus * bslices);
+  const int rem = blockIdx.x % (nus * bslices);
+  const int us = rem / bslices, bs = rem % bslices;
+  const int b0 = bs * 16, K = 4 * h;
+  const int jb = lane & 15, ku = lane >> 4;
+  // A fragments: tile t of this wave = output units 16*(wv*TW + t) + jb; local k' = 16s + 4ku + m -> gate s/2, unit
+  // us*32 + 16*(s%2) + 4ku + m of the workgroup's own gate columns
+  f32x4 areg[4][8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      areg[t][s8] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (t < TW)
+        areg[t][s8] = *reinterpret_cast<const f32x4*>(WhhT + ((size_t)d * h + 16 * (wv * TW + t) + jb) * K + (s8 >> 1) * h +
+                                                       us * 32 + 16 * (s8 & 1) + 4 * ku);
+    }
+  const int row = tid >> 5, ul = tid & 31;                  // epilogue role: (batch row, unit) of the 16 x 32 tile
+  const int b = b0 + row, u = us * 32 + ul;
+  const bool live = b < B;
+  float dc_carry = 0.f;
+  const int hq = h / 4;                                     // float4 per partial row
+  auto slot_base = [&](int slot) { return ring + ((size_t)(slot * 2 + d) * bslices + bs) * nus * nus * 512; };
+  // producer side: float4 i of this thread = (row pr, units 4*pc .. +3) of the partial tile -> block of consumer pc/8
+  auto prod_ptr = [&](int slot, int i) {
+    const int idx = tid + i * kThreads, pr = idx / hq, pc = idx % hq;
+    return slot_base(slot) + ((size_t)((pc >> 3) * nus + us) * 16 + pr) * 32 + 4 * (pc & 7);
+  };
+
+  {  // all four slots start with the "odd generation" tag (low mantissa bit 1) on every element, then the grid meets once
+    const u32x4 sent = {kSentinel | 1u, kSentinel | 1u, kSentinel | 1u, kSentinel | 1u};
+    for (int slot = 0; slot < 4; ++slot)
+      for (int i = 0; i < TW; ++i) store_sc1_u4(prod_ptr(slot, i), sent);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+  }
+
+  for (int step = 0; step < T; ++step) {
+    const int fs = T - 1 - step;
+    const int tt = d == 0 ? fs : T - 1 - fs;                // time index handled now
+    const int tp = d == 0 ? tt - 1 : tt + 1;                // forward-earlier neighbour (c_{t-1})
+    const bool has_prev = (d == 0) ? (tt > 0) : (tt < T - 1);
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cc = 0.f, cpv = 0.f, dov = 0.f;
+    if (live) {
+      const size_t sidx = (((size_t)tt * 2 + d) * B + b) * h + u;
+      g4 = *reinterpret_cast<const float4*>(R + sidx * 4);
+      cc = Cs[sidx];
+      if (has_prev) cpv = Cs[(((size_t)tp * 2 + d) * B + b) * h + u];
+      dov = dOut[((size_t)tt * B + b) * 2 * h + d * h + u];
+      if (step == 0 && dHn) dov += dHn[((size_t)d * B + b) * h + u];
+    }
+    float rec = 0.f;
+    if (step > 0) {
+      // poll the nus blocks addressed to this workgroup in slot (step-1)%4: thread = (producer group pg, row pr, 4 units pc);
+      // its loads i = producers pg + 4i (always four loads: the ones beyond TW repeat the first and are ignored)
+      const int pg = tid >> 7, pr = (tid & 127) >> 3, pc = tid & 7;
+      const float* cbase = slot_base((step - 1) & 3) + (size_t)us * nus * 512;
+      const float* src[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) src[i] = cbase + ((size_t)(pg + 4 * (i < TW ? i : 0)) * 16 + pr) * 32 + 4 * pc;
+      const unsigned pending = (1u << TW) - 1u;
+      const unsigned gen = ((unsigned)(step - 1) >> 2) & 1u;         // generation of slot (step-1)%4: every element carries it in its low bit
+      u32x4 q[4];
+      int spins = 0;
+      while (true) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = load_sc1_u4(src[i]);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : : "memory");
+        unsigned raw = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (((q[i][0] & q[i][1] & q[i][2] & q[i][3]) & 1u) != gen || ((q[i][0] | q[i][1] | q[i][2] | q[i][3]) & 1u) != gen) raw |= 1u << i;
+        raw &= pending;
+        if (!raw) break;
+        if (++spins > (kSpinLimit >> 6) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < TW) sum += (f32x4){__uint_as_float(q[i][0]), __uint_as_float(q[i][1]), __uint_as_float(q[i][2]), __uint_as_float(q[i][3])};
+      *reinterpret_cast<f32x4*>(Ql + (pg * 16 + pr) * kQLS + 4 * pc) = sum;
+      __syncthreads();
+      if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // a bounded wait expired somewhere
+#pragma unroll
+      for (int g = 0; g < 4; ++g) rec += Ql[(g * 16 + row) * kQLS + ul];
+    }
+    {
+      const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
+      const float tc = tanh_f(cc);
+      const float dh = dov + rec;
+      const float dc = fmaf(dh * go, 1.f - tc * tc, dc_carry);
+      dc_carry = dc * gf;
+      const float dg[4] = {dc * gg * gi * (1.f - gi), dc * cpv * gf * (1.f - gf), dc * gi * (1.f - gg * gg), dh * tc * go * (1.f - go)};
+      if (live) {
+        float* g = dG + (((size_t)tt * B + b) * 2 + d) * K + u;
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) g[gate * h] = dg[gate];
+      }
+#pragma unroll
+      for (int gate = 0; gate < 4; ++gate) Dl[row * kDLS + gate * 32 + ul] = live ? dg[gate] : 0.f;
+    }
+    if (step + 1 < T) {
+      __syncthreads();                                       // the dG tile is complete (and Ql is free again)
+      f32x4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* drow = Dl + jb * kDLS + 4 * ku;
+      f32x4 ball[8];                                         // all eight B fragments requested up front (8 KiB tile)
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) ball[s8] = *reinterpret_cast<const f32x4*>(drow + 16 * s8);
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const f32x4 bv = ball[s8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (t < TW) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[t][s8][m], bv[m], acc[t], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < TW) *reinterpret_cast<f32x4*>(Pl + jb * kPLS + 16 * (wv * TW + t) + 4 * ku) = acc[t];
+      __syncthreads();
+      const unsigned gtag = ((unsigned)step >> 2) & 1u;      // generation of slot step%4, carried in the low mantissa bit
+      for (int i = 0; i < TW; ++i) {
+        const int idx = tid + i * kThreads, pr = idx / hq, pc = idx % hq;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Pl + pr * kPLS + 4 * pc);
+        store_sc1_u4(prod_ptr(step & 3, i), (u32x4){(__float_as_uint(v[0]) & ~1u) | gtag, (__float_as_uint(v[1]) & ~1u) | gtag,
+                                                   (__float_as_uint(v[2]) & ~1u) | gtag, (__float_as_uint(v[3]) & ~1u) | gtag});
+      }
+    }
+  }
+}
+
 // TSG_LSTM_PERSIST: unset = auto (persistent launch for sequences of >= 8 steps: 8.2 vs 17.3 us/step at
 // [B=128,T=128,h=512], 7.4 vs 11.3 us/step at [64,20,512]), 0 = never, 1 = whenever the grid fits.
 static int persist_mode() {
@@ -825,4 +1009,47 @@ extern "C" int tsg_lstm_bwd(const void* WhhT, const void* R, const void* Cs, con
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), 0, st, (const float*)WhhT, (const float*)R, (const float*)Cs,
                        (const float*)dOut, (const float*)dHn, (float*)dG, (float*)dC_ws, B, T, h, step);
   return check_launch(fn);
+}
+
+extern "C" long long tsg_lstm_bwd_ws_bytes(int B, int T, int h) {
+  (void)T;
+  if (B <= 0 || h <= 0 || h % 128 || h > kPersistMaxH) return 0;
+  const long long nus = h / 32, bslices = cdiv(B, 16);
+  return 256 + 4LL * 2 * bslices * nus * nus * 512 * (long long)sizeof(float);
+}
+
+extern "C" int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
+                               void* dG, void* dC_ws, void* ws, long long ws_bytes, int B, int T, int h, int dtype,
+                               void* stream) {
+  const char* fn = "tsg_lstm_bwd_ws";
+  const long long need = tsg_lstm_bwd_ws_bytes(B, T, h);
+  if (ws && need > 0 && ws_bytes >= need && T > 1 && persist_wanted(T) && aligned16(ws)) {
+    for (const void* p : {WhhT, R, Cs, dOut, (const void*)dG}) {
+      if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+      if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
+    }
+    int rc = lstm_check(fn, B, T, h, dtype);
+    if (rc) return rc;
+    auto st = static_cast<hipStream_t>(stream);
+    const int pgrid = 2 * (h / 32) * cdiv(B, 16);
+    const size_t plds = sizeof(float) * ((size_t)16 * kDLS + 16 * kPLS + 4 * 16 * kQLS);
+    auto pk = lstm_bwd_persist2_kernel;
+    static int capacity = -1;
+    if (capacity < 0) {
+      int dev = 0, cus = 0, per = 0;
+      hipError_t e1 = allow_lds(pk, plds);
+      if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
+      if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, kThreads, plds);
+      capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;
+    }
+    if (pgrid <= capacity) {
+      hipError_t e = hipMemsetAsync(ws, 0, 256, st);
+      if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+      hipLaunchKernelGGL(pk, dim3(pgrid), dim3(kThreads), plds, st, (const float*)WhhT, (const float*)R, (const float*)Cs,
+                         (const float*)dOut, (const float*)dHn, (float*)dG, (float*)((char*)ws + 256), (unsigned*)ws, B, T, h);
+      return check_launch(fn);
+    }
+  }
+  return tsg_lstm_bwd(WhhT, R, Cs, dOut, dHn, dG, dC_ws, B, T, h, dtype, stream);
 }

@@ -398,7 +398,10 @@ class _BiLSTMLayer(torch.autograd.Function):
         WhhT = W_hh.transpose(1, 2).contiguous()
         dG = torch.empty(T, B, 2, 4 * h, device=x.device, dtype=torch.float32)
         dC = torch.empty(2, B, h, device=x.device, dtype=torch.float32)
-        _call("tsg_lstm_bwd", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC), B, T, h, TSG_F32)
+        nb = int(load().tsg_lstm_bwd_ws_bytes(B, T, h))                      # ring workspace of the persistent backward (0: none)
+        ws = torch.empty(nb // 4 + 4, device=x.device, dtype=torch.float32) if nb > 0 else None
+        _call("tsg_lstm_bwd_ws", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC),
+              ptr(ws) if ws is not None else None, nb, B, T, h, TSG_F32)
         dGf = dG.view(T * B, 8 * h)
         dx = _mm(dGf, W_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         dbias = dGf.sum(0)

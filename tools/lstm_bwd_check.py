@@ -17,12 +17,18 @@ WT = W.transpose(1, 2).contiguous()
 res = []
 for hn in (None, dHn):
     dG = torch.full((T, B, 2, 4 * h), 3.0, device="cuda"); dC = torch.zeros(2, B, h, device="cuda")
-    rc = lib.tsg_lstm_bwd(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), ptr(hn) if hn is not None else None, ptr(dG), ptr(dC), B, T, h, TSG_F32, st)
+    if os.environ.get("TSG_WS") == "1":
+        nb = lib.tsg_lstm_bwd_ws_bytes(B, T, h); assert nb > 0, "no persistent backward for this shape"
+        ws = torch.empty(nb // 4 + 4, device="cuda")
+        rc = lib.tsg_lstm_bwd_ws(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), ptr(hn) if hn is not None else None, ptr(dG), ptr(dC), ptr(ws), nb, B, T, h, TSG_F32, st)
+        torch.cuda.synchronize(); print("ws err word", int(ws[:1].view(torch.int32)[0]))
+    else:
+        rc = lib.tsg_lstm_bwd(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), ptr(hn) if hn is not None else None, ptr(dG), ptr(dC), B, T, h, TSG_F32, st)
     torch.cuda.synchronize(); assert rc == 0, lib.tsg_last_error()
     res.append(dG.cpu())
 f = f"/tmp/lstm_bwd_{B}_{T}_{h}.pt"
 mode = os.environ.get("TSG_LSTM_PERSIST", "auto")
-if mode == "0":
+if mode == "0" and os.environ.get("TSG_WS") != "1":
     torch.save(res, f); print("reference written", f)
 else:
     ref = torch.load(f)
