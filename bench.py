@@ -39,6 +39,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 _T0 = time.time()
 
 
+# stdout carries exactly ONE line, the JSON result: fd 1 is pointed at stderr for everything else that may print there
+# (RCCL prints a five-line version banner on stdout when a communicator is created), the result goes to the saved fd.
+_RESULT_FD = os.dup(1)
+os.dup2(2, 1)
+
+
 def log(msg):
     """progress on stderr (stdout carries exactly one JSON line)"""
     if int(os.environ.get("RANK", 0)) == 0:
@@ -323,7 +329,7 @@ def main():
                           "global_batch": a.B * world, "parallelism": f"dp{world}", "grad_bytes": dp.grad_bytes},
                "roofline": roof, "alt_gemm_modes": alt, "kernels": kern,
                "cpu_baseline": cpu_baseline(a.model, params, a.T, a.N, a.cpu_sample) if (a.cpu_sample > 0 and world == 1) else None}
-        print(json.dumps(out), flush=True)
+        os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
