@@ -143,8 +143,12 @@ int tsg_lstm_bwd(const void* WhhT, const void* R, const void* Cs, const void* dO
  * sentinel-marked, write-through 128-byte lines (no atomics or fences per step).  Falls back to tsg_lstm_bwd when ws is
  * NULL / too small, the grid does not fit the device or T < 8 (TSG_LSTM_PERSIST=0/1: never / always).            */
 long long tsg_lstm_bwd_ws_bytes(int B, int T, int h);
+/* 1 when tsg_lstm_bwd_ws will take the persistent path for this shape and workspace size (then, and only then, it also
+ * fills dbias [2,4h] = d(b_ih + b_hh), the sum of dG over time and batch, when dbias is non-NULL).                  */
+int tsg_lstm_bwd_ws_persistent(int B, int T, int h, long long ws_bytes);
 int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
-                    void* dG, void* dC_ws, void* ws, long long ws_bytes, int B, int T, int h, int dtype, void* stream);
+                    void* dG, void* dC_ws, void* ws, long long ws_bytes, void* dbias, int B, int T, int h, int dtype,
+                    void* stream);
 
 /* ---- dense projection GEMM on the fp32 matrix cores ("tsg_gemm_*" of SURVEY section 8b) ------------------------------
  * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL): torch.nn.Linear's layout, i.e. the d x d projections of the path

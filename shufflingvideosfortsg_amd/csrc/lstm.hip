@@ -750,7 +750,7 @@ constexpr int kQLS = 36;                         // polled partial sums row stri
 __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
     const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
     const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG,
-    float* __restrict__ ring, unsigned* __restrict__ sync, int B, int T, int h) {
+    float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int T, int h) {
   extern __shared__ __align__(16) float smem2[];
   float* Dl = smem2;                              // [16][kDLS]  this workgroup's dG tile, local column g*32 + ul
   float* Pl = Dl + 16 * kDLS;                     // [16][kPLS]  partial dh of all h units, gathered for whole-line stores
@@ -778,6 +778,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
   const int b = b0 + row, u = us * 32 + ul;
   const bool live = b < B;
   float dc_carry = 0.f;
+  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};                    // this thread's sum over the time steps of its four gate gradients
   const int hq = h / 4;                                     // float4 per partial row
   auto slot_base = [&](int slot) { return ring + ((size_t)(slot * 2 + d) * bslices + bs) * nus * nus * 512; };
   // producer side: float4 i of this thread = (row pr, units 4*pc .. +3) of the partial tile -> block of consumer pc/8
@@ -873,7 +874,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
         for (int gate = 0; gate < 4; ++gate) g[gate * h] = dg[gate];
       }
 #pragma unroll
-      for (int gate = 0; gate < 4; ++gate) Dl[row * kDLS + gate * 32 + ul] = live ? dg[gate] : 0.f;
+      for (int gate = 0; gate < 4; ++gate) {
+        Dl[row * kDLS + gate * 32 + ul] = live ? dg[gate] : 0.f;
+        if (live) dbsum[gate] += dg[gate];
+      }
     }
     if (step + 1 < T) {
       __syncthreads();                                       // the dG tile is complete (and Ql is free again)
@@ -906,6 +910,18 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
         store_sc1_u4(prod_ptr(step & 3, i), (u32x4){(__float_as_uint(v[0]) & ~1u) | gtag, (__float_as_uint(v[1]) & ~1u) | gtag,
                                                    (__float_as_uint(v[2]) & ~1u) | gtag, (__float_as_uint(v[3]) & ~1u) | gtag});
       }
+    }
+  }
+  if (dbias) {                                              // d(b_ih + b_hh)[d][gate*h + u] += sum over this workgroup's rows and all steps
+    __syncthreads();
+#pragma unroll
+    for (int gate = 0; gate < 4; ++gate) Dl[row * kDLS + gate * 32 + ul] = dbsum[gate];
+    __syncthreads();
+    if (tid < 128) {
+      float sgu = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sgu += Dl[r * kDLS + tid];
+      atomicAdd(dbias + (size_t)d * K + (tid >> 5) * h + us * 32 + (tid & 31), sgu);
     }
   }
 }
@@ -1018,12 +1034,31 @@ extern "C" long long tsg_lstm_bwd_ws_bytes(int B, int T, int h) {
   return 256 + 4LL * 2 * bslices * nus * nus * 512 * (long long)sizeof(float);
 }
 
+static int bwd_persist_capacity(size_t plds) {
+  static int capacity = -1;
+  if (capacity < 0) {
+    int dev = 0, cus = 0, per = 0;
+    hipError_t e1 = allow_lds(lstm_bwd_persist2_kernel, plds);
+    if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
+    if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, lstm_bwd_persist2_kernel, kThreads, plds);
+    capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;
+  }
+  return capacity;
+}
+static constexpr size_t kBwd2Lds = sizeof(float) * ((size_t)16 * kDLS + 16 * kPLS + 4 * 16 * kQLS);
+
+extern "C" int tsg_lstm_bwd_ws_persistent(int B, int T, int h, long long ws_bytes) {
+  const long long need = tsg_lstm_bwd_ws_bytes(B, T, h);
+  return need > 0 && ws_bytes >= need && T > 1 && persist_wanted(T) && 2 * (h / 32) * cdiv(B, 16) <= bwd_persist_capacity(kBwd2Lds);
+}
+
 extern "C" int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
-                               void* dG, void* dC_ws, void* ws, long long ws_bytes, int B, int T, int h, int dtype,
-                               void* stream) {
+                               void* dG, void* dC_ws, void* ws, long long ws_bytes, void* dbias, int B, int T, int h,
+                               int dtype, void* stream) {
   const char* fn = "tsg_lstm_bwd_ws";
   const long long need = tsg_lstm_bwd_ws_bytes(B, T, h);
-  if (ws && need > 0 && ws_bytes >= need && T > 1 && persist_wanted(T) && aligned16(ws)) {
+  if (ws && aligned16(ws) && tsg_lstm_bwd_ws_persistent(B, T, h, ws_bytes)) {
     for (const void* p : {WhhT, R, Cs, dOut, (const void*)dG}) {
       if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
       if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
@@ -1032,24 +1067,14 @@ extern "C" int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, 
     if (rc) return rc;
     auto st = static_cast<hipStream_t>(stream);
     const int pgrid = 2 * (h / 32) * cdiv(B, 16);
-    const size_t plds = sizeof(float) * ((size_t)16 * kDLS + 16 * kPLS + 4 * 16 * kQLS);
-    auto pk = lstm_bwd_persist2_kernel;
-    static int capacity = -1;
-    if (capacity < 0) {
-      int dev = 0, cus = 0, per = 0;
-      hipError_t e1 = allow_lds(pk, plds);
-      if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
-      if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, kThreads, plds);
-      capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;
-    }
-    if (pgrid <= capacity) {
-      hipError_t e = hipMemsetAsync(ws, 0, 256, st);
-      if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-      hipLaunchKernelGGL(pk, dim3(pgrid), dim3(kThreads), plds, st, (const float*)WhhT, (const float*)R, (const float*)Cs,
-                         (const float*)dOut, (const float*)dHn, (float*)dG, (float*)((char*)ws + 256), (unsigned*)ws, B, T, h);
-      return check_launch(fn);
-    }
+    hipError_t e = hipMemsetAsync(ws, 0, 256, st);
+    if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, sizeof(float) * 8 * h, st);
+    if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+    hipLaunchKernelGGL(lstm_bwd_persist2_kernel, dim3(pgrid), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT, (const float*)R,
+                       (const float*)Cs, (const float*)dOut, (const float*)dHn, (float*)dG, (float*)((char*)ws + 256),
+                       (unsigned*)ws, (float*)dbias, B, T, h);
+    return check_launch(fn);
   }
+  (void)need;
   return tsg_lstm_bwd(WhhT, R, Cs, dOut, dHn, dG, dC_ws, B, T, h, dtype, stream);
 }

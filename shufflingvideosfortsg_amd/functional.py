@@ -400,11 +400,14 @@ class _BiLSTMLayer(torch.autograd.Function):
         dC = torch.empty(2, B, h, device=x.device, dtype=torch.float32)
         nb = int(load().tsg_lstm_bwd_ws_bytes(B, T, h))                      # ring workspace of the persistent backward (0: none)
         ws = torch.empty(nb // 4 + 4, device=x.device, dtype=torch.float32) if nb > 0 else None
+        fused_db = ws is not None and bool(load().tsg_lstm_bwd_ws_persistent(B, T, h, nb))   # persistent path also sums dG -> dbias
+        dbias = torch.empty(8 * h, device=x.device, dtype=torch.float32) if fused_db else None
         _call("tsg_lstm_bwd_ws", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC),
-              ptr(ws) if ws is not None else None, nb, B, T, h, TSG_F32)
+              ptr(ws) if ws is not None else None, nb, ptr(dbias) if fused_db else None, B, T, h, TSG_F32)
         dGf = dG.view(T * B, 8 * h)
         dx = _mm(dGf, W_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
-        dbias = dGf.sum(0)
+        if dbias is None:
+            dbias = dGf.sum(0)
         # dW_hh[d] = sum_t dG_t[d]^T h_{t-1}[d]: the step whose h_{t-1} is the zero state drops out, so both operands are
         # plain strided VIEWS (rows t=1.. of dG with rows ..T-2 of out for the forward direction, the mirror image for
         # the reverse one) -- no shifted copy of out, no per-direction copy of dG

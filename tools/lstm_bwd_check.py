@@ -20,7 +20,7 @@ for hn in (None, dHn):
     if os.environ.get("TSG_WS") == "1":
         nb = lib.tsg_lstm_bwd_ws_bytes(B, T, h); assert nb > 0, "no persistent backward for this shape"
         ws = torch.empty(nb // 4 + 4, device="cuda")
-        rc = lib.tsg_lstm_bwd_ws(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), ptr(hn) if hn is not None else None, ptr(dG), ptr(dC), ptr(ws), nb, B, T, h, TSG_F32, st)
+        rc = lib.tsg_lstm_bwd_ws(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), ptr(hn) if hn is not None else None, ptr(dG), ptr(dC), ptr(ws), nb, None, B, T, h, TSG_F32, st)
         torch.cuda.synchronize(); print("ws err word", int(ws[:1].view(torch.int32)[0]))
     else:
         rc = lib.tsg_lstm_bwd(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), ptr(hn) if hn is not None else None, ptr(dG), ptr(dC), B, T, h, TSG_F32, st)
