@@ -131,9 +131,8 @@ int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, 
 
 /* backward of the recurrence: dOut [T,B,2h] (+ optional dHn [2,B,h] added at each direction's last step)
  * -> dG [T,B,2,4h] = dL/d(pre-activation gates); the caller derives dX, dW_ih, dW_hh, db from it with
- * GEMMs.  WhhT [2,h,4h] is W_hh transposed per direction; dC_ws is a [2,B,h] float workspace (cell-gradient carry
- * of the launch-per-step kernels; the opt-in persistent backward, TSG_LSTM_PERSIST_BWD=1, uses its first 256 bytes
- * as sync words).                                                                                            */
+ * GEMMs.  WhhT [2,h,4h] is W_hh transposed per direction; dC_ws is a [2,B,h] float workspace (the cell-gradient carry
+ * between the per-step launches).                                                                            */
 int tsg_lstm_bwd(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
                  void* dG, void* dC_ws, int B, int T, int h, int dtype, void* stream);
 

@@ -560,183 +560,15 @@ static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, PERSISTENT variant: the mirror image of lstm_fwd_persist_kernel.  Workgroup = (direction, 32 hidden
-// units, 16 batch rows), one per CU, all T steps in one launch.  The recurrent term
-//     dh_t[b,u] = dOut_t[b,u] + sum_k dG_{t+1}[b,k] W_hh[k,u]          (k over the 4h gate columns)
-// is a [32 units] x [16 rows] tile with K = 4h: the 8 waves are 2 unit-tiles x 4 K-quarters, each wave keeps its
-// 16 x h slice of W_hh^T in registers (128 VGPRs at h = 512), the four K-quarter partial tiles meet in LDS, and thread
-// (row, unit) then finishes its own (b, u) pair -- cell backward with the cell-gradient carry in a register -- and
-// writes its four gate gradients as whole 128-byte write-through lines (32 units x 4 B per row and gate).
-// Hand-off = the data is the flag, as in the forward: dG is sentinel-marked by its producers, the grid meets once,
-// and consumers poll their 16-row slab of dG_{t+1} (128 KiB at h = 512) until no element is the sentinel.
-// ---------------------------------------------------------------------------------------------
-constexpr int kBSlabV = 16 * kPersistMaxH / kThreads;        // float4 of the 16 x 4h slab per thread (16 at h = 512)
-constexpr int kPS = 36;                                      // partial-tile row stride (floats)
-
-__global__ __launch_bounds__(kThreads) void lstm_bwd_persist_kernel(
-    const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
-    const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG,
-    unsigned* __restrict__ sync, int B, int T, int h, int SLS) {
-  extern __shared__ __align__(16) float Sl[];              // [16][SLS] slab of dG_{t+1}, then Pl [4][16][kPS] partial tiles
-  float* Pl = Sl + 16 * SLS;
-  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
-  const int uslices = h / 32, bslices = (B + 15) / 16;
-  const int d = blockIdx.x / (uslices * bslices);
-  const int rem = blockIdx.x % (uslices * bslices);
-  const int us = rem / bslices, bs = rem % bslices;
-  const int b0 = bs * 16, K = 4 * h;
-  const int ut = wv & 1, kq4 = wv >> 1;                     // this wave's unit tile (16 units) and K quarter
-  const int jb = lane & 15, ku = lane >> 4;
-  const int kbeg = kq4 * (K / 4);                           // K/4 = h columns per quarter
-  // A fragments: row i = jb -> unit us*32 + ut*16 + jb of W_hh^T; lane quad ku holds columns kbeg + 16j + 4ku .. +3
-  f32x4 areg[kPersistMaxH / 16];
-  {
-    const float* wrow = WhhT + ((size_t)d * h + us * 32 + ut * 16 + jb) * K + kbeg + 4 * ku;
-#pragma unroll
-    for (int j = 0; j < kPersistMaxH / 16; ++j)
-      areg[j] = (16 * j < h) ? *reinterpret_cast<const f32x4*>(wrow + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  // epilogue role: thread = (batch row, unit) of the workgroup's 16 x 32 tile
-  const int row = tid >> 5, col = tid & 31;
-  const int b = b0 + row, u = us * 32 + col;
-  const bool live = b < B;
-  float dc_carry = 0.f;
-  const int nrow4 = K / 4;                                  // float4 per dG row of one direction
-
-  {  // sentinel-mark the dG elements this thread will produce (whole lines per wave instruction), then meet once
-    if (live)
-      for (int t = 0; t < T; ++t) {
-        float* g = dG + (((size_t)t * B + b) * 2 + d) * K + u;
-#pragma unroll
-        for (int gate = 0; gate < 4; ++gate) store_sc1_u(g + gate * h, kSentinel);
-      }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int spins = 0;
-      while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kSpinLimit || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-    __syncthreads();
-    if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-  }
-
-  for (int step = 0; step < T; ++step) {
-    const int fs = T - 1 - step;
-    const int tt = d == 0 ? fs : T - 1 - fs;                // time index handled now
-    const int tn = d == 0 ? tt + 1 : tt - 1;                // the step processed just before
-    const int tp = d == 0 ? tt - 1 : tt + 1;                // forward-earlier neighbour (c_{t-1})
-    const bool has_prev = (d == 0) ? (tt > 0) : (tt < T - 1);
-    // cell-backward operands of this thread's (b, u): requested now, used after the MFMAs
-    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float cc = 0.f, cpv = 0.f, dov = 0.f;
-    if (live) {
-      const size_t sidx = (((size_t)tt * 2 + d) * B + b) * h + u;
-      g4 = *reinterpret_cast<const float4*>(R + sidx * 4);
-      cc = Cs[sidx];
-      if (has_prev) cpv = Cs[(((size_t)tp * 2 + d) * B + b) * h + u];
-      dov = dOut[((size_t)tt * B + b) * 2 * h + d * h + u];
-      if (step == 0 && dHn) dov += dHn[((size_t)d * B + b) * h + u];
-    }
-    float rec = 0.f;
-    if (step > 0) {
-      // poll the 16-row slab of dG_{tn} until no element of this thread's float4 is the sentinel (loads unconditional and
-      // consumed by the s_waitcnt asm directly, see the forward kernel)
-      unsigned pending = 0u;
-      const float* src[kBSlabV];
-#pragma unroll
-      for (int i = 0; i < kBSlabV; ++i) {
-        const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
-        const bool ok = r < 16 && b0 + r < B;
-        if (ok) pending |= 1u << i;
-        src[i] = dG + (((size_t)tn * B + (ok ? b0 + r : b0)) * 2 + d) * K + (ok ? c4 * 4 : 0);
-      }
-      static_assert(kBSlabV == 16, "the wait below lists 16 loads");
-      u32x4 q[kBSlabV];
-      int spins = 0;
-      while (true) {
-#pragma unroll
-        for (int i = 0; i < kBSlabV; ++i) q[i] = load_sc1_u4(src[i]);
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]),
-                       "+v"(q[8]), "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15])
-                     : : "memory");
-        unsigned raw = 0u;
-#pragma unroll
-        for (int i = 0; i < kBSlabV; ++i)
-          if (q[i][0] == kSentinel || q[i][1] == kSentinel || q[i][2] == kSentinel || q[i][3] == kSentinel) raw |= 1u << i;
-        raw &= pending;
-        if (!raw) break;
-        if (++spins > (kSpinLimit >> 6) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < kBSlabV; ++i) {
-        const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
-        if (r < 16) {
-          const u32x4 z = (pending & (1u << i)) ? q[i] : (u32x4){0u, 0u, 0u, 0u};
-          *reinterpret_cast<u32x4*>(Sl + r * SLS + c4 * 4) = z;
-        }
-      }
-      __syncthreads();
-      if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // a bounded wait expired somewhere
-      // D[unit i][batch j] += sum_k W^T[i][k] dG[j][k] over this wave's K quarter; B operand rows = batch jb
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-      const float* grow = Sl + jb * SLS + kbeg + 4 * ku;
-      constexpr int NJ = kPersistMaxH / 16, PFD = 4;
-      f32x4 bq[PFD];
-#pragma unroll
-      for (int j = 0; j < PFD; ++j) bq[j] = *reinterpret_cast<const f32x4*>(grow + 16 * j);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const f32x4 bv = bq[j % PFD];
-        if (j + PFD < NJ && 16 * (j + PFD) < h) bq[j % PFD] = *reinterpret_cast<const f32x4*>(grow + 16 * (j + PFD));
-        if (16 * j < h) {
-#pragma unroll
-          for (int m = 0; m < 4; m += 2) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[j][m], bv[m], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[j][m + 1], bv[m + 1], acc2, 0, 0, 0);
-          }
-        }
-      }
-      acc += acc2;
-      // partial tile: lane (batch jb, unit quad ku) holds units ut*16 + 4ku .. +3 of its row -> Pl[kq4][jb][ut*16 + 4ku]
-      *reinterpret_cast<f32x4*>(Pl + (kq4 * 16 + jb) * kPS + ut * 16 + 4 * ku) = acc;
-      __syncthreads();
-#pragma unroll
-      for (int qk = 0; qk < 4; ++qk) rec += Pl[(qk * 16 + row) * kPS + col];
-    }
-    if (live) {
-      const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
-      const float tc = tanh_f(cc);
-      const float dh = dov + rec;
-      const float dc = fmaf(dh * go, 1.f - tc * tc, dc_carry);
-      dc_carry = dc * gf;
-      float* g = dG + (((size_t)tt * B + b) * 2 + d) * K + u;
-      store_sc1(g, dc * gg * gi * (1.f - gi));
-      store_sc1(g + h, dc * cpv * gf * (1.f - gf));
-      store_sc1(g + 2 * h, dc * gi * (1.f - gg * gg));
-      store_sc1(g + 3 * h, dh * tc * go * (1.f - go));
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// backward, PERSISTENT variant 2 (the default when the caller provides the ring workspace): exchange dh, not dG.
+// backward, PERSISTENT (the default when the caller provides the ring workspace): exchange dh, not dG.
+// (A first version mirrored the forward literally -- consumers polling the sentinel-marked 4h-wide dG slab, 128 KiB per
+// workgroup and step -- and measured 17.9 us per step against 14.9 for the launch-per-step kernels; see DESIGN.md.)
 // Workgroup = (direction, 32 units, 16 batch rows) as in the forward.  Its OWN gate gradients of the step before
 // (16 rows x 128 gate columns, in LDS) are the B operand, its 128 x h slice of W_hh (registers, 128 VGPRs at h = 512)
 // the A operand of  partial_dh[16 rows][ALL h units] = dG_own W_hh[own gate rows, :]  -- no operand has to be fetched.
 // What is exchanged is the reduction: every workgroup writes its partial tile as whole 128-byte write-through lines into
 // a ring slot (one 2 KiB block per consumer), and polls the h/32 blocks addressed to it -- 32 KiB per workgroup and
-// step, like the forward's h slab and a quarter of the dG slab of variant 1.  Ring = 4 slots, slot = step % 4, and the
+// step, like the forward's h slab and a quarter of a dG slab.  Ring = 4 slots, slot = step % 4, and the
 // "written" mark is a generation tag instead of a sentinel: every partial value carries (step/4) % 2 in its lowest
 // mantissa bit (a perturbation of at most one ulp of a partial sum); a consumer accepts a float4 when all four tags
 // match the generation it expects, so a slot needs no re-marking between uses (re-marking with sentinel lines doubled
@@ -992,34 +824,6 @@ extern "C" int tsg_lstm_bwd(const void* WhhT, const void* R, const void* Cs, con
   if (rc) return rc;
   auto kern = lstm_bwd_step_kernel;
   auto st = static_cast<hipStream_t>(stream);
-  // persistent path (see lstm_bwd_persist_kernel): dC_ws doubles as the 256-byte sync area (the cell-gradient carry
-  // lives in registers there)
-  // Opt-in (TSG_LSTM_PERSIST_BWD=1): parity-clean but slower than the step kernels, 17.9 vs 14.9 us/step at
-  // [128,128,512] -- its slab is the 4h-wide dG (128 KiB per workgroup and step through L1-bypassing loads, 33 MB
-  // chip-wide), four times the forward's, while the step kernels share those rows through the XCD L2s.
-  static const bool bwd_persist = [] { const char* e = getenv("TSG_LSTM_PERSIST_BWD"); return e && atoi(e) > 0; }();
-  if (bwd_persist && h % 32 == 0 && h <= kPersistMaxH && T > 1 && (size_t)2 * B * h >= 64) {
-    const int pgrid = 2 * (h / 32) * cdiv(B, 16);
-    const int SLS = 4 * kPersistMaxH + 8;
-    const size_t plds = sizeof(float) * ((size_t)16 * SLS + 4 * 16 * kPS);
-    auto pk = lstm_bwd_persist_kernel;
-    static int capacity = -1;
-    if (capacity < 0) {
-      int dev = 0, cus = 0, per = 0;
-      hipError_t e1 = allow_lds(pk, plds);
-      if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
-      if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, kThreads, plds);
-      capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;
-    }
-    if (pgrid <= capacity) {
-      hipError_t e = hipMemsetAsync(dC_ws, 0, 256, st);
-      if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-      hipLaunchKernelGGL(pk, dim3(pgrid), dim3(kThreads), plds, st, (const float*)WhhT, (const float*)R, (const float*)Cs,
-                         (const float*)dOut, (const float*)dHn, (float*)dG, (unsigned*)dC_ws, B, T, h, SLS);
-      return check_launch(fn);
-    }
-  }
   const int grid = 2 * cdiv(h, 16) * cdiv(B, 32);
   for (int step = 0; step < T; ++step)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), 0, st, (const float*)WhhT, (const float*)R, (const float*)Cs,

@@ -96,25 +96,28 @@ def test_bilstm_persistent_kernel():
 
 
 def test_bilstm_persistent_backward_kernel():
-    """The opt-in persistent backward (TSG_LSTM_PERSIST_BWD=1: W_hh^T stationary in registers, K split over the waves,
-    consumers poll the sentinel-marked dG slab) must give the launch-per-step kernels' gradients."""
-    import subprocess, sys, os
-    code = (
-        "import torch, sys, os; sys.path.insert(0, %r)\n"
-        "from shufflingvideosfortsg_amd import _lib; from shufflingvideosfortsg_amd._lib import ptr, TSG_F32\n"
-        "lib=_lib.load(); B,T,h=50,24,64; g=torch.Generator().manual_seed(1); st=torch.cuda.current_stream().cuda_stream\n"
-        "Gx=(torch.randn(T,B,2,4*h,generator=g)*0.5).cuda(); W=(torch.randn(2,4*h,h,generator=g)/h**0.5).cuda()\n"
-        "dOut=torch.randn(T,B,2*h,generator=g).cuda(); dHn=torch.randn(2,B,h,generator=g).cuda()\n"
-        "out=torch.empty(T,B,2*h,device='cuda'); R=torch.empty(T,2,B,h,4,device='cuda'); Cs=torch.empty(T,2,B,h,device='cuda')\n"
-        "assert lib.tsg_lstm_fwd(ptr(Gx),ptr(W),ptr(out),ptr(R),ptr(Cs),None,B,T,h,TSG_F32,st)==0\n"
-        "WT=W.transpose(1,2).contiguous(); dG=torch.full((T,B,2,4*h),3.0,device='cuda'); dC=torch.zeros(2,B,h,device='cuda')\n"
-        "assert lib.tsg_lstm_bwd(ptr(WT),ptr(R),ptr(Cs),ptr(dOut),ptr(dHn),ptr(dG),ptr(dC),B,T,h,TSG_F32,st)==0\n"
-        "torch.cuda.synchronize(); torch.save(dG.cpu(), sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for mode in ("0", "1"):
-        f = f"/tmp/tsg_bwd_persist_{mode}.pt"
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, TSG_LSTM_PERSIST_BWD=mode), capture_output=True, text=True, timeout=120)
-        assert r.returncode == 0, r.stdout + r.stderr
-        outs.append(torch.load(f))
-    assert torch.isfinite(outs[1]).all()
-    torch.testing.assert_close(outs[1], outs[0], atol=1e-5, rtol=1e-5)
+    """The persistent backward (tsg_lstm_bwd_ws: own dG tile x W_hh slice -> partial dh tiles exchanged through the ring
+    workspace) must give the launch-per-step kernels' gate gradients, with and without dHn, and the fused bias gradient."""
+    from shufflingvideosfortsg_amd import _lib
+    from shufflingvideosfortsg_amd._lib import ptr, TSG_F32
+    lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+    for (B, T, h) in [(50, 24, 128), (128, 40, 256), (7, 9, 512)]:
+        g = torch.Generator().manual_seed(B)
+        Gx = (torch.randn(T, B, 2, 4 * h, generator=g) * 0.5).cuda(); W = (torch.randn(2, 4 * h, h, generator=g) / h ** 0.5).cuda()
+        dOut = torch.randn(T, B, 2 * h, generator=g).cuda(); dHn = torch.randn(2, B, h, generator=g).cuda()
+        out = torch.empty(T, B, 2 * h, device="cuda"); R = torch.empty(T, 2, B, h, 4, device="cuda"); Cs = torch.empty(T, 2, B, h, device="cuda")
+        assert lib.tsg_lstm_fwd(ptr(Gx), ptr(W), ptr(out), ptr(R), ptr(Cs), None, B, T, h, TSG_F32, st) == 0
+        WT = W.transpose(1, 2).contiguous()
+        nb = lib.tsg_lstm_bwd_ws_bytes(B, T, h)
+        assert nb > 0 and lib.tsg_lstm_bwd_ws_persistent(B, T, h, nb) == 1
+        for hn in (None, dHn):
+            ref = torch.full((T, B, 2, 4 * h), 3.0, device="cuda"); dC = torch.zeros(2, B, h, device="cuda")
+            assert lib.tsg_lstm_bwd(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), ptr(hn) if hn is not None else None, ptr(ref), ptr(dC), B, T, h, TSG_F32, st) == 0
+            got = torch.full((T, B, 2, 4 * h), 5.0, device="cuda"); ws = torch.empty(nb // 4 + 4, device="cuda"); db = torch.empty(8 * h, device="cuda")
+            assert lib.tsg_lstm_bwd_ws(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), ptr(hn) if hn is not None else None, ptr(got), ptr(dC), ptr(ws), nb,
+                                       ptr(db), B, T, h, TSG_F32, st) == 0
+            torch.cuda.synchronize()
+            assert int(ws[:1].view(torch.int32)[0]) == 0 and torch.isfinite(got).all()
+            torch.testing.assert_close(got, ref, atol=2e-5, rtol=1e-4)
+            torch.testing.assert_close(db, ref.sum((0, 1)).reshape(-1), atol=2e-3, rtol=1e-4)
+    assert lib.tsg_lstm_bwd_ws_bytes(4, 8, 48) == 0 and lib.tsg_lstm_bwd_ws_persistent(4, 8, 48, 1 << 30) == 0     # h % 128 != 0: step kernels
