@@ -121,3 +121,26 @@ def test_bilstm_persistent_backward_kernel():
             torch.testing.assert_close(got, ref, atol=2e-5, rtol=1e-4)
             torch.testing.assert_close(db, ref.sum((0, 1)).reshape(-1), atol=2e-3, rtol=1e-4)
     assert lib.tsg_lstm_bwd_ws_bytes(4, 8, 48) == 0 and lib.tsg_lstm_bwd_ws_persistent(4, 8, 48, 1 << 30) == 0     # h % 128 != 0: step kernels
+
+
+@pytest.mark.parametrize("shape", [(7, 9, 32), (20, 8, 64), (33, 12, 128), (128, 16, 512), (17, 30, 96)])
+def test_bilstm_persistent_forward_small_shapes(shape):
+    """Persistent forward (chosen automatically for T >= 8, h % 32 == 0) vs the launch-per-step kernels (no sync workspace)
+    at small / ragged shapes: batch not a multiple of 16, one to sixteen unit slices, workgroups with dead rows."""
+    from shufflingvideosfortsg_amd import _lib
+    from shufflingvideosfortsg_amd._lib import ptr, TSG_F32
+    B, T, h = shape
+    lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(B + h)
+    Gx = (torch.randn(T, B, 2, 4 * h, generator=g) * 0.5).cuda(); W = (torch.randn(2, 4 * h, h, generator=g) / h ** 0.5).cuda()
+    res = []
+    for ws in (None, torch.zeros(64, dtype=torch.int32, device="cuda")):
+        out = torch.full((T, B, 2 * h), 9.0, device="cuda"); R = torch.empty(T, 2, B, h, 4, device="cuda"); Cs = torch.empty(T, 2, B, h, device="cuda")
+        assert lib.tsg_lstm_fwd(ptr(Gx), ptr(W), ptr(out), ptr(R), ptr(Cs), ptr(ws) if ws is not None else None, B, T, h, TSG_F32, st) == 0
+        torch.cuda.synchronize()
+        if ws is not None:
+            assert int(ws[0]) == 0
+        res.append((out, R, Cs))
+    for a, b in zip(*res):
+        assert torch.isfinite(a).all()
+        torch.testing.assert_close(a, b, atol=1e-5, rtol=1e-5)
