@@ -19,9 +19,13 @@ class _KernelTimer:
     def __init__(self):
         self.on = False
         self.records = []
+        self.only = None
 
-    def enable(self):
-        self.on, self.records = True, []
+    def enable(self, only=None):
+        """``only``: tuple of entry-point name prefixes to time (None = every call).  An event pair is a pair of barrier
+        packets on the queue: around every one of the ~45 short operand-split launches of an "f32s" step they cost 3.5 ms,
+        so bench.py times only the hot-path kernels its roofline needs."""
+        self.on, self.records, self.only = True, [], only
 
     def disable(self):
         self.on = False
@@ -44,7 +48,7 @@ def _call(name: str, like: torch.Tensor, *args) -> None:
     """Invoke one C-ABI entry point on ``like``'s current stream and raise on a non-zero return."""
     fn = getattr(load(), name)
     st = stream_of(like)
-    if kernel_timer.on:
+    if kernel_timer.on and (kernel_timer.only is None or name.startswith(kernel_timer.only)):
         stream = torch.cuda.current_stream(like.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)

@@ -29,8 +29,14 @@ def _params(I, h, layers, g):
     (130, 9, 64, 36),        # batch > one 128-row pass, h not a multiple of 16 / 64
     (2, 128, 1024, 512),     # north-star video shape (B reduced)
 ])
-def test_bilstm_parity(B, T, I, h):
+@pytest.mark.parametrize("gemm", [None, "f32s"])
+def test_bilstm_parity(B, T, I, h, gemm, request):
+    """BiLSTM (2 layers) forward + backward vs the oracle's explicit recurrence; also with the input / weight-gradient
+    GEMMs in the split-precision mode, at the same tolerances."""
+    from shufflingvideosfortsg_amd import engine
     from shufflingvideosfortsg_amd.model.networks.RNN import BiLSTM
+    engine.precision(gemm)
+    request.addfinalizer(lambda: engine.precision(None))
     g = torch.Generator().manual_seed(9)
     p = {k: v.requires_grad_(True) for k, v in _params(I, h, 2, g).items()}
     x = torch.randn(B, T, I, generator=g, requires_grad=True)

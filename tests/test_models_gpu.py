@@ -135,11 +135,15 @@ def test_query_aware_encoder_golden(golden):
     _check_grads(m, g.wgrads)
 
 
+@pytest.mark.parametrize("gemm", [None, "f32s"])
 @pytest.mark.parametrize("tag", ["nomask", "mask"])
-def test_baseline_golden(golden, tag):
+def test_baseline_golden(golden, tag, gemm, request):
     """Full QAVE forward + span_ground_loss + backward: outputs, loss, decoded spans, every parameter
-    gradient equal to the reference's."""
+    gradient equal to the reference's -- in the strict-fp32 and in the split-precision GEMM mode, same tolerances."""
+    from shufflingvideosfortsg_amd import engine
     from shufflingvideosfortsg_amd import loss as L
+    engine.precision(gemm)
+    request.addfinalizer(lambda: engine.precision(None))
     from shufflingvideosfortsg_amd.model import Baseline
     g = golden("baseline_" + tag)
     m = Baseline(*_sets(24, 8, 12, 16, tag == "mask"), LOG, 0.0)
