@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
   unsigned long long tph[4] = {0, 0, 0, 0}, tm0 = 0, tm1 = 0;       // per-phase s_memtime sums of this wave (100 MHz ticks? no: shader clock)
 #define TSG_TICK(i) { tm1 = __builtin_amdgcn_s_memtime(); tph[i] += tm1 - tm0; tm0 = tm1; }
 #else
-#define TSG_TICK(i)
+#define TSG_TICK(i) {}
 #endif
   for (int step = 0; step < T; ++step) {
 #ifdef TSG_LSTM_TIMING
@@ -640,7 +640,13 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
     if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   }
 
+#ifdef TSG_LSTM_TIMING
+  unsigned long long tph[5] = {0, 0, 0, 0, 0}, tm0 = 0, tm1 = 0;
+#endif
   for (int step = 0; step < T; ++step) {
+#ifdef TSG_LSTM_TIMING
+    tm0 = __builtin_amdgcn_s_memtime();
+#endif
     const int fs = T - 1 - step;
     const int tt = d == 0 ? fs : T - 1 - fs;                // time index handled now
     const int tp = d == 0 ? tt - 1 : tt + 1;                // forward-earlier neighbour (c_{t-1})
@@ -683,6 +689,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
           break;
         }
       }
+      TSG_TICK(0)                                            // poll: all partial blocks landed
       f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -711,18 +718,18 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
         if (live) dbsum[gate] += dg[gate];
       }
     }
+    if (step > 0) TSG_TICK(1)                                // reduce + cell backward + dG / Dl stores issued
     if (step + 1 < T) {
       __syncthreads();                                       // the dG tile is complete (and Ql is free again)
       f32x4 acc[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const float* drow = Dl + jb * kDLS + 4 * ku;
-      f32x4 ball[8];                                         // all eight B fragments requested up front (8 KiB tile)
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) ball[s8] = *reinterpret_cast<const f32x4*>(drow + 16 * s8);
-#pragma unroll
+      f32x4 bnext = *reinterpret_cast<const f32x4*>(drow);   // B fragment of step s8+1 requested before the MFMAs of step s8
+#pragma unroll                                               // (all eight up front pushed the kernel into scratch: 256 VGPRs + spills)
       for (int s8 = 0; s8 < 8; ++s8) {
-        const f32x4 bv = ball[s8];
+        const f32x4 bv = bnext;
+        if (s8 + 1 < 8) bnext = *reinterpret_cast<const f32x4*>(drow + 16 * (s8 + 1));
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           if (t < TW) {
@@ -735,6 +742,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
       for (int t = 0; t < 4; ++t)
         if (t < TW) *reinterpret_cast<f32x4*>(Pl + jb * kPLS + 16 * (wv * TW + t) + 4 * ku) = acc[t];
       __syncthreads();
+      if (step > 0) TSG_TICK(2)                              // MFMA + gather
       const unsigned gtag = ((unsigned)step >> 2) & 1u;      // generation of slot step%4, carried in the low mantissa bit
       for (int i = 0; i < TW; ++i) {
         const int idx = tid + i * kThreads, pr = idx / hq, pc = idx % hq;
@@ -742,8 +750,13 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
         store_sc1_u4(prod_ptr(step & 3, i), (u32x4){(__float_as_uint(v[0]) & ~1u) | gtag, (__float_as_uint(v[1]) & ~1u) | gtag,
                                                    (__float_as_uint(v[2]) & ~1u) | gtag, (__float_as_uint(v[3]) & ~1u) | gtag});
       }
+      if (step > 0) TSG_TICK(3)                              // partial stores issued
     }
   }
+#ifdef TSG_LSTM_TIMING
+  if (blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 4; ++i) sync[8 + i] = (unsigned)(tph[i] / (unsigned long long)(T - 2));
+#endif
   if (dbias) {                                              // d(b_ih + b_hh)[d][gate*h + u] += sum over this workgroup's rows and all steps
     __syncthreads();
 #pragma unroll
