@@ -547,10 +547,6 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
 #endif
 }
 
-}  // namespace
-}  // namespace tsg
-
-using namespace tsg;
 
 static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
   if (dtype != TSG_F32) return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (fp32 only)", fn, dtype);
@@ -770,6 +766,11 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
     }
   }
 }
+
+}  // namespace
+}  // namespace tsg
+
+using namespace tsg;
 
 // TSG_LSTM_PERSIST: unset = auto (persistent launch for sequences of >= 8 steps: 8.2 vs 17.3 us/step at
 // [B=128,T=128,h=512], 7.4 vs 11.3 us/step at [64,20,512]), 0 = never, 1 = whenever the grid fits.
