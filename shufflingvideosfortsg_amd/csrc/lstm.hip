@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
   }
 
 #ifdef TSG_LSTM_TIMING
-  unsigned long long tph[5] = {0, 0, 0, 0, 0}, tm0 = 0, tm1 = 0;
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tm0 = 0, tm1 = 0;
 #endif
   for (int step = 0; step < T; ++step) {
 #ifdef TSG_LSTM_TIMING
@@ -717,6 +717,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
     if (step > 0) TSG_TICK(1)                                // reduce + cell backward + dG / Dl stores issued
     if (step + 1 < T) {
       __syncthreads();                                       // the dG tile is complete (and Ql is free again)
+      if (step > 0) TSG_TICK(4)                              // (timing builds: the wait at this barrier)
       f32x4 acc[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -727,9 +728,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
         const f32x4 bv = bnext;
         if (s8 + 1 < 8) bnext = *reinterpret_cast<const f32x4*>(drow + 16 * (s8 + 1));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (t < TW) {
-#pragma unroll
+        for (int t = 0; t < 4; ++t) {                        // four MFMAs in a row on one accumulator.  (Interleaving the tiles'
+          if (t < TW) {                                      // accumulators, pairwise or round-robin, measured 20.5 instead of
+#pragma unroll                                               // 12.5 us per step in this kernel.)
             for (int m = 0; m < 4; ++m) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[t][s8][m], bv[m], acc[t], 0, 0, 0);
           }
         }
@@ -737,6 +738,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         if (t < TW) *reinterpret_cast<f32x4*>(Pl + jb * kPLS + 16 * (wv * TW + t) + 4 * ku) = acc[t];
+      if (step > 0) TSG_TICK(5)                              // (timing builds: MFMAs issued and their results written to LDS)
       __syncthreads();
       if (step > 0) TSG_TICK(2)                              // MFMA + gather
       const unsigned gtag = ((unsigned)step >> 2) & 1u;      // generation of slot step%4, carried in the low mantissa bit
@@ -751,7 +753,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
   }
 #ifdef TSG_LSTM_TIMING
   if (blockIdx.x == 0 && tid == 0)
-    for (int i = 0; i < 4; ++i) sync[8 + i] = (unsigned)(tph[i] / (unsigned long long)(T - 2));
+    for (int i = 0; i < 6; ++i) sync[8 + i] = (unsigned)(tph[i] / (unsigned long long)(T - 2));
 #endif
   if (dbias) {                                              // d(b_ih + b_hh)[d][gate*h + u] += sum over this workgroup's rows and all steps
     __syncthreads();

@@ -26,5 +26,5 @@ nb = lib.tsg_lstm_bwd_ws_bytes(B, T, h)
 if nb > 0:
     ws = torch.empty(nb // 4 + 4, device=dev)
     b2 = t(lambda: lib.tsg_lstm_bwd_ws(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC), ptr(ws), nb, None, B, T, h, TSG_F32, st))
-    print(f"persistent backward (ring exchange): {b2*1e3/T:.2f} us/step ({b2:.2f} ms), err word {int(ws[:1].view(torch.int32)[0])}, phase ticks {ws[8:12].view(torch.int32).tolist()}")
+    print(f"persistent backward (ring exchange): {b2*1e3/T:.2f} us/step ({b2:.2f} ms), err word {int(ws[:1].view(torch.int32)[0])}, phase ticks [poll, reduce+cell, gather barrier, stores, Dl barrier, MFMA] {ws[8:14].view(torch.int32).tolist()}")
 print(f"B={B} T={T} h={h}: fwd {f*1e3/T:.2f} us/step ({f:.2f} ms), bwd {b*1e3/T:.2f} us/step ({b:.2f} ms)")
