@@ -575,6 +575,7 @@ constexpr int kDLS = 128 + 8;                    // own-dG tile row stride (floa
 constexpr int kPLS = kPersistMaxH + 8;           // partial-dh gather row stride
 constexpr int kQLS = 36;                         // polled partial sums row stride
 
+template <int TW>                                 // 16-unit tiles per wave = h / 128 (compile time: no branch between MFMAs)
 __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
     const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
     const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG,
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
   float* Pl = Dl + 16 * kDLS;                     // [16][kPLS]  partial dh of all h units, gathered for whole-line stores
   float* Ql = Pl + 16 * kPLS;                     // [4][16][kQLS] sums of the polled blocks per producer group
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
-  const int nus = h / 32, bslices = (B + 15) / 16, TW = h / 128;      // TW = 16-unit tiles per wave = float4 per thread
+  const int nus = h / 32, bslices = (B + 15) / 16;         // TW = h / 128 = 16-unit tiles per wave = float4 per thread
   const int d = blockIdx.x / (nus * bslices);
   const int rem = blockIdx.x % (nus * bslices);
   const int us = rem / bslices, bs = rem % bslices;
@@ -592,14 +593,12 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
   const int jb = lane & 15, ku = lane >> 4;
   // A fragments: tile t of this wave = output units 16*(wv*TW + t) + jb; local k' = 16s + 4ku + m -> gate s/2, unit
   // us*32 + 16*(s%2) + 4ku + m of the workgroup's own gate columns
-  f32x4 areg[4][8];
+  f32x4 areg[TW][8];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < TW; ++t)
 #pragma unroll
     for (int s8 = 0; s8 < 8; ++s8) {
-      areg[t][s8] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (t < TW)
-        areg[t][s8] = *reinterpret_cast<const f32x4*>(WhhT + ((size_t)d * h + 16 * (wv * TW + t) + jb) * K + (s8 >> 1) * h +
+      areg[t][s8] = *reinterpret_cast<const f32x4*>(WhhT + ((size_t)d * h + 16 * (wv * TW + t) + jb) * K + (s8 >> 1) * h +
                                                        us * 32 + 16 * (s8 & 1) + 4 * ku);
     }
   const int row = tid >> 5, ul = tid & 31;                  // epilogue role: (batch row, unit) of the 16 x 32 tile
@@ -718,9 +717,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
     if (step + 1 < T) {
       __syncthreads();                                       // the dG tile is complete (and Ql is free again)
       if (step > 0) TSG_TICK(4)                              // (timing builds: the wait at this barrier)
-      f32x4 acc[4];
+      f32x4 acc[TW];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < TW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const float* drow = Dl + jb * kDLS + 4 * ku;
       f32x4 bnext = *reinterpret_cast<const f32x4*>(drow);   // B fragment of step s8+1 requested before the MFMAs of step s8
 #pragma unroll                                               // (all eight up front pushed the kernel into scratch: 256 VGPRs + spills)
@@ -728,16 +727,12 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
         const f32x4 bv = bnext;
         if (s8 + 1 < 8) bnext = *reinterpret_cast<const f32x4*>(drow + 16 * (s8 + 1));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {                        // four MFMAs in a row on one accumulator.  (Interleaving the tiles'
-          if (t < TW) {                                      // accumulators, pairwise or round-robin, measured 20.5 instead of
-#pragma unroll                                               // 12.5 us per step in this kernel.)
-            for (int m = 0; m < 4; ++m) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[t][s8][m], bv[m], acc[t], 0, 0, 0);
-          }
-        }
+        for (int m = 0; m < 4; ++m)                          // round-robin over the tiles: consecutive MFMAs on different accumulators
+#pragma unroll
+          for (int t = 0; t < TW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[t][s8][m], bv[m], acc[t], 0, 0, 0);
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (t < TW) *reinterpret_cast<f32x4*>(Pl + jb * kPLS + 16 * (wv * TW + t) + 4 * ku) = acc[t];
+      for (int t = 0; t < TW; ++t) *reinterpret_cast<f32x4*>(Pl + jb * kPLS + 16 * (wv * TW + t) + 4 * ku) = acc[t];
       if (step > 0) TSG_TICK(5)                              // (timing builds: MFMAs issued and their results written to LDS)
       __syncthreads();
       if (step > 0) TSG_TICK(2)                              // MFMA + gather
@@ -858,10 +853,10 @@ static int bwd_persist_capacity(size_t plds) {
   static int capacity = -1;
   if (capacity < 0) {
     int dev = 0, cus = 0, per = 0;
-    hipError_t e1 = allow_lds(lstm_bwd_persist2_kernel, plds);
+    hipError_t e1 = allow_lds(lstm_bwd_persist2_kernel<4>, plds);
     if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
     if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, lstm_bwd_persist2_kernel, kThreads, plds);
+    if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, lstm_bwd_persist2_kernel<4>, kThreads, plds);
     capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;
   }
   return capacity;
@@ -890,7 +885,9 @@ extern "C" int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, 
     hipError_t e = hipMemsetAsync(ws, 0, 256, st);
     if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, sizeof(float) * 8 * h, st);
     if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-    hipLaunchKernelGGL(lstm_bwd_persist2_kernel, dim3(pgrid), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT, (const float*)R,
+    auto pk = h == 512 ? lstm_bwd_persist2_kernel<4> : h == 384 ? lstm_bwd_persist2_kernel<3>
+            : h == 256 ? lstm_bwd_persist2_kernel<2> : lstm_bwd_persist2_kernel<1>;
+    hipLaunchKernelGGL(pk, dim3(pgrid), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT, (const float*)R,
                        (const float*)Cs, (const float*)dOut, (const float*)dHn, (float*)dG, (float*)((char*)ws + 256),
                        (unsigned*)ws, (float*)dbias, B, T, h);
     return check_launch(fn);
