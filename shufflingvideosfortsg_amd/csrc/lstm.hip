@@ -362,6 +362,7 @@ __device__ __forceinline__ void store_sc1_u(float* p, unsigned v) {
   asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 
+template <int HJ>                                 // h / 16 when known at compile time (no branch between MFMAs), else 0
 __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
     const float* __restrict__ Gx, const float* __restrict__ Whh, float* __restrict__ out,
     float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS) {
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
       // reads ahead of the MFMAs that consume it -- issued one at a time, each read's latency (~100+ cycles) sat in
       // front of its two MFMAs and the chain ran at 111 instead of 32-64 cycles per MFMA (s_memtime instrumentation)
       const float* hrow = Hl + jb * HLS + 4 * ku;
-      constexpr int NJ = kPersistMaxH / 16, PFD = 4;
+      constexpr int NJ = HJ > 0 ? HJ : kPersistMaxH / 16, PFD = NJ < 4 ? NJ : 4;
       f32x4 bq[PFD], acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < PFD; ++j) bq[j] = *reinterpret_cast<const f32x4*>(hrow + 16 * j);
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
       for (int j = 0; j < NJ; ++j) {
         const f32x4 bv = bq[j % PFD];
         if (j + PFD < NJ) bq[j % PFD] = *reinterpret_cast<const f32x4*>(hrow + 16 * (j + PFD));     // columns beyond h are never
-        if (16 * j < h) {                                                                            // consumed (wave-uniform)
+        if (HJ > 0 || 16 * j < h) {                                                                  // consumed (wave-uniform)
 #pragma unroll
           for (int m = 0; m < 4; m += 2) {                   // two accumulator chains: a dependent MFMA waits for its predecessor
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[j][m], bv[m], acc, 0, 0, 0);
@@ -793,7 +794,8 @@ extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R,
     const int grid = 2 * (h / 32) * cdiv(B, 16);
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
     const size_t plds = sizeof(float) * ((size_t)16 * HLS + 16 * 33);
-    auto pk = lstm_fwd_persist_kernel;
+    auto pk = h == 512 ? lstm_fwd_persist_kernel<32> : h == 256 ? lstm_fwd_persist_kernel<16> : h == 384 ? lstm_fwd_persist_kernel<24>
+            : h == 128 ? lstm_fwd_persist_kernel<8> : lstm_fwd_persist_kernel<0>;
     static int capacity = -1;
     if (capacity < 0) {
       int dev = 0, cus = 0, per = 0;
