@@ -258,7 +258,9 @@ struct TileStage {
   }
 };
 
-template <bool DROP>
+// FULL: head widths are exactly DHMAX (the common d/8 = 128 case): the channel-count guards fold away, so no wave-uniform
+// branch stands between the MFMAs (with the run-time guards every MFMA group sat behind one).
+template <bool DROP, bool FULL>
 __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void mha_fwd_mfma_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, float* __restrict__ LSE,
@@ -275,8 +277,8 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(2,
   const float* Qb = Q + (size_t)b * Tq * dk + hd * dh;
   const float* Kb = K + (size_t)b * Tk * dk + hd * dh;
   const float* Vb = V + (size_t)b * Tk * dv + hd * dvh;
-  const int nsteps = (dh + 3) / 4;         // MFMA pairs over the head channels
-  const int ctiles = (dvh + 31) / 32;
+  const int nsteps = FULL ? DHMAX / 4 : (dh + 3) / 4;       // MFMA pairs over the head channels
+  const int ctiles = FULL ? DHMAX / 32 : (dvh + 31) / 32;
 
   // K_h / V_h rows of a 32-key block: 4 float4 per thread each, requested first (they fly during the Q staging);
   // inside the loop the NEXT block is requested while the current one is in the MFMAs (zero fill beyond Tk / head width)
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(2,
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < DHMAX / 4; ++s)
-      qf[s] = (s < nsteps && 4 * s + 2 * kk < dh) ? *reinterpret_cast<const float2*>(Ql + (wv * 32 + jq) * KS + 4 * s + 2 * kk)
+      qf[s] = (FULL || (s < nsteps && 4 * s + 2 * kk < dh)) ? *reinterpret_cast<const float2*>(Ql + (wv * 32 + jq) * KS + 4 * s + 2 * kk)
                                                   : make_float2(0.f, 0.f);
     __syncthreads();
   }
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(2,
     const float* krow = Kl + jq * KS + 2 * kk;            // A operand: K[key = lane&31][channel pair]
 #pragma unroll
     for (int s = 0; s < DHMAX / 4; ++s) {
-      if (s < nsteps) {                                   // wave-uniform
+      if (FULL || s < nsteps) {                           // wave-uniform
         const float2 a = *reinterpret_cast<const float2*>(krow + 4 * s);
         st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[s].x, st, 0, 0, 0);
         st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[s].y, st, 0, 0, 0);
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(2,
     // O^T += V^T P^T : A operand V[key = rho(r) + 4*kk][channel = ct*32 + lane&31], B operand = st[r]
 #pragma unroll
     for (int ct = 0; ct < DHMAX / 32; ++ct) {
-      if (ct < ctiles) {
+      if (FULL || ct < ctiles) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
 #pragma unroll
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(2,
   const float inv = 1.f / l_run;
 #pragma unroll
   for (int ct = 0; ct < DHMAX / 32; ++ct)
-    if (ct < ctiles) {
+    if (FULL || ct < ctiles) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(256) void mha_bwd_delta_kernel(const float* __restr
 
 __device__ __forceinline__ int rho(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
 
-template <bool DROP>
+template <bool DROP, bool FULL>
 __global__ __launch_bounds__(kMfmaThreads) void mha_bwd_mfma_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ delta,
@@ -607,9 +609,9 @@ __global__ __launch_bounds__(kMfmaThreads) void mha_bwd_mfma_kernel(
   const float* lse = LSE + ((size_t)b * H + hd) * Tq;
   const float* dlt = delta + ((size_t)b * H + hd) * Tq;
   const int c0 = wv * 32;                                  // this wave's channel tile
-  const bool has_k = c0 < dh, has_v = c0 < dvh;
-  const int ks_steps = has_k ? ((dh - c0 < 32 ? dh - c0 : 32) + 3) / 4 : 0;   // paired MFMA steps over my channels
-  const int vs_steps = has_v ? ((dvh - c0 < 32 ? dvh - c0 : 32) + 3) / 4 : 0;
+  const bool has_k = FULL || c0 < dh, has_v = FULL || c0 < dvh;
+  const int ks_steps = FULL ? 8 : has_k ? ((dh - c0 < 32 ? dh - c0 : 32) + 3) / 4 : 0;   // paired MFMA steps over my channels
+  const int vs_steps = FULL ? 8 : has_v ? ((dvh - c0 < 32 ? dvh - c0 : 32) + 3) / 4 : 0;
 
   TileStage<32 * (DHMAX / 4) / kMfmaThreads> t0, t1;
   for (int k0 = 0; k0 < Tk; k0 += 32) {
@@ -639,13 +641,13 @@ __global__ __launch_bounds__(kMfmaThreads) void mha_bwd_mfma_kernel(
       for (int r = 0; r < 16; ++r) { sp[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        if (s < ks_steps) {
+        if (FULL || s < ks_steps) {
           const float2 a = *reinterpret_cast<const float2*>(Ql + jl * KS + c0 + 4 * s + 2 * kk);
           const float2 bb = *reinterpret_cast<const float2*>(Kl + jl * KS + c0 + 4 * s + 2 * kk);
           sp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, sp, 0, 0, 0);
           sp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, sp, 0, 0, 0);
         }
-        if (s < vs_steps) {
+        if (FULL || s < vs_steps) {
           const float2 a = *reinterpret_cast<const float2*>(Gl + jl * VS2 + c0 + 4 * s + 2 * kk);
           const float2 bb = *reinterpret_cast<const float2*>(Vl + jl * VS2 + c0 + 4 * s + 2 * kk);
           dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, dp, 0, 0, 0);
@@ -782,7 +784,9 @@ extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O,
     const size_t qstage = sizeof(float) * (size_t)QB * KS, ostage = sizeof(float) * (size_t)QB * VS;
     if (qstage > lds) lds = qstage;
     if (ostage > lds) lds = ostage;
-    auto kern = dc.thresh ? mha_fwd_mfma_kernel<true> : mha_fwd_mfma_kernel<false>;
+    const bool full = dh == DHMAX && dvh == DHMAX;
+    auto kern = dc.thresh ? (full ? mha_fwd_mfma_kernel<true, true> : mha_fwd_mfma_kernel<true, false>)
+                          : (full ? mha_fwd_mfma_kernel<false, true> : mha_fwd_mfma_kernel<false, false>);
     if (lds > 64 * 1024) {
       hipError_t e = allow_lds(kern, lds);
       if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
@@ -822,7 +826,9 @@ extern "C" int tsg_mha_bwd(const void* Q, const void* K, const void* V, const vo
     if (rc) return rc;
     const int KS = roundup(dh, 64) + 2, VS2 = roundup(dvh, 64) + 2;
     const size_t lds = sizeof(float) * ((size_t)64 * (KS + VS2) + 2 * 4 * 16 * 64 + 32 * 66 + 64);
-    auto kern = dc.thresh ? mha_bwd_mfma_kernel<true> : mha_bwd_mfma_kernel<false>;
+    const bool full = dh == DHMAX && dvh == DHMAX;
+    auto kern = dc.thresh ? (full ? mha_bwd_mfma_kernel<true, true> : mha_bwd_mfma_kernel<true, false>)
+                          : (full ? mha_bwd_mfma_kernel<false, true> : mha_bwd_mfma_kernel<false, false>);
     if (lds > 64 * 1024) {
       hipError_t e = allow_lds(kern, lds);
       if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
