@@ -27,6 +27,8 @@ extern "C" {
 #define TSG_VERSION 1
 #define TSG_F32 0
 #define TSG_BF16 1
+#define TSG_F32S 2   /* fp32 storage; the LSTM recurrence's W_hh products run as split-precision bf16 MFMAs
+                        (hi*hi + hi*lo + lo*hi, fp32 accumulation) -- accepted by tsg_lstm_fwd / tsg_lstm_bwd[_ws] only */
 
 #define TSG_E_NULL   (-1)   /* a required pointer is NULL                      */
 #define TSG_E_SHAPE  (-2)   /* non-positive or unsupported dimension           */

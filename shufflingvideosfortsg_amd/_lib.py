@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: libtsg_hip.so reuses torch'
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSG_HIP_LIB", os.path.join(_HERE, "libtsg_hip.so"))   # override: developer builds
-TSG_F32, TSG_BF16 = 0, 1
+TSG_F32, TSG_BF16, TSG_F32S = 0, 1, 2
 
 _lib = None
 

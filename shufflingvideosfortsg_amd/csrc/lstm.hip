@@ -362,12 +362,42 @@ __device__ __forceinline__ void store_sc1_u(float* p, unsigned v) {
   asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 
-template <int HJ>                                 // h / 16 when known at compile time (no branch between MFMAs), else 0
-__global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
+// Split-precision arithmetic of the recurrence (dtype TSG_F32S): both operands of the step's product are written as
+// hi + lo with hi = rne_bf16(x), lo = rne_bf16(x - hi), and  W h ~= W_hi h_hi + W_hi h_lo + W_lo h_hi  runs on the bf16
+// MFMA (v_mfma_f32_16x16x32_bf16, 16 cycles for 8x the k of the 32-cycle fp32 16x16x4) with fp32 accumulation: 48
+// MFMAs of 16 cycles per wave and step at h = 512 instead of 128 of 32.  Only the lo*lo term (2^-18 relative) is
+// dropped -- the same arithmetic as the split-precision GEMMs around the recurrence (split_bf16.hip).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // (rne(a), rne(b)) packed, a in the low half
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pk_bf16(a, b);
+  lo = pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+__device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, u32x4& hi, u32x4& lo) {
+  unsigned h[4], l[4];
+  split_pair(x0[0], x0[1], h[0], l[0]); split_pair(x0[2], x0[3], h[1], l[1]);
+  split_pair(x1[0], x1[1], h[2], l[2]); split_pair(x1[2], x1[3], h[3], l[3]);
+  hi = (u32x4){h[0], h[1], h[2], h[3]};
+  lo = (u32x4){l[0], l[1], l[2], l[3]};
+}
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+constexpr int kHLB = kPersistMaxH / 2 + 8;       // bf16 slab plane row stride in dwords (= 8 mod 64)
+constexpr int kSlabFloats = 2 * 16 * kHLB;       // LDS dwords of the slab region: two bf16 planes (>= the fp32 slab's 16 x 520)
+
+template <int HJ, bool SPLIT>                     // HJ = h / 16 when known at compile time (no branch between MFMAs), else 0;
+__global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT: split-precision bf16 MFMA arithmetic (needs HJ > 0, even)
     const float* __restrict__ Gx, const float* __restrict__ Whh, float* __restrict__ out,
     float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS) {
-  extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice, then Ht [16][33]
-  float* Ht = Hl + 16 * HLS;                             // this step's h tile (16 rows x 32 units), gathered for whole-line stores
+  extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice (SPLIT: two bf16 planes
+  float* Ht = Hl + kSlabFloats;                          // [16][kHLB] dwords), then Ht [16][33] = this step's h tile (16 rows x
+  unsigned* Hhi = reinterpret_cast<unsigned*>(Hl);       // 32 units), gathered for whole-line stores
+  unsigned* Hlo = Hhi + 16 * kHLB;
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int uslices = h / 32, bslices = (B + 15) / 16;
   const int d = blockIdx.x / (uslices * bslices);
@@ -383,8 +413,16 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
 
   // A fragments: row i = jb -> (unit u0 + (jb>>2), gate jb&3); lane quad ku holds columns 16j + 4ku .. +3 = the k values
   // of FOUR MFMAs (component m = k 16j + 4ku + m), matching the ds_read_b128 of the h slab below
-  f32x4 areg[kPersistMaxH / 16];
-  {
+  // SPLIT: lane quad ku holds k = 32j + 8ku .. +7 of the bf16 MFMA's k block j, as hi and lo planes (4 VGPRs each)
+  constexpr int NA = SPLIT ? 1 : kPersistMaxH / 16, NJB = SPLIT ? HJ / 2 : 1;
+  f32x4 areg[NA];
+  u32x4 ahi[NJB], alo[NJB];
+  if constexpr (SPLIT) {
+    const float* wrow = Whh + (size_t)d * 4 * h * h + (size_t)((jb & 3) * h + u0 + (jb >> 2)) * h + 8 * ku;
+#pragma unroll
+    for (int j = 0; j < NJB; ++j)
+      split8(*reinterpret_cast<const f32x4*>(wrow + 32 * j), *reinterpret_cast<const f32x4*>(wrow + 32 * j + 4), ahi[j], alo[j]);
+  } else {
     const float* wrow = Whh + (size_t)d * 4 * h * h + (size_t)((jb & 3) * h + u0 + (jb >> 2)) * h + 4 * ku;
 #pragma unroll
     for (int j = 0; j < kPersistMaxH / 16; ++j)
@@ -486,11 +524,46 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
 #pragma unroll
       for (int i = 0; i < kSlabV; ++i) {
         const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
-        if (r < 16) *reinterpret_cast<f32x4*>(Hl + r * HLS + c4 * 4) = v[i];
+        if constexpr (SPLIT) {
+          uint2 hi2, lo2;
+          split_pair(v[i][0], v[i][1], hi2.x, lo2.x);
+          split_pair(v[i][2], v[i][3], hi2.y, lo2.y);
+          if (r < 16) {
+            *reinterpret_cast<uint2*>(Hhi + r * kHLB + c4 * 2) = hi2;
+            *reinterpret_cast<uint2*>(Hlo + r * kHLB + c4 * 2) = lo2;
+          }
+        } else {
+          if (r < 16) *reinterpret_cast<f32x4*>(Hl + r * HLS + c4 * 4) = v[i];
+        }
       }
       __syncthreads();
       TSG_TICK(1)                                            // slab in LDS, workgroup met
       if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // a bounded wait expired somewhere
+      if constexpr (SPLIT) {
+        // B operand: k block j of row jb = 4 dwords at 16j + 4ku of each plane, one ds_read_b128 per plane, requested PFB
+        // blocks ahead; three independent accumulator chains (hi*hi, hi*lo, lo*hi), the two small ones summed first
+        const unsigned* hr = Hhi + jb * kHLB + 4 * ku;
+        constexpr int PFB = NJB < 3 ? NJB : 3;
+        u32x4 bh[PFB], bl[PFB];
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < PFB; ++j) {
+          bh[j] = *reinterpret_cast<const u32x4*>(hr + 16 * j);
+          bl[j] = *reinterpret_cast<const u32x4*>(hr + 16 * kHLB + 16 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < NJB; ++j) {
+          const u32x4 vh = bh[j % PFB], vl = bl[j % PFB];
+          if (j + PFB < NJB) {
+            bh[j % PFB] = *reinterpret_cast<const u32x4*>(hr + 16 * (j + PFB));
+            bl[j % PFB] = *reinterpret_cast<const u32x4*>(hr + 16 * kHLB + 16 * (j + PFB));
+          }
+          acc = mfma_bf16(ahi[j], vh, acc);
+          acc2 = mfma_bf16(ahi[j], vl, acc2);
+          acc3 = mfma_bf16(alo[j], vh, acc3);
+        }
+        acc += acc2 + acc3;
+      } else {
       // B operand: one ds_read_b128 per 16 columns (row stride = 8 mod 64: conflict-free 16-lane groups), requested PFD
       // reads ahead of the MFMAs that consume it -- issued one at a time, each read's latency (~100+ cycles) sat in
       // front of its two MFMAs and the chain ran at 111 instead of 32-64 cycles per MFMA (s_memtime instrumentation)
@@ -512,6 +585,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
         }
       }
       acc += acc2;
+      }
     }
 #ifdef TSG_LSTM_TIMING
     asm volatile("" : "+v"(acc));
@@ -550,7 +624,8 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(
 
 
 static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
-  if (dtype != TSG_F32) return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (fp32 only)", fn, dtype);
+  if (dtype != TSG_F32 && dtype != TSG_F32S)
+    return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32 or TSG_F32S)", fn, dtype);
   if (B <= 0 || T <= 0 || h <= 0) return set_error(TSG_E_SHAPE, "%s: non-positive dimension B=%d T=%d h=%d", fn, B, T, h);
   if (h % 4) return set_error(TSG_E_ALIGN, "%s: hidden size %d must be a multiple of 4", fn, h);
   return 0;
@@ -573,17 +648,21 @@ static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
 // generation has been read by everyone before its next one is written.
 // ---------------------------------------------------------------------------------------------
 constexpr int kDLS = 128 + 8;                    // own-dG tile row stride (floats), = 8 mod 64
+constexpr int kDLB = 64 + 8;                     // split-precision mode: row stride (dwords) of each bf16 plane of that tile
+constexpr int kDlFloats = 2 * 16 * kDLB;         // LDS dwords of the dG tile region (>= 16 * kDLS)
 constexpr int kPLS = kPersistMaxH + 8;           // partial-dh gather row stride
 constexpr int kQLS = 36;                         // polled partial sums row stride
 
-template <int TW>                                 // 16-unit tiles per wave = h / 128 (compile time: no branch between MFMAs)
-__global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
+template <int TW, bool SPLIT>                     // TW = 16-unit tiles per wave = h / 128 (compile time: no branch between MFMAs);
+__global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPLIT: split-precision bf16 MFMA arithmetic
     const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
     const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG,
     float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int T, int h) {
   extern __shared__ __align__(16) float smem2[];
   float* Dl = smem2;                              // [16][kDLS]  this workgroup's dG tile, local column g*32 + ul
-  float* Pl = Dl + 16 * kDLS;                     // [16][kPLS]  partial dh of all h units, gathered for whole-line stores
+  unsigned* Dhi = reinterpret_cast<unsigned*>(Dl);          // (SPLIT: the same tile as two bf16 planes [16][kDLB] dwords)
+  unsigned* Dlo = Dhi + 16 * kDLB;
+  float* Pl = Dl + kDlFloats;                     // [16][kPLS]  partial dh of all h units, gathered for whole-line stores
   float* Ql = Pl + 16 * kPLS;                     // [4][16][kQLS] sums of the polled blocks per producer group
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int nus = h / 32, bslices = (B + 15) / 16;         // TW = h / 128 = 16-unit tiles per wave = float4 per thread
@@ -594,14 +673,24 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
   const int jb = lane & 15, ku = lane >> 4;
   // A fragments: tile t of this wave = output units 16*(wv*TW + t) + jb; local k' = 16s + 4ku + m -> gate s/2, unit
   // us*32 + 16*(s%2) + 4ku + m of the workgroup's own gate columns
-  f32x4 areg[TW][8];
+  // SPLIT: k block kb of the bf16 MFMA = gate kb, units us*32 + 8ku .. +7 (8 consecutive floats of the W_hh^T row)
+  constexpr int NA8 = SPLIT ? 1 : 8, NKB = SPLIT ? 4 : 1;
+  f32x4 areg[TW][NA8];
+  u32x4 ahi[TW][NKB], alo[TW][NKB];
 #pragma unroll
-  for (int t = 0; t < TW; ++t)
+  for (int t = 0; t < TW; ++t) {
+    const float* wrow = WhhT + ((size_t)d * h + 16 * (wv * TW + t) + jb) * K + us * 32;
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8) {
-      areg[t][s8] = *reinterpret_cast<const f32x4*>(WhhT + ((size_t)d * h + 16 * (wv * TW + t) + jb) * K + (s8 >> 1) * h +
-                                                       us * 32 + 16 * (s8 & 1) + 4 * ku);
+      for (int kb = 0; kb < 4; ++kb)
+        split8(*reinterpret_cast<const f32x4*>(wrow + kb * h + 8 * ku), *reinterpret_cast<const f32x4*>(wrow + kb * h + 8 * ku + 4),
+               ahi[t][kb], alo[t][kb]);
+    } else {
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8)
+        areg[t][s8] = *reinterpret_cast<const f32x4*>(wrow + (s8 >> 1) * h + 16 * (s8 & 1) + 4 * ku);
     }
+  }
   const int row = tid >> 5, ul = tid & 31;                  // epilogue role: (batch row, unit) of the 16 x 32 tile
   const int b = b0 + row, u = us * 32 + ul;
   const bool live = b < B;
@@ -710,7 +799,15 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
       }
 #pragma unroll
       for (int gate = 0; gate < 4; ++gate) {
-        Dl[row * kDLS + gate * 32 + ul] = live ? dg[gate] : 0.f;
+        const float dgv = live ? dg[gate] : 0.f;
+        if constexpr (SPLIT) {
+          unsigned hi, lo;
+          split_pair(dgv, 0.f, hi, lo);
+          reinterpret_cast<unsigned short*>(Dhi)[row * 2 * kDLB + gate * 32 + ul] = (unsigned short)hi;
+          reinterpret_cast<unsigned short*>(Dlo)[row * 2 * kDLB + gate * 32 + ul] = (unsigned short)lo;
+        } else {
+          Dl[row * kDLS + gate * 32 + ul] = dgv;
+        }
         if (live) dbsum[gate] += dg[gate];
       }
     }
@@ -721,6 +818,31 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
       f32x4 acc[TW];
 #pragma unroll
       for (int t = 0; t < TW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (SPLIT) {
+        // per k block: hi*hi into acc, hi*lo and lo*hi into a second accumulator per tile (summed at the end); consecutive
+        // MFMAs always sit on different accumulators
+        f32x4 accc[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) accc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned* dr = Dhi + jb * kDLB + 4 * ku;
+        u32x4 nh = *reinterpret_cast<const u32x4*>(dr), nl = *reinterpret_cast<const u32x4*>(dr + 16 * kDLB);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const u32x4 vh = nh, vl = nl;
+          if (kb + 1 < 4) {
+            nh = *reinterpret_cast<const u32x4*>(dr + 16 * (kb + 1));
+            nl = *reinterpret_cast<const u32x4*>(dr + 16 * kDLB + 16 * (kb + 1));
+          }
+#pragma unroll
+          for (int t = 0; t < TW; ++t) acc[t] = mfma_bf16(ahi[t][kb], vh, acc[t]);
+#pragma unroll
+          for (int t = 0; t < TW; ++t) accc[t] = mfma_bf16(ahi[t][kb], vl, accc[t]);
+#pragma unroll
+          for (int t = 0; t < TW; ++t) accc[t] = mfma_bf16(alo[t][kb], vh, accc[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[t] += accc[t];
+      } else {
       const float* drow = Dl + jb * kDLS + 4 * ku;
       f32x4 bnext = *reinterpret_cast<const f32x4*>(drow);   // B fragment of step s8+1 requested before the MFMAs of step s8
 #pragma unroll                                               // (all eight up front pushed the kernel into scratch: 256 VGPRs + spills)
@@ -731,6 +853,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
         for (int m = 0; m < 4; ++m)                          // round-robin over the tiles: consecutive MFMAs on different accumulators
 #pragma unroll
           for (int t = 0; t < TW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[t][s8][m], bv[m], acc[t], 0, 0, 0);
+      }
       }
 #pragma unroll
       for (int t = 0; t < TW; ++t) *reinterpret_cast<f32x4*>(Pl + jb * kPLS + 16 * (wv * TW + t) + 4 * ku) = acc[t];
@@ -793,16 +916,21 @@ extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R,
   if (sync_ws && persist_wanted(T) && h % 32 == 0 && h <= kPersistMaxH && T > 1) {
     const int grid = 2 * (h / 32) * cdiv(B, 16);
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
-    const size_t plds = sizeof(float) * ((size_t)16 * HLS + 16 * 33);
-    auto pk = h == 512 ? lstm_fwd_persist_kernel<32> : h == 256 ? lstm_fwd_persist_kernel<16> : h == 384 ? lstm_fwd_persist_kernel<24>
-            : h == 128 ? lstm_fwd_persist_kernel<8> : lstm_fwd_persist_kernel<0>;
+    const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 33);
+    static_assert(kSlabFloats >= 16 * (kPersistMaxH + 8), "slab region holds the fp32 slab too");
+    const bool split = dtype == TSG_F32S;                  // other hidden sizes: the fp32 arithmetic (more accurate, slower)
+    auto pk = h == 512 ? (split ? lstm_fwd_persist_kernel<32, true> : lstm_fwd_persist_kernel<32, false>)
+            : h == 256 ? (split ? lstm_fwd_persist_kernel<16, true> : lstm_fwd_persist_kernel<16, false>)
+            : h == 384 ? (split ? lstm_fwd_persist_kernel<24, true> : lstm_fwd_persist_kernel<24, false>)
+            : h == 128 ? (split ? lstm_fwd_persist_kernel<8, true> : lstm_fwd_persist_kernel<8, false>)
+            : lstm_fwd_persist_kernel<0, false>;
     static int capacity = -1;
     if (capacity < 0) {
       int dev = 0, cus = 0, per = 0;
-      hipError_t e1 = allow_lds(pk, sizeof(float) * (16 * (kPersistMaxH + 8) + 16 * 33));
+      hipError_t e1 = allow_lds(pk, plds);
       if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
       if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, kThreads, sizeof(float) * (16 * (kPersistMaxH + 8) + 16 * 33));
+      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, kThreads, plds);
       capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;      // count ONE workgroup per CU: margin against over-reporting
     }
     if (grid <= capacity) {
@@ -855,15 +983,16 @@ static int bwd_persist_capacity(size_t plds) {
   static int capacity = -1;
   if (capacity < 0) {
     int dev = 0, cus = 0, per = 0;
-    hipError_t e1 = allow_lds(lstm_bwd_persist2_kernel<4>, plds);
+    hipError_t e1 = allow_lds(lstm_bwd_persist2_kernel<4, false>, plds);
     if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
     if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, lstm_bwd_persist2_kernel<4>, kThreads, plds);
+    if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, lstm_bwd_persist2_kernel<4, false>, kThreads, plds);
     capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;
   }
   return capacity;
 }
-static constexpr size_t kBwd2Lds = sizeof(float) * ((size_t)16 * kDLS + 16 * kPLS + 4 * 16 * kQLS);
+static constexpr size_t kBwd2Lds = sizeof(float) * ((size_t)kDlFloats + 16 * kPLS + 4 * 16 * kQLS);
+static_assert(kDlFloats >= 16 * kDLS, "dG tile region holds the fp32 tile too");
 
 extern "C" int tsg_lstm_bwd_ws_persistent(int B, int T, int h, long long ws_bytes) {
   const long long need = tsg_lstm_bwd_ws_bytes(B, T, h);
@@ -887,8 +1016,11 @@ extern "C" int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, 
     hipError_t e = hipMemsetAsync(ws, 0, 256, st);
     if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, sizeof(float) * 8 * h, st);
     if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-    auto pk = h == 512 ? lstm_bwd_persist2_kernel<4> : h == 384 ? lstm_bwd_persist2_kernel<3>
-            : h == 256 ? lstm_bwd_persist2_kernel<2> : lstm_bwd_persist2_kernel<1>;
+    const bool split = dtype == TSG_F32S;
+    auto pk = h == 512 ? (split ? lstm_bwd_persist2_kernel<4, true> : lstm_bwd_persist2_kernel<4, false>)
+            : h == 384 ? (split ? lstm_bwd_persist2_kernel<3, true> : lstm_bwd_persist2_kernel<3, false>)
+            : h == 256 ? (split ? lstm_bwd_persist2_kernel<2, true> : lstm_bwd_persist2_kernel<2, false>)
+            : (split ? lstm_bwd_persist2_kernel<1, true> : lstm_bwd_persist2_kernel<1, false>);
     hipLaunchKernelGGL(pk, dim3(pgrid), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT, (const float*)R,
                        (const float*)Cs, (const float*)dOut, (const float*)dHn, (float*)dG, (float*)((char*)ws + 256),
                        (unsigned*)ws, (float*)dbias, B, T, h);

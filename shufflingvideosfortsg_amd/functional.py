@@ -9,7 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import TSG_F32, check, load, ptr, require_device, stream_of
+from ._lib import TSG_F32, TSG_F32S, check, load, ptr, require_device, stream_of
 
 
 class _KernelTimer:
@@ -386,7 +386,9 @@ class _BiLSTMLayer(torch.autograd.Function):
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=torch.float32)
         Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
         sync = torch.empty(64, device=x.device, dtype=torch.int32)          # persistent-kernel arrival counters
-        _call("tsg_lstm_fwd", x, ptr(Gx), ptr(W_hh), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, TSG_F32)
+        # outside the strict-fp32 mode the recurrence's W_hh products are split-precision bf16 MFMAs as well (TSG_F32S)
+        ctx.rec_dtype = TSG_F32 if _GEMM_DTYPE is None else TSG_F32S
+        _call("tsg_lstm_fwd", x, ptr(Gx), ptr(W_hh), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, ctx.rec_dtype)
         ctx.lstm_sync = sync
         ctx.save_for_backward(x, W_ih, W_hh, out, R, Cs)
         ctx.mark_non_differentiable(Cs)
@@ -407,7 +409,7 @@ class _BiLSTMLayer(torch.autograd.Function):
         fused_db = ws is not None and bool(load().tsg_lstm_bwd_ws_persistent(B, T, h, nb))   # persistent path also sums dG -> dbias
         dbias = torch.empty(8 * h, device=x.device, dtype=torch.float32) if fused_db else None
         _call("tsg_lstm_bwd_ws", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC),
-              ptr(ws) if ws is not None else None, nb, ptr(dbias) if fused_db else None, B, T, h, TSG_F32)
+              ptr(ws) if ws is not None else None, nb, ptr(dbias) if fused_db else None, B, T, h, ctx.rec_dtype)
         dGf = dG.view(T * B, 8 * h)
         dx = _mm(dGf, W_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         if dbias is None:

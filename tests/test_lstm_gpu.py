@@ -150,3 +150,58 @@ def test_bilstm_persistent_forward_small_shapes(shape):
     for a, b in zip(*res):
         assert torch.isfinite(a).all()
         torch.testing.assert_close(a, b, atol=1e-5, rtol=1e-5)
+
+
+def _rec64(Gx, W):
+    """float64 restatement of the recurrence on pre-computed input gates: Gx [T,B,2,4h], W [2,4h,h] -> out [T,B,2h]."""
+    T, B, _, h4 = Gx.shape
+    h = h4 // 4
+    Gx, W = Gx.double(), W.double()
+    out = torch.zeros(T, B, 2 * h, dtype=torch.float64)
+    for d in range(2):
+        hp = torch.zeros(B, h, dtype=torch.float64); c = torch.zeros(B, h, dtype=torch.float64)
+        for t in (range(T) if d == 0 else range(T - 1, -1, -1)):
+            i, f, g, o = (Gx[t, :, d] + hp @ W[d].t()).split(h, 1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            hp = torch.sigmoid(o) * torch.tanh(c)
+            out[t, :, d * h:(d + 1) * h] = hp
+    return out
+
+
+@pytest.mark.parametrize("shape", [(32, 128, 512), (96, 40, 256), (33, 12, 128), (20, 24, 384)])
+def test_bilstm_split_precision_recurrence(shape):
+    """dtype TSG_F32S: the persistent kernels evaluate W_hh h (forward) and dG W_hh (backward) as split-precision bf16
+    MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate).  Against a float64 recurrence the forward error must stay at the
+    fp32 kernels' level (bound: 2e-5 after up to 128 steps), and the gate gradients must match the fp32 kernels'."""
+    from shufflingvideosfortsg_amd import _lib
+    from shufflingvideosfortsg_amd._lib import ptr, TSG_F32, TSG_F32S
+    B, T, h = shape
+    lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(T + h)
+    Gx_c = torch.randn(T, B, 2, 4 * h, generator=g) * 0.5; W_c = torch.randn(2, 4 * h, h, generator=g) / h ** 0.5
+    Gx, W = Gx_c.cuda(), W_c.cuda()
+    dOut = torch.randn(T, B, 2 * h, generator=g).cuda(); WT = W.transpose(1, 2).contiguous()
+    ref64 = _rec64(Gx_c, W_c)
+    res = {}
+    for dt in (TSG_F32, TSG_F32S):
+        sync = torch.zeros(64, dtype=torch.int32, device="cuda")
+        out = torch.full((T, B, 2 * h), 9.0, device="cuda"); R = torch.empty(T, 2, B, h, 4, device="cuda"); Cs = torch.empty(T, 2, B, h, device="cuda")
+        assert lib.tsg_lstm_fwd(ptr(Gx), ptr(W), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, dt, st) == 0
+        nb = lib.tsg_lstm_bwd_ws_bytes(B, T, h)
+        assert nb > 0 and lib.tsg_lstm_bwd_ws_persistent(B, T, h, nb) == 1
+        dG = torch.full((T, B, 2, 4 * h), 5.0, device="cuda"); dC = torch.zeros(2, B, h, device="cuda")
+        ws = torch.empty(nb // 4 + 4, device="cuda"); db = torch.empty(8 * h, device="cuda")
+        # backward of BOTH modes from the fp32 forward's saved gates, so that only the backward arithmetic differs
+        Rb, Cb = (R, Cs) if dt == TSG_F32 else res[TSG_F32][3:5]
+        assert lib.tsg_lstm_bwd_ws(ptr(WT), ptr(Rb), ptr(Cb), ptr(dOut), None, ptr(dG), ptr(dC), ptr(ws), nb, ptr(db), B, T, h, dt, st) == 0
+        torch.cuda.synchronize()
+        assert int(sync[0]) == 0 and int(ws[:1].view(torch.int32)[0]) == 0
+        assert torch.isfinite(out).all() and torch.isfinite(dG).all()
+        res[dt] = (out, dG, db, R, Cs)
+    e32 = (res[TSG_F32][0].cpu().double() - ref64).abs().max().item()
+    e3s = (res[TSG_F32S][0].cpu().double() - ref64).abs().max().item()
+    print(f"[B={B},T={T},h={h}] max |h - h_f64|: fp32 MFMA {e32:.2e}, split bf16 MFMA {e3s:.2e}")
+    assert e3s < 2e-5, (e32, e3s)
+    scale = res[TSG_F32][1].abs().max().item()
+    torch.testing.assert_close(res[TSG_F32S][1], res[TSG_F32][1], atol=2e-5 * max(scale, 1.0), rtol=1e-4)
+    torch.testing.assert_close(res[TSG_F32S][2], res[TSG_F32][2], atol=2e-3, rtol=1e-4)

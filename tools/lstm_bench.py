@@ -4,7 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from shufflingvideosfortsg_amd import _lib
-from shufflingvideosfortsg_amd._lib import ptr, TSG_F32
+from shufflingvideosfortsg_amd._lib import ptr
+TSG_F32 = int(os.environ.get('TSG_REC_DTYPE', '0'))     # 0 = fp32 MFMA recurrence, 2 = split-precision bf16 MFMA (TSG_F32S)
 B, T, h = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (128, 128, 512)))
 lib = _lib.load(); dev = "cuda"; stream = torch.cuda.current_stream(); st = stream.cuda_stream
 Gx = torch.randn(T, B, 2, 4 * h, device=dev) * 0.5; W = torch.randn(2, 4 * h, h, device=dev) / h ** 0.5
@@ -27,4 +28,4 @@ if nb > 0:
     ws = torch.empty(nb // 4 + 4, device=dev)
     b2 = t(lambda: lib.tsg_lstm_bwd_ws(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC), ptr(ws), nb, None, B, T, h, TSG_F32, st))
     print(f"persistent backward (ring exchange): {b2*1e3/T:.2f} us/step ({b2:.2f} ms), err word {int(ws[:1].view(torch.int32)[0])}, phase ticks [poll, reduce+cell, gather barrier, stores, Dl barrier, MFMA] {ws[8:14].view(torch.int32).tolist()}")
-print(f"B={B} T={T} h={h}: fwd {f*1e3/T:.2f} us/step ({f:.2f} ms), bwd {b*1e3/T:.2f} us/step ({b:.2f} ms)")
+print(f"rec dtype {TSG_F32} B={B} T={T} h={h}: fwd {f*1e3/T:.2f} us/step ({f:.2f} ms), bwd {b*1e3/T:.2f} us/step ({b:.2f} ms)")
