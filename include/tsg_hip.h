@@ -30,6 +30,7 @@ extern "C" {
 #define TSG_F32S 2   /* fp32 storage; the LSTM recurrence's W_hh products run as split-precision bf16 MFMAs
                         (hi*hi + hi*lo + lo*hi, fp32 accumulation) -- accepted by tsg_lstm_fwd / tsg_lstm_bwd[_ws] only */
 
+#define TSG_LSTM_SYNC_BYTES 2048   /* size of tsg_lstm_fwd's sync_ws */
 #define TSG_E_NULL   (-1)   /* a required pointer is NULL                      */
 #define TSG_E_SHAPE  (-2)   /* non-positive or unsupported dimension           */
 #define TSG_E_ALIGN  (-3)   /* pointer / leading dimension not 16-B aligned    */
@@ -124,7 +125,7 @@ int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, cons
  * tsg_lstm_fwd runs the T sequential steps (one launch per step covering both directions):
  *   Whh [2,4h,h];  out [T,B,2h] (forward half | reverse half);  saved for backward: R [T,2,B,h,4]
  *   (activated gates) and Cs [T,2,B,h] (cell states).  Limits: h % 4 == 0.
- * sync_ws: caller-owned 256-byte workspace (may be NULL).  When given, T >= 8 (TSG_LSTM_PERSIST=0/1 in the
+ * sync_ws: caller-owned workspace of TSG_LSTM_SYNC_BYTES bytes (may be NULL).  When given, T >= 8 (TSG_LSTM_PERSIST=0/1 in the
  *   environment: never / always), h % 32 == 0, h <= 512 and the grid fits the device, ONE persistent launch runs all T steps (W_hh stationary in
  *   registers; workgroups hand h_t over by polling the sentinel-marked `out` slab itself); word 0 of sync_ws is
  *   non-zero afterwards if a bounded wait expired (results then invalid).  Otherwise one launch per time step.   */

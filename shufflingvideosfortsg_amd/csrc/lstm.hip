@@ -341,25 +341,82 @@ constexpr int kSpinLimit = 1 << 22;
 constexpr int kSlabV = 16 * (kPersistMaxH / 4) / kThreads;   // float4 of the 16-row slab per thread (4 at h = 512)
 constexpr unsigned kSentinel = 0x7fa5c3e1u;     // a signalling-NaN bit pattern: never the value of h = o * tanh(c)
 
+#ifndef TSG_ST_BITS
+#define TSG_ST_BITS "sc1"        // write-through to memory (agent scope)
+#endif
+#ifndef TSG_LD_BITS
+#define TSG_LD_BITS "sc1"        // agent scope: the per-CU L1 is bypassed
+#endif
 __device__ __forceinline__ f32x4 load_sc1_x4(const float* p) {
   f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off " TSG_LD_BITS : "=v"(v) : "v"(p) : "memory");
   return v;
 }
 __device__ __forceinline__ void store_sc1(float* p, float v) {
-  asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dword %0, %1, off " TSG_ST_BITS : : "v"(p), "v"(v) : "memory");
 }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 load_sc1_u4(const float* p) {           // integer typed: the sentinel is a NaN pattern
   u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off " TSG_LD_BITS : "=v"(v) : "v"(p) : "memory");
   return v;
 }
 __device__ __forceinline__ void store_sc1_u4(float* p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off " TSG_ST_BITS : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_sc1_u(float* p, unsigned v) {
-  asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dword %0, %1, off " TSG_ST_BITS : : "v"(p), "v"(v) : "memory");
+}
+
+// Exchange stores.  Each XCD has its own L2, and an agent-scope (sc1) load is served by the L2 of the XCD it is issued on
+// when the line was written there.  When every producer and consumer of an exchange group runs on ONE XCD the h / partial
+// tiles can therefore stay in that L2 (plain stores: 4.6 vs 6.7 us per backward step, 4.5 vs 4.9 forward); a consumer on
+// another XCD would never see them, so the fast path is taken only when the group has VERIFIED its placement: every
+// workgroup ORs 1 << HW_REG_XCC_ID into its group's mask word before the start barrier and reads the mask after it
+// (one bit set = co-located).  Otherwise the stores are write-through as before.  The workgroup -> role mapping below puts
+// the groups on one XCD each under the usual round-robin dispatch (workgroup i -> XCD i % 8) whenever their size divides
+// the per-XCD share; correctness never depends on that.
+__device__ __forceinline__ void store_x(float* p, float v, bool local) {
+  if (local) asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dword %0, %1, off " TSG_ST_BITS : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_x_u4(float* p, u32x4 v, bool local) {
+  if (local) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off " TSG_ST_BITS : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ int xcd_major_index() {          // position of this workgroup when the grid is ordered by (XCD, arrival)
+  const int g = gridDim.x, x = blockIdx.x & 7, s = blockIdx.x >> 3;
+  return x * (g >> 3) + min(x, g & 7) + s;
+}
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 15u;
+}
+constexpr int kSyncGroupWord = 16;               // sync[16 + group] = XCD mask of exchange group (direction, batch slice)
+constexpr int kSyncBytes = TSG_LSTM_SYNC_BYTES;  // error word, arrival counter, debug / timing words, <= 256 group masks
+static_assert(kSyncBytes >= 4 * (kSyncGroupWord + 256), "group masks fit the sync workspace");
+// start barrier of the persistent kernels: publish this workgroup's XCD in its group's mask, meet the grid once, and
+// report whether the whole group sits on one XCD.  false + error word set when the bounded wait expires.
+__device__ __forceinline__ bool grid_start(unsigned* sync, int group, int l2x) {
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_or(sync + kSyncGroupWord + group, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" : : "v"(old) : "memory");       // the mask update has been performed before this workgroup counts as arrived
+    __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kSpinLimit || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned mask = __hip_atomic_load(sync + kSyncGroupWord + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool local = l2x != 0 && __builtin_popcount(__builtin_amdgcn_readfirstlane(mask)) == 1;
+  if (local && threadIdx.x == 0) __hip_atomic_fetch_add(sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sync[3] = workgroups on the L2-local path
+  return local;
 }
 
 // Split-precision arithmetic of the recurrence (dtype TSG_F32S): both operands of the step's product are written as
@@ -393,16 +450,15 @@ constexpr int kSlabFloats = 2 * 16 * kHLB;       // LDS dwords of the slab regio
 template <int HJ, bool SPLIT>                     // HJ = h / 16 when known at compile time (no branch between MFMAs), else 0;
 __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT: split-precision bf16 MFMA arithmetic (needs HJ > 0, even)
     const float* __restrict__ Gx, const float* __restrict__ Whh, float* __restrict__ out,
-    float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS) {
+    float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS, int l2x) {
   extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice (SPLIT: two bf16 planes
   float* Ht = Hl + kSlabFloats;                          // [16][kHLB] dwords), then Ht [16][33] = this step's h tile (16 rows x
   unsigned* Hhi = reinterpret_cast<unsigned*>(Hl);       // 32 units), gathered for whole-line stores
   unsigned* Hlo = Hhi + 16 * kHLB;
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int uslices = h / 32, bslices = (B + 15) / 16;
-  const int d = blockIdx.x / (uslices * bslices);
-  const int rem = blockIdx.x % (uslices * bslices);
-  const int us = rem / bslices, bs = rem % bslices;
+  const int vidx = xcd_major_index(), group = vidx / uslices;     // exchange group = (direction, batch slice): its uslices
+  const int us = vidx % uslices, d = group / bslices, bs = group % bslices;   // workgroups are neighbours in XCD-major order
   const int at = wv;                                      // 8 waves = 8 A-tiles (32 units) x ONE 16-row batch tile: the slab a
                                                           // workgroup fetches per step is 16 rows (32 KiB at h = 512), half of the
                                                           // 4 x 2 arrangement's, for the same MFMA work per wave
@@ -444,20 +500,9 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int spins = 0;
-      while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kSpinLimit || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-    __syncthreads();
-    if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   }
+  const bool local = grid_start(sync, group, l2x);
+  if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
 
 #ifdef TSG_LSTM_TIMING
   unsigned long long tph[4] = {0, 0, 0, 0}, tm0 = 0, tm1 = 0;       // per-phase s_memtime sums of this wave (100 MHz ticks? no: shader clock)
@@ -605,7 +650,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
     __syncthreads();                                        // tile complete; the slab in LDS is free again
     {
       const int row = tid >> 5, col = tid & 31;
-      if (b0 + row < B) store_sc1(out + ((size_t)tt * B + b0 + row) * 2 * h + d * h + us * 32 + col, Ht[row * 33 + col]);
+      if (b0 + row < B) store_x(out + ((size_t)tt * B + b0 + row) * 2 * h + d * h + us * 32 + col, Ht[row * 33 + col], local);
     }
     if (live) {
       const size_t s = (((size_t)tt * 2 + d) * B + b) * h + u;
@@ -657,7 +702,7 @@ template <int TW, bool SPLIT>                     // TW = 16-unit tiles per wave
 __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPLIT: split-precision bf16 MFMA arithmetic
     const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
     const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG,
-    float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int T, int h) {
+    float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int T, int h, int l2x) {
   extern __shared__ __align__(16) float smem2[];
   float* Dl = smem2;                              // [16][kDLS]  this workgroup's dG tile, local column g*32 + ul
   unsigned* Dhi = reinterpret_cast<unsigned*>(Dl);          // (SPLIT: the same tile as two bf16 planes [16][kDLB] dwords)
@@ -666,9 +711,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
   float* Ql = Pl + 16 * kPLS;                     // [4][16][kQLS] sums of the polled blocks per producer group
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int nus = h / 32, bslices = (B + 15) / 16;         // TW = h / 128 = 16-unit tiles per wave = float4 per thread
-  const int d = blockIdx.x / (nus * bslices);
-  const int rem = blockIdx.x % (nus * bslices);
-  const int us = rem / bslices, bs = rem % bslices;
+  const int vidx = xcd_major_index(), group = vidx / nus;   // exchange group = (direction, batch slice), see the forward kernel
+  const int us = vidx % nus, d = group / bslices, bs = group % bslices;
   const int b0 = bs * 16, K = 4 * h;
   const int jb = lane & 15, ku = lane >> 4;
   // A fragments: tile t of this wave = output units 16*(wv*TW + t) + jb; local k' = 16s + 4ku + m -> gate s/2, unit
@@ -710,20 +754,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
       for (int i = 0; i < TW; ++i) store_sc1_u4(prod_ptr(slot, i), sent);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int spins = 0;
-      while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kSpinLimit || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-    __syncthreads();
-    if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   }
+  const bool local = grid_start(sync, group, l2x);
+  if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
 
 #ifdef TSG_LSTM_TIMING
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tm0 = 0, tm1 = 0;
@@ -864,8 +897,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
       for (int i = 0; i < TW; ++i) {
         const int idx = tid + i * kThreads, pr = idx / hq, pc = idx % hq;
         const f32x4 v = *reinterpret_cast<const f32x4*>(Pl + pr * kPLS + 4 * pc);
-        store_sc1_u4(prod_ptr(step & 3, i), (u32x4){(__float_as_uint(v[0]) & ~1u) | gtag, (__float_as_uint(v[1]) & ~1u) | gtag,
-                                                   (__float_as_uint(v[2]) & ~1u) | gtag, (__float_as_uint(v[3]) & ~1u) | gtag});
+        store_x_u4(prod_ptr(step & 3, i), (u32x4){(__float_as_uint(v[0]) & ~1u) | gtag, (__float_as_uint(v[1]) & ~1u) | gtag,
+                                                 (__float_as_uint(v[2]) & ~1u) | gtag, (__float_as_uint(v[3]) & ~1u) | gtag}, local);
       }
       if (step > 0) TSG_TICK(3)                              // partial stores issued
     }
@@ -898,6 +931,11 @@ using namespace tsg;
 static int persist_mode() {
   static int v = -2;
   if (v == -2) { const char* e = getenv("TSG_LSTM_PERSIST"); v = e ? atoi(e) : -1; }
+  return v;
+}
+static int l2_exchange() {        // TSG_LSTM_L2X=0: always write-through exchange stores (A/B measurements)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TSG_LSTM_L2X"); v = e ? (atoi(e) != 0) : 1; }
   return v;
 }
 static bool persist_wanted(int T) { const int m = persist_mode(); return m > 0 || (m < 0 && T >= 8); }
@@ -934,10 +972,10 @@ extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R,
       capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;      // count ONE workgroup per CU: margin against over-reporting
     }
     if (grid <= capacity) {
-      hipError_t e = hipMemsetAsync(sync_ws, 0, 256, st);
+      hipError_t e = hipMemsetAsync(sync_ws, 0, kSyncBytes, st);
       if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
       hipLaunchKernelGGL(pk, dim3(grid), dim3(kThreads), plds, st, (const float*)Gx, (const float*)Whh, (float*)out,
-                         (float*)R, (float*)Cs, (unsigned*)sync_ws, B, T, h, HLS);
+                         (float*)R, (float*)Cs, (unsigned*)sync_ws, B, T, h, HLS, l2_exchange());
       return check_launch(fn);
     }
   }
@@ -976,7 +1014,7 @@ extern "C" long long tsg_lstm_bwd_ws_bytes(int B, int T, int h) {
   (void)T;
   if (B <= 0 || h <= 0 || h % 128 || h > kPersistMaxH) return 0;
   const long long nus = h / 32, bslices = cdiv(B, 16);
-  return 256 + 4LL * 2 * bslices * nus * nus * 512 * (long long)sizeof(float);
+  return kSyncBytes + 4LL * 2 * bslices * nus * nus * 512 * (long long)sizeof(float);
 }
 
 static int bwd_persist_capacity(size_t plds) {
@@ -1013,7 +1051,7 @@ extern "C" int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, 
     if (rc) return rc;
     auto st = static_cast<hipStream_t>(stream);
     const int pgrid = 2 * (h / 32) * cdiv(B, 16);
-    hipError_t e = hipMemsetAsync(ws, 0, 256, st);
+    hipError_t e = hipMemsetAsync(ws, 0, kSyncBytes, st);
     if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, sizeof(float) * 8 * h, st);
     if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
     const bool split = dtype == TSG_F32S;
@@ -1022,8 +1060,8 @@ extern "C" int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, 
             : h == 256 ? (split ? lstm_bwd_persist2_kernel<2, true> : lstm_bwd_persist2_kernel<2, false>)
             : (split ? lstm_bwd_persist2_kernel<1, true> : lstm_bwd_persist2_kernel<1, false>);
     hipLaunchKernelGGL(pk, dim3(pgrid), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT, (const float*)R,
-                       (const float*)Cs, (const float*)dOut, (const float*)dHn, (float*)dG, (float*)((char*)ws + 256),
-                       (unsigned*)ws, (float*)dbias, B, T, h);
+                       (const float*)Cs, (const float*)dOut, (const float*)dHn, (float*)dG, (float*)((char*)ws + kSyncBytes),
+                       (unsigned*)ws, (float*)dbias, B, T, h, l2_exchange());
     return check_launch(fn);
   }
   (void)need;

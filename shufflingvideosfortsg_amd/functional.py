@@ -385,7 +385,7 @@ class _BiLSTMLayer(torch.autograd.Function):
         out = torch.empty(T, B, 2 * h, device=x.device, dtype=torch.float32)
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=torch.float32)
         Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
-        sync = torch.empty(64, device=x.device, dtype=torch.int32)          # persistent-kernel arrival counters
+        sync = torch.empty(512, device=x.device, dtype=torch.int32)         # TSG_LSTM_SYNC_BYTES: persistent-kernel sync words
         # outside the strict-fp32 mode the recurrence's W_hh products are split-precision bf16 MFMAs as well (TSG_F32S)
         ctx.rec_dtype = TSG_F32 if _GEMM_DTYPE is None else TSG_F32S
         _call("tsg_lstm_fwd", x, ptr(Gx), ptr(W_hh), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, ctx.rec_dtype)

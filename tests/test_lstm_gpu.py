@@ -88,7 +88,7 @@ def test_bilstm_persistent_kernel():
         "lib=_lib.load(); B,T,h=96,40,256; g=torch.Generator().manual_seed(1)\n"
         "Gx=(torch.randn(T,B,2,4*h,generator=g)*0.5).cuda(); W=(torch.randn(2,4*h,h,generator=g)/h**0.5).cuda()\n"
         "outs=[]\n"
-        "for ws in (None, torch.zeros(64,dtype=torch.int32,device='cuda')):\n"
+        "for ws in (None, torch.zeros(512,dtype=torch.int32,device='cuda')):\n"
         "    out=torch.empty(T,B,2*h,device='cuda'); R=torch.empty(T,2,B,h,4,device='cuda'); Cs=torch.empty(T,2,B,h,device='cuda')\n"
         "    rc=lib.tsg_lstm_fwd(ptr(Gx),ptr(W),ptr(out),ptr(R),ptr(Cs),ptr(ws) if ws is not None else None,B,T,h,TSG_F32,torch.cuda.current_stream().cuda_stream)\n"
         "    torch.cuda.synchronize(); assert rc==0\n"
@@ -140,7 +140,7 @@ def test_bilstm_persistent_forward_small_shapes(shape):
     g = torch.Generator().manual_seed(B + h)
     Gx = (torch.randn(T, B, 2, 4 * h, generator=g) * 0.5).cuda(); W = (torch.randn(2, 4 * h, h, generator=g) / h ** 0.5).cuda()
     res = []
-    for ws in (None, torch.zeros(64, dtype=torch.int32, device="cuda")):
+    for ws in (None, torch.zeros(512, dtype=torch.int32, device="cuda")):
         out = torch.full((T, B, 2 * h), 9.0, device="cuda"); R = torch.empty(T, 2, B, h, 4, device="cuda"); Cs = torch.empty(T, 2, B, h, device="cuda")
         assert lib.tsg_lstm_fwd(ptr(Gx), ptr(W), ptr(out), ptr(R), ptr(Cs), ptr(ws) if ws is not None else None, B, T, h, TSG_F32, st) == 0
         torch.cuda.synchronize()
@@ -184,7 +184,7 @@ def test_bilstm_split_precision_recurrence(shape):
     ref64 = _rec64(Gx_c, W_c)
     res = {}
     for dt in (TSG_F32, TSG_F32S):
-        sync = torch.zeros(64, dtype=torch.int32, device="cuda")
+        sync = torch.zeros(512, dtype=torch.int32, device="cuda")
         out = torch.full((T, B, 2 * h), 9.0, device="cuda"); R = torch.empty(T, 2, B, h, 4, device="cuda"); Cs = torch.empty(T, 2, B, h, device="cuda")
         assert lib.tsg_lstm_fwd(ptr(Gx), ptr(W), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, dt, st) == 0
         nb = lib.tsg_lstm_bwd_ws_bytes(B, T, h)

@@ -17,7 +17,7 @@ def run(ws):
     return out
 ref = run(None)
 for i in range(reps):
-    ws = torch.zeros(64, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(512, dtype=torch.int32, device="cuda")
     out = run(ws)
     d = (out - ref).abs()
     bad_t = (d.amax(dim=(1, 2)) > 1e-5).nonzero().flatten().tolist()

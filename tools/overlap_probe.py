@@ -12,7 +12,7 @@ Gx = torch.randn(T, B, 2, 4 * h, device=dev) * 0.5; W = torch.randn(2, 4 * h, h,
 out = torch.empty(T, B, 2 * h, device=dev); R = torch.empty(T, 2, B, h, 4, device=dev); Cs = torch.empty(T, 2, B, h, device=dev)
 dOut = torch.randn(T, B, 2 * h, device=dev); WT = W.transpose(1, 2).contiguous()
 dG = torch.empty(T, B, 2, 4 * h, device=dev); dC = torch.empty(2, B, h, device=dev)
-sync = torch.zeros(64, device=dev, dtype=torch.int32)
+sync = torch.zeros(512, device=dev, dtype=torch.int32)
 lib.tsg_lstm_fwd(ptr(Gx), ptr(W), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, TSG_F32, main.cuda_stream)
 a = torch.randn(4096, 16384, device=dev); x = torch.randn(16384, 1024, device=dev); c = torch.empty(4096, 1024, device=dev)
 def lstm_b(): lib.tsg_lstm_bwd(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC), B, T, h, TSG_F32, main.cuda_stream)
