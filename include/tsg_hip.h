@@ -131,6 +131,10 @@ int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, cons
  *   non-zero afterwards if a bounded wait expired (results then invalid).  Otherwise one launch per time step.   */
 int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                  int B, int T, int h, int dtype, void* stream);
+/* Same, with the bias b_ih + b_hh [2,4h] added inside the kernel (bias may be NULL): for callers whose input GEMM has
+ * no bias epilogue, Gx = X W_ih^T.                                                                                  */
+int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
+                      int B, int T, int h, int dtype, void* stream);
 
 /* backward of the recurrence: dOut [T,B,2h] (+ optional dHn [2,B,h] added at each direction's last step)
  * -> dG [T,B,2,4h] = dL/d(pre-activation gates); the caller derives dX, dW_ih, dW_hh, db from it with
@@ -166,6 +170,11 @@ int tsg_linear_fwd(const void* x, const void* w, const void* bias, void* y, int 
  * 3x longer contraction then gives hi·hi + hi·lo + lo·hi (fp32-GEMM-level error).  cols % 4 == 0.                    */
 int tsg_split_bf16x3(const void* x, void* out, long long rows, long long cols, long long ld_out, long long plane_stride,
                      int right_operand, void* stream);
+/* Same from a strided, row-shifted source: output row r is source row r - row_shift (row stride ld_in floats, a multiple
+ * of 4), zeros when that row is outside [0, rows).  Serves the h_{t-1} operand of the LSTM weight-gradient GEMM: a column
+ * slice of out [T*B, 2h] shifted by +-B rows, without materialising the shifted copy.                                */
+int tsg_split_bf16x3_shift(const void* x, long long ld_in, long long row_shift, void* out, long long rows, long long cols,
+                           long long ld_out, long long plane_stride, int right_operand, void* stream);
 
 #ifdef __cplusplus
 }

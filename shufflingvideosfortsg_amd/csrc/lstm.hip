@@ -51,7 +51,7 @@ __device__ __forceinline__ float tanh_f(float x) {
 // (PF chunks in flight), so the K loop has no workgroup barrier.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
-    const float* __restrict__ Gx, const float* __restrict__ Whh, float* __restrict__ out,
+    const float* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh, float* __restrict__ out,
     float* __restrict__ R, float* __restrict__ Cs, int B, int T, int h, int step, int WS) {
   extern __shared__ __align__(16) float lds[];
   float* Wl = lds;                              // [16][WS]   rows (u,g) -> W_hh[d][g*h + u0+u][:]
@@ -96,6 +96,10 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
     if (live) {
       const float* g = Gx + (((size_t)tt * B + b) * 2 + d) * 4 * h + u;
       gx[0] = g[0]; gx[1] = g[h]; gx[2] = g[2 * h]; gx[3] = g[3 * h];
+      if (bias) {                                 // b_ih + b_hh not folded into Gx by the caller's GEMM
+        const float* bb = bias + (size_t)d * 4 * h + u;
+        gx[0] += bb[0]; gx[1] += bb[h]; gx[2] += bb[2 * h]; gx[3] += bb[3 * h];
+      }
       if (!first) cprev = Cs[(((size_t)tp * 2 + d) * B + b) * h + u];
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -449,12 +453,14 @@ constexpr int kSlabFloats = 2 * 16 * kHLB;       // LDS dwords of the slab regio
 
 template <int HJ, bool SPLIT>                     // HJ = h / 16 when known at compile time (no branch between MFMAs), else 0;
 __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT: split-precision bf16 MFMA arithmetic (needs HJ > 0, even)
-    const float* __restrict__ Gx, const float* __restrict__ Whh, float* __restrict__ out,
+    const float* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh, float* __restrict__ out,
     float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS, int l2x) {
   extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice (SPLIT: two bf16 planes
   float* Ht = Hl + kSlabFloats;                          // [16][kHLB] dwords), then Ht [16][33] = this step's h tile (16 rows x
   unsigned* Hhi = reinterpret_cast<unsigned*>(Hl);       // 32 units), gathered for whole-line stores
   unsigned* Hlo = Hhi + 16 * kHLB;
+  volatile unsigned* fail = reinterpret_cast<unsigned*>(Ht + 16 * 33);     // raised by a wave whose bounded wait expired
+  if (threadIdx.x == 0) *fail = 0u;
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int uslices = h / 32, bslices = (B + 15) / 16;
   const int vidx = xcd_major_index(), group = vidx / uslices;     // exchange group = (direction, batch slice): its uslices
@@ -488,6 +494,11 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
   const bool live = b < B;
   float cprev = 0.f;
   const int nrow4 = h / 4;                                 // float4 per h row
+  float bi[4] = {0.f, 0.f, 0.f, 0.f};                      // b_ih + b_hh of this lane's unit when the caller's GEMM left it out
+  if (bias) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bi[k] = bias[(size_t)d * 4 * h + k * h + u];
+  }
 
   {
     // Every lane marks the elements of `out` it will store (all T steps) with the sentinel -- the same lane, the same
@@ -519,7 +530,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
     float gx[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) {
       const float* g = Gx + (((size_t)tt * B + b) * 2 + d) * 4 * h + u;
-      gx[0] = g[0]; gx[1] = g[h]; gx[2] = g[2 * h]; gx[3] = g[3 * h];
+      gx[0] = g[0] + bi[0]; gx[1] = g[h] + bi[1]; gx[2] = g[2 * h] + bi[2]; gx[3] = g[3 * h] + bi[3];
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (step > 0) {
@@ -553,8 +564,11 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
           if (raw) __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
           if (!raw) break;
-          if (++spins > (kSpinLimit >> 6) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          // the error word (a memory round trip) is looked at on every 32nd retry only; a wave that gives up also raises the
+          // workgroup's LDS flag, which is what the other waves check after the barrier below
+          if ((++spins & 31) == 0 && (spins > (kSpinLimit >> 6) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *fail = 1u;
             break;
           }
         }
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
       }
       __syncthreads();
       TSG_TICK(1)                                            // slab in LDS, workgroup met
-      if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // a bounded wait expired somewhere
+      if (*fail) return;                                     // a bounded wait expired in this workgroup
       if constexpr (SPLIT) {
         // B operand: k block j of row jb = 4 dwords at 16j + 4ku of each plane, one ds_read_b128 per plane, requested PFB
         // blocks ahead; three independent accumulator chains (hi*hi, hi*lo, lo*hi), the two small ones summed first
@@ -709,6 +723,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
   unsigned* Dlo = Dhi + 16 * kDLB;
   float* Pl = Dl + kDlFloats;                     // [16][kPLS]  partial dh of all h units, gathered for whole-line stores
   float* Ql = Pl + 16 * kPLS;                     // [4][16][kQLS] sums of the polled blocks per producer group
+  volatile unsigned* fail = reinterpret_cast<unsigned*>(Ql + 4 * 16 * kQLS);   // raised by a wave whose bounded wait expired
+  if (threadIdx.x == 0) *fail = 0u;
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int nus = h / 32, bslices = (B + 15) / 16;         // TW = h / 128 = 16-unit tiles per wave = float4 per thread
   const int vidx = xcd_major_index(), group = vidx / nus;   // exchange group = (direction, batch slice), see the forward kernel
@@ -802,8 +818,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
           if (((q[i][0] & q[i][1] & q[i][2] & q[i][3]) & 1u) != gen || ((q[i][0] | q[i][1] | q[i][2] | q[i][3]) & 1u) != gen) raw |= 1u << i;
         raw &= pending;
         if (!raw) break;
-        if (++spins > (kSpinLimit >> 6) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        if ((++spins & 31) == 0 && (spins > (kSpinLimit >> 6) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
           __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *fail = 1u;                                        // (error word read on every 32nd retry only, see the forward kernel)
           break;
         }
       }
@@ -814,7 +831,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
         if (i < TW) sum += (f32x4){__uint_as_float(q[i][0]), __uint_as_float(q[i][1]), __uint_as_float(q[i][2]), __uint_as_float(q[i][3])};
       *reinterpret_cast<f32x4*>(Ql + (pg * 16 + pr) * kQLS + 4 * pc) = sum;
       __syncthreads();
-      if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // a bounded wait expired somewhere
+      if (*fail) return;                                     // a bounded wait expired in this workgroup
 #pragma unroll
       for (int g = 0; g < 4; ++g) rec += Ql[(g * 16 + row) * kQLS + ul];
     }
@@ -942,7 +959,13 @@ static bool persist_wanted(int T) { const int m = persist_mode(); return m > 0 |
 
 extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                             int B, int T, int h, int dtype, void* stream) {
+  return tsg_lstm_fwd_bias(Gx, nullptr, Whh, out, R, Cs, sync_ws, B, T, h, dtype, stream);
+}
+
+extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
+                                 int B, int T, int h, int dtype, void* stream) {
   const char* fn = "tsg_lstm_fwd";
+  if (bias && !aligned16(bias)) return set_error(TSG_E_ALIGN, "%s: bias %p is not 16-byte aligned", fn, bias);
   for (const void* p : {Gx, Whh, (const void*)out, (const void*)R, (const void*)Cs}) {
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
     if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
@@ -954,7 +977,7 @@ extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R,
   if (sync_ws && persist_wanted(T) && h % 32 == 0 && h <= kPersistMaxH && T > 1) {
     const int grid = 2 * (h / 32) * cdiv(B, 16);
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
-    const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 33);
+    const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 33 + 4);
     static_assert(kSlabFloats >= 16 * (kPersistMaxH + 8), "slab region holds the fp32 slab too");
     const bool split = dtype == TSG_F32S;                  // other hidden sizes: the fp32 arithmetic (more accurate, slower)
     auto pk = h == 512 ? (split ? lstm_fwd_persist_kernel<32, true> : lstm_fwd_persist_kernel<32, false>)
@@ -974,7 +997,7 @@ extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R,
     if (grid <= capacity) {
       hipError_t e = hipMemsetAsync(sync_ws, 0, kSyncBytes, st);
       if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-      hipLaunchKernelGGL(pk, dim3(grid), dim3(kThreads), plds, st, (const float*)Gx, (const float*)Whh, (float*)out,
+      hipLaunchKernelGGL(pk, dim3(grid), dim3(kThreads), plds, st, (const float*)Gx, (const float*)bias, (const float*)Whh, (float*)out,
                          (float*)R, (float*)Cs, (unsigned*)sync_ws, B, T, h, HLS, l2_exchange());
       return check_launch(fn);
     }
@@ -987,7 +1010,7 @@ extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R,
   if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
   const int grid = 2 * cdiv(h, 4);
   for (int step = 0; step < T; ++step)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, (const float*)Gx, (const float*)Whh, (float*)out,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, (const float*)Gx, (const float*)bias, (const float*)Whh, (float*)out,
                        (float*)R, (float*)Cs, B, T, h, step, WS);
   return check_launch(fn);
 }
@@ -1029,7 +1052,7 @@ static int bwd_persist_capacity(size_t plds) {
   }
   return capacity;
 }
-static constexpr size_t kBwd2Lds = sizeof(float) * ((size_t)kDlFloats + 16 * kPLS + 4 * 16 * kQLS);
+static constexpr size_t kBwd2Lds = sizeof(float) * ((size_t)kDlFloats + 16 * kPLS + 4 * 16 * kQLS + 4);
 static_assert(kDlFloats >= 16 * kDLS, "dG tile region holds the fp32 tile too");
 
 extern "C" int tsg_lstm_bwd_ws_persistent(int B, int T, int h, long long ws_bytes) {

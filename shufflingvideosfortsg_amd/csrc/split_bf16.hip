@@ -17,12 +17,14 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {          // finite input
 }
 
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
-                                                         long rows, int cols4, long ld_out, long plane, int right) {
+                                                         long rows, int cols4, long ld_out, long plane, int right,
+                                                         long ld_in, long row_shift) {
   const long total = rows * cols4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
     const long r = i / cols4;
     const int c = static_cast<int>(i - r * cols4) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(x + r * (cols4 * 4L) + c);
+    const long rs = r - row_shift;                                 // source row (zeros outside the matrix)
+    const float4 v = (rs >= 0 && rs < rows) ? *reinterpret_cast<const float4*>(x + rs * ld_in + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float e[4] = {v.x, v.y, v.z, v.w};
     unsigned hi[4], lo[4];
 #pragma unroll
@@ -43,20 +45,26 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 }  // namespace
 }  // namespace tsg
 
-extern "C" int tsg_split_bf16x3(const void* x, void* out, long long rows, long long cols, long long ld_out, long long plane_stride,
-                                int right_operand, void* stream) {
+extern "C" int tsg_split_bf16x3_shift(const void* x, long long ld_in, long long row_shift, void* out, long long rows, long long cols,
+                                      long long ld_out, long long plane_stride, int right_operand, void* stream) {
   using namespace tsg;
-  if (!x || !out) return set_error(TSG_E_NULL, "tsg_split_bf16x3: null pointer");
-  if (rows < 0 || cols < 0 || (cols & 3) || (ld_out & 3) || (plane_stride & 3))
-    return set_error(TSG_E_SHAPE, "tsg_split_bf16x3: rows=%lld cols=%lld ld_out=%lld plane=%lld (cols, ld_out, plane must be multiples of 4)",
-                     rows, cols, ld_out, plane_stride);
+  const char* fn = "tsg_split_bf16x3";
+  if (!x || !out) return set_error(TSG_E_NULL, "%s: null pointer", fn);
+  if (rows < 0 || cols < 0 || (cols & 3) || (ld_out & 3) || (plane_stride & 3) || (ld_in & 3) || ld_in < cols)
+    return set_error(TSG_E_SHAPE, "%s: rows=%lld cols=%lld ld_in=%lld ld_out=%lld plane=%lld (cols, ld_in, ld_out, plane must be multiples of 4, ld_in >= cols)",
+                     fn, rows, cols, ld_in, ld_out, plane_stride);
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 7))
-    return set_error(TSG_E_ALIGN, "tsg_split_bf16x3: x must be 16-byte and out 8-byte aligned");
+    return set_error(TSG_E_ALIGN, "%s: x must be 16-byte and out 8-byte aligned", fn);
   if (rows == 0 || cols == 0) return 0;
   const long total = rows * (cols / 4);
   const int grid = static_cast<int>(total / 256 + 1 < 256L * 16 ? total / 256 + 1 : 256L * 16);
   hipLaunchKernelGGL(split_bf16_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const float*>(x), static_cast<unsigned short*>(out), rows, static_cast<int>(cols / 4),
-                     ld_out, plane_stride, right_operand);
-  return check_launch("tsg_split_bf16x3");
+                     ld_out, plane_stride, right_operand, static_cast<long>(ld_in), static_cast<long>(row_shift));
+  return check_launch(fn);
+}
+
+extern "C" int tsg_split_bf16x3(const void* x, void* out, long long rows, long long cols, long long ld_out, long long plane_stride,
+                                int right_operand, void* stream) {
+  return tsg_split_bf16x3_shift(x, cols, 0, out, rows, cols, ld_out, plane_stride, right_operand, stream);
 }

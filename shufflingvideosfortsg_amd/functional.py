@@ -92,6 +92,18 @@ def split_bf16x3(x: torch.Tensor, k_dim: int, right: bool) -> torch.Tensor:
     return out
 
 
+def split_bf16x3_rows_shifted(x: torch.Tensor, col0: int, cols: int, row_shift: int, right: bool) -> torch.Tensor:
+    """Columns [col0, col0+cols) of fp32 contiguous x [R,C], rows shifted down by ``row_shift`` (zeros shifted in), as
+    the row-stacked bf16 planes [3R, cols] of a GEMM operand contracted over the rows (tsg_split_bf16x3_shift) -- the
+    h_{t-1} operand of the LSTM weight-gradient GEMM without the shifted copy."""
+    require_device(x)
+    x = _f32c(x)
+    R, C = x.shape
+    out = torch.empty(3 * R, cols, device=x.device, dtype=torch.bfloat16)
+    _call("tsg_split_bf16x3_shift", x, x.data_ptr() + 4 * col0, C, row_shift, ptr(out), R, cols, cols, R * cols, int(right))
+    return out
+
+
 def _split_operand(m: torch.Tensor, k_dim: int, right: bool) -> torch.Tensor:
     """Split a (possibly transposed-view) fp32 matrix without materialising the transpose."""
     if m.is_contiguous():
@@ -379,16 +391,17 @@ class _BiLSTMLayer(torch.autograd.Function):
         if W_ih.shape != (8 * h, I) or W_hh.shape != (2, 4 * h, h) or bias.numel() != 8 * h:
             raise ValueError(f"bilstm: shape mismatch x{tuple(x.shape)} W_ih{tuple(W_ih.shape)} W_hh{tuple(W_hh.shape)}")
         if _GEMM_DTYPE is None:
-            Gx = torch.addmm(bias, x.view(T * B, I), W_ih.t())                # [T,B,2,4h]; bias in the GEMM epilogue
+            Gx, kbias = torch.addmm(bias, x.view(T * B, I), W_ih.t()), None   # [T,B,2,4h]; bias in the GEMM epilogue
         else:
-            Gx = _mm(x.view(T * B, I), W_ih.t()).add_(bias)
+            Gx, kbias = _mm(x.view(T * B, I), W_ih.t()), bias                 # bias added inside the recurrence kernel
         out = torch.empty(T, B, 2 * h, device=x.device, dtype=torch.float32)
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=torch.float32)
         Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
         sync = torch.empty(512, device=x.device, dtype=torch.int32)         # TSG_LSTM_SYNC_BYTES: persistent-kernel sync words
         # outside the strict-fp32 mode the recurrence's W_hh products are split-precision bf16 MFMAs as well (TSG_F32S)
         ctx.rec_dtype = TSG_F32 if _GEMM_DTYPE is None else TSG_F32S
-        _call("tsg_lstm_fwd", x, ptr(Gx), ptr(W_hh), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, ctx.rec_dtype)
+        _call("tsg_lstm_fwd_bias", x, ptr(Gx), ptr(kbias) if kbias is not None else None, ptr(W_hh), ptr(out), ptr(R), ptr(Cs),
+              ptr(sync), B, T, h, ctx.rec_dtype)
         ctx.lstm_sync = sync
         ctx.save_for_backward(x, W_ih, W_hh, out, R, Cs)
         ctx.mark_non_differentiable(Cs)
@@ -426,13 +439,13 @@ class _BiLSTMLayer(torch.autograd.Function):
         elif _GEMM_DTYPE == "f32s" and (T * B) % 4 == 0 and h % 4 == 0 and I % 4 == 0:
             # one split of dG along the T·B contraction serves the three weight-gradient GEMMs (column slices of the
             # [3·T·B, 8h] planes are strided views the GEMM takes as they are); the K-concatenated planes cannot be
-            # sliced in time, so here h_{t-1} is the shifted copy with its zero row
+            # sliced in time, so h_{t-1} is split from `out` with a row shift (zero row shifted in) by the split kernel
             S = split_bf16x3(dGf, 0, False)
-            mm3 = lambda a3, b: torch.mm(a3.t(), split_bf16x3(b, 0, True), out_dtype=torch.float32)
-            zero = out.new_zeros(1, B, h)
-            dW_ih = mm3(S, x.view(T * B, I))
-            dW_hh = torch.stack([mm3(S[:, :4 * h], torch.cat([zero, out[:-1, :, :h]], 0).reshape(T * B, h)),
-                                 mm3(S[:, 4 * h:], torch.cat([out[1:, :, h:], zero], 0).reshape(T * B, h))])
+            mm3 = lambda a3, b3: torch.mm(a3.t(), b3, out_dtype=torch.float32)
+            o2 = out.view(T * B, 2 * h)
+            dW_ih = mm3(S, split_bf16x3(x.view(T * B, I), 0, True))
+            dW_hh = torch.stack([mm3(S[:, :4 * h], split_bf16x3_rows_shifted(o2, 0, h, B, True)),      # h_{t-1}, forward direction
+                                 mm3(S[:, 4 * h:], split_bf16x3_rows_shifted(o2, h, h, -B, True))])    # h_{t+1}, reverse direction
         else:
             dW_ih = _mm(dGf.t(), x.view(T * B, I))
             dW_hh = torch.stack([_mm(gf.t(), hf), _mm(gr.t(), hr)])

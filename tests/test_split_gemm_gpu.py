@@ -28,3 +28,44 @@ def test_split_bf16x3_and_split_gemm():
             assert err < 1e-5, err
     finally:
         TF.set_gemm_dtype(None)
+
+
+def test_split_bf16x3_shifted_rows():
+    """tsg_split_bf16x3_shift: a column slice of a wider matrix, rows shifted by +-s with zero rows shifted in, equals the
+    split of the materialised shifted copy (the h_{t-1} operand of the LSTM weight-gradient GEMM)."""
+    torch.manual_seed(5)
+    R, C, s = 48, 64, 8
+    x = torch.randn(R, C, device="cuda")
+    for col0, cols, shift in [(0, 32, s), (32, 32, -s), (16, 24, 0), (0, 64, R)]:
+        sl = x[:, col0:col0 + cols]
+        if shift > 0:
+            ref = torch.cat([torch.zeros(min(shift, R), cols, device="cuda"), sl[:max(R - shift, 0)]], 0)
+        elif shift < 0:
+            ref = torch.cat([sl[-shift:], torch.zeros(-shift, cols, device="cuda")], 0)
+        else:
+            ref = sl.contiguous()
+        got = TF.split_bf16x3_rows_shifted(x, col0, cols, shift, True)
+        assert torch.equal(got, TF.split_bf16x3(ref, 0, True)), (col0, cols, shift)
+
+
+def test_lstm_fwd_bias_entry():
+    """tsg_lstm_fwd_bias(Gx, bias) == tsg_lstm_fwd(Gx + bias), persistent and launch-per-step kernels."""
+    from shufflingvideosfortsg_amd import _lib
+    from shufflingvideosfortsg_amd._lib import ptr, TSG_F32
+    lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+    for (B, T, h), use_ws in [((20, 12, 128), True), ((5, 6, 36), False)]:
+        g = torch.Generator().manual_seed(h)
+        Gx = (torch.randn(T, B, 2, 4 * h, generator=g) * 0.5).cuda(); W = (torch.randn(2, 4 * h, h, generator=g) / h ** 0.5).cuda()
+        bias = torch.randn(2, 4 * h, generator=g).cuda()
+        res = []
+        for fused in (False, True):
+            ws = torch.zeros(512, dtype=torch.int32, device="cuda") if use_ws else None
+            out = torch.empty(T, B, 2 * h, device="cuda"); R = torch.empty(T, 2, B, h, 4, device="cuda"); Cs = torch.empty(T, 2, B, h, device="cuda")
+            gin = Gx if fused else Gx + bias.view(1, 1, 2, 4 * h)
+            rc = lib.tsg_lstm_fwd_bias(ptr(gin), ptr(bias) if fused else None, ptr(W), ptr(out), ptr(R), ptr(Cs),
+                                       ptr(ws) if ws is not None else None, B, T, h, TSG_F32, st)
+            torch.cuda.synchronize()
+            assert rc == 0 and (ws is None or int(ws[0]) == 0)
+            res.append((out, R, Cs))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
