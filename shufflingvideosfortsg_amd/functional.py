@@ -376,6 +376,42 @@ class _LinearHip(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LinearSplit(torch.autograd.Function):
+    """y = x w^T (+ b) with the two large GEMMs (forward, input gradient) in the split-precision mode; the weight
+    gradient dY^T x has a small output and a T*B-long contraction, which the library's fp32 GEMM handles at the fp32 MFMA
+    peak and its bf16 one does not, so it stays an fp32 GEMM."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, x, w, b):
+        x2 = _f32c(x).view(-1, x.shape[-1])
+        y = _mm(x2, w.t())
+        if b is not None:
+            y += b
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = b is not None
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = _f32c(dy).view(-1, w.shape[0])
+        dx = _mm(dy2, w).view(*dy.shape[:-1], w.shape[1]) if ctx.needs_input_grad[0] else None
+        dw = dy2.t() @ x2 if ctx.needs_input_grad[1] else None
+        db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    """torch.nn.functional.linear; in the "f32s" GEMM mode the large projections of the path (>= 2048 rows: SCDM W_a
+    attention.py:104-106, the matching head's and the boundary head's first Linear) run as split-precision GEMMs."""
+    rows = x.numel() // max(x.shape[-1], 1)
+    if _GEMM_DTYPE == "f32s" and x.is_cuda and rows >= 2048 and rows % 4 == 0 and x.shape[-1] % 4 == 0 and w.shape[0] % 4 == 0:
+        return _LinearSplit.apply(x, w, b)
+    return torch.nn.functional.linear(x, w, b)
+
+
 def linear_hip(x, w, b=None):
     """torch.nn.functional.linear on the hand-written fp32 MFMA GEMM (include/tsg_hip.h: tsg_linear_fwd).  Opt-in: rocBLAS
     is ~18 % faster at the path's shapes, so the modules keep F.linear."""

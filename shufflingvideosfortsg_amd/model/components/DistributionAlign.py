@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import functional as TF
 from ..networks.RNN import BiLSTM
 
 
@@ -91,5 +92,5 @@ class VideoTextSemanticMatch(nn.Module):
             return self.predict(temporal_feat, query_feat), temporal_feat
         lin1, act, lin2 = self.predict.predict[0], self.predict.predict[1], self.predict.predict[2]
         Dv = video_feat.size(-1)
-        hid = F.linear(video_feat, lin1.weight[:, :Dv]) + F.linear(query_feat, lin1.weight[:, Dv:], lin1.bias).unsqueeze(1)
+        hid = TF.linear(video_feat, lin1.weight[:, :Dv]) + F.linear(query_feat, lin1.weight[:, Dv:], lin1.bias).unsqueeze(1)
         return lin2(act(hid)).squeeze(dim=2), None

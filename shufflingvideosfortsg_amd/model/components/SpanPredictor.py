@@ -64,7 +64,7 @@ class MLP_predictor(nn.Module):
 
     def forward(self, crossmodal_feat, v_mask=None):
         W1, b1, w2, b2 = self._stacked()
-        y = F.linear(crossmodal_feat, W1)
+        y = TF.linear(crossmodal_feat, W1)
         cs = y.new_zeros(y.size(0), y.size(2))
         return TF.boundary_score(y, cs, b1, w2, b2, None, v_mask)
 
@@ -73,7 +73,7 @@ class MLP_predictor(nn.Module):
         the first Linear is a per-sample row, the [B,T,Dv+Ds] concat is never built."""
         Dv = video_feat.size(-1)
         W1, b1, w2, b2 = self._stacked()
-        y = F.linear(video_feat, W1[:, :Dv])
+        y = TF.linear(video_feat, W1[:, :Dv])
         cs = F.linear(sent_feat, W1[:, Dv:])
         return TF.boundary_score(y, cs, b1, w2, b2, gate, v_mask)
 

@@ -109,6 +109,6 @@ class SCDM_Attention(nn.Module):
         self.w = nn.Linear(hidden_dim, 1, bias=False)
 
     def forward(self, video_feat, sent_feat):
-        a = self.W_a(video_feat)
+        a = TF.linear(video_feat, self.W_a.weight, self.W_a.bias)
         s = self.W_s(sent_feat)
         return TF.scdm_attn(a, s, self.w.weight, sent_feat)
