@@ -175,6 +175,10 @@ int tsg_split_bf16x3(const void* x, void* out, long long rows, long long cols, l
  * slice of out [T*B, 2h] shifted by +-B rows, without materialising the shifted copy.                                */
 int tsg_split_bf16x3_shift(const void* x, long long ld_in, long long row_shift, void* out, long long rows, long long cols,
                            long long ld_out, long long plane_stride, int right_operand, void* stream);
+/* Transposing variant for operands contracted over the ROWS of x: out[c*ld_out + p*plane_stride + r] (r contiguous), same
+ * planes, shift and zero fill.  rows % 16 == 0.                                                                      */
+int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_shift, void* out, long long rows, long long cols,
+                       long long ld_out, long long plane_stride, int right_operand, void* stream);
 
 #ifdef __cplusplus
 }

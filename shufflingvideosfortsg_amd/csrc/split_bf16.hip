@@ -42,6 +42,60 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
   }
 }
 
+
+// Transposing variant: out[c][p*plane + r] (the contraction index r contiguous), for GEMM operands contracted over the
+// ROWS of x -- the library's bf16 GEMM runs the weight-gradient shape [8h x 3TB] x [3TB x (I+2h)] 18 % faster when both
+// operands are K-contiguous (tools/probe_dw_layout.py).  64 x 64 tiles through LDS: float4 loads along the columns,
+// (row, row+1) pairs packed per column on the way in, 32-byte stores along the rows on the way out.
+constexpr int kTS = 68;            // LDS row stride in bf16 elements (34 dwords: conflict-free ds_write_b64 / ds_read_b64)
+__global__ __launch_bounds__(256) void split_bf16_t_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
+                                                           long rows, int cols, long ld_out, long plane, int right,
+                                                           long ld_in, long row_shift) {
+  __shared__ __align__(8) unsigned short Th[64 * kTS], Tl[64 * kTS];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const long r0 = 64L * blockIdx.x;
+  const int c0 = 64 * blockIdx.y;
+  unsigned hi[4][4], lo[4][4];                                   // [row i of the thread's 4][column k of its 4]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long r = r0 + 4 * ty + i, rs = r - row_shift;
+    const int c = c0 + 4 * tx;
+    const float4 v = (r < rows && rs >= 0 && rs < rows && c < cols) ? *reinterpret_cast<const float4*>(x + rs * ld_in + c)
+                                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[i][k] = bf16_rne(e[k]);
+      const float rem = e[k] - __uint_as_float(hi[i][k] << 16);
+      lo[i][k] = (hi[i][k] & 0x7f80u) == 0x7f80u ? 0u : bf16_rne(rem);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    *reinterpret_cast<uint2*>(Th + (4 * tx + k) * kTS + 4 * ty) = make_uint2(hi[0][k] | (hi[1][k] << 16), hi[2][k] | (hi[3][k] << 16));
+    *reinterpret_cast<uint2*>(Tl + (4 * tx + k) * kTS + 4 * ty) = make_uint2(lo[0][k] | (lo[1][k] << 16), lo[2][k] | (lo[3][k] << 16));
+  }
+  __syncthreads();
+  const int cl = tid >> 2, seg = tid & 3;                        // output row (= input column) and its 16-element segment
+  const int c = c0 + cl;
+  const long r = r0 + 16 * seg;
+  if (c < cols && r < rows) {                                    // rows % 16 == 0 (checked on the host): whole segments
+    uint2 H[4], L[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      H[j] = *reinterpret_cast<const uint2*>(Th + cl * kTS + 16 * seg + 4 * j);
+      L[j] = *reinterpret_cast<const uint2*>(Tl + cl * kTS + 16 * seg + 4 * j);
+    }
+    unsigned short* o = out + (long)c * ld_out + r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<uint2*>(o + 4 * j) = H[j];
+      *reinterpret_cast<uint2*>(o + plane + 4 * j) = right ? L[j] : H[j];
+      *reinterpret_cast<uint2*>(o + 2 * plane + 4 * j) = right ? H[j] : L[j];
+    }
+  }
+}
+
 }  // namespace
 }  // namespace tsg
 
@@ -67,4 +121,24 @@ extern "C" int tsg_split_bf16x3_shift(const void* x, long long ld_in, long long 
 extern "C" int tsg_split_bf16x3(const void* x, void* out, long long rows, long long cols, long long ld_out, long long plane_stride,
                                 int right_operand, void* stream) {
   return tsg_split_bf16x3_shift(x, cols, 0, out, rows, cols, ld_out, plane_stride, right_operand, stream);
+}
+
+extern "C" int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_shift, void* out, long long rows, long long cols,
+                                  long long ld_out, long long plane_stride, int right_operand, void* stream) {
+  using namespace tsg;
+  const char* fn = "tsg_split_bf16x3_t";
+  if (!x || !out) return set_error(TSG_E_NULL, "%s: null pointer", fn);
+  if (rows < 0 || cols < 0 || (cols & 3) || (rows & 15) || (ld_out & 3) || (plane_stride & 3) || (ld_in & 3) || ld_in < cols)
+    return set_error(TSG_E_SHAPE, "%s: rows=%lld cols=%lld ld_in=%lld ld_out=%lld plane=%lld (rows %% 16, cols / ld_in / ld_out / plane %% 4, ld_in >= cols)",
+                     fn, rows, cols, ld_in, ld_out, plane_stride);
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 7))
+    return set_error(TSG_E_ALIGN, "%s: x must be 16-byte and out 8-byte aligned", fn);
+  if (rows == 0 || cols == 0) return 0;
+  const dim3 grid(static_cast<unsigned>((rows + 63) / 64), static_cast<unsigned>((cols + 63) / 64));
+  if (grid.y > 65535u) return set_error(TSG_E_SHAPE, "%s: cols=%lld too large", fn, cols);
+  hipLaunchKernelGGL(split_bf16_t_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float*>(x), static_cast<unsigned short*>(out), static_cast<long>(rows), static_cast<int>(cols),
+                     static_cast<long>(ld_out), static_cast<long>(plane_stride), right_operand, static_cast<long>(ld_in),
+                     static_cast<long>(row_shift));
+  return check_launch(fn);
 }

@@ -110,6 +110,19 @@ def split_bf16x3_rows_shifted(x: torch.Tensor, col0: int, cols: int, row_shift: 
     return out
 
 
+def split_bf16x3_t(x: torch.Tensor, col0: int, cols: int, row_shift: int, right: bool, out: torch.Tensor, out_row0: int = 0):
+    """Transposing split (tsg_split_bf16x3_t): columns [col0, col0+cols) of fp32 contiguous x [R,C], rows shifted by
+    ``row_shift`` -> rows [out_row0, out_row0+cols) of the bf16 buffer ``out`` [W, 3R] whose row c holds the three planes
+    of input column c one after the other (contraction index contiguous)."""
+    require_device(x)
+    x = _f32c(x)
+    R, C = x.shape
+    if out.dim() != 2 or out.shape[1] != 3 * R or not out.is_contiguous() or out.dtype != torch.bfloat16 or out_row0 + cols > out.shape[0]:
+        raise ValueError("split_bf16x3_t: bad output buffer")
+    _call("tsg_split_bf16x3_t", x, x.data_ptr() + 4 * col0, C, row_shift, out.data_ptr() + 2 * out_row0 * 3 * R, R, cols, 3 * R, R, int(right))
+    return out
+
+
 def _split_operand(m: torch.Tensor, k_dim: int, right: bool) -> torch.Tensor:
     """Split a (possibly transposed-view) fp32 matrix without materialising the transpose."""
     if m.is_contiguous():
@@ -478,6 +491,20 @@ class _BiLSTMLayer(torch.autograd.Function):
         if T == 1:
             dW_ih = _mm(dGf.t(), x.view(T * B, I))
             dW_hh = torch.zeros_like(W_hh)
+        elif _GEMM_DTYPE == "f32s" and (T * B) % 16 == 0 and h % 4 == 0 and I % 4 == 0:
+            # as below, with both operands written K-contiguous by the transposing split (the layout the library's bf16
+            # GEMM runs this shape fastest in)
+            TB = T * B
+            o2 = out.view(TB, 2 * h)
+            At = torch.empty(8 * h, 3 * TB, device=x.device, dtype=torch.bfloat16)
+            Bt = torch.empty(I + 2 * h, 3 * TB, device=x.device, dtype=torch.bfloat16)
+            split_bf16x3_t(dGf, 0, 8 * h, 0, False, At)
+            split_bf16x3_t(x.view(TB, I), 0, I, 0, True, Bt, 0)
+            split_bf16x3_t(o2, 0, h, B, True, Bt, I)                        # h_{t-1}, forward direction
+            split_bf16x3_t(o2, h, h, -B, True, Bt, I + h)                   # h_{t+1}, reverse direction
+            D = torch.mm(At, Bt.t(), out_dtype=torch.float32)
+            dW_ih = D[:, :I]
+            dW_hh = torch.stack([D[:4 * h, I:I + h], D[4 * h:, I + h:]])
         elif _GEMM_DTYPE == "f32s" and (T * B) % 4 == 0 and h % 4 == 0 and I % 4 == 0:
             # one split of dG along the T·B contraction serves the three weight-gradient GEMMs (column slices of the
             # [3·T·B, 8h] planes are strided views the GEMM takes as they are); the K-concatenated planes cannot be

@@ -69,3 +69,19 @@ def test_lstm_fwd_bias_entry():
             res.append((out, R, Cs))
         for a, b in zip(*res):
             assert torch.equal(a, b)
+
+
+def test_split_bf16x3_transposed():
+    """tsg_split_bf16x3_t writes the same planes as the row-stacked split, transposed (contraction index contiguous), for
+    column slices, row shifts, ragged tiles and side-by-side operands in one buffer."""
+    torch.manual_seed(6)
+    for R, C in [(48, 64), (160, 200), (64, 8)]:
+        x = torch.randn(R, C, device="cuda") * 3
+        W = C + 8
+        buf = torch.full((W, 3 * R), 7.0, device="cuda", dtype=torch.bfloat16)
+        for col0, cols, shift, right, row0 in [(0, C, 0, False, 0), (0, C // 2, 16, True, 4), (C // 2, C // 2, -16, True, 8)]:
+            TF.split_bf16x3_t(x, col0, cols, shift, right, buf, row0)
+            ref = TF.split_bf16x3_rows_shifted(x, col0, cols, shift, right)            # [3R, cols]
+            assert torch.equal(buf[row0:row0 + cols], ref.t()), (R, C, col0, cols, shift)
+            assert (buf[row0 + cols:] == 7.0).all() and (buf[:row0] == 7.0).all()
+            buf.fill_(7.0)
