@@ -132,9 +132,10 @@ int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, cons
 int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                  int B, int T, int h, int dtype, void* stream);
 /* Same, with the bias b_ih + b_hh [2,4h] added inside the kernel (bias may be NULL): for callers whose input GEMM has
- * no bias epilogue, Gx = X W_ih^T.                                                                                  */
+ * no bias epilogue, Gx = X W_ih^T.  batch_major != 0: Gx is [B,T,2,4h] and out [B,T,2h] -- the layout of the model's
+ * activations (BiLSTM batch_first=True, RNN.py:27), no transposed copies around the recurrence; R and Cs stay time-major. */
 int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
-                      int B, int T, int h, int dtype, void* stream);
+                      int B, int T, int h, int dtype, int batch_major, void* stream);
 
 /* backward of the recurrence: dOut [T,B,2h] (+ optional dHn [2,B,h] added at each direction's last step)
  * -> dG [T,B,2,4h] = dL/d(pre-activation gates); the caller derives dX, dW_ih, dW_hh, db from it with
@@ -155,6 +156,10 @@ int tsg_lstm_bwd_ws_persistent(int B, int T, int h, long long ws_bytes);
 int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
                     void* dG, void* dC_ws, void* ws, long long ws_bytes, void* dbias, int B, int T, int h, int dtype,
                     void* stream);
+/* Same with the layout of dOut / dG selectable: batch_major != 0 -> dOut [B,T,2h], dG [B,T,2,4h].                    */
+int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
+                           void* dG, void* dC_ws, void* ws, long long ws_bytes, void* dbias, int B, int T, int h, int dtype,
+                           int batch_major, void* stream);
 
 /* ---- dense projection GEMM on the fp32 matrix cores ("tsg_gemm_*" of SURVEY section 8b) ------------------------------
  * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL): torch.nn.Linear's layout, i.e. the d x d projections of the path
@@ -171,14 +176,16 @@ int tsg_linear_fwd(const void* x, const void* w, const void* bias, void* y, int 
 int tsg_split_bf16x3(const void* x, void* out, long long rows, long long cols, long long ld_out, long long plane_stride,
                      int right_operand, void* stream);
 /* Same from a strided, row-shifted source: output row r is source row r - row_shift (row stride ld_in floats, a multiple
- * of 4), zeros when that row is outside [0, rows).  Serves the h_{t-1} operand of the LSTM weight-gradient GEMM: a column
- * slice of out [T*B, 2h] shifted by +-B rows, without materialising the shifted copy.                                */
-int tsg_split_bf16x3_shift(const void* x, long long ld_in, long long row_shift, void* out, long long rows, long long cols,
-                           long long ld_out, long long plane_stride, int right_operand, void* stream);
+ * of 4), zeros when that row is outside [0, rows) or -- with period > 0, rows being consecutive sequences of `period`
+ * steps -- outside r's own sequence.  Serves the h_{t-1} operand of the LSTM weight-gradient GEMM: a column slice of
+ * out [T*B, 2h] shifted by +-B rows (time-major) or of out [B*T, 2h] shifted by +-1 with period T (batch-major), without
+ * materialising the shifted copy.                                                                                    */
+int tsg_split_bf16x3_shift(const void* x, long long ld_in, long long row_shift, long long period, void* out, long long rows,
+                           long long cols, long long ld_out, long long plane_stride, int right_operand, void* stream);
 /* Transposing variant for operands contracted over the ROWS of x: out[c*ld_out + p*plane_stride + r] (r contiguous), same
  * planes, shift and zero fill.  rows % 16 == 0.                                                                      */
-int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_shift, void* out, long long rows, long long cols,
-                       long long ld_out, long long plane_stride, int right_operand, void* stream);
+int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_shift, long long period, void* out, long long rows,
+                       long long cols, long long ld_out, long long plane_stride, int right_operand, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,9 @@ namespace tsg {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// row of (time t, batch item b) in the caller's sequence tensors (Gx, out, dOut, dG): time-major [T,B,..] or, with bm != 0,
+// batch-major [B,T,..] -- the layout of the model's activations, so that no transposed copy is needed around the recurrence
+__device__ __forceinline__ size_t seq_row(int t, int b, int B, int T, int bm) { return bm ? (size_t)b * T + t : (size_t)t * B + b; }
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;       // 8 waves x 16 batch rows = 128 rows per pass
 constexpr int KC = 32;                          // operand columns per LDS chunk
@@ -52,7 +55,7 @@ __device__ __forceinline__ float tanh_f(float x) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
     const float* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh, float* __restrict__ out,
-    float* __restrict__ R, float* __restrict__ Cs, int B, int T, int h, int step, int WS) {
+    float* __restrict__ R, float* __restrict__ Cs, int B, int T, int h, int step, int WS, int bm) {
   extern __shared__ __align__(16) float lds[];
   float* Wl = lds;                              // [16][WS]   rows (u,g) -> W_hh[d][g*h + u0+u][:]
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
     // cell-update operands: requested now, used after the MFMAs
     float gx[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
     if (live) {
-      const float* g = Gx + (((size_t)tt * B + b) * 2 + d) * 4 * h + u;
+      const float* g = Gx + (seq_row(tt, b, B, T, bm) * 2 + d) * 4 * h + u;
       gx[0] = g[0]; gx[1] = g[h]; gx[2] = g[2 * h]; gx[3] = g[3 * h];
       if (bias) {                                 // b_ih + b_hh not folded into Gx by the caller's GEMM
         const float* bb = bias + (size_t)d * 4 * h + u;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int r = lr + 8 * q, k = c * KC + lc;
-          st[q] = (bt + r < B && k < h) ? *reinterpret_cast<const float4*>(out + ((size_t)tp * B + bt + r) * 2 * h + d * h + k)
+          st[q] = (bt + r < B && k < h) ? *reinterpret_cast<const float4*>(out + seq_row(tp, bt + r, B, T, bm) * 2 * h + d * h + k)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       };
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_step_kernel(
       const size_t s = (((size_t)tt * 2 + d) * B + b) * h + u;
       Cs[s] = c;
       *reinterpret_cast<float4*>(R + s * 4) = make_float4(gi, gf, gg, go);
-      out[((size_t)tt * B + b) * 2 * h + d * h + u] = hv;
+      out[seq_row(tt, b, B, T, bm) * 2 * h + d * h + u] = hv;
     }
   }
 }
@@ -176,7 +179,7 @@ constexpr int HSB = KC + 8;                     // slot row stride: = 8 mod 32 -
 __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
     const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
     const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG, float* __restrict__ dCn,
-    int B, int T, int h, int step) {
+    int B, int T, int h, int step, int bm) {
   __shared__ __align__(16) float ring_all[4 * NBUFB * kStageRows * HSB];
   const int tid = threadIdx.x, lane = tid & 63, kq = wave_id();
   float* ring = ring_all + kq * (NBUFB * kStageRows * HSB);
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
       g4[i] = *reinterpret_cast<const float4*>(R + s * 4);
       cc[i] = Cs[s];
       if (has_prev) cpv[i] = Cs[(((size_t)tp * 2 + d) * B + b) * h + u];
-      dov[i] = dOut[((size_t)tt * B + b) * 2 * h + d * h + u];
+      dov[i] = dOut[seq_row(tt, b, B, T, bm) * 2 * h + d * h + u];
       if (last) { if (dHn) dov[i] += dHn[cs]; } else dcv[i] = dCn[cs];
     }
   }
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = lr + 8 * q;
-        st[q] = (b0 + r < B && k < K) ? *reinterpret_cast<const float4*>(dG + (((size_t)tn * B + b0 + r) * 2 + d) * K + k)
+        st[q] = (b0 + r < B && k < K) ? *reinterpret_cast<const float4*>(dG + (seq_row(tn, b0 + r, B, T, bm) * 2 + d) * K + k)
                                       : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(kBwdThreads) void lstm_bwd_step_kernel(
       dgate[i][3] = dh * tc * go * (1.f - go);
       dCn[((size_t)d * B + b) * h + u0 + 4 * ku + rsel + i] = dc * gf;
     }
-    float* dst = dG + (((size_t)tt * B + b) * 2 + d) * K + u0 + 4 * ku + rsel;
+    float* dst = dG + (seq_row(tt, b, B, T, bm) * 2 + d) * K + u0 + 4 * ku + rsel;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (ok[1]) *reinterpret_cast<float2*>(dst + g * h) = make_float2(dgate[0][g], dgate[1][g]);
@@ -454,7 +457,7 @@ constexpr int kSlabFloats = 2 * 16 * kHLB;       // LDS dwords of the slab regio
 template <int HJ, bool SPLIT>                     // HJ = h / 16 when known at compile time (no branch between MFMAs), else 0;
 __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT: split-precision bf16 MFMA arithmetic (needs HJ > 0, even)
     const float* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh, float* __restrict__ out,
-    float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS, int l2x) {
+    float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS, int l2x, int bm) {
   extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice (SPLIT: two bf16 planes
   float* Ht = Hl + kSlabFloats;                          // [16][kHLB] dwords), then Ht [16][33] = this step's h tile (16 rows x
   unsigned* Hhi = reinterpret_cast<unsigned*>(Hl);       // 32 units), gathered for whole-line stores
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
     {
       const int row = tid >> 5, col = tid & 31;              // the same whole-line pattern as the h stores of the step loop
       if (b0 + row < B)
-        for (int t = 0; t < T; ++t) store_sc1_u(out + ((size_t)t * B + b0 + row) * 2 * h + d * h + us * 32 + col, kSentinel);
+        for (int t = 0; t < T; ++t) store_sc1_u(out + seq_row(t, b0 + row, B, T, bm) * 2 * h + d * h + us * 32 + col, kSentinel);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
     const int tp = d == 0 ? tt - 1 : tt + 1;
     float gx[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) {
-      const float* g = Gx + (((size_t)tt * B + b) * 2 + d) * 4 * h + u;
+      const float* g = Gx + (seq_row(tt, b, B, T, bm) * 2 + d) * 4 * h + u;
       gx[0] = g[0] + bi[0]; gx[1] = g[h] + bi[1]; gx[2] = g[2 * h] + bi[2]; gx[3] = g[3 * h] + bi[3];
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
           const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
           const bool ok = r < 16 && b0 + r < B;
           if (ok) pending |= 1u << i;
-          src[i] = out + ((size_t)tp * B + (ok ? b0 + r : b0)) * 2 * h + d * h + (ok ? c4 * 4 : 0);
+          src[i] = out + seq_row(tp, ok ? b0 + r : b0, B, T, bm) * 2 * h + d * h + (ok ? c4 * 4 : 0);
         }
         // (measured and dropped: two or three staggered copies of the poll in flight -- the extra slab traffic costs more
         // than the shorter retry saves, 13.7 vs 11.5 us per step)
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
     __syncthreads();                                        // tile complete; the slab in LDS is free again
     {
       const int row = tid >> 5, col = tid & 31;
-      if (b0 + row < B) store_x(out + ((size_t)tt * B + b0 + row) * 2 * h + d * h + us * 32 + col, Ht[row * 33 + col], local);
+      if (b0 + row < B) store_x(out + seq_row(tt, b0 + row, B, T, bm) * 2 * h + d * h + us * 32 + col, Ht[row * 33 + col], local);
     }
     if (live) {
       const size_t s = (((size_t)tt * 2 + d) * B + b) * h + u;
@@ -716,7 +719,7 @@ template <int TW, bool SPLIT>                     // TW = 16-unit tiles per wave
 __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPLIT: split-precision bf16 MFMA arithmetic
     const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
     const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG,
-    float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int T, int h, int l2x) {
+    float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int T, int h, int l2x, int bm) {
   extern __shared__ __align__(16) float smem2[];
   float* Dl = smem2;                              // [16][kDLS]  this workgroup's dG tile, local column g*32 + ul
   unsigned* Dhi = reinterpret_cast<unsigned*>(Dl);          // (SPLIT: the same tile as two bf16 planes [16][kDLB] dwords)
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
       g4 = *reinterpret_cast<const float4*>(R + sidx * 4);
       cc = Cs[sidx];
       if (has_prev) cpv = Cs[(((size_t)tp * 2 + d) * B + b) * h + u];
-      dov = dOut[((size_t)tt * B + b) * 2 * h + d * h + u];
+      dov = dOut[seq_row(tt, b, B, T, bm) * 2 * h + d * h + u];
       if (step == 0 && dHn) dov += dHn[((size_t)d * B + b) * h + u];
     }
     float rec = 0.f;
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
       dc_carry = dc * gf;
       const float dg[4] = {dc * gg * gi * (1.f - gi), dc * cpv * gf * (1.f - gf), dc * gi * (1.f - gg * gg), dh * tc * go * (1.f - go)};
       if (live) {
-        float* g = dG + (((size_t)tt * B + b) * 2 + d) * K + u;
+        float* g = dG + (seq_row(tt, b, B, T, bm) * 2 + d) * K + u;
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) g[gate * h] = dg[gate];
       }
@@ -959,11 +962,12 @@ static bool persist_wanted(int T) { const int m = persist_mode(); return m > 0 |
 
 extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                             int B, int T, int h, int dtype, void* stream) {
-  return tsg_lstm_fwd_bias(Gx, nullptr, Whh, out, R, Cs, sync_ws, B, T, h, dtype, stream);
+  return tsg_lstm_fwd_bias(Gx, nullptr, Whh, out, R, Cs, sync_ws, B, T, h, dtype, 0, stream);
 }
 
 extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
-                                 int B, int T, int h, int dtype, void* stream) {
+                                 int B, int T, int h, int dtype, int batch_major, void* stream) {
+  const int bm = batch_major != 0;
   const char* fn = "tsg_lstm_fwd";
   if (bias && !aligned16(bias)) return set_error(TSG_E_ALIGN, "%s: bias %p is not 16-byte aligned", fn, bias);
   for (const void* p : {Gx, Whh, (const void*)out, (const void*)R, (const void*)Cs}) {
@@ -998,7 +1002,7 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
       hipError_t e = hipMemsetAsync(sync_ws, 0, kSyncBytes, st);
       if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
       hipLaunchKernelGGL(pk, dim3(grid), dim3(kThreads), plds, st, (const float*)Gx, (const float*)bias, (const float*)Whh, (float*)out,
-                         (float*)R, (float*)Cs, (unsigned*)sync_ws, B, T, h, HLS, l2_exchange());
+                         (float*)R, (float*)Cs, (unsigned*)sync_ws, B, T, h, HLS, l2_exchange(), bm);
       return check_launch(fn);
     }
   }
@@ -1011,12 +1015,20 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
   const int grid = 2 * cdiv(h, 4);
   for (int step = 0; step < T; ++step)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, (const float*)Gx, (const float*)bias, (const float*)Whh, (float*)out,
-                       (float*)R, (float*)Cs, B, T, h, step, WS);
+                       (float*)R, (float*)Cs, B, T, h, step, WS, bm);
   return check_launch(fn);
 }
 
+static int lstm_bwd_steps(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
+                         void* dG, void* dC_ws, int B, int T, int h, int dtype, int bm, void* stream);
+
 extern "C" int tsg_lstm_bwd(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
                             void* dG, void* dC_ws, int B, int T, int h, int dtype, void* stream) {
+  return lstm_bwd_steps(WhhT, R, Cs, dOut, dHn, dG, dC_ws, B, T, h, dtype, 0, stream);
+}
+
+static int lstm_bwd_steps(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
+                          void* dG, void* dC_ws, int B, int T, int h, int dtype, int bm, void* stream) {
   const char* fn = "tsg_lstm_bwd";
   for (const void* p : {WhhT, R, Cs, dOut, (const void*)dG, (const void*)dC_ws}) {
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
@@ -1029,7 +1041,7 @@ extern "C" int tsg_lstm_bwd(const void* WhhT, const void* R, const void* Cs, con
   const int grid = 2 * cdiv(h, 16) * cdiv(B, 32);
   for (int step = 0; step < T; ++step)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), 0, st, (const float*)WhhT, (const float*)R, (const float*)Cs,
-                       (const float*)dOut, (const float*)dHn, (float*)dG, (float*)dC_ws, B, T, h, step);
+                       (const float*)dOut, (const float*)dHn, (float*)dG, (float*)dC_ws, B, T, h, step, bm);
   return check_launch(fn);
 }
 
@@ -1063,7 +1075,14 @@ extern "C" int tsg_lstm_bwd_ws_persistent(int B, int T, int h, long long ws_byte
 extern "C" int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
                                void* dG, void* dC_ws, void* ws, long long ws_bytes, void* dbias, int B, int T, int h,
                                int dtype, void* stream) {
+  return tsg_lstm_bwd_ws_layout(WhhT, R, Cs, dOut, dHn, dG, dC_ws, ws, ws_bytes, dbias, B, T, h, dtype, 0, stream);
+}
+
+extern "C" int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
+                                      void* dG, void* dC_ws, void* ws, long long ws_bytes, void* dbias, int B, int T, int h,
+                                      int dtype, int batch_major, void* stream) {
   const char* fn = "tsg_lstm_bwd_ws";
+  const int bm = batch_major != 0;
   const long long need = tsg_lstm_bwd_ws_bytes(B, T, h);
   if (ws && aligned16(ws) && tsg_lstm_bwd_ws_persistent(B, T, h, ws_bytes)) {
     for (const void* p : {WhhT, R, Cs, dOut, (const void*)dG}) {
@@ -1084,9 +1103,9 @@ extern "C" int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, 
             : (split ? lstm_bwd_persist2_kernel<1, true> : lstm_bwd_persist2_kernel<1, false>);
     hipLaunchKernelGGL(pk, dim3(pgrid), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT, (const float*)R,
                        (const float*)Cs, (const float*)dOut, (const float*)dHn, (float*)dG, (float*)((char*)ws + kSyncBytes),
-                       (unsigned*)ws, (float*)dbias, B, T, h, l2_exchange());
+                       (unsigned*)ws, (float*)dbias, B, T, h, l2_exchange(), bm);
     return check_launch(fn);
   }
   (void)need;
-  return tsg_lstm_bwd(WhhT, R, Cs, dOut, dHn, dG, dC_ws, B, T, h, dtype, stream);
+  return lstm_bwd_steps(WhhT, R, Cs, dOut, dHn, dG, dC_ws, B, T, h, dtype, bm, stream);
 }

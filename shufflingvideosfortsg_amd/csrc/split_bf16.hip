@@ -16,15 +16,22 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {          // finite input
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+// row r takes source row r - shift when that row exists and, with period > 0 (rows = consecutive sequences of `period`
+// steps, the batch-major layout), lies in the same sequence
+__device__ __forceinline__ bool shift_ok(long r, long shift, long rows, long period) {
+  if (period > 0) { const long t = r % period - shift; return t >= 0 && t < period; }
+  return r - shift >= 0 && r - shift < rows;
+}
+
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
                                                          long rows, int cols4, long ld_out, long plane, int right,
-                                                         long ld_in, long row_shift) {
+                                                         long ld_in, long row_shift, long period) {
   const long total = rows * cols4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
     const long r = i / cols4;
     const int c = static_cast<int>(i - r * cols4) * 4;
-    const long rs = r - row_shift;                                 // source row (zeros outside the matrix)
-    const float4 v = (rs >= 0 && rs < rows) ? *reinterpret_cast<const float4*>(x + rs * ld_in + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long rs = r - row_shift;                                 // source row (zeros outside the matrix / the row's period)
+    const float4 v = shift_ok(r, row_shift, rows, period) ? *reinterpret_cast<const float4*>(x + rs * ld_in + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float e[4] = {v.x, v.y, v.z, v.w};
     unsigned hi[4], lo[4];
 #pragma unroll
@@ -50,7 +57,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 constexpr int kTS = 68;            // LDS row stride in bf16 elements (34 dwords: conflict-free ds_write_b64 / ds_read_b64)
 __global__ __launch_bounds__(256) void split_bf16_t_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
                                                            long rows, int cols, long ld_out, long plane, int right,
-                                                           long ld_in, long row_shift) {
+                                                           long ld_in, long row_shift, long period) {
   __shared__ __align__(8) unsigned short Th[64 * kTS], Tl[64 * kTS];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const long r0 = 64L * blockIdx.x;
@@ -60,7 +67,7 @@ __global__ __launch_bounds__(256) void split_bf16_t_kernel(const float* __restri
   for (int i = 0; i < 4; ++i) {
     const long r = r0 + 4 * ty + i, rs = r - row_shift;
     const int c = c0 + 4 * tx;
-    const float4 v = (r < rows && rs >= 0 && rs < rows && c < cols) ? *reinterpret_cast<const float4*>(x + rs * ld_in + c)
+    const float4 v = (r < rows && c < cols && shift_ok(r, row_shift, rows, period)) ? *reinterpret_cast<const float4*>(x + rs * ld_in + c)
                                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
     const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -99,12 +106,12 @@ __global__ __launch_bounds__(256) void split_bf16_t_kernel(const float* __restri
 }  // namespace
 }  // namespace tsg
 
-extern "C" int tsg_split_bf16x3_shift(const void* x, long long ld_in, long long row_shift, void* out, long long rows, long long cols,
-                                      long long ld_out, long long plane_stride, int right_operand, void* stream) {
+extern "C" int tsg_split_bf16x3_shift(const void* x, long long ld_in, long long row_shift, long long period, void* out, long long rows,
+                                      long long cols, long long ld_out, long long plane_stride, int right_operand, void* stream) {
   using namespace tsg;
   const char* fn = "tsg_split_bf16x3";
   if (!x || !out) return set_error(TSG_E_NULL, "%s: null pointer", fn);
-  if (rows < 0 || cols < 0 || (cols & 3) || (ld_out & 3) || (plane_stride & 3) || (ld_in & 3) || ld_in < cols)
+  if (rows < 0 || cols < 0 || (cols & 3) || (ld_out & 3) || (plane_stride & 3) || (ld_in & 3) || ld_in < cols || period < 0)
     return set_error(TSG_E_SHAPE, "%s: rows=%lld cols=%lld ld_in=%lld ld_out=%lld plane=%lld (cols, ld_in, ld_out, plane must be multiples of 4, ld_in >= cols)",
                      fn, rows, cols, ld_in, ld_out, plane_stride);
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 7))
@@ -114,17 +121,17 @@ extern "C" int tsg_split_bf16x3_shift(const void* x, long long ld_in, long long 
   const int grid = static_cast<int>(total / 256 + 1 < 256L * 16 ? total / 256 + 1 : 256L * 16);
   hipLaunchKernelGGL(split_bf16_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const float*>(x), static_cast<unsigned short*>(out), rows, static_cast<int>(cols / 4),
-                     ld_out, plane_stride, right_operand, static_cast<long>(ld_in), static_cast<long>(row_shift));
+                     ld_out, plane_stride, right_operand, static_cast<long>(ld_in), static_cast<long>(row_shift), static_cast<long>(period));
   return check_launch(fn);
 }
 
 extern "C" int tsg_split_bf16x3(const void* x, void* out, long long rows, long long cols, long long ld_out, long long plane_stride,
                                 int right_operand, void* stream) {
-  return tsg_split_bf16x3_shift(x, cols, 0, out, rows, cols, ld_out, plane_stride, right_operand, stream);
+  return tsg_split_bf16x3_shift(x, cols, 0, 0, out, rows, cols, ld_out, plane_stride, right_operand, stream);
 }
 
-extern "C" int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_shift, void* out, long long rows, long long cols,
-                                  long long ld_out, long long plane_stride, int right_operand, void* stream) {
+extern "C" int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_shift, long long period, void* out, long long rows,
+                                  long long cols, long long ld_out, long long plane_stride, int right_operand, void* stream) {
   using namespace tsg;
   const char* fn = "tsg_split_bf16x3_t";
   if (!x || !out) return set_error(TSG_E_NULL, "%s: null pointer", fn);
@@ -139,6 +146,6 @@ extern "C" int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_
   hipLaunchKernelGGL(split_bf16_t_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const float*>(x), static_cast<unsigned short*>(out), static_cast<long>(rows), static_cast<int>(cols),
                      static_cast<long>(ld_out), static_cast<long>(plane_stride), right_operand, static_cast<long>(ld_in),
-                     static_cast<long>(row_shift));
+                     static_cast<long>(row_shift), static_cast<long>(period));
   return check_launch(fn);
 }

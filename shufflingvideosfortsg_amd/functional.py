@@ -93,7 +93,7 @@ def split_bf16x3(x: torch.Tensor, k_dim: int, right: bool) -> torch.Tensor:
 
 
 def split_bf16x3_rows_shifted(x: torch.Tensor, col0: int, cols: int, row_shift: int, right: bool,
-                              out: torch.Tensor = None, out_col0: int = 0) -> torch.Tensor:
+                              out: torch.Tensor = None, out_col0: int = 0, period: int = 0) -> torch.Tensor:
     """Columns [col0, col0+cols) of fp32 contiguous x [R,C], rows shifted down by ``row_shift`` (zeros shifted in), as
     the row-stacked bf16 planes [3R, cols] of a GEMM operand contracted over the rows (tsg_split_bf16x3_shift) -- the
     h_{t-1} operand of the LSTM weight-gradient GEMM without the shifted copy.  With ``out`` [3R, W] given, the planes
@@ -106,20 +106,21 @@ def split_bf16x3_rows_shifted(x: torch.Tensor, col0: int, cols: int, row_shift: 
     W = out.shape[1]
     if out.shape[0] != 3 * R or not out.is_contiguous() or out.dtype != torch.bfloat16 or out_col0 + cols > W or (out_col0 | W) % 4:
         raise ValueError("split_bf16x3_rows_shifted: bad output buffer")
-    _call("tsg_split_bf16x3_shift", x, x.data_ptr() + 4 * col0, C, row_shift, out.data_ptr() + 2 * out_col0, R, cols, W, R * W, int(right))
+    _call("tsg_split_bf16x3_shift", x, x.data_ptr() + 4 * col0, C, row_shift, period, out.data_ptr() + 2 * out_col0, R, cols, W, R * W, int(right))
     return out
 
 
-def split_bf16x3_t(x: torch.Tensor, col0: int, cols: int, row_shift: int, right: bool, out: torch.Tensor, out_row0: int = 0):
+def split_bf16x3_t(x: torch.Tensor, col0: int, cols: int, row_shift: int, right: bool, out: torch.Tensor, out_row0: int = 0,
+                   period: int = 0):
     """Transposing split (tsg_split_bf16x3_t): columns [col0, col0+cols) of fp32 contiguous x [R,C], rows shifted by
-    ``row_shift`` -> rows [out_row0, out_row0+cols) of the bf16 buffer ``out`` [W, 3R] whose row c holds the three planes
+    ``row_shift`` (within sequences of ``period`` rows when period > 0) -> rows [out_row0, out_row0+cols) of the bf16 buffer ``out`` [W, 3R] whose row c holds the three planes
     of input column c one after the other (contraction index contiguous)."""
     require_device(x)
     x = _f32c(x)
     R, C = x.shape
     if out.dim() != 2 or out.shape[1] != 3 * R or not out.is_contiguous() or out.dtype != torch.bfloat16 or out_row0 + cols > out.shape[0]:
         raise ValueError("split_bf16x3_t: bad output buffer")
-    _call("tsg_split_bf16x3_t", x, x.data_ptr() + 4 * col0, C, row_shift, out.data_ptr() + 2 * out_row0 * 3 * R, R, cols, 3 * R, R, int(right))
+    _call("tsg_split_bf16x3_t", x, x.data_ptr() + 4 * col0, C, row_shift, period, out.data_ptr() + 2 * out_row0 * 3 * R, R, cols, 3 * R, R, int(right))
     return out
 
 
@@ -432,32 +433,35 @@ def linear_hip(x, w, b=None):
 
 
 class _BiLSTMLayer(torch.autograd.Function):
-    """One bidirectional LSTM layer from zero state, TIME-MAJOR.  x [T,B,I]; W_ih [8h,I] (forward rows,
-    then reverse), bias [8h] (b_ih + b_hh), W_hh [2,4h,h]  ->  out [T,B,2h].  The input GEMM and the
-    weight-gradient GEMMs are library GEMMs (rocBLAS via torch); the recurrence is libtsg_hip.so."""
+    """One bidirectional LSTM layer from zero state.  x [T,B,I] (time-major) or, with ``bm``, [B,T,I] (batch-major, the
+    model's layout: the kernels index the sequence tensors either way, so no transposed copies surround the recurrence);
+    W_ih [8h,I] (forward rows, then reverse), bias [8h] (b_ih + b_hh), W_hh [2,4h,h]  ->  out [T,B,2h] / [B,T,2h] and the
+    cell states Cs [T,2,B,h] (always time-major).  The input GEMM and the weight-gradient GEMMs are library GEMMs (rocBLAS
+    via torch); the recurrence is libtsg_hip.so."""
 
     @staticmethod
     @_fwd
-    def forward(ctx, x, W_ih, bias, W_hh):
+    def forward(ctx, x, W_ih, bias, W_hh, bm=False):
         require_device(x, W_ih, bias, W_hh)
         x, W_ih, bias, W_hh = _f32c(x), _f32c(W_ih), _f32c(bias), _f32c(W_hh)
-        T, B, I = x.shape
+        (B, T, I) = x.shape if bm else (x.shape[1], x.shape[0], x.shape[2])
         h = W_hh.shape[2]
         if W_ih.shape != (8 * h, I) or W_hh.shape != (2, 4 * h, h) or bias.numel() != 8 * h:
             raise ValueError(f"bilstm: shape mismatch x{tuple(x.shape)} W_ih{tuple(W_ih.shape)} W_hh{tuple(W_hh.shape)}")
         if _GEMM_DTYPE is None:
-            Gx, kbias = torch.addmm(bias, x.view(T * B, I), W_ih.t()), None   # [T,B,2,4h]; bias in the GEMM epilogue
+            Gx, kbias = torch.addmm(bias, x.view(T * B, I), W_ih.t()), None   # [rows,2,4h]; bias in the GEMM epilogue
         else:
             Gx, kbias = _mm(x.view(T * B, I), W_ih.t()), bias                 # bias added inside the recurrence kernel
-        out = torch.empty(T, B, 2 * h, device=x.device, dtype=torch.float32)
+        out = torch.empty((B, T, 2 * h) if bm else (T, B, 2 * h), device=x.device, dtype=torch.float32)
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=torch.float32)
         Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
         sync = torch.empty(512, device=x.device, dtype=torch.int32)         # TSG_LSTM_SYNC_BYTES: persistent-kernel sync words
         # outside the strict-fp32 mode the recurrence's W_hh products are split-precision bf16 MFMAs as well (TSG_F32S)
         ctx.rec_dtype = TSG_F32 if _GEMM_DTYPE is None else TSG_F32S
         _call("tsg_lstm_fwd_bias", x, ptr(Gx), ptr(kbias) if kbias is not None else None, ptr(W_hh), ptr(out), ptr(R), ptr(Cs),
-              ptr(sync), B, T, h, ctx.rec_dtype)
+              ptr(sync), B, T, h, ctx.rec_dtype, int(bm))
         ctx.lstm_sync = sync
+        ctx.bm = bool(bm)
         ctx.save_for_backward(x, W_ih, W_hh, out, R, Cs)
         ctx.mark_non_differentiable(Cs)
         return out, Cs
@@ -466,68 +470,60 @@ class _BiLSTMLayer(torch.autograd.Function):
     @_bwd
     def backward(ctx, dOut, _dCs):
         x, W_ih, W_hh, out, R, Cs = ctx.saved_tensors
-        T, B, I = x.shape
+        bm = ctx.bm
+        (B, T, I) = x.shape if bm else (x.shape[1], x.shape[0], x.shape[2])
         h = W_hh.shape[2]
+        TB = T * B
         dOut = _f32c(dOut)
         WhhT = W_hh.transpose(1, 2).contiguous()
-        dG = torch.empty(T, B, 2, 4 * h, device=x.device, dtype=torch.float32)
+        dG = torch.empty((B, T, 2, 4 * h) if bm else (T, B, 2, 4 * h), device=x.device, dtype=torch.float32)
         dC = torch.empty(2, B, h, device=x.device, dtype=torch.float32)
         nb = int(load().tsg_lstm_bwd_ws_bytes(B, T, h))                      # ring workspace of the persistent backward (0: none)
         ws = torch.empty(nb // 4 + 4, device=x.device, dtype=torch.float32) if nb > 0 else None
         fused_db = ws is not None and bool(load().tsg_lstm_bwd_ws_persistent(B, T, h, nb))   # persistent path also sums dG -> dbias
         dbias = torch.empty(8 * h, device=x.device, dtype=torch.float32) if fused_db else None
-        _call("tsg_lstm_bwd_ws", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC),
-              ptr(ws) if ws is not None else None, nb, ptr(dbias) if fused_db else None, B, T, h, ctx.rec_dtype)
-        dGf = dG.view(T * B, 8 * h)
-        dx = _mm(dGf, W_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
+        _call("tsg_lstm_bwd_ws_layout", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC),
+              ptr(ws) if ws is not None else None, nb, ptr(dbias) if fused_db else None, B, T, h, ctx.rec_dtype, int(bm))
+        dGf = dG.view(TB, 8 * h)
+        dx = _mm(dGf, W_ih).view(x.shape) if ctx.needs_input_grad[0] else None
         if dbias is None:
             dbias = dGf.sum(0)
-        # dW_hh[d] = sum_t dG_t[d]^T h_{t-1}[d]: the step whose h_{t-1} is the zero state drops out, so both operands are
-        # plain strided VIEWS (rows t=1.. of dG with rows ..T-2 of out for the forward direction, the mirror image for
-        # the reverse one) -- no shifted copy of out, no per-direction copy of dG
-        if T > 1:
-            gf, hf = dG[1:, :, 0].reshape((T - 1) * B, 4 * h), out[:-1, :, :h].reshape((T - 1) * B, h)
-            gr, hr = dG[:-1, :, 1].reshape((T - 1) * B, 4 * h), out[1:, :, h:].reshape((T - 1) * B, h)
+        # dW_hh[d] = sum_t dG_t[d]^T h_{t-1}[d] (h_{t+1} for the reverse direction): in row terms the partner of row r is
+        # row r -+ B of `out` (time-major) or row r -+ 1 of the same sequence (batch-major), zero at the sequence ends
+        shift, period = (1, T) if bm else (B, 0)
+        x2, o2 = x.view(TB, I), out.view(TB, 2 * h)
         if T == 1:
-            dW_ih = _mm(dGf.t(), x.view(T * B, I))
+            dW_ih = _mm(dGf.t(), x2)
             dW_hh = torch.zeros_like(W_hh)
-        elif _GEMM_DTYPE == "f32s" and (T * B) % 16 == 0 and h % 4 == 0 and I % 4 == 0:
-            # as below, with both operands written K-contiguous by the transposing split (the layout the library's bf16
-            # GEMM runs this shape fastest in)
-            TB = T * B
-            o2 = out.view(TB, 2 * h)
+        elif _GEMM_DTYPE == "f32s" and TB % 16 == 0 and h % 4 == 0 and I % 4 == 0:
+            # ONE GEMM: the right operand is [x | h_{t-1} forward | h_{t+1} reverse] side by side, so that
+            # D = dG^T [x | hf | hr] holds dW_ih and both dW_hh blocks (the two cross-direction blocks are computed and
+            # dropped: 1/3 more flops, but one [8h x (I+2h)] GEMM that fills the chip instead of a [8h x I] one plus two
+            # [4h x h] ones whose 80 output tiles left two thirds of it idle: 0.6 vs 1.1 ms per video layer); both
+            # operands are written K-contiguous by the transposing split, the layout the library's bf16 GEMM runs this
+            # shape fastest in; the shifted h rows come straight from `out` (no shifted copies)
             At = torch.empty(8 * h, 3 * TB, device=x.device, dtype=torch.bfloat16)
             Bt = torch.empty(I + 2 * h, 3 * TB, device=x.device, dtype=torch.bfloat16)
             split_bf16x3_t(dGf, 0, 8 * h, 0, False, At)
-            split_bf16x3_t(x.view(TB, I), 0, I, 0, True, Bt, 0)
-            split_bf16x3_t(o2, 0, h, B, True, Bt, I)                        # h_{t-1}, forward direction
-            split_bf16x3_t(o2, h, h, -B, True, Bt, I + h)                   # h_{t+1}, reverse direction
+            split_bf16x3_t(x2, 0, I, 0, True, Bt, 0)
+            split_bf16x3_t(o2, 0, h, shift, True, Bt, I, period)             # h_{t-1}, forward direction
+            split_bf16x3_t(o2, h, h, -shift, True, Bt, I + h, period)        # h_{t+1}, reverse direction
             D = torch.mm(At, Bt.t(), out_dtype=torch.float32)
             dW_ih = D[:, :I]
             dW_hh = torch.stack([D[:4 * h, I:I + h], D[4 * h:, I + h:]])
-        elif _GEMM_DTYPE == "f32s" and (T * B) % 4 == 0 and h % 4 == 0 and I % 4 == 0:
-            # one split of dG along the T·B contraction serves the three weight-gradient GEMMs (column slices of the
-            # [3·T·B, 8h] planes are strided views the GEMM takes as they are); the K-concatenated planes cannot be
-            # sliced in time, so h_{t-1} is split from `out` with a row shift (zero row shifted in) by the split kernel
-            # ... and ONE GEMM: the right operand is [x | h_{t-1} forward | h_{t+1} reverse] side by side, so that
-            # D = dG^T [x | hf | hr] holds dW_ih and both dW_hh blocks (the two cross-direction blocks are computed and
-            # dropped: 1/3 more flops, but one [8h x (I+2h)] GEMM that fills the chip instead of a [8h x I] one plus two
-            # [4h x h] ones whose 80 output tiles left two thirds of it idle: 0.6 vs 1.1 ms per video layer)
-            S = split_bf16x3(dGf, 0, False)
-            o2 = out.view(T * B, 2 * h)
-            Rc = torch.empty(3 * T * B, I + 2 * h, device=x.device, dtype=torch.bfloat16)
-            split_bf16x3_rows_shifted(x.view(T * B, I), 0, I, 0, True, Rc, 0)
-            split_bf16x3_rows_shifted(o2, 0, h, B, True, Rc, I)             # h_{t-1}, forward direction
-            split_bf16x3_rows_shifted(o2, h, h, -B, True, Rc, I + h)        # h_{t+1}, reverse direction
-            D = torch.mm(S.t(), Rc, out_dtype=torch.float32)
-            dW_ih = D[:, :I]
-            dW_hh = torch.stack([D[:4 * h, I:I + h], D[4 * h:, I + h:]])
         else:
-            dW_ih = _mm(dGf.t(), x.view(T * B, I))
+            # the step whose partner is the zero state drops out, so both operands are plain strided VIEWS
+            dW_ih = _mm(dGf.t(), x2)
+            if bm:
+                gf, hf = dG[:, 1:, 0].reshape(B * (T - 1), 4 * h), out[:, :-1, :h].reshape(B * (T - 1), h)
+                gr, hr = dG[:, :-1, 1].reshape(B * (T - 1), 4 * h), out[:, 1:, h:].reshape(B * (T - 1), h)
+            else:
+                gf, hf = dG[1:, :, 0].reshape((T - 1) * B, 4 * h), out[:-1, :, :h].reshape((T - 1) * B, h)
+                gr, hr = dG[:-1, :, 1].reshape((T - 1) * B, 4 * h), out[1:, :, h:].reshape((T - 1) * B, h)
             dW_hh = torch.stack([_mm(gf.t(), hf), _mm(gr.t(), hr)])
-        return dx, dW_ih, dbias, dW_hh
+        return dx, dW_ih, dbias, dW_hh, None
 
 
-def bilstm_layer(x_tm, W_ih, bias, W_hh):
-    """Time-major layer: x_tm [T,B,I] -> (out [T,B,2h], Cs [T,2,B,h] cell states, not differentiable)."""
-    return _BiLSTMLayer.apply(x_tm, W_ih, bias, W_hh)
+def bilstm_layer(x, W_ih, bias, W_hh, batch_major=False):
+    """x [T,B,I] (or [B,T,I] with batch_major) -> (out in the same layout, Cs [T,2,B,h] cell states, not differentiable)."""
+    return _BiLSTMLayer.apply(x, W_ih, bias, W_hh, batch_major)

@@ -23,19 +23,20 @@ class BiLSTM(nn.Module):
 
     def _hip_forward(self, x):
         L, p = self.lstm, self.lstm.dropout
-        inp, hn, cn = x.transpose(0, 1).contiguous(), [], []          # time-major inside (see csrc/lstm.hip)
+        bm = os.environ.get("TSG_LSTM_LAYOUT", "bm") != "tm"   # default: batch-major throughout, the kernels index [B,T,..]
+        inp, hn, cn = (x if bm else x.transpose(0, 1).contiguous()), [], []     # directly; "tm" = transposed copies (A/B timing)
         for k in range(self.num_layers):
             g = lambda n: getattr(L, f"{n}_l{k}")
             gr = lambda n: getattr(L, f"{n}_l{k}_reverse")
             W_ih = torch.cat([g("weight_ih"), gr("weight_ih")], 0)
             bias = torch.cat([g("bias_ih") + g("bias_hh"), gr("bias_ih") + gr("bias_hh")])
             W_hh = torch.stack([g("weight_hh"), gr("weight_hh")])
-            out, Cs = TF.bilstm_layer(inp, W_ih, bias, W_hh)
+            out, Cs = TF.bilstm_layer(inp, W_ih, bias, W_hh, batch_major=bm)
             h = self.hidden_size
-            hn += [out[-1, :, :h], out[0, :, h:]]
+            hn += [out[:, -1, :h], out[:, 0, h:]] if bm else [out[-1, :, :h], out[0, :, h:]]
             cn += [Cs[-1, 0], Cs[0, 1]]
             inp = F.dropout(out, p, self.training) if (p > 0 and k + 1 < self.num_layers) else out
-        return out.transpose(0, 1).contiguous(), torch.stack(hn, 0), torch.stack(cn, 0)
+        return (out if bm else out.transpose(0, 1).contiguous()), torch.stack(hn, 0), torch.stack(cn, 0)
 
     def forward(self, x, h0=None, c0=None):
         """-> (out [B,L,2h], hn [2*layers,B,h], cn); zero initial state on x's device (the reference

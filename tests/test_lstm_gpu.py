@@ -205,3 +205,36 @@ def test_bilstm_split_precision_recurrence(shape):
     scale = res[TSG_F32][1].abs().max().item()
     torch.testing.assert_close(res[TSG_F32S][1], res[TSG_F32][1], atol=2e-5 * max(scale, 1.0), rtol=1e-4)
     torch.testing.assert_close(res[TSG_F32S][2], res[TSG_F32][2], atol=2e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("shape,dt", [((128, 16, 512), 0), ((128, 16, 512), 2), ((33, 12, 128), 2), ((5, 6, 36), 0), ((20, 3, 64), 0)])
+def test_bilstm_batch_major_layout(shape, dt):
+    """batch_major != 0 (Gx [B,T,2,4h], out / dOut [B,T,2h], dG [B,T,2,4h]) gives exactly the time-major results,
+    transposed -- persistent and launch-per-step kernels, forward and backward, fused bias gradient."""
+    from shufflingvideosfortsg_amd import _lib
+    from shufflingvideosfortsg_amd._lib import ptr
+    B, T, h = shape
+    lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(B * T + h)
+    Gx = (torch.randn(T, B, 2, 4 * h, generator=g) * 0.5).cuda(); W = (torch.randn(2, 4 * h, h, generator=g) / h ** 0.5).cuda()
+    dOut = torch.randn(T, B, 2 * h, generator=g).cuda(); WT = W.transpose(1, 2).contiguous()
+    nb = lib.tsg_lstm_bwd_ws_bytes(B, T, h)
+    res = []
+    for bm in (0, 1):
+        tr = (lambda t: t.transpose(0, 1).contiguous()) if bm else (lambda t: t)
+        gx, do = tr(Gx), tr(dOut)
+        sync = torch.zeros(512, dtype=torch.int32, device="cuda")
+        out = torch.full_like(do, 9.0); R = torch.empty(T, 2, B, h, 4, device="cuda"); Cs = torch.empty(T, 2, B, h, device="cuda")
+        assert lib.tsg_lstm_fwd_bias(ptr(gx), None, ptr(W), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, dt, bm, st) == 0
+        dG = torch.full_like(gx, 5.0); dC = torch.zeros(2, B, h, device="cuda")
+        ws = torch.empty(nb // 4 + 4, device="cuda") if nb > 0 else None
+        fused = ws is not None and lib.tsg_lstm_bwd_ws_persistent(B, T, h, nb) == 1
+        db = torch.zeros(8 * h, device="cuda")
+        assert lib.tsg_lstm_bwd_ws_layout(ptr(WT), ptr(R), ptr(Cs), ptr(do), None, ptr(dG), ptr(dC), ptr(ws) if ws is not None else None, nb,
+                                          ptr(db) if fused else None, B, T, h, dt, bm, st) == 0
+        torch.cuda.synchronize()
+        assert int(sync[0]) == 0
+        res.append((tr(out) if bm else out, tr(dG) if bm else dG, R, Cs))
+    for a, b in zip(*res):
+        assert torch.isfinite(a).all()
+        torch.testing.assert_close(a, b, atol=0, rtol=0)

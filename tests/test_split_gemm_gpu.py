@@ -63,7 +63,7 @@ def test_lstm_fwd_bias_entry():
             out = torch.empty(T, B, 2 * h, device="cuda"); R = torch.empty(T, 2, B, h, 4, device="cuda"); Cs = torch.empty(T, 2, B, h, device="cuda")
             gin = Gx if fused else Gx + bias.view(1, 1, 2, 4 * h)
             rc = lib.tsg_lstm_fwd_bias(ptr(gin), ptr(bias) if fused else None, ptr(W), ptr(out), ptr(R), ptr(Cs),
-                                       ptr(ws) if ws is not None else None, B, T, h, TSG_F32, st)
+                                       ptr(ws) if ws is not None else None, B, T, h, TSG_F32, 0, st)
             torch.cuda.synchronize()
             assert rc == 0 and (ws is None or int(ws[0]) == 0)
             res.append((out, R, Cs))
@@ -85,3 +85,20 @@ def test_split_bf16x3_transposed():
             assert torch.equal(buf[row0:row0 + cols], ref.t()), (R, C, col0, cols, shift)
             assert (buf[row0 + cols:] == 7.0).all() and (buf[:row0] == 7.0).all()
             buf.fill_(7.0)
+
+
+def test_split_shift_within_sequences():
+    """period > 0: rows are consecutive sequences of `period` steps (batch-major [B*T, C]); a shift never crosses into the
+    neighbouring sequence -- both split kernels, against the shifted copy built per sequence."""
+    torch.manual_seed(8)
+    Bn, T, C = 6, 8, 32
+    x = torch.randn(Bn * T, C, device="cuda")
+    x3 = x.view(Bn, T, C)
+    z = torch.zeros(Bn, 1, C, device="cuda")
+    for shift, ref3 in [(1, torch.cat([z, x3[:, :-1]], 1)), (-1, torch.cat([x3[:, 1:], z], 1))]:
+        ref = TF.split_bf16x3(ref3.reshape(Bn * T, C).contiguous(), 0, True)
+        got = TF.split_bf16x3_rows_shifted(x, 0, C, shift, True, period=T)
+        assert torch.equal(got, ref)
+        buf = torch.empty(C, 3 * Bn * T, device="cuda", dtype=torch.bfloat16)
+        TF.split_bf16x3_t(x, 0, C, shift, True, buf, 0, period=T)
+        assert torch.equal(buf, ref.t())
