@@ -74,4 +74,7 @@ def synthetic_batch(B, T, N, video_dim=1024, word_dim=300, seed=1234, pair=False
                 for k, v in list(out[gt].items()):
                     if isinstance(v, torch.Tensor):
                         out[gt][k] = v.to(device)
+                # the collate's list of [start, end] pairs becomes ONE resident index tensor: the losses gather with it
+                # three times per step, and a list would be a blocking host-to-device copy each time
+                out[gt]["framestps"] = torch.tensor(out[gt]["framestps"], dtype=torch.long).to(device)
     return out
