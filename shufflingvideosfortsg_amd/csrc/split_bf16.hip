@@ -6,6 +6,7 @@
 // The left operand uses the plane pattern (hi, hi, lo), the right operand (hi, lo, hi).
 // HBM-bound elementwise pass: 4 B read + 6 B written per element.
 #include "tsg_common.h"
+#include <cstdlib>
 
 namespace tsg {
 namespace {
@@ -52,53 +53,69 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 
 // Transposing variant: out[c][p*plane + r] (the contraction index r contiguous), for GEMM operands contracted over the
 // ROWS of x -- the library's bf16 GEMM runs the weight-gradient shape [8h x 3TB] x [3TB x (I+2h)] 18 % faster when both
-// operands are K-contiguous (tools/probe_dw_layout.py).  64 x 64 tiles through LDS: float4 loads along the columns,
-// (row, row+1) pairs packed per column on the way in, 32-byte stores along the rows on the way out.
-constexpr int kTS = 68;            // LDS row stride in bf16 elements (34 dwords: conflict-free ds_write_b64 / ds_read_b64)
+// operands are K-contiguous (tools/probe_dw_layout.py).  TR x TC tiles through LDS: float4 loads along the columns,
+// (row, row+1) pairs packed per column on the way in, 32-byte segments along the rows on the way out.
+template <int TR, int TC>
 __global__ __launch_bounds__(256) void split_bf16_t_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
                                                            long rows, int cols, long ld_out, long plane, int right,
-                                                           long ld_in, long row_shift, long period) {
-  __shared__ __align__(8) unsigned short Th[64 * kTS], Tl[64 * kTS];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const long r0 = 64L * blockIdx.x;
-  const int c0 = 64 * blockIdx.y;
-  unsigned hi[4][4], lo[4][4];                                   // [row i of the thread's 4][column k of its 4]
+                                                           long ld_in, long row_shift, long period, int swap) {
+  constexpr int LS = TR + 4;                 // LDS row stride in bf16 elements: (TR+4)/2 dwords = 2 mod 32 -> conflict-free b64
+  constexpr int TPR = TC / 4;                // threads along a tile row (float4 each)
+  constexpr int RPP = 4 * (256 / TPR);       // rows per load pass (4 consecutive rows per thread)
+  static_assert(TR % RPP == 0 && (TC * TR / 16) % 256 == 0, "tile shape");
+  __shared__ __align__(8) unsigned short Th[TC * LS], Tl[TC * LS];
+  const int tid = threadIdx.x, tx = tid % TPR, ty = tid / TPR;
+  // blockIdx.x runs along the COLUMNS: workgroups in flight together then read whole contiguous rows; with x along the rows
+  // they all read the same 256-byte column window at a power-of-two row stride, i.e. the same memory channels
+  const long r0 = (long)TR * (swap ? blockIdx.x : blockIdx.y);
+  const int c0 = TC * (swap ? blockIdx.y : blockIdx.x);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long r = r0 + 4 * ty + i, rs = r - row_shift;
-    const int c = c0 + 4 * tx;
-    const float4 v = (r < rows && c < cols && shift_ok(r, row_shift, rows, period)) ? *reinterpret_cast<const float4*>(x + rs * ld_in + c)
-                                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float e[4] = {v.x, v.y, v.z, v.w};
+  for (int pass = 0; pass < TR / RPP; ++pass) {
+    unsigned hi[4][4], lo[4][4];                                 // [row i of the thread's 4][column k of its 4]
+    const int rl = pass * RPP + 4 * ty;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long r = r0 + rl + i;
+      const int c = c0 + 4 * tx;
+      const float4 v = (r < rows && c < cols && shift_ok(r, row_shift, rows, period))
+                           ? *reinterpret_cast<const float4*>(x + (r - row_shift) * ld_in + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[i][k] = bf16_rne(e[k]);
+        const float rem = e[k] - __uint_as_float(hi[i][k] << 16);
+        lo[i][k] = (hi[i][k] & 0x7f80u) == 0x7f80u ? 0u : bf16_rne(rem);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      hi[i][k] = bf16_rne(e[k]);
-      const float rem = e[k] - __uint_as_float(hi[i][k] << 16);
-      lo[i][k] = (hi[i][k] & 0x7f80u) == 0x7f80u ? 0u : bf16_rne(rem);
+      *reinterpret_cast<uint2*>(Th + (4 * tx + k) * LS + rl) = make_uint2(hi[0][k] | (hi[1][k] << 16), hi[2][k] | (hi[3][k] << 16));
+      *reinterpret_cast<uint2*>(Tl + (4 * tx + k) * LS + rl) = make_uint2(lo[0][k] | (lo[1][k] << 16), lo[2][k] | (lo[3][k] << 16));
     }
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    *reinterpret_cast<uint2*>(Th + (4 * tx + k) * kTS + 4 * ty) = make_uint2(hi[0][k] | (hi[1][k] << 16), hi[2][k] | (hi[3][k] << 16));
-    *reinterpret_cast<uint2*>(Tl + (4 * tx + k) * kTS + 4 * ty) = make_uint2(lo[0][k] | (lo[1][k] << 16), lo[2][k] | (lo[3][k] << 16));
   }
   __syncthreads();
-  const int cl = tid >> 2, seg = tid & 3;                        // output row (= input column) and its 16-element segment
-  const int c = c0 + cl;
-  const long r = r0 + 16 * seg;
-  if (c < cols && r < rows) {                                    // rows % 16 == 0 (checked on the host): whole segments
-    uint2 H[4], L[4];
+  constexpr int SPR = TR / 16;                                   // 16-element segments per output row
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      H[j] = *reinterpret_cast<const uint2*>(Th + cl * kTS + 16 * seg + 4 * j);
-      L[j] = *reinterpret_cast<const uint2*>(Tl + cl * kTS + 16 * seg + 4 * j);
-    }
-    unsigned short* o = out + (long)c * ld_out + r;
+  for (int q = 0; q < TC * SPR / 256; ++q) {
+    const int sidx = q * 256 + tid, cl = sidx / SPR, seg = sidx % SPR;     // output row (= input column) and its segment
+    const int c = c0 + cl;
+    const long r = r0 + 16 * seg;
+    if (c < cols && r < rows) {                                  // rows % 16 == 0 (checked on the host): whole segments
+      uint2 H[4], L[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<uint2*>(o + 4 * j) = H[j];
-      *reinterpret_cast<uint2*>(o + plane + 4 * j) = right ? L[j] : H[j];
-      *reinterpret_cast<uint2*>(o + 2 * plane + 4 * j) = right ? H[j] : L[j];
+      for (int j = 0; j < 4; ++j) {
+        H[j] = *reinterpret_cast<const uint2*>(Th + cl * LS + 16 * seg + 4 * j);
+        L[j] = *reinterpret_cast<const uint2*>(Tl + cl * LS + 16 * seg + 4 * j);
+      }
+      unsigned short* o = out + (long)c * ld_out + r;             // 16-byte aligned (host check)
+      const uint4 H0 = make_uint4(H[0].x, H[0].y, H[1].x, H[1].y), H1 = make_uint4(H[2].x, H[2].y, H[3].x, H[3].y);
+      const uint4 L0 = make_uint4(L[0].x, L[0].y, L[1].x, L[1].y), L1 = make_uint4(L[2].x, L[2].y, L[3].x, L[3].y);
+      *reinterpret_cast<uint4*>(o) = H0;
+      *reinterpret_cast<uint4*>(o + 8) = H1;
+      *reinterpret_cast<uint4*>(o + plane) = right ? L0 : H0;
+      *reinterpret_cast<uint4*>(o + plane + 8) = right ? L1 : H1;
+      *reinterpret_cast<uint4*>(o + 2 * plane) = right ? H0 : L0;
+      *reinterpret_cast<uint4*>(o + 2 * plane + 8) = right ? H1 : L1;
     }
   }
 }
@@ -135,17 +152,24 @@ extern "C" int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_
   using namespace tsg;
   const char* fn = "tsg_split_bf16x3_t";
   if (!x || !out) return set_error(TSG_E_NULL, "%s: null pointer", fn);
-  if (rows < 0 || cols < 0 || (cols & 3) || (rows & 15) || (ld_out & 3) || (plane_stride & 3) || (ld_in & 3) || ld_in < cols)
-    return set_error(TSG_E_SHAPE, "%s: rows=%lld cols=%lld ld_in=%lld ld_out=%lld plane=%lld (rows %% 16, cols / ld_in / ld_out / plane %% 4, ld_in >= cols)",
+  if (rows < 0 || cols < 0 || (cols & 3) || (rows & 15) || (ld_out & 7) || (plane_stride & 7) || (ld_in & 3) || ld_in < cols)
+    return set_error(TSG_E_SHAPE, "%s: rows=%lld cols=%lld ld_in=%lld ld_out=%lld plane=%lld (rows %% 16, cols / ld_in %% 4, ld_out / plane %% 8, ld_in >= cols)",
                      fn, rows, cols, ld_in, ld_out, plane_stride);
-  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 7))
-    return set_error(TSG_E_ALIGN, "%s: x must be 16-byte and out 8-byte aligned", fn);
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+    return set_error(TSG_E_ALIGN, "%s: x and out must be 16-byte aligned", fn);
   if (rows == 0 || cols == 0) return 0;
-  const dim3 grid(static_cast<unsigned>((rows + 63) / 64), static_cast<unsigned>((cols + 63) / 64));
-  if (grid.y > 65535u) return set_error(TSG_E_SHAPE, "%s: cols=%lld too large", fn, cols);
-  hipLaunchKernelGGL(split_bf16_t_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+  static int tile = -1;                                            // TSG_SPLIT_T_TILE: 0 = 64x64, 1 = 64 rows x 128 cols, 2 = 128 x 64
+  if (tile < 0) { const char* e = getenv("TSG_SPLIT_T_TILE"); tile = e ? atoi(e) : 0; }
+  const int TR = tile == 3 ? 256 : tile == 2 ? 128 : 64, TC = tile == 3 ? 32 : tile == 1 ? 128 : 64;
+  static int swap = -1;
+  if (swap < 0) { const char* e = getenv("TSG_SPLIT_T_ROWMAJOR_GRID"); swap = e ? atoi(e) : 0; }
+  const unsigned gr = static_cast<unsigned>((rows + TR - 1) / TR), gc = static_cast<unsigned>((cols + TC - 1) / TC);
+  const dim3 grid(swap ? gr : gc, swap ? gc : gr);
+  if (grid.y > 65535u) return set_error(TSG_E_SHAPE, "%s: rows=%lld cols=%lld too large", fn, rows, cols);
+  auto kern = tile == 3 ? split_bf16_t_kernel<256, 32> : tile == 2 ? split_bf16_t_kernel<128, 64> : tile == 1 ? split_bf16_t_kernel<64, 128> : split_bf16_t_kernel<64, 64>;
+  hipLaunchKernelGGL(kern, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const float*>(x), static_cast<unsigned short*>(out), static_cast<long>(rows), static_cast<int>(cols),
                      static_cast<long>(ld_out), static_cast<long>(plane_stride), right_operand, static_cast<long>(ld_in),
-                     static_cast<long>(row_shift), static_cast<long>(period));
+                     static_cast<long>(row_shift), static_cast<long>(period), swap);
   return check_launch(fn);
 }
