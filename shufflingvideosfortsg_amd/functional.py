@@ -315,6 +315,7 @@ class _MHA(torch.autograd.Function):
         ctx.save_for_backward(Q, K, V, O, lse)
         ctx.cfg = (int(n_heads), float(scale), int(bool(causal)))
         ctx.drop = (float(p_drop), int(seed), int(offset))          # the backward regenerates the same mask
+        ctx.set_materialize_grads(False)                            # no zero tensors for the non-differentiable maps' grads
         if want_maps:
             ctx.mark_non_differentiable(A, S)
             return O, A, S
@@ -326,7 +327,7 @@ class _MHA(torch.autograd.Function):
         Q, K, V, O, lse = ctx.saved_tensors
         n_heads, scale, causal = ctx.cfg
         p_drop, seed, offset = ctx.drop
-        dO = _f32c(dO)
+        dO = _f32c(dO) if dO is not None else torch.zeros_like(O)
         B, Tq, dk = Q.shape
         _, Tk, dv = V.shape
         dQ = torch.empty_like(Q); dK = torch.empty_like(K); dV = torch.empty_like(V)
@@ -464,6 +465,7 @@ class _BiLSTMLayer(torch.autograd.Function):
         ctx.bm = bool(bm)
         ctx.save_for_backward(x, W_ih, W_hh, out, R, Cs)
         ctx.mark_non_differentiable(Cs)
+        ctx.set_materialize_grads(False)            # autograd would otherwise zero-fill a Cs-sized gradient every backward
         return out, Cs
 
     @staticmethod
@@ -474,7 +476,7 @@ class _BiLSTMLayer(torch.autograd.Function):
         (B, T, I) = x.shape if bm else (x.shape[1], x.shape[0], x.shape[2])
         h = W_hh.shape[2]
         TB = T * B
-        dOut = _f32c(dOut)
+        dOut = _f32c(dOut) if dOut is not None else torch.zeros_like(out)
         WhhT = W_hh.transpose(1, 2).contiguous()
         dG = torch.empty((B, T, 2, 4 * h) if bm else (T, B, 2, 4 * h), device=x.device, dtype=torch.float32)
         dC = torch.empty(2, B, h, device=x.device, dtype=torch.float32)

@@ -24,8 +24,19 @@ class MomentPooling(nn.Module):
     def average_mask(self, feat, mask):
         return torch.sum(mask_logits(feat, mask, mask_value=0.0), dim=1) / (torch.sum(mask, dim=1, keepdim=True) + 1e-6)
 
+    def average_masks(self, feat, masks):
+        """The masked means of ``average_mask`` for several masks at once: mask_logits(feat, m, 0) summed over time is the
+        batched product m^T feat, so the three ranges are ONE [B,3,T] x [B,T,D] bmm that reads feat once (and one bmm back),
+        instead of four [B,T,D] elementwise passes and a reduction per range."""
+        M = torch.stack([m.type_as(feat) for m in masks], 1)                       # [B,K,T]
+        return torch.bmm(M, feat) / (M.sum(2, keepdim=True) + 1e-6)               # [B,K,D]
+
     def forward(self, feat, target_mask, fore_mask, back_mask):
-        tgt = self.average_mask(feat, target_mask)
-        fore = self.foreback_context(torch.cat((self.average_mask(feat, fore_mask), tgt), -1))
-        back = self.foreback_context(torch.cat((tgt, self.average_mask(feat, back_mask)), -1))
+        if feat.dim() == 3 and target_mask.dim() == 2:
+            pooled = self.average_masks(feat, (target_mask, fore_mask, back_mask))
+            tgt, fore_avg, back_avg = pooled[:, 0], pooled[:, 1], pooled[:, 2]
+        else:
+            tgt, fore_avg, back_avg = (self.average_mask(feat, m) for m in (target_mask, fore_mask, back_mask))
+        fore = self.foreback_context(torch.cat((fore_avg, tgt), -1))
+        back = self.foreback_context(torch.cat((tgt, back_avg), -1))
         return self.fc_classifier_domain_video(self.dropout(torch.cat((tgt, fore, back), -1)))
