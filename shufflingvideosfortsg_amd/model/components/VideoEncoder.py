@@ -54,7 +54,8 @@ class rnn_recalibration_layer(nn.Module):
             # fused tail: sent_linear(P @ words) = P @ (words W_l^T) + b_l, so the Linear runs on the N word rows
             # instead of the T clip rows and bias / sigmoid / gate are the attention kernel's epilogue
             VW = F.linear(word_feat, self.sent_linear.weight)
-            return TF.scdm_gate(TF.linear(rnn_output, att.W_a.weight, att.W_a.bias), att.W_s(word_feat), att.w.weight, VW, self.sent_linear.bias, rnn_output)
+            a, s = att.projections(rnn_output, word_feat)
+            return TF.scdm_gate(a, s, att.w.weight, VW, self.sent_linear.bias, rnn_output)
         C = self.attention(rnn_output, word_feat)
         channel_attn = self.sent_linear(C)
         if self.ca_activ in ['sigmoid']:

@@ -109,6 +109,14 @@ class SCDM_Attention(nn.Module):
         self.w = nn.Linear(hidden_dim, 1, bias=False)
 
     def forward(self, video_feat, sent_feat):
-        a = TF.linear(video_feat, self.W_a.weight, self.W_a.bias)
-        s = self.W_s(sent_feat)
+        a, s = self.projections(video_feat, sent_feat)
         return TF.scdm_attn(a, s, self.w.weight, sent_feat)
+
+    def projections(self, video_feat, sent_feat):
+        """(W_a v, W_s s + b): the bias of W_a rides on the N word rows instead of the T clip rows -- tanh(W_s s_n + W_a v_t + b)
+        is the same sum, and the [B,T,H] bias pass (and its [B*T,H] -> [H] gradient reduction) becomes a [B,N,H] one."""
+        a = TF.linear(video_feat, self.W_a.weight, None)
+        s = self.W_s(sent_feat)
+        if self.W_a.bias is not None:
+            s = s + self.W_a.bias
+        return a, s
