@@ -93,4 +93,6 @@ class VideoTextSemanticMatch(nn.Module):
         lin1, act, lin2 = self.predict.predict[0], self.predict.predict[1], self.predict.predict[2]
         Dv = video_feat.size(-1)
         hid = TF.linear(video_feat, lin1.weight[:, :Dv]) + F.linear(query_feat, lin1.weight[:, Dv:], lin1.bias).unsqueeze(1)
+        # (measured and dropped: the 1-output Linear as torch.matmul(hid, w) -- its mv / ger backward is slower than the two
+        # degenerate GEMMs: 17.24 vs 17.04 ms per step)
         return lin2(act(hid)).squeeze(dim=2), None

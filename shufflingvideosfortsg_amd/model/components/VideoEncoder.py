@@ -53,7 +53,7 @@ class rnn_recalibration_layer(nn.Module):
         if self.ca_activ in ['sigmoid'] and type(att) is SCDM_Attention and word_feat.size(-1) == self.sent_linear.in_features:
             # fused tail: sent_linear(P @ words) = P @ (words W_l^T) + b_l, so the Linear runs on the N word rows
             # instead of the T clip rows and bias / sigmoid / gate are the attention kernel's epilogue
-            VW = F.linear(word_feat, self.sent_linear.weight)
+            VW = TF.linear(word_feat, self.sent_linear.weight)
             a, s = att.projections(rnn_output, word_feat)
             return TF.scdm_gate(a, s, att.w.weight, VW, self.sent_linear.bias, rnn_output)
         C = self.attention(rnn_output, word_feat)

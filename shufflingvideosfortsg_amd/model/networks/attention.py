@@ -116,7 +116,7 @@ class SCDM_Attention(nn.Module):
         """(W_a v, W_s s + b): the bias of W_a rides on the N word rows instead of the T clip rows -- tanh(W_s s_n + W_a v_t + b)
         is the same sum, and the [B,T,H] bias pass (and its [B*T,H] -> [H] gradient reduction) becomes a [B,N,H] one."""
         a = TF.linear(video_feat, self.W_a.weight, None)
-        s = self.W_s(sent_feat)
+        s = TF.linear(sent_feat, self.W_s.weight, None)
         if self.W_a.bias is not None:
             s = s + self.W_a.bias
         return a, s
