@@ -499,28 +499,27 @@ class _BiLSTMLayer(torch.autograd.Function):
             dW_ih = _mm(dGf.t(), x2)
             dW_hh = torch.zeros_like(W_hh)
         elif fast:
-            # ONE GEMM: the right operand is [x | h_{t-1} forward | h_{t+1} reverse] side by side, so that
-            # D = dG^T [x | hf | hr] holds dW_ih and both dW_hh blocks (the two cross-direction blocks are computed and
-            # dropped: 1/3 more flops, but one [8h x (I+2h)] GEMM that fills the chip instead of a [8h x I] one plus two
-            # [4h x h] ones whose 80 output tiles left two thirds of it idle: 0.6 vs 1.1 ms per video layer); both
-            # operands are written K-contiguous by the transposing split, the layout the library's bf16 GEMM runs this
-            # shape fastest in; the shifted h rows come straight from `out` (no shifted copies)
+            # ONE batched GEMM over the two directions: D[d] = dG[d]^T [x | h_{t-+1}[d]] holds dW_ih[d] and dW_hh[d].  (Three
+            # separate GEMMs had 199 / 80 / 80 output tiles and ran at 0.8 / 0.33 / 0.33 PFLOP/s, 1.11 ms per video layer;
+            # one [8h x (I+2h)] GEMM that also computes the two cross-direction blocks: 0.59 ms; the 2-batch bmm without
+            # them: 0.43 ms.)  Both operands are written K-contiguous by the transposing split, the layout the library's
+            # bf16 GEMM runs this shape fastest in; the shifted h rows come straight from `out` (no shifted copies).
             At = torch.empty(8 * h, 3 * TB, device=x.device, dtype=torch.bfloat16)
-            Bt = torch.empty(I + 2 * h, 3 * TB, device=x.device, dtype=torch.bfloat16)
+            Bt = torch.empty(2 * (I + h), 3 * TB, device=x.device, dtype=torch.bfloat16)     # [2][I + h][3TB]
             split_bf16x3_t(dGf, 0, 8 * h, 0, False, At)
             if ctx.needs_input_grad[0]:
                 # dX = dG W_ih from the SAME planes: At viewed as [(gate column, plane), T*B] is the transposed left operand
                 # with the contraction ordered (column, plane); W_ih's (hi, lo, hi) planes in that order, K-contiguous, are a
-                # 24 MB permute of its split.  No second pass over dG (110 us per layer), and the library runs this layout
-                # 5 % faster than the row-major one (tools/probe_dw_layout.py 16384 1024 12288: 396 vs 417 us)
+                # 24 MB permute of its split.  No second pass over dG (110 us per layer).
                 Wt = split_bf16x3(W_ih, 1, True).view(8 * h, 3, I).permute(2, 0, 1).reshape(I, 24 * h)
                 dx = torch.mm(At.view(24 * h, TB).t(), Wt.t(), out_dtype=torch.float32).view(x.shape)
             split_bf16x3_t(x2, 0, I, 0, True, Bt, 0)
+            Bt[I + h:2 * I + h].copy_(Bt[:I])                                # x planes for the reverse direction's batch
             split_bf16x3_t(o2, 0, h, shift, True, Bt, I, period)             # h_{t-1}, forward direction
-            split_bf16x3_t(o2, h, h, -shift, True, Bt, I + h, period)        # h_{t+1}, reverse direction
-            D = torch.mm(At, Bt.t(), out_dtype=torch.float32)
-            dW_ih = D[:, :I]
-            dW_hh = torch.stack([D[:4 * h, I:I + h], D[4 * h:, I + h:]])
+            split_bf16x3_t(o2, h, h, -shift, True, Bt, 2 * I + h, period)    # h_{t+1}, reverse direction
+            D = torch.bmm(At.view(2, 4 * h, 3 * TB), Bt.view(2, I + h, 3 * TB).transpose(1, 2), out_dtype=torch.float32)
+            dW_ih = D[:, :, :I].reshape(8 * h, I)
+            dW_hh = D[:, :, I:]
         else:
             # the step whose partner is the zero state drops out, so both operands are plain strided VIEWS
             dW_ih = _mm(dGf.t(), x2)
