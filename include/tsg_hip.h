@@ -183,9 +183,11 @@ int tsg_split_bf16x3(const void* x, void* out, long long rows, long long cols, l
 int tsg_split_bf16x3_shift(const void* x, long long ld_in, long long row_shift, long long period, void* out, long long rows,
                            long long cols, long long ld_out, long long plane_stride, int right_operand, void* stream);
 /* Transposing variant for operands contracted over the ROWS of x: out[c*ld_out + p*plane_stride + r] (r contiguous), same
- * planes, shift and zero fill.  rows % 16 == 0.                                                                      */
+ * planes, shift and zero fill.  rows % 16 == 0.  dup_offset != 0: a second copy of the output is written dup_offset
+ * elements after the first (the x planes of the weight-gradient bmm appear in both directions' batches).              */
 int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_shift, long long period, void* out, long long rows,
-                       long long cols, long long ld_out, long long plane_stride, int right_operand, void* stream);
+                       long long cols, long long ld_out, long long plane_stride, int right_operand, long long dup_offset,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -36,7 +36,7 @@ _SIGNATURES = {
     "tsg_linear_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "tsg_split_bf16x3": [_P, _P, c_longlong, c_longlong, c_longlong, c_longlong, _I, _P],
     "tsg_split_bf16x3_shift": [_P, c_longlong, c_longlong, c_longlong, _P, c_longlong, c_longlong, c_longlong, c_longlong, _I, _P],
-    "tsg_split_bf16x3_t": [_P, c_longlong, c_longlong, c_longlong, _P, c_longlong, c_longlong, c_longlong, c_longlong, _I, _P],
+    "tsg_split_bf16x3_t": [_P, c_longlong, c_longlong, c_longlong, _P, c_longlong, c_longlong, c_longlong, c_longlong, _I, c_longlong, _P],
     "tsg_mha_bwd": [_P] * 10 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
 }
 _RESTYPE = {"tsg_last_error": c_char_p, "tsg_lstm_bwd_ws_bytes": c_longlong}

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 template <int TR, int TC>
 __global__ __launch_bounds__(256) void split_bf16_t_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
                                                            long rows, int cols, long ld_out, long plane, int right,
-                                                           long ld_in, long row_shift, long period, int swap) {
+                                                           long ld_in, long row_shift, long period, int swap, long dup) {
   constexpr int LS = TR + 4;                 // LDS row stride in bf16 elements: (TR+4)/2 dwords = 2 mod 32 -> conflict-free b64
   constexpr int TPR = TC / 4;                // threads along a tile row (float4 each)
   constexpr int RPP = 4 * (256 / TPR);       // rows per load pass (4 consecutive rows per thread)
@@ -116,6 +116,15 @@ __global__ __launch_bounds__(256) void split_bf16_t_kernel(const float* __restri
       *reinterpret_cast<uint4*>(o + plane + 8) = right ? L1 : H1;
       *reinterpret_cast<uint4*>(o + 2 * plane) = right ? H0 : L0;
       *reinterpret_cast<uint4*>(o + 2 * plane + 8) = right ? H1 : L1;
+      if (dup) {                                                 // second copy of the same planes, `dup` elements further on
+        unsigned short* o2 = o + dup;
+        *reinterpret_cast<uint4*>(o2) = H0;
+        *reinterpret_cast<uint4*>(o2 + 8) = H1;
+        *reinterpret_cast<uint4*>(o2 + plane) = right ? L0 : H0;
+        *reinterpret_cast<uint4*>(o2 + plane + 8) = right ? L1 : H1;
+        *reinterpret_cast<uint4*>(o2 + 2 * plane) = right ? H0 : L0;
+        *reinterpret_cast<uint4*>(o2 + 2 * plane + 8) = right ? H1 : L1;
+      }
     }
   }
 }
@@ -148,15 +157,16 @@ extern "C" int tsg_split_bf16x3(const void* x, void* out, long long rows, long l
 }
 
 extern "C" int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_shift, long long period, void* out, long long rows,
-                                  long long cols, long long ld_out, long long plane_stride, int right_operand, void* stream) {
+                                  long long cols, long long ld_out, long long plane_stride, int right_operand, long long dup_offset,
+                                  void* stream) {
   using namespace tsg;
   const char* fn = "tsg_split_bf16x3_t";
   if (!x || !out) return set_error(TSG_E_NULL, "%s: null pointer", fn);
   if (rows < 0 || cols < 0 || (cols & 3) || (rows & 15) || (ld_out & 7) || (plane_stride & 7) || (ld_in & 3) || ld_in < cols)
     return set_error(TSG_E_SHAPE, "%s: rows=%lld cols=%lld ld_in=%lld ld_out=%lld plane=%lld (rows %% 16, cols / ld_in %% 4, ld_out / plane %% 8, ld_in >= cols)",
                      fn, rows, cols, ld_in, ld_out, plane_stride);
-  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
-    return set_error(TSG_E_ALIGN, "%s: x and out must be 16-byte aligned", fn);
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) || (dup_offset & 7))
+    return set_error(TSG_E_ALIGN, "%s: x and out must be 16-byte aligned, dup_offset a multiple of 8", fn);
   if (rows == 0 || cols == 0) return 0;
   static int tile = -1;                                            // TSG_SPLIT_T_TILE: 0 = 64x64, 1 = 64 rows x 128 cols, 2 = 128 x 64
   if (tile < 0) { const char* e = getenv("TSG_SPLIT_T_TILE"); tile = e ? atoi(e) : 0; }
@@ -170,6 +180,6 @@ extern "C" int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_
   hipLaunchKernelGGL(kern, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const float*>(x), static_cast<unsigned short*>(out), static_cast<long>(rows), static_cast<int>(cols),
                      static_cast<long>(ld_out), static_cast<long>(plane_stride), right_operand, static_cast<long>(ld_in),
-                     static_cast<long>(row_shift), static_cast<long>(period), swap);
+                     static_cast<long>(row_shift), static_cast<long>(period), swap, static_cast<long>(dup_offset));
   return check_launch(fn);
 }

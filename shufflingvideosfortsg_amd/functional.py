@@ -6,6 +6,7 @@ kernels run on torch's current stream.
 """
 from __future__ import annotations
 
+import os
 import torch
 
 from . import _lib
@@ -111,7 +112,7 @@ def split_bf16x3_rows_shifted(x: torch.Tensor, col0: int, cols: int, row_shift: 
 
 
 def split_bf16x3_t(x: torch.Tensor, col0: int, cols: int, row_shift: int, right: bool, out: torch.Tensor, out_row0: int = 0,
-                   period: int = 0):
+                   period: int = 0, dup_row0: int = None):
     """Transposing split (tsg_split_bf16x3_t): columns [col0, col0+cols) of fp32 contiguous x [R,C], rows shifted by
     ``row_shift`` (within sequences of ``period`` rows when period > 0) -> rows [out_row0, out_row0+cols) of the bf16 buffer ``out`` [W, 3R] whose row c holds the three planes
     of input column c one after the other (contraction index contiguous)."""
@@ -120,7 +121,11 @@ def split_bf16x3_t(x: torch.Tensor, col0: int, cols: int, row_shift: int, right:
     R, C = x.shape
     if out.dim() != 2 or out.shape[1] != 3 * R or not out.is_contiguous() or out.dtype != torch.bfloat16 or out_row0 + cols > out.shape[0]:
         raise ValueError("split_bf16x3_t: bad output buffer")
-    _call("tsg_split_bf16x3_t", x, x.data_ptr() + 4 * col0, C, row_shift, period, out.data_ptr() + 2 * out_row0 * 3 * R, R, cols, 3 * R, R, int(right))
+    if dup_row0 is not None and (dup_row0 + cols > out.shape[0] or abs(dup_row0 - out_row0) < cols):
+        raise ValueError("split_bf16x3_t: bad duplicate destination")
+    dup = 0 if dup_row0 is None else (dup_row0 - out_row0) * 3 * R                 # second copy at rows [dup_row0, dup_row0+cols)
+    _call("tsg_split_bf16x3_t", x, x.data_ptr() + 4 * col0, C, row_shift, period, out.data_ptr() + 2 * out_row0 * 3 * R, R, cols, 3 * R, R,
+          int(right), dup)
     return out
 
 
@@ -513,8 +518,7 @@ class _BiLSTMLayer(torch.autograd.Function):
                 # 24 MB permute of its split.  No second pass over dG (110 us per layer).
                 Wt = split_bf16x3(W_ih, 1, True).view(8 * h, 3, I).permute(2, 0, 1).reshape(I, 24 * h)
                 dx = torch.mm(At.view(24 * h, TB).t(), Wt.t(), out_dtype=torch.float32).view(x.shape)
-            split_bf16x3_t(x2, 0, I, 0, True, Bt, 0)
-            Bt[I + h:2 * I + h].copy_(Bt[:I])                                # x planes for the reverse direction's batch
+            split_bf16x3_t(x2, 0, I, 0, True, Bt, 0, dup_row0=I + h)         # x planes, in both directions' batches
             split_bf16x3_t(o2, 0, h, shift, True, Bt, I, period)             # h_{t-1}, forward direction
             split_bf16x3_t(o2, h, h, -shift, True, Bt, 2 * I + h, period)    # h_{t+1}, reverse direction
             D = torch.bmm(At.view(2, 4 * h, 3 * TB), Bt.view(2, I + h, 3 * TB).transpose(1, 2), out_dtype=torch.float32)

@@ -85,6 +85,9 @@ def test_split_bf16x3_transposed():
             assert torch.equal(buf[row0:row0 + cols], ref.t()), (R, C, col0, cols, shift)
             assert (buf[row0 + cols:] == 7.0).all() and (buf[:row0] == 7.0).all()
             buf.fill_(7.0)
+        TF.split_bf16x3_t(x, 0, C // 2, 0, True, buf, 0, dup_row0=C // 2 + 4)          # duplicate destination
+        ref = TF.split_bf16x3_rows_shifted(x, 0, C // 2, 0, True).t()
+        assert torch.equal(buf[:C // 2], ref) and torch.equal(buf[C // 2 + 4:C + 4], ref) and (buf[C // 2:C // 2 + 4] == 7.0).all()
 
 
 def test_split_shift_within_sequences():
