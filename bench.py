@@ -257,6 +257,7 @@ def main():
         dt = float(t.item())
     if not torch.isfinite(loss):
         raise SystemExit("non-finite loss in the timed region")
+    functional.check_lstm_errors()                        # a persistent LSTM launch whose bounded wait expired -> invalid run
 
     # side measurements, outside the timed region above and never `value`: the same K steps in the other library-GEMM
     # modes (strict fp32 library GEMMs, and the bf16 operands that BASELINE config 2 names)

@@ -137,6 +137,12 @@ int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, 
 int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                       int B, int T, int h, int dtype, int batch_major, void* stream);
 
+/* Error sink of the persistent kernels: an int in memory the host can read without synchronising (pinned / host-mapped, or
+ * device memory), set to 1 by any persistent launch whose bounded wait expired (its results are then invalid; word 0 of
+ * that launch's sync workspace is set as well).  NULL (default) disables it.  The Python host registers a pinned word and
+ * checks it on every LSTM call, so a failed launch raises at the next call instead of passing silently.               */
+int tsg_lstm_error_sink(void* flag);
+
 /* backward of the recurrence: dOut [T,B,2h] (+ optional dHn [2,B,h] added at each direction's last step)
  * -> dG [T,B,2,4h] = dL/d(pre-activation gates); the caller derives dX, dW_ih, dW_hh, db from it with
  * GEMMs.  WhhT [2,h,4h] is W_hh transposed per direction; dC_ws is a [2,B,h] float workspace (the cell-gradient carry

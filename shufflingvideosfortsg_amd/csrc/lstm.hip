@@ -403,9 +403,16 @@ __device__ __forceinline__ unsigned xcc_id() {
 constexpr int kSyncGroupWord = 16;               // sync[16 + group] = XCD mask of exchange group (direction, batch slice)
 constexpr int kSyncBytes = TSG_LSTM_SYNC_BYTES;  // error word, arrival counter, debug / timing words, <= 256 group masks
 static_assert(kSyncBytes >= 4 * (kSyncGroupWord + 256), "group masks fit the sync workspace");
+// A bounded wait expired: raise the launch's error word (what the other workgroups look at) and, when the caller registered
+// one (tsg_lstm_error_sink), the process-wide sink -- host-mapped memory the host can read without synchronising, so a
+// failed launch is reported by the next call instead of silently leaving invalid results.
+__device__ __forceinline__ void raise_error(unsigned* sync, unsigned* esink) {
+  __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (esink) __hip_atomic_store(esink, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // start barrier of the persistent kernels: publish this workgroup's XCD in its group's mask, meet the grid once, and
 // report whether the whole group sits on one XCD.  false + error word set when the bounded wait expires.
-__device__ __forceinline__ bool grid_start(unsigned* sync, int group, int l2x) {
+__device__ __forceinline__ bool grid_start(unsigned* sync, int group, int l2x, unsigned* esink) {
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_or(sync + kSyncGroupWord + group, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" : : "v"(old) : "memory");       // the mask update has been performed before this workgroup counts as arrived
@@ -414,7 +421,7 @@ __device__ __forceinline__ bool grid_start(unsigned* sync, int group, int l2x) {
     while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > kSpinLimit || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-        __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        raise_error(sync, esink);
         break;
       }
     }
@@ -457,7 +464,7 @@ constexpr int kSlabFloats = 2 * 16 * kHLB;       // LDS dwords of the slab regio
 template <int HJ, bool SPLIT>                     // HJ = h / 16 when known at compile time (no branch between MFMAs), else 0;
 __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT: split-precision bf16 MFMA arithmetic (needs HJ > 0, even)
     const float* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh, float* __restrict__ out,
-    float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS, int l2x, int bm) {
+    float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS, int flags, int bm, unsigned* __restrict__ esink) {
   extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice (SPLIT: two bf16 planes
   float* Ht = Hl + kSlabFloats;                          // [16][kHLB] dwords), then Ht [16][33] = this step's h tile (16 rows x
   unsigned* Hhi = reinterpret_cast<unsigned*>(Hl);       // 32 units), gathered for whole-line stores
@@ -515,7 +522,8 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  const bool local = grid_start(sync, group, l2x);
+  if ((flags & 2) && blockIdx.x == 0) return;                // TSG_LSTM_INJECT_TIMEOUT: workgroup 0 never arrives (test of the error path)
+  const bool local = grid_start(sync, group, flags & 1, esink);
   if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
 
 #ifdef TSG_LSTM_TIMING
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
           // the error word (a memory round trip) is looked at on every 32nd retry only; a wave that gives up also raises the
           // workgroup's LDS flag, which is what the other waves check after the barrier below
           if ((++spins & 31) == 0 && (spins > (kSpinLimit >> 6) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-            __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            raise_error(sync, esink);
             *fail = 1u;
             break;
           }
@@ -719,7 +727,7 @@ template <int TW, bool SPLIT>                     // TW = 16-unit tiles per wave
 __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPLIT: split-precision bf16 MFMA arithmetic
     const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
     const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG,
-    float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int T, int h, int l2x, int bm) {
+    float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int T, int h, int flags, int bm, unsigned* __restrict__ esink) {
   extern __shared__ __align__(16) float smem2[];
   float* Dl = smem2;                              // [16][kDLS]  this workgroup's dG tile, local column g*32 + ul
   unsigned* Dhi = reinterpret_cast<unsigned*>(Dl);          // (SPLIT: the same tile as two bf16 planes [16][kDLB] dwords)
@@ -774,7 +782,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  const bool local = grid_start(sync, group, l2x);
+  if ((flags & 2) && blockIdx.x == 0) return;                // TSG_LSTM_INJECT_TIMEOUT: workgroup 0 never arrives (test of the error path)
+  const bool local = grid_start(sync, group, flags & 1, esink);
   if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
 
 #ifdef TSG_LSTM_TIMING
@@ -822,7 +831,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
         raw &= pending;
         if (!raw) break;
         if ((++spins & 31) == 0 && (spins > (kSpinLimit >> 6) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-          __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          raise_error(sync, esink);
           *fail = 1u;                                        // (error word read on every 32nd retry only, see the forward kernel)
           break;
         }
@@ -958,6 +967,12 @@ static int l2_exchange() {        // TSG_LSTM_L2X=0: always write-through exchan
   if (v < 0) { const char* e = getenv("TSG_LSTM_L2X"); v = e ? (atoi(e) != 0) : 1; }
   return v;
 }
+static unsigned* g_error_sink = nullptr;
+extern "C" int tsg_lstm_error_sink(void* p) { g_error_sink = static_cast<unsigned*>(p); return 0; }
+static int launch_flags() {       // bit 0: L2-local exchange allowed; bit 1: inject a start-barrier timeout (tests)
+  const char* e = getenv("TSG_LSTM_INJECT_TIMEOUT");
+  return (l2_exchange() ? 1 : 0) | ((e && atoi(e) != 0) ? 2 : 0);
+}
 static bool persist_wanted(int T) { const int m = persist_mode(); return m > 0 || (m < 0 && T >= 8); }
 
 extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
@@ -1002,7 +1017,7 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
       hipError_t e = hipMemsetAsync(sync_ws, 0, kSyncBytes, st);
       if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
       hipLaunchKernelGGL(pk, dim3(grid), dim3(kThreads), plds, st, (const float*)Gx, (const float*)bias, (const float*)Whh, (float*)out,
-                         (float*)R, (float*)Cs, (unsigned*)sync_ws, B, T, h, HLS, l2_exchange(), bm);
+                         (float*)R, (float*)Cs, (unsigned*)sync_ws, B, T, h, HLS, launch_flags(), bm, g_error_sink);
       return check_launch(fn);
     }
   }
@@ -1103,7 +1118,7 @@ extern "C" int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const voi
             : (split ? lstm_bwd_persist2_kernel<1, true> : lstm_bwd_persist2_kernel<1, false>);
     hipLaunchKernelGGL(pk, dim3(pgrid), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT, (const float*)R,
                        (const float*)Cs, (const float*)dOut, (const float*)dHn, (float*)dG, (float*)((char*)ws + kSyncBytes),
-                       (unsigned*)ws, (float*)dbias, B, T, h, l2_exchange(), bm);
+                       (unsigned*)ws, (float*)dbias, B, T, h, launch_flags(), bm, g_error_sink);
     return check_launch(fn);
   }
   (void)need;

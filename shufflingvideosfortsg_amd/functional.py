@@ -45,6 +45,27 @@ class _KernelTimer:
 kernel_timer = _KernelTimer()
 
 
+class LstmWaitExpired(RuntimeError):
+    pass
+
+
+_lstm_sink = None          # pinned host word the persistent LSTM kernels set when a bounded wait expires (tsg_lstm_error_sink)
+
+
+def check_lstm_errors() -> None:
+    """Raise if a persistent LSTM launch reported an expired bounded wait since the last check (its outputs are invalid).
+    Reads a pinned host word -- no synchronisation; called on every LSTM launch, and by bench.py / the tests at the end."""
+    global _lstm_sink
+    if _lstm_sink is None:
+        _lstm_sink = torch.zeros(1, dtype=torch.int32).pin_memory()
+        check(load().tsg_lstm_error_sink(_lstm_sink.data_ptr()), "tsg_lstm_error_sink")
+    elif int(_lstm_sink[0]) != 0:
+        _lstm_sink[0] = 0
+        raise LstmWaitExpired("a persistent LSTM kernel's bounded wait expired (workgroups not co-resident, e.g. the GPU is shared "
+                              "with another process?): the recurrence outputs of that launch are invalid.  TSG_LSTM_PERSIST=0 "
+                              "selects the launch-per-step kernels.")
+
+
 def _call(name: str, like: torch.Tensor, *args) -> None:
     """Invoke one C-ABI entry point on ``like``'s current stream and raise on a non-zero return."""
     fn = getattr(load(), name)
@@ -464,6 +485,7 @@ class _BiLSTMLayer(torch.autograd.Function):
         sync = torch.empty(512, device=x.device, dtype=torch.int32)         # TSG_LSTM_SYNC_BYTES: persistent-kernel sync words
         # outside the strict-fp32 mode the recurrence's W_hh products are split-precision bf16 MFMAs as well (TSG_F32S)
         ctx.rec_dtype = TSG_F32 if _GEMM_DTYPE is None else TSG_F32S
+        check_lstm_errors()
         _call("tsg_lstm_fwd_bias", x, ptr(Gx), ptr(kbias) if kbias is not None else None, ptr(W_hh), ptr(out), ptr(R), ptr(Cs),
               ptr(sync), B, T, h, ctx.rec_dtype, int(bm))
         ctx.lstm_sync = sync
@@ -489,6 +511,7 @@ class _BiLSTMLayer(torch.autograd.Function):
         ws = torch.empty(nb // 4 + 4, device=x.device, dtype=torch.float32) if nb > 0 else None
         fused_db = ws is not None and bool(load().tsg_lstm_bwd_ws_persistent(B, T, h, nb))   # persistent path also sums dG -> dbias
         dbias = torch.empty(8 * h, device=x.device, dtype=torch.float32) if fused_db else None
+        check_lstm_errors()
         _call("tsg_lstm_bwd_ws_layout", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC),
               ptr(ws) if ws is not None else None, nb, ptr(dbias) if fused_db else None, B, T, h, ctx.rec_dtype, int(bm))
         dGf = dG.view(TB, 8 * h)

@@ -238,3 +238,27 @@ def test_bilstm_batch_major_layout(shape, dt):
     for a, b in zip(*res):
         assert torch.isfinite(a).all()
         torch.testing.assert_close(a, b, atol=0, rtol=0)
+
+
+def test_persistent_lstm_timeout_is_reported():
+    """A persistent launch whose start barrier cannot complete (TSG_LSTM_INJECT_TIMEOUT: workgroup 0 never arrives) must not
+    hang, must set the launch's error word, and must surface as LstmWaitExpired on the next LSTM call (pinned error sink,
+    no synchronisation needed)."""
+    import subprocess, sys, os
+    code = (
+        "import torch, sys, os; sys.path.insert(0, %r)\n"
+        "from shufflingvideosfortsg_amd import functional as TF\n"
+        "T,B,I,h=16,32,64,128; g=torch.Generator().manual_seed(0)\n"
+        "x=torch.randn(T,B,I,generator=g).cuda(); W_ih=(torch.randn(8*h,I,generator=g)*0.1).cuda(); b=torch.zeros(8*h).cuda(); W_hh=(torch.randn(2,4*h,h,generator=g)*0.1).cuda()\n"
+        "out,_=TF.bilstm_layer(x,W_ih,b,W_hh); torch.cuda.synchronize(); TF.check_lstm_errors(); assert torch.isfinite(out).all()\n"
+        "os.environ['TSG_LSTM_INJECT_TIMEOUT']='1'\n"
+        "out,_=TF.bilstm_layer(x,W_ih,b,W_hh); torch.cuda.synchronize()\n"
+        "os.environ['TSG_LSTM_INJECT_TIMEOUT']='0'\n"
+        "try:\n"
+        "    TF.bilstm_layer(x,W_ih,b,W_hh); print('NOT RAISED')\n"
+        "except TF.LstmWaitExpired as e:\n"
+        "    print('raised ok')\n"
+        "out,_=TF.bilstm_layer(x,W_ih,b,W_hh); torch.cuda.synchronize(); TF.check_lstm_errors(); assert torch.isfinite(out).all(); print('recovered ok')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "raised ok" in r.stdout and "recovered ok" in r.stdout, r.stdout + r.stderr
