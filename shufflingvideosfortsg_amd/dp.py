@@ -1,6 +1,6 @@
 """Data parallelism for the grounding models: one process per GPU, full replica per rank, ONE flat
-fp32 gradient buffer that is all-reduced (sum) over RCCL/xGMI in a few large buckets while the
-backward is still running, then scaled by 1/world.  (The reference only has a single-process
+fp32 gradient buffer, gathered bucket by bucket as the gradients appear and all-reduced (sum) over
+RCCL/xGMI in a few large buckets while the backward is still running, then scaled by 1/world.  (The reference only has a single-process
 ``nn.DataParallel`` wrapper that its launcher pins to one GPU -- train.py:343, helper_function.py:17.)
 
 Clip-query pairs are independent in forward/backward (no BatchNorm; LayerNorm is per row), so the
@@ -16,8 +16,14 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce:
-    """Owns the gradients of ``module`` as views into one contiguous buffer and averages them
-    across ranks.  Usage per step:  ``dp.zero_grad(); loss.backward(); dp.finish(); optim.step()``.
+    """Averages the gradients of ``module`` across ranks through one contiguous buffer.
+    Usage per step:  ``dp.zero_grad(); loss.backward(); dp.finish(); optim.step()``.
+
+    Gradients are produced by autograd as individual tensors (``.grad`` starts each step as None, so nothing is
+    accumulated into a zeroed buffer: that cost one small add kernel per parameter, ~150 launches a step).  When the
+    last parameter of a bucket has its gradient, ONE multi-tensor copy gathers the bucket into its slice of the flat
+    buffer, ``.grad`` of its parameters is re-pointed at that slice, and the slice's all-reduce starts -- while the backward
+    of the earlier layers is still running.  With one rank there is no exchange and the flat buffer is not touched at all.
 
     bucket_mb: target bucket size.  xGMI is point-to-point (7 links/GPU), so few large ring
     reductions beat many small ones; 32 MiB buckets give ~6 buckets for the 186 MB d=1024 model.
@@ -32,28 +38,36 @@ class FlatGradAllReduce:
         if not self.params:
             raise ValueError("module has no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
+        self._force = dist.is_initialized() and __import__("os").environ.get("TSG_FORCE_DIST") == "1"
+        self.active = self.world > 1 or self._force          # is there an exchange at all?
         # backward produces gradients roughly in reverse registration order: lay the buffer out that
         # way so that each bucket is a contiguous slice that completes early
         order = list(reversed(self.params))
-        total = sum(p.numel() for p in order)
-        self.flat = torch.zeros(total, device=dev, dtype=dt)
-        self.buckets = []          # (start, end, n_params)
-        cap = max(1, int(bucket_mb * (1 << 20) / self.flat.element_size()))
-        off = start = count = 0
-        self._bucket_of = {}
+        self._numel = sum(p.numel() for p in order)
+        self._esize = torch.empty(0, dtype=dt).element_size()
+        self.flat = torch.zeros(self._numel, device=dev, dtype=dt) if self.active else None
+        self.buckets = []          # (start, end, [params])
+        cap = max(1, int(bucket_mb * (1 << 20) / self._esize))
+        off = start = 0
+        cur: List[torch.nn.Parameter] = []
+        self._bucket_of, self._view = {}, {}
         for p in order:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            if self.active:
+                self._view[id(p)] = self.flat[off:off + n].view_as(p)
             self._bucket_of[id(p)] = len(self.buckets)
-            off += n; count += 1
+            off += n; cur.append(p)
             if off - start >= cap:
-                self.buckets.append((start, off, count)); start, count = off, 0
-        if count:
-            self.buckets.append((start, off, count))
+                self.buckets.append((start, off, cur)); start, cur = off, []
+        if cur:
+            self.buckets.append((start, off, cur))
         self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
         self._handles = []
-        self._force = dist.is_initialized() and __import__("os").environ.get("TSG_FORCE_DIST") == "1"
-        self.overlap = overlap and (self.world > 1 or self._force)
+        self.overlap = overlap and self.active
+        # RCCL averages inside the reduction (no extra pass over the buffer); gloo has no AVG: sum, then one division
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         if self.overlap:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
@@ -63,42 +77,57 @@ class FlatGradAllReduce:
 
     # -- per-step protocol ----------------------------------------------------------------
     def zero_grad(self):
-        self.flat.zero_()
-        for p in self.params:                     # an optimizer may have detached the views
-            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
-                    p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * self.flat.element_size():
-                raise RuntimeError("a parameter's .grad no longer aliases the flat buffer "
-                                   "(use dp.zero_grad(), not optimizer.zero_grad(set_to_none=True))")
+        for p in self.params:
+            p.grad = None
         self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
         self._handles = []
+
+    def _gather(self, b):
+        """Bucket b's gradients -> its slice of the flat buffer (one multi-tensor copy; parameters without a gradient
+        contribute zeros), ``.grad`` re-pointed at the slice."""
+        _, _, params = self.buckets[b]
+        have = [p for p in params if p.grad is not None]
+        none = [self._view[id(p)] for p in params if p.grad is None]
+        if have:
+            torch._foreach_copy_([self._view[id(p)] for p in have], [p.grad for p in have])
+        if none:
+            torch._foreach_zero_(none)
+        for p in params:
+            p.grad = self._view[id(p)]
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
-        self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._gather(b)
+        self._launched[b] = True
+        self._handles.append(dist.all_reduce(self.flat[s:e], op=self._op, group=self.group, async_op=True))
 
     def _hook(self, p):
         b = self._bucket_of[id(p)]
         self._ready[b] += 1
-        if self._ready[b] == self.buckets[b][2]:
+        if self._ready[b] == len(self.buckets[b][2]) and not self._launched[b]:
             self._launch(b)
 
     def finish(self):
         """Complete the gradient exchange: afterwards every rank holds the mean gradient."""
-        if self.world == 1 and not self._force:
+        if not self.active:
             return
         if self.overlap:
-            for b, (s, e, n) in enumerate(self.buckets):   # parameters that received no gradient
-                if self._ready[b] != n:
+            for b in range(len(self.buckets)):             # buckets with parameters that received no gradient
+                if not self._launched[b]:
                     self._launch(b)
         else:
-            self._handles = [dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+            for b in range(len(self.buckets)):
+                self._gather(b)
+            self._handles = [dist.all_reduce(self.flat, op=self._op, group=self.group, async_op=True)]
         for h in self._handles:
             h.wait()
-        self.flat.div_(self.world)
+        if not self._avg:
+            self.flat.div_(self.world)
 
     @property
     def grad_bytes(self) -> int:
-        return self.flat.numel() * self.flat.element_size()
+        return self._numel * self._esize
 
 
 def shard_batch(batch, rank: int, world: int):
