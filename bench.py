@@ -185,8 +185,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs in the CPU-baseline sample (0 = skip); bounded to ~20 s")
     ap.add_argument("--no-micro", action="store_true", help="skip the stand-alone K2 launches")
     ap.add_argument("--dtype", default="f32s", choices=["f32", "bf16", "f32s"],
-                    help="library-GEMM mode of the LSTM input / weight-gradient GEMMs; the HIP kernels are f32 in all of them.  "
-                         "f32s (default): split-precision bf16 MFMA GEMMs, hi*hi+hi*lo+lo*hi with fp32 accumulate -- error at the "
+                    help="precision mode of the GEMM-shaped glue (LSTM GEMMs and recurrence products, large projections); the hot-path "
+                         "HIP kernels are f32 in all of them.  "
+                         "f32s (default): split-precision bf16 MFMA products, hi*hi+hi*lo+lo*hi with fp32 accumulate -- error at the "
                          "fp32 GEMM's level, the parity suite passes at the fp32 tolerances, and it is above the bf16 that BASELINE "
                          "config 2 names; f32: rocBLAS fp32 GEMMs; bf16: bf16 operands, fp32 accumulate (~1e-3 from the reference)")
     ap.add_argument("--predictor", default="mlp", choices=["mlp", "self_attn"],
@@ -265,8 +266,8 @@ def main():
     NOTES = {"f32": "all-f32 (rocBLAS fp32 MFMA GEMMs)",
              "bf16": "library GEMM operands bf16, fp32 accumulate; HIP kernels, recurrent state, softmax, losses, optimizer "
                      "f32; deviates ~1e-3 from the fp32 reference",
-             "f32s": "LSTM input/weight-gradient GEMMs as split-precision bf16 MFMA GEMMs (hi*hi+hi*lo+lo*hi, fp32 "
-                     "accumulate: fp32-GEMM-level error, passes the fp32 parity suite); everything else f32"}
+             "f32s": "LSTM GEMMs, LSTM recurrence products and the large projections as split-precision bf16 MFMA products "
+                     "(hi*hi+hi*lo+lo*hi, fp32 accumulate: fp32-GEMM-level error, passes the fp32 parity suite); everything else f32"}
     alt = []
     gdt_main = gdt
     for mode in ([] if a.no_alt else [m for m in MODES if m != a.dtype]):
