@@ -461,25 +461,29 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 constexpr int kHLB = kPersistMaxH / 2 + 8;       // bf16 slab plane row stride in dwords (= 8 mod 64)
 constexpr int kSlabFloats = 2 * 16 * kHLB;       // LDS dwords of the slab region: two bf16 planes (>= the fp32 slab's 16 x 520)
 
-template <int HJ, bool SPLIT>                     // HJ = h / 16 when known at compile time (no branch between MFMAs), else 0;
-__global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT: split-precision bf16 MFMA arithmetic (needs HJ > 0, even)
+template <int HJ, bool SPLIT, int NW>             // HJ = h / 16 when known at compile time (no branch between MFMAs), else 0;
+__global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT: split-precision bf16 MFMA arithmetic (needs HJ > 0, even);
+                                                                        // NW = waves = A-tiles per workgroup (8: 32 units, one workgroup
+                                                                        // per CU; 4: 16 units, two independent chains per CU)
     const float* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh, float* __restrict__ out,
     float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS, int flags, int bm, unsigned* __restrict__ esink) {
+  constexpr int NT = 64 * NW, UW = 4 * NW, HTS = UW + 1;  // threads, units per workgroup, h-tile row stride
+  constexpr int SV = 16 * (kPersistMaxH / 4) / NT;         // float4 of the 16-row slab per thread (4 / 8 at h = 512)
   extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice (SPLIT: two bf16 planes
   float* Ht = Hl + kSlabFloats;                          // [16][kHLB] dwords), then Ht [16][33] = this step's h tile (16 rows x
   unsigned* Hhi = reinterpret_cast<unsigned*>(Hl);       // 32 units), gathered for whole-line stores
   unsigned* Hlo = Hhi + 16 * kHLB;
-  volatile unsigned* fail = reinterpret_cast<unsigned*>(Ht + 16 * 33);     // raised by a wave whose bounded wait expired
+  volatile unsigned* fail = reinterpret_cast<unsigned*>(Ht + 16 * 33);     // (region sized for UW = 32)     // raised by a wave whose bounded wait expired
   if (threadIdx.x == 0) *fail = 0u;
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
-  const int uslices = h / 32, bslices = (B + 15) / 16;
+  const int uslices = h / UW, bslices = (B + 15) / 16;
   const int vidx = xcd_major_index(), group = vidx / uslices;     // exchange group = (direction, batch slice): its uslices
   const int us = vidx % uslices, d = group / bslices, bs = group % bslices;   // workgroups are neighbours in XCD-major order
   const int at = wv;                                      // 8 waves = 8 A-tiles (32 units) x ONE 16-row batch tile: the slab a
                                                           // workgroup fetches per step is 16 rows (32 KiB at h = 512), half of the
                                                           // 4 x 2 arrangement's, for the same MFMA work per wave
   const int jb = lane & 15, ku = lane >> 4;
-  const int u0 = us * 32 + at * 4;                        // first unit of this wave's A-tile
+  const int u0 = us * UW + at * 4;                        // first unit of this wave's A-tile
   const int b0 = bs * 16;
   // sync[0] = error word, sync[1] = arrival counter of the one start barrier
 
@@ -515,9 +519,9 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
     // address and the same write-through path as the later h store, so the two stay ordered -- and the grid meets once
     // (arrival counter sync[1]) so that no consumer can poll an element before its sentinel is in memory.
     {
-      const int row = tid >> 5, col = tid & 31;              // the same whole-line pattern as the h stores of the step loop
+      const int row = tid / UW, col = tid % UW;              // the same whole-line pattern as the h stores of the step loop
       if (b0 + row < B)
-        for (int t = 0; t < T; ++t) store_sc1_u(out + seq_row(t, b0 + row, B, T, bm) * 2 * h + d * h + us * 32 + col, kSentinel);
+        for (int t = 0; t < T; ++t) store_sc1_u(out + seq_row(t, b0 + row, B, T, bm) * 2 * h + d * h + us * UW + col, kSentinel);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -545,30 +549,34 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (step > 0) {
-      f32x4 v[kSlabV];
+      f32x4 v[SV];
       {
         // poll the slab until no element of this thread's 8 float4 is the sentinel (loads unconditional, see above)
         unsigned pending = 0u;
-        const float* src[kSlabV];
+        const float* src[SV];
 #pragma unroll
-        for (int i = 0; i < kSlabV; ++i) {
-          const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
+        for (int i = 0; i < SV; ++i) {
+          const int idx = tid + i * NT, r = idx / nrow4, c4 = idx % nrow4;
           const bool ok = r < 16 && b0 + r < B;
           if (ok) pending |= 1u << i;
           src[i] = out + seq_row(tp, ok ? b0 + r : b0, B, T, bm) * 2 * h + d * h + (ok ? c4 * 4 : 0);
         }
         // (measured and dropped: two or three staggered copies of the poll in flight -- the extra slab traffic costs more
         // than the shorter retry saves, 13.7 vs 11.5 us per step)
-        static_assert(kSlabV == 4, "the wait below lists 4 loads");
+        static_assert(SV == 4 || SV == 8, "the wait below lists 4 or 8 loads");
         int spins = 0;
-        u32x4 q[kSlabV];
+        u32x4 q[SV];
         while (true) {
 #pragma unroll
-          for (int i = 0; i < kSlabV; ++i) q[i] = load_sc1_u4(src[i]);
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : : "memory");
+          for (int i = 0; i < SV; ++i) q[i] = load_sc1_u4(src[i]);
+          if constexpr (SV == 4)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : : "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4 % SV]), "+v"(q[5 % SV]),
+                         "+v"(q[6 % SV]), "+v"(q[7 % SV]) : : "memory");
           unsigned raw = 0u;
 #pragma unroll
-          for (int i = 0; i < kSlabV; ++i)
+          for (int i = 0; i < SV; ++i)
             if (q[i][0] == kSentinel || q[i][1] == kSentinel || q[i][2] == kSentinel || q[i][3] == kSentinel) raw |= 1u << i;
           raw &= pending;
 #ifdef TSG_DEBUG_SENTINEL
@@ -584,16 +592,16 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
           }
         }
 #pragma unroll
-        for (int i = 0; i < kSlabV; ++i)
+        for (int i = 0; i < SV; ++i)
           if (!(pending & (1u << i))) q[i] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < kSlabV; ++i)
+        for (int i = 0; i < SV; ++i)
           v[i] = (f32x4){__uint_as_float(q[i][0]), __uint_as_float(q[i][1]), __uint_as_float(q[i][2]), __uint_as_float(q[i][3])};
       }
       TSG_TICK(0)                                            // poll: slab complete in registers
 #pragma unroll
-      for (int i = 0; i < kSlabV; ++i) {
-        const int idx = tid + i * kThreads, r = idx / nrow4, c4 = idx % nrow4;
+      for (int i = 0; i < SV; ++i) {
+        const int idx = tid + i * NT, r = idx / nrow4, c4 = idx % nrow4;
         if constexpr (SPLIT) {
           uint2 hi2, lo2;
           split_pair(v[i][0], v[i][1], hi2.x, lo2.x);
@@ -670,12 +678,12 @@ __global__ __launch_bounds__(kThreads) void lstm_fwd_persist_kernel(   // SPLIT:
       gg = tanh_f(acc[2] + gx[2]); go = sigmoid_f(acc[3] + gx[3]);
       c = fmaf(gf, cprev, gi * gg);
       cprev = c;
-      Ht[jb * 33 + at * 4 + ku] = go * tanh_f(c);
+      Ht[jb * HTS + at * 4 + ku] = go * tanh_f(c);
     }
     __syncthreads();                                        // tile complete; the slab in LDS is free again
     {
-      const int row = tid >> 5, col = tid & 31;
-      if (b0 + row < B) store_x(out + seq_row(tt, b0 + row, B, T, bm) * 2 * h + d * h + us * 32 + col, Ht[row * 33 + col], local);
+      const int row = tid / UW, col = tid % UW;
+      if (b0 + row < B) store_x(out + seq_row(tt, b0 + row, B, T, bm) * 2 * h + d * h + us * UW + col, Ht[row * HTS + col], local);
     }
     if (live) {
       const size_t s = (((size_t)tt * 2 + d) * B + b) * h + u;
@@ -994,29 +1002,35 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
   auto st = static_cast<hipStream_t>(stream);
   // persistent path: weights stationary, one launch for all T steps -- needs every workgroup resident
   if (sync_ws && persist_wanted(T) && h % 32 == 0 && h <= kPersistMaxH && T > 1) {
-    const int grid = 2 * (h / 32) * cdiv(B, 16);
+    static int nw_env = -1;                                 // TSG_LSTM_NW=4: 16-unit workgroups of 4 waves, two per CU (experiment)
+    if (nw_env < 0) { const char* e = getenv("TSG_LSTM_NW"); nw_env = (e && atoi(e) == 4) ? 4 : 8; }
+    const bool split = dtype == TSG_F32S;                  // other hidden sizes: the fp32 arithmetic (more accurate, slower)
+    const int NW = (nw_env == 4 && h == 512 && split) ? 4 : 8;
+    const int grid = 2 * (h / (4 * NW)) * cdiv(B, 16);
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
     const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 33 + 4);
     static_assert(kSlabFloats >= 16 * (kPersistMaxH + 8), "slab region holds the fp32 slab too");
-    const bool split = dtype == TSG_F32S;                  // other hidden sizes: the fp32 arithmetic (more accurate, slower)
-    auto pk = h == 512 ? (split ? lstm_fwd_persist_kernel<32, true> : lstm_fwd_persist_kernel<32, false>)
-            : h == 256 ? (split ? lstm_fwd_persist_kernel<16, true> : lstm_fwd_persist_kernel<16, false>)
-            : h == 384 ? (split ? lstm_fwd_persist_kernel<24, true> : lstm_fwd_persist_kernel<24, false>)
-            : h == 128 ? (split ? lstm_fwd_persist_kernel<8, true> : lstm_fwd_persist_kernel<8, false>)
-            : lstm_fwd_persist_kernel<0, false>;
-    static int capacity = -1;
-    if (capacity < 0) {
+    auto pk = NW == 4 ? lstm_fwd_persist_kernel<32, true, 4>
+            : h == 512 ? (split ? lstm_fwd_persist_kernel<32, true, 8> : lstm_fwd_persist_kernel<32, false, 8>)
+            : h == 256 ? (split ? lstm_fwd_persist_kernel<16, true, 8> : lstm_fwd_persist_kernel<16, false, 8>)
+            : h == 384 ? (split ? lstm_fwd_persist_kernel<24, true, 8> : lstm_fwd_persist_kernel<24, false, 8>)
+            : h == 128 ? (split ? lstm_fwd_persist_kernel<8, true, 8> : lstm_fwd_persist_kernel<8, false, 8>)
+            : lstm_fwd_persist_kernel<0, false, 8>;
+    static int capacity[2] = {-1, -1};                     // [NW == 4]
+    int& cap = capacity[NW == 4];
+    if (cap < 0) {
       int dev = 0, cus = 0, per = 0;
       hipError_t e1 = allow_lds(pk, plds);
       if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
       if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, kThreads, plds);
-      capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;      // count ONE workgroup per CU: margin against over-reporting
+      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, 64 * NW, plds);
+      // count ONE workgroup per CU (two of the 4-wave ones): margin against over-reporting
+      cap = (e1 == hipSuccess) ? cus * (NW == 4 ? (per >= 2 ? 2 : 0) : (per > 0 ? 1 : 0)) : 0;
     }
-    if (grid <= capacity) {
+    if (grid <= cap) {
       hipError_t e = hipMemsetAsync(sync_ws, 0, kSyncBytes, st);
       if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-      hipLaunchKernelGGL(pk, dim3(grid), dim3(kThreads), plds, st, (const float*)Gx, (const float*)bias, (const float*)Whh, (float*)out,
+      hipLaunchKernelGGL(pk, dim3(grid), dim3(64 * NW), plds, st, (const float*)Gx, (const float*)bias, (const float*)Whh, (float*)out,
                          (float*)R, (float*)Cs, (unsigned*)sync_ws, B, T, h, HLS, launch_flags(), bm, g_error_sink);
       return check_launch(fn);
     }
