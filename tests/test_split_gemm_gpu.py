@@ -105,3 +105,28 @@ def test_split_shift_within_sequences():
         buf = torch.empty(C, 3 * Bn * T, device="cuda", dtype=torch.bfloat16)
         TF.split_bf16x3_t(x, 0, C, shift, True, buf, 0, period=T)
         assert torch.equal(buf, ref.t())
+
+
+def test_linear_split_precision_matches_fp32():
+    """functional.linear in the f32s mode (forward and input gradient as split-precision GEMMs, weight gradient fp32) vs
+    torch.nn.functional.linear in float64: error at the fp32 GEMM's level; small inputs fall through to F.linear."""
+    import torch.nn.functional as F
+    torch.manual_seed(11)
+    x = torch.randn(64, 64, 256, device="cuda", requires_grad=True)          # 4096 rows
+    w = (torch.randn(128, 256, device="cuda") * 0.06).requires_grad_(True)
+    b = torch.randn(128, device="cuda", requires_grad=True)
+    g = torch.randn(64, 64, 128, device="cuda")
+    ref = F.linear(x.double(), w.double(), b.double())
+    gx, gw, gb = torch.autograd.grad(ref, (x, w, b), g.double())
+    TF.set_gemm_dtype("f32s")
+    try:
+        y = TF.linear(x, w, b)
+        assert y.grad_fn is not None and "LinearSplit" in type(y.grad_fn).__name__
+        dx, dw, db = torch.autograd.grad(y, (x, w, b), g)
+        small = TF.linear(x[:1, :8], w, b)                                  # 8 rows: plain F.linear
+        assert "LinearSplit" not in type(small.grad_fn).__name__
+    finally:
+        TF.set_gemm_dtype(None)
+    for got, want in [(y, ref), (dx, gx), (dw, gw), (db, gb)]:
+        err = (got.double() - want).abs().max().item() / want.abs().max().item()
+        assert err < 2e-5, err
