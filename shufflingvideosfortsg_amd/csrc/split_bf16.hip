@@ -67,6 +67,9 @@ __global__ __launch_bounds__(256) void split_bf16_t_kernel(const float* __restri
   const int tid = threadIdx.x, tx = tid % TPR, ty = tid / TPR;
   // blockIdx.x runs along the COLUMNS: workgroups in flight together then read whole contiguous rows; with x along the rows
   // they all read the same 256-byte column window at a power-of-two row stride, i.e. the same memory channels
+  // (measured: the read side alone runs at 5.2 TB/s, the write side alone -- 128-byte segments in 3 x 64 output rows per
+  // workgroup -- at 3.7 TB/s, together 3.6; longer segments (128 x 64, 256 x 32 tiles) and grouping row tiles of one
+  // column tile on neighbouring workgroups changed nothing, so 64 x 64 with the column-major grid stays)
   const long r0 = (long)TR * (swap ? blockIdx.x : blockIdx.y);
   const int c0 = TC * (swap ? blockIdx.y : blockIdx.x);
 #pragma unroll

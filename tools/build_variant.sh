@@ -6,9 +6,10 @@ name=$1; shift
 mkdir -p tools/_ablate/obj_$name
 for f in shufflingvideosfortsg_amd/csrc/*.hip; do
   b=$(basename $f .hip)
-  extra=""; [ "$b" = "lstm" ] && extra="$*"
-  if [ "$b" = "lstm" ] || [ ! -f tools/_ablate/obj_$name/$b.o ]; then
-    if [ "$b" != "lstm" ] && [ -f shufflingvideosfortsg_amd/csrc/obj/$b.o ]; then cp shufflingvideosfortsg_amd/csrc/obj/$b.o tools/_ablate/obj_$name/$b.o; continue; fi
+  extra=""
+  tgt=${TSG_VARIANT_SRC:-lstm}
+  if [ "$b" = "$tgt" ] || [ ! -f tools/_ablate/obj_$name/$b.o ]; then
+    if [ "$b" != "$tgt" ] && [ -f shufflingvideosfortsg_amd/csrc/obj/$b.o ]; then cp shufflingvideosfortsg_amd/csrc/obj/$b.o tools/_ablate/obj_$name/$b.o; continue; fi
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=fast -fno-math-errno "$@" -c $f -o tools/_ablate/obj_$name/$b.o
   fi
 done
