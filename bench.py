@@ -213,7 +213,10 @@ def main():
     torch.manual_seed(0)
     log(f"building {a.model} (d={a.d}) on {torch.cuda.get_device_name(local)}")
     model = engine.build_model(a.model, params).to(dev).train()
-    dp = FlatGradAllReduce(model)
+    # gradient exchange after the backward by default: a bucket all-reduce launched DURING the backward would share the CUs
+    # with the persistent LSTM kernels (which need every CU for the length of a layer: their start is delayed and their
+    # exchange groups may lose the one-XCD placement) for at most ~1 ms of hidden communication (186 MB per step)
+    dp = FlatGradAllReduce(model, overlap=os.environ.get("TSG_DP_OVERLAP", "0") == "1")
     opt = engine.make_optimizer(model, params)
     batch = data.synthetic_batch(a.B, a.T, a.N, seed=1234 + rank, pair=(a.model == "gmd"), device=dev)
 
