@@ -536,17 +536,33 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
 #else
 #define TSG_TICK(i) {}
 #endif
+  float gxn[4] = {0.f, 0.f, 0.f, 0.f};                     // input gates of the NEXT step (see the loop head)
+  if (live) {
+    const float* g = Gx + (seq_row(d == 0 ? 0 : T - 1, b, B, T, bm) * 2 + d) * 4 * h + u;
+    gxn[0] = g[0]; gxn[1] = g[h]; gxn[2] = g[2 * h]; gxn[3] = g[3 * h];
+  }
   for (int step = 0; step < T; ++step) {
 #ifdef TSG_LSTM_TIMING
     tm0 = __builtin_amdgcn_s_memtime();
 #endif
     const int tt = d == 0 ? step : T - 1 - step;
     const int tp = d == 0 ? tt - 1 : tt + 1;
-    float gx[4] = {0.f, 0.f, 0.f, 0.f};
-    if (live) {
-      const float* g = Gx + (seq_row(tt, b, B, T, bm) * 2 + d) * 4 * h + u;
-      gx[0] = g[0] + bi[0]; gx[1] = g[h] + bi[1]; gx[2] = g[2 * h] + bi[2]; gx[3] = g[3 * h] + bi[3];
-    }
+    // The input gates of a step are requested one step AHEAD (right after the previous step's poll): the poll's
+    // s_waitcnt vmcnt(0) waits for everything this wave has in flight, and a Gx load issued in front of it put an HBM
+    // round trip (~1.5 us) into every hand-off that itself takes 0.24 us (tools/ubench/l2_pingpong.hip).
+    // They are taken over right AFTER the poll (whose wait has covered them), never at the loop head, where the wait for
+    // them would also wait for the stores of the step before.
+    float gx[4];
+    auto prefetch_gx = [&]() {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gx[k] = gxn[k] + bi[k];
+      if (live && step + 1 < T) {
+        const int tn = d == 0 ? step + 1 : T - 2 - step;
+        const float* g = Gx + (seq_row(tn, b, B, T, bm) * 2 + d) * 4 * h + u;
+        gxn[0] = g[0]; gxn[1] = g[h]; gxn[2] = g[2 * h]; gxn[3] = g[3 * h];
+      }
+    };
+    if (step == 0) prefetch_gx();
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (step > 0) {
       f32x4 v[SV];
@@ -599,6 +615,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
           v[i] = (f32x4){__uint_as_float(q[i][0]), __uint_as_float(q[i][1]), __uint_as_float(q[i][2]), __uint_as_float(q[i][3])};
       }
       TSG_TICK(0)                                            // poll: slab complete in registers
+      prefetch_gx();
 #pragma unroll
       for (int i = 0; i < SV; ++i) {
         const int idx = tid + i * NT, r = idx / nrow4, c4 = idx % nrow4;
@@ -808,6 +825,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float cc = 0.f, cpv = 0.f, dov = 0.f;
     if (live) {
+      // (requested here, in front of the poll; requesting them one step ahead, after the previous poll -- what the forward
+      // kernel does with its input gates -- measured 5.0 instead of 4.6 us per step)
       const size_t sidx = (((size_t)tt * 2 + d) * B + b) * h + u;
       g4 = *reinterpret_cast<const float4*>(R + sidx * 4);
       cc = Cs[sidx];
