@@ -83,16 +83,17 @@ class MultiHead(nn.Module):
         self.A_softmax = None
 
     def _core(self, query, key, value, maps):
-        q, k, v = self.wq(query), self.wk(key), self.wv(value)
+        # TF.linear = F.linear, or the split-precision GEMMs in the f32s mode when the operand has >= 2048 rows
+        q, k, v = TF.linear(query, self.wq.weight), TF.linear(key, self.wk.weight), TF.linear(value, self.wv.weight)
         return TF.mha(q, k, v, self.n_heads, self.attention.scale, bool(self.attention.causal), return_maps=maps,
                       p_drop=self.attention._p())
 
     def forward(self, query, key, value):
-        return self.wo(self._core(query, key, value, False))
+        return TF.linear(self._core(query, key, value, False), self.wo.weight)
 
     def A_forward(self, query, key, value):
         o, self.A, self.A_softmax = self._core(query, key, value, True)
-        return self.wo(o)
+        return TF.linear(o, self.wo.weight)
 
 
 class SCDM_Attention(nn.Module):
