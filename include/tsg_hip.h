@@ -167,6 +167,21 @@ int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const void* Cs, cons
                            void* dG, void* dC_ws, void* ws, long long ws_bytes, void* dbias, int B, int T, int h, int dtype,
                            int batch_major, void* stream);
 
+/* ---- K4: the four GMD training losses in one launch each way (grounding/loss.py:6-51, combined as train.py:142-165) -----
+ * ps, pe [B,T] span start / end probabilities; om, pm [B,T] matching logits of the original / shuffled video; od, pd [B,2]
+ * order-discriminator logits; fs, pfs int64 [B,2] ground-truth (start, end) clip indices of the original / shuffled video;
+ * tl, ptl [B,T] temporal labels (0/1 as float); vm [B,T] video mask (float).  out[4] = (span_ground_loss,
+ * BCE_loss(om,tl,vm) + BCE_loss(pm,ptl,vm), matching_KL_divergence(masked_softmax(om,tl), masked_softmax(pm,ptl), fs, pfs),
+ * temporal_order_discrimination_loss(od, pd)) -- the caller applies the lambda weights.  ws: 32-byte workspace (zeroed by
+ * the call; kept for the backward).  T <= 2048.  The backward writes the gradients of ps, pe, om, pm, od, pd given dL[4].  */
+int tsg_gmd_losses_fwd(const void* ps, const void* pe, const void* om, const void* pm, const void* od, const void* pd,
+                       const void* fs, const void* pfs, const void* tl, const void* ptl, const void* vm,
+                       void* ws, void* out, int B, int T, void* stream);
+int tsg_gmd_losses_bwd(const void* ps, const void* pe, const void* om, const void* pm, const void* od, const void* pd,
+                       const void* fs, const void* pfs, const void* tl, const void* ptl, const void* vm,
+                       const void* ws, const void* dL, void* dps, void* dpe, void* dom, void* dpm, void* dod, void* dpd,
+                       int B, int T, void* stream);
+
 /* ---- dense projection GEMM on the fp32 matrix cores ("tsg_gemm_*" of SURVEY section 8b) ------------------------------
  * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL): torch.nn.Linear's layout, i.e. the d x d projections of the path
  * (SCDM W_a / W_s attention.py:104-106, sent_linear VideoEncoder.py:48, MultiHead wq/wk/wv/wo attention.py:63-66, the

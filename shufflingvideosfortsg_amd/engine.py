@@ -92,6 +92,15 @@ def gmd_step(model, batch, params):
                                  batch["pseudo_video"], batch["video_mask"],
                                  gt["temporal_labels"], gt["fore_masks"], gt["back_masks"],
                                  pgt["temporal_labels"], pgt["fore_masks"], pgt["back_masks"])
+    fs, pfs = gt["framestps"], pgt["framestps"]
+    if (om.is_cuda and isinstance(fs, torch.Tensor) and isinstance(pfs, torch.Tensor) and om.dim() == 2 and om.size(1) <= 2048
+            and od.dim() == 2 and od.size(1) == 2):
+        # K4: the four losses in one launch each way (csrc/losses.hip) instead of ~100 small torch launches
+        from . import functional as TF
+        out = TF.gmd_losses(span["start"], span["end"], om, pm, od, pd, fs, pfs, gt["temporal_labels"], pgt["temporal_labels"],
+                            batch["video_mask"])
+        lg, l1, l2, ld = out[0], params["loss_m1_lambda"] * out[1], params["loss_m2_lambda"] * out[2], out[3]
+        return lg + l1 + l2 + params["loss_disc_lambda"] * ld, (lg, l1, l2, ld), span
     lg = L.span_ground_loss(span["start"], span["end"], gt["framestps"])
     l1 = params["loss_m1_lambda"] * (L.BCE_loss(om, gt["temporal_labels"], batch["video_mask"])
                                      + L.BCE_loss(pm, pgt["temporal_labels"], batch["video_mask"]))

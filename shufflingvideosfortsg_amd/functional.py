@@ -417,6 +417,47 @@ class _LinearHip(torch.autograd.Function):
         return dx, dw, db
 
 
+class _GmdLosses(torch.autograd.Function):
+    """The four GMD training losses (K4, csrc/losses.hip) -> out[4] = (span, matching BCE, matching KL, order CE)."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm):
+        require_device(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm)
+        ps, pe, om, pm, od, pd = (_f32c(t) for t in (ps, pe, om, pm, od, pd))
+        tl, ptl, vm = (t.to(torch.float32).contiguous() for t in (tl, ptl, vm))     # labels / masks arrive as int or bool
+        fs, pfs = fs.to(torch.long).contiguous(), pfs.to(torch.long).contiguous()
+        B, T = om.shape
+        for t in (ps, pe, pm, tl, ptl, vm):
+            if t.shape != (B, T):
+                raise ValueError(f"gmd_losses: expected [{B},{T}] tensors, got {tuple(t.shape)}")
+        if od.shape != (B, 2) or pd.shape != (B, 2) or fs.shape != (B, 2) or pfs.shape != (B, 2):
+            raise ValueError("gmd_losses: od / pd / fs / pfs must be [B,2]")
+        ws = torch.empty(8, device=om.device, dtype=torch.float32)
+        out = torch.empty(4, device=om.device, dtype=torch.float32)
+        _call("tsg_gmd_losses_fwd", om, ptr(ps), ptr(pe), ptr(om), ptr(pm), ptr(od), ptr(pd), ptr(fs), ptr(pfs), ptr(tl), ptr(ptl),
+              ptr(vm), ptr(ws), ptr(out), B, T)
+        ctx.save_for_backward(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, ws)
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dL):
+        ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, ws = ctx.saved_tensors
+        B, T = om.shape
+        dL = _f32c(dL)
+        dps, dpe, dom, dpm = (torch.empty_like(om) for _ in range(4))
+        dod, dpd = torch.empty_like(od), torch.empty_like(pd)
+        _call("tsg_gmd_losses_bwd", om, ptr(ps), ptr(pe), ptr(om), ptr(pm), ptr(od), ptr(pd), ptr(fs), ptr(pfs), ptr(tl), ptr(ptl),
+              ptr(vm), ptr(ws), ptr(dL), ptr(dps), ptr(dpe), ptr(dom), ptr(dpm), ptr(dod), ptr(dpd), B, T)
+        return dps, dpe, dom, dpm, dod, dpd, None, None, None, None, None
+
+
+def gmd_losses(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm):
+    """-> tensor [4]: span_ground_loss, BCE(om)+BCE(pm), matching KL, order-discrimination CE (include/tsg_hip.h, K4)."""
+    return _GmdLosses.apply(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm)
+
+
 class _LinearSplit(torch.autograd.Function):
     """y = x w^T (+ b) with the two large GEMMs (forward, input gradient) in the split-precision mode; the weight
     gradient dY^T x has a small output and a T*B-long contraction, which the library's fp32 GEMM handles at the fp32 MFMA

@@ -1,0 +1,62 @@
+"""K4 (csrc/losses.hip): the four GMD training losses in one launch each way vs the torch formulation of
+shufflingvideosfortsg_amd.loss (itself pinned to the reference's loss.py by the golden tests) and vs the CPU oracle."""
+import pytest
+import torch
+
+from oracle import tsg_oracle as O
+from shufflingvideosfortsg_amd import functional as TF
+from shufflingvideosfortsg_amd import loss as L
+from shufflingvideosfortsg_amd.model.networks.attention import masked_softmax
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(B, T, seed, clamp_case=False):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    ps, pe = torch.softmax(r(B, T), 1), torch.softmax(r(B, T), 1)
+    om, pm, od, pd = r(B, T) * 2, r(B, T) * 2, r(B, 2), r(B, 2)
+    s1 = torch.randint(0, max(T // 2, 1), (B,), generator=g)
+    e1 = torch.minimum(s1 + torch.randint(0, T, (B,), generator=g), torch.full((B,), T - 1))
+    s2 = torch.randint(0, T, (B,), generator=g) if clamp_case else torch.minimum(s1 + 3, torch.full((B,), T - 1))   # slices that run past T-1
+    fs = torch.stack([s1, e1], 1); pfs = torch.stack([s2, torch.minimum(s2 + (e1 - s1), torch.full((B,), T - 1))], 1)
+    tl = (torch.rand(B, T, generator=g) > 0.4).float(); ptl = (torch.rand(B, T, generator=g) > 0.4).float()
+    n = torch.randint(max(T // 2, 1), T + 1, (B,), generator=g)
+    vm = (torch.arange(T)[None, :] < n[:, None]).float()
+    return ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm
+
+
+def _torch_losses(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm):
+    return torch.stack([L.span_ground_loss(ps, pe, fs), L.BCE_loss(om, tl, vm) + L.BCE_loss(pm, ptl, vm),
+                        L.matching_KL_divergence(masked_softmax(om, tl), masked_softmax(pm, ptl), fs, pfs),
+                        L.temporal_order_discrimination_loss(od, pd)])
+
+
+@pytest.mark.parametrize("B,T,clamp", [(64, 128, False), (5, 33, True), (3, 300, True), (1, 4, False), (130, 64, True)])
+def test_gmd_losses_kernel_vs_torch(B, T, clamp):
+    cpu = _inputs(B, T, B * 7 + T, clamp)
+    wgt = torch.tensor([0.7, 1.3, 2.0, 0.5])
+    ref_in = [t.clone().double().requires_grad_(True) if i < 6 else t for i, t in enumerate(cpu)]
+    ref = _torch_losses(*ref_in)
+    (ref * wgt.double()).sum().backward()
+    dev = [t.cuda().requires_grad_(True) if i < 6 else t.cuda() for i, t in enumerate(cpu)]
+    out = TF.gmd_losses(*dev)
+    (out * wgt.cuda()).sum().backward()
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), atol=2e-5, rtol=2e-5)
+    for i, name in enumerate(["ps", "pe", "om", "pm", "od", "pd"]):
+        torch.testing.assert_close(dev[i].grad.cpu().double(), ref_in[i].grad, atol=2e-6, rtol=2e-4, msg=lambda s, n=name: f"d{n}: {s}")
+
+
+def test_gmd_losses_kernel_vs_oracle():
+    """The same four numbers from the CPU oracle's restatement of the reference's loss.py."""
+    ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm = _inputs(16, 64, 5)
+    g = torch.Generator().manual_seed(1)                    # moments that fit both videos: the oracle slices, it does not clamp
+    s1 = torch.randint(0, 20, (16,), generator=g); ln = torch.randint(1, 30, (16,), generator=g); s2 = torch.randint(0, 30, (16,), generator=g)
+    fs, pfs = torch.stack([s1, s1 + ln - 1], 1), torch.stack([s2, s2 + ln - 1], 1)
+    tl, ptl = tl.int(), ptl.int()                           # integer labels, as the collate functions deliver them
+    out = TF.gmd_losses(*(t.cuda() for t in (ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm))).cpu()
+    want = torch.stack([O.span_ground_loss(ps, pe, fs.tolist()),
+                        O.bce_loss(om, tl, vm) + O.bce_loss(pm, ptl, vm),
+                        O.matching_kl_divergence(O.masked_softmax(om, tl), O.masked_softmax(pm, ptl), fs.tolist(), pfs.tolist()),
+                        O.temporal_order_discrimination_loss(od, pd)])
+    torch.testing.assert_close(out, want, atol=2e-5, rtol=2e-5)
