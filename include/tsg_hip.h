@@ -172,15 +172,17 @@ int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const void* Cs, cons
  * order-discriminator logits; fs, pfs int64 [B,2] ground-truth (start, end) clip indices of the original / shuffled video;
  * tl, ptl [B,T] temporal labels (0/1 as float); vm [B,T] video mask (float).  out[4] = (span_ground_loss,
  * BCE_loss(om,tl,vm) + BCE_loss(pm,ptl,vm), matching_KL_divergence(masked_softmax(om,tl), masked_softmax(pm,ptl), fs, pfs),
- * temporal_order_discrimination_loss(od, pd)) -- the caller applies the lambda weights.  ws: 32-byte workspace (zeroed by
- * the call; kept for the backward).  T <= 2048.  The backward writes the gradients of ps, pe, om, pm, od, pd given dL[4].  */
+ * temporal_order_discrimination_loss(od, pd)), all un-weighted, and out[4] = out[0] + lam_match out[1] + lam_kl out[2] +
+ * lam_disc out[3], the training loss of train.py:160 (out holds 5 floats).  ws: 32-byte workspace (zeroed by the call; kept
+ * for the backward).  T <= 2048.  The backward writes the gradients of ps, pe, om, pm, od, pd given dL[4] (gradient of the
+ * four losses) and / or dtotal[1] (gradient of out[4]); either may be NULL.                                              */
 int tsg_gmd_losses_fwd(const void* ps, const void* pe, const void* om, const void* pm, const void* od, const void* pd,
                        const void* fs, const void* pfs, const void* tl, const void* ptl, const void* vm,
-                       void* ws, void* out, int B, int T, void* stream);
+                       void* ws, void* out, int B, int T, float lam_match, float lam_kl, float lam_disc, void* stream);
 int tsg_gmd_losses_bwd(const void* ps, const void* pe, const void* om, const void* pm, const void* od, const void* pd,
                        const void* fs, const void* pfs, const void* tl, const void* ptl, const void* vm,
-                       const void* ws, const void* dL, void* dps, void* dpe, void* dom, void* dpm, void* dod, void* dpd,
-                       int B, int T, void* stream);
+                       const void* ws, const void* dL, const void* dtotal, void* dps, void* dpe, void* dom, void* dpm, void* dod,
+                       void* dpd, int B, int T, float lam_match, float lam_kl, float lam_disc, void* stream);
 
 /* ---- dense projection GEMM on the fp32 matrix cores ("tsg_gemm_*" of SURVEY section 8b) ------------------------------
  * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL): torch.nn.Linear's layout, i.e. the d x d projections of the path

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kLossThreads) void gmd_losses_fwd_kernel(
     const float* __restrict__ ps, const float* __restrict__ pe, const float* __restrict__ om, const float* __restrict__ pm,
     const float* __restrict__ od, const float* __restrict__ pd, const long long* __restrict__ fs, const long long* __restrict__ pfs,
     const float* __restrict__ tl, const float* __restrict__ ptl, const float* __restrict__ vm,
-    float* __restrict__ ws, float* __restrict__ out, int B, int T) {
+    float* __restrict__ ws, float* __restrict__ out, int B, int T, float lam1, float lam2, float lam3) {
   extern __shared__ float sm[];
   float* p1 = sm; float* p2 = sm + T;
   __shared__ float red[kLossThreads / 64];
@@ -85,27 +85,30 @@ __global__ __launch_bounds__(kLossThreads) void gmd_losses_fwd_kernel(
       __threadfence();
       const float a0 = atomicAdd(ws + 0, 0.f), a1 = atomicAdd(ws + 1, 0.f), a2 = atomicAdd(ws + 2, 0.f), a3 = atomicAdd(ws + 3, 0.f),
                   a4 = atomicAdd(ws + 4, 0.f);
-      out[0] = a0 / B;
-      out[1] = a1 / (a2 + kEps);
-      out[2] = a3 / B;
-      out[3] = a4 / (2.f * B);
+      const float l0 = a0 / B, l1 = a1 / (a2 + kEps), l2 = a3 / B, l3 = a4 / (2.f * B);
+      out[0] = l0; out[1] = l1; out[2] = l2; out[3] = l3;
+      out[4] = l0 + lam1 * l1 + lam2 * l2 + lam3 * l3;          // the training loss of train.py:160
     }
   }
 }
 
-// ws[2] = sum of the mask from the forward.  dL[4] = gradient of the four losses.
+// ws[2] = sum of the mask from the forward.  dL[4] = gradient of the four losses, dtot[1] = gradient of their weighted sum (either may be NULL).
 __global__ __launch_bounds__(kLossThreads) void gmd_losses_bwd_kernel(
     const float* __restrict__ ps, const float* __restrict__ pe, const float* __restrict__ om, const float* __restrict__ pm,
     const float* __restrict__ od, const float* __restrict__ pd, const long long* __restrict__ fs, const long long* __restrict__ pfs,
     const float* __restrict__ tl, const float* __restrict__ ptl, const float* __restrict__ vm, const float* __restrict__ ws,
-    const float* __restrict__ dL, float* __restrict__ dps, float* __restrict__ dpe, float* __restrict__ dom, float* __restrict__ dpm,
-    float* __restrict__ dod, float* __restrict__ dpd, int B, int T) {
+    const float* __restrict__ dL, const float* __restrict__ dtot, float* __restrict__ dps, float* __restrict__ dpe,
+    float* __restrict__ dom, float* __restrict__ dpm, float* __restrict__ dod, float* __restrict__ dpd, int B, int T,
+    float lam1, float lam2, float lam3) {
   extern __shared__ float sm[];
   float* p1 = sm; float* p2 = sm + T; float* g1 = sm + 2 * T; float* g2 = sm + 3 * T;    // probabilities and dKL/dp
   __shared__ float red[kLossThreads / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
   const size_t row = (size_t)b * T;
-  const float gsp = dL[0] / B, gbce = dL[1] / (ws[2] + kEps), gkl = dL[2] / B, gce = dL[3] / (2.f * B);
+  // gradient of loss i = (gradient of out[i], if given) + (gradient of the weighted total, if given) * lambda_i
+  const float gt = dtot ? dtot[0] : 0.f;
+  const float gsp = ((dL ? dL[0] : 0.f) + gt) / B, gbce = ((dL ? dL[1] : 0.f) + gt * lam1) / (ws[2] + kEps),
+              gkl = ((dL ? dL[2] : 0.f) + gt * lam2) / B, gce = ((dL ? dL[3] : 0.f) + gt * lam3) / (2.f * B);
   float z1 = 0.f, z2 = 0.f;
   for (int t = tid; t < T; t += kLossThreads) {
     const float e1 = __expf(om[row + t]) * tl[row + t], e2 = __expf(pm[row + t]) * ptl[row + t];
@@ -162,7 +165,7 @@ using namespace tsg;
 
 extern "C" int tsg_gmd_losses_fwd(const void* ps, const void* pe, const void* om, const void* pm, const void* od, const void* pd,
                                   const void* fs, const void* pfs, const void* tl, const void* ptl, const void* vm,
-                                  void* ws, void* out, int B, int T, void* stream) {
+                                  void* ws, void* out, int B, int T, float lam_match, float lam_kl, float lam_disc, void* stream) {
   const char* fn = "tsg_gmd_losses_fwd";
   for (const void* p : {ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, (const void*)ws, (const void*)out})
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
@@ -173,24 +176,26 @@ extern "C" int tsg_gmd_losses_fwd(const void* ps, const void* pe, const void* om
   if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
   hipLaunchKernelGGL(gmd_losses_fwd_kernel, dim3(B), dim3(kLossThreads), sizeof(float) * 2 * T, st, (const float*)ps, (const float*)pe,
                      (const float*)om, (const float*)pm, (const float*)od, (const float*)pd, (const long long*)fs,
-                     (const long long*)pfs, (const float*)tl, (const float*)ptl, (const float*)vm, (float*)ws, (float*)out, B, T);
+                     (const long long*)pfs, (const float*)tl, (const float*)ptl, (const float*)vm, (float*)ws, (float*)out, B, T,
+                     lam_match, lam_kl, lam_disc);
   return check_launch(fn);
 }
 
 extern "C" int tsg_gmd_losses_bwd(const void* ps, const void* pe, const void* om, const void* pm, const void* od, const void* pd,
                                   const void* fs, const void* pfs, const void* tl, const void* ptl, const void* vm,
-                                  const void* ws, const void* dL, void* dps, void* dpe, void* dom, void* dpm, void* dod, void* dpd,
-                                  int B, int T, void* stream) {
+                                  const void* ws, const void* dL, const void* dtotal, void* dps, void* dpe, void* dom, void* dpm,
+                                  void* dod, void* dpd, int B, int T, float lam_match, float lam_kl, float lam_disc, void* stream) {
   const char* fn = "tsg_gmd_losses_bwd";
-  for (const void* p : {ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, ws, dL, (const void*)dps, (const void*)dpe, (const void*)dom,
+  for (const void* p : {ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, ws, (const void*)dps, (const void*)dpe, (const void*)dom,
                         (const void*)dpm, (const void*)dod, (const void*)dpd})
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+  if (!dL && !dtotal) return set_error(TSG_E_NULL, "%s: dL and dtotal are both NULL", fn);
   int rc = loss_check(fn, B, T);
   if (rc) return rc;
   hipLaunchKernelGGL(gmd_losses_bwd_kernel, dim3(B), dim3(kLossThreads), sizeof(float) * 4 * T, static_cast<hipStream_t>(stream),
                      (const float*)ps, (const float*)pe, (const float*)om, (const float*)pm, (const float*)od, (const float*)pd,
                      (const long long*)fs, (const long long*)pfs, (const float*)tl, (const float*)ptl, (const float*)vm,
-                     (const float*)ws, (const float*)dL, (float*)dps, (float*)dpe, (float*)dom, (float*)dpm, (float*)dod,
-                     (float*)dpd, B, T);
+                     (const float*)ws, (const float*)dL, (const float*)dtotal, (float*)dps, (float*)dpe, (float*)dom, (float*)dpm,
+                     (float*)dod, (float*)dpd, B, T, lam_match, lam_kl, lam_disc);
   return check_launch(fn);
 }

@@ -97,10 +97,11 @@ def gmd_step(model, batch, params):
             and od.dim() == 2 and od.size(1) == 2):
         # K4: the four losses in one launch each way (csrc/losses.hip) instead of ~100 small torch launches
         from . import functional as TF
-        out = TF.gmd_losses(span["start"], span["end"], om, pm, od, pd, fs, pfs, gt["temporal_labels"], pgt["temporal_labels"],
-                            batch["video_mask"])
-        lg, l1, l2, ld = out[0], params["loss_m1_lambda"] * out[1], params["loss_m2_lambda"] * out[2], out[3]
-        return lg + l1 + l2 + params["loss_disc_lambda"] * ld, (lg, l1, l2, ld), span
+        lam = (params["loss_m1_lambda"], params["loss_m2_lambda"], params["loss_disc_lambda"])
+        parts, total = TF.gmd_losses(span["start"], span["end"], om, pm, od, pd, fs, pfs, gt["temporal_labels"],
+                                     pgt["temporal_labels"], batch["video_mask"], lam)
+        p = parts.detach()                                  # the parts are for logging; the gradient flows through `total`
+        return total, (p[0], lam[0] * p[1], lam[1] * p[2], p[3]), span
     lg = L.span_ground_loss(span["start"], span["end"], gt["framestps"])
     l1 = params["loss_m1_lambda"] * (L.BCE_loss(om, gt["temporal_labels"], batch["video_mask"])
                                      + L.BCE_loss(pm, pgt["temporal_labels"], batch["video_mask"]))

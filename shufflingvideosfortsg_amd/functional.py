@@ -418,11 +418,12 @@ class _LinearHip(torch.autograd.Function):
 
 
 class _GmdLosses(torch.autograd.Function):
-    """The four GMD training losses (K4, csrc/losses.hip) -> out[4] = (span, matching BCE, matching KL, order CE)."""
+    """The four GMD training losses (K4, csrc/losses.hip) -> (parts[4] = span, matching BCE, matching KL, order CE, all
+    un-weighted; total = span + lam[0] BCE + lam[1] KL + lam[2] CE)."""
 
     @staticmethod
     @_fwd
-    def forward(ctx, ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm):
+    def forward(ctx, ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, lam):
         require_device(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm)
         ps, pe, om, pm, od, pd = (_f32c(t) for t in (ps, pe, om, pm, od, pd))
         tl, ptl, vm = (t.to(torch.float32).contiguous() for t in (tl, ptl, vm))     # labels / masks arrive as int or bool
@@ -434,28 +435,36 @@ class _GmdLosses(torch.autograd.Function):
         if od.shape != (B, 2) or pd.shape != (B, 2) or fs.shape != (B, 2) or pfs.shape != (B, 2):
             raise ValueError("gmd_losses: od / pd / fs / pfs must be [B,2]")
         ws = torch.empty(8, device=om.device, dtype=torch.float32)
-        out = torch.empty(4, device=om.device, dtype=torch.float32)
+        out = torch.empty(5, device=om.device, dtype=torch.float32)
+        lam = tuple(float(v) for v in lam)
         _call("tsg_gmd_losses_fwd", om, ptr(ps), ptr(pe), ptr(om), ptr(pm), ptr(od), ptr(pd), ptr(fs), ptr(pfs), ptr(tl), ptr(ptl),
-              ptr(vm), ptr(ws), ptr(out), B, T)
+              ptr(vm), ptr(ws), ptr(out), B, T, *lam)
         ctx.save_for_backward(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, ws)
-        return out
+        ctx.lam = lam
+        ctx.set_materialize_grads(False)
+        return out[:4], out[4]
 
     @staticmethod
     @_bwd
-    def backward(ctx, dL):
+    def backward(ctx, dL, dtot):
         ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, ws = ctx.saved_tensors
         B, T = om.shape
-        dL = _f32c(dL)
         dps, dpe, dom, dpm = (torch.empty_like(om) for _ in range(4))
         dod, dpd = torch.empty_like(od), torch.empty_like(pd)
+        if dL is None and dtot is None:
+            dL = torch.zeros(4, device=om.device, dtype=torch.float32)
+        dL = _f32c(dL) if dL is not None else None
+        dtot = _f32c(dtot).reshape(1) if dtot is not None else None
         _call("tsg_gmd_losses_bwd", om, ptr(ps), ptr(pe), ptr(om), ptr(pm), ptr(od), ptr(pd), ptr(fs), ptr(pfs), ptr(tl), ptr(ptl),
-              ptr(vm), ptr(ws), ptr(dL), ptr(dps), ptr(dpe), ptr(dom), ptr(dpm), ptr(dod), ptr(dpd), B, T)
-        return dps, dpe, dom, dpm, dod, dpd, None, None, None, None, None
+              ptr(vm), ptr(ws), ptr(dL) if dL is not None else None, ptr(dtot) if dtot is not None else None,
+              ptr(dps), ptr(dpe), ptr(dom), ptr(dpm), ptr(dod), ptr(dpd), B, T, *ctx.lam)
+        return dps, dpe, dom, dpm, dod, dpd, None, None, None, None, None, None
 
 
-def gmd_losses(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm):
-    """-> tensor [4]: span_ground_loss, BCE(om)+BCE(pm), matching KL, order-discrimination CE (include/tsg_hip.h, K4)."""
-    return _GmdLosses.apply(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm)
+def gmd_losses(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, lam=(1.0, 1.0, 1.0)):
+    """-> (parts [4]: span_ground_loss, BCE(om)+BCE(pm), matching KL, order-discrimination CE -- un-weighted;
+    total = parts[0] + lam[0] parts[1] + lam[1] parts[2] + lam[2] parts[3])   (include/tsg_hip.h, K4)."""
+    return _GmdLosses.apply(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, lam)
 
 
 class _LinearSplit(torch.autograd.Function):

@@ -40,7 +40,8 @@ def test_gmd_losses_kernel_vs_torch(B, T, clamp):
     ref = _torch_losses(*ref_in)
     (ref * wgt.double()).sum().backward()
     dev = [t.cuda().requires_grad_(True) if i < 6 else t.cuda() for i, t in enumerate(cpu)]
-    out = TF.gmd_losses(*dev)
+    out, total = TF.gmd_losses(*dev, lam=(0.3, 0.6, 0.9))
+    torch.testing.assert_close(total, out[0] + 0.3 * out[1] + 0.6 * out[2] + 0.9 * out[3])
     (out * wgt.cuda()).sum().backward()
     torch.testing.assert_close(out.cpu().double(), ref.detach(), atol=2e-5, rtol=2e-5)
     for i, name in enumerate(["ps", "pe", "om", "pm", "od", "pd"]):
@@ -54,9 +55,27 @@ def test_gmd_losses_kernel_vs_oracle():
     s1 = torch.randint(0, 20, (16,), generator=g); ln = torch.randint(1, 30, (16,), generator=g); s2 = torch.randint(0, 30, (16,), generator=g)
     fs, pfs = torch.stack([s1, s1 + ln - 1], 1), torch.stack([s2, s2 + ln - 1], 1)
     tl, ptl = tl.int(), ptl.int()                           # integer labels, as the collate functions deliver them
-    out = TF.gmd_losses(*(t.cuda() for t in (ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm))).cpu()
+    out = TF.gmd_losses(*(t.cuda() for t in (ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm)))[0].cpu()
     want = torch.stack([O.span_ground_loss(ps, pe, fs.tolist()),
                         O.bce_loss(om, tl, vm) + O.bce_loss(pm, ptl, vm),
                         O.matching_kl_divergence(O.masked_softmax(om, tl), O.masked_softmax(pm, ptl), fs.tolist(), pfs.tolist()),
                         O.temporal_order_discrimination_loss(od, pd)])
     torch.testing.assert_close(out, want, atol=2e-5, rtol=2e-5)
+
+
+def test_gmd_losses_total_gradient():
+    """Gradient through the weighted total (what engine.gmd_step back-propagates) = the weighted sum of the parts' gradients,
+    also when both outputs carry gradient."""
+    cpu = _inputs(12, 48, 3)
+    lam = (0.5, 2.0, 1.5)
+    w = torch.tensor([1.0, lam[0], lam[1], lam[2]])
+    g = []
+    for mode in ("total", "parts", "both"):
+        dev = [t.cuda().requires_grad_(True) if i < 6 else t.cuda() for i, t in enumerate(cpu)]
+        parts, total = TF.gmd_losses(*dev, lam=lam)
+        loss = {"total": total, "parts": (parts * w.cuda()).sum(), "both": 0.5 * total + 0.5 * (parts * w.cuda()).sum()}[mode]
+        loss.backward()
+        g.append([d.grad.clone() for d in dev[:6]])
+    for a, b, c in zip(*g):
+        torch.testing.assert_close(a, b, atol=1e-7, rtol=1e-5)
+        torch.testing.assert_close(a, c, atol=1e-7, rtol=1e-5)

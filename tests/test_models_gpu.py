@@ -161,10 +161,12 @@ def test_baseline_golden(golden, tag, gemm, request):
     torch.testing.assert_close(score.cpu(), g.t("score"), **TOL)
 
 
+@pytest.mark.parametrize("losses", ["torch", "k4"])
 @pytest.mark.parametrize("gemm", [None, "f32s"])
-def test_gmd_golden(golden, gemm, request):
+def test_gmd_golden(golden, gemm, losses, request):
     """Full GMD train step (original + shuffled video, four losses) and eval_forward vs the reference; also with the
-    LSTM GEMMs in split-precision mode ("f32s"), which must meet the SAME fp32 tolerances."""
+    LSTM GEMMs in split-precision mode ("f32s"), which must meet the SAME fp32 tolerances.  losses: the collate's lists of
+    frame stamps select the torch formulation of the four losses, resident index tensors the fused kernel K4."""
     from shufflingvideosfortsg_amd import engine
     engine.precision(gemm)
     request.addfinalizer(lambda: engine.precision(None))
@@ -179,7 +181,11 @@ def test_gmd_golden(golden, gemm, request):
              "query_mask": None,
              "gt": {"framestps": g.a["framestps"].tolist(), "temporal_labels": c("ot"), "fore_masks": c("of"), "back_masks": c("ob")},
              "pseudo_gt": {"framestps": g.a["pframestps"].tolist(), "temporal_labels": c("pt"), "fore_masks": c("pf"), "back_masks": c("pb")}}
+    if losses == "k4":
+        for k in ("gt", "pseudo_gt"):
+            batch[k]["framestps"] = torch.tensor(batch[k]["framestps"], dtype=torch.long).cuda()
     loss, (lg, l1, l2, ld), span = engine.gmd_step(m, batch, engine.default_params())
+    assert (loss.grad_fn is not None) and (("GmdLosses" in type(loss.grad_fn).__name__) == (losses == "k4"))
     for got, key in ((span["start"], "start"), (span["end"], "end"), (lg, "lg"), (l1, "l1"), (l2, "l2"), (ld, "ld"), (loss, "loss")):
         torch.testing.assert_close(got.detach().cpu(), g.t(key), **TOL, msg=lambda m_, key=key: f"{key}: {m_}")
     loss.backward()
