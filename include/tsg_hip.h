@@ -184,6 +184,15 @@ int tsg_gmd_losses_bwd(const void* ps, const void* pe, const void* om, const voi
                        const void* ws, const void* dL, const void* dtotal, void* dps, void* dpe, void* dom, void* dpm, void* dod,
                        void* dpd, int B, int T, float lam_match, float lam_kl, float lam_disc, void* stream);
 
+/* ---- K5: matching head (VideoTextSemanticMatch = VideoTextConcat + TwoLayerdMLP, components/DistributionAlign.py:51-98)
+ * after the video-half GEMM, as K3 does for the boundary head: y [B,T,H] = video @ W1v^T (no bias), cs [B,H] = query @ W1s^T
+ * + b1, w2 [H], b2 [1]:   logits[b,t] = w2 . act(y[b,t,:] + cs[b,:]) + b2,   activation 0 = relu, 1 = tanh, 2 = sigmoid.
+ * The backward writes dy [B,T,H] and accumulates dcs [B,H], dw2 [H], db2 [1] (zeroed by the call).  H % 4 == 0, H <= 1024. */
+int tsg_match_head_fwd(const void* y, const void* cs, const void* w2, const void* b2, void* logits,
+                       int B, int T, int H, int activation, void* stream);
+int tsg_match_head_bwd(const void* y, const void* cs, const void* w2, const void* dlogits, void* dy, void* dcs,
+                       void* dw2, void* db2, int B, int T, int H, int activation, void* stream);
+
 /* ---- dense projection GEMM on the fp32 matrix cores ("tsg_gemm_*" of SURVEY section 8b) ------------------------------
  * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL): torch.nn.Linear's layout, i.e. the d x d projections of the path
  * (SCDM W_a / W_s attention.py:104-106, sent_linear VideoEncoder.py:48, MultiHead wq/wk/wv/wo attention.py:63-66, the

@@ -1,0 +1,185 @@
+// K5 -- matching head for gfx950: the part of VideoTextSemanticMatch (reference grounding/model/components/
+// DistributionAlign.py:51-98: VideoTextConcat -> TwoLayerdMLP) that follows the video-half GEMM.  As in K3 the first
+// Linear is split W1 = [W1v | W1s]: the sentence half is a per-pair row cs[b] = W1s q[b] + b1, so
+//     z[b,t,:] = y[b,t,:] + cs[b,:],   y = W1v video;      l[b,t] = w2 . act(z[b,t,:]) + b2,   act in {relu, tanh, sigmoid}
+// and the [B,T,Dv+Dq] concat tensor never exists.  As torch ops the tail (add, activation, the 1-output Linear) is three
+// passes over [B,T,H] forward and two degenerate GEMMs (K = 1 and M = 1) plus two passes backward.
+// forward : one wave per clip row (float4 per lane, coalesced), wave reduction of the dot product.  Reads y once.
+// backward: dy[b,t,:] = dl[b,t] act'(z) w2;  dcs[b,:] = sum_t dy[b,t,:];  dw2 = sum_{b,t} dl act(z);  db2 = sum dl.
+//           Workgroup = (pair, 32 clips): lanes own hidden columns, so dcs / dw2 are per-lane running sums over the
+//           workgroup's rows, folded across its waves in LDS and added to the outputs with atomics (zeroed by the call).
+#include "tsg_common.h"
+
+namespace tsg {
+namespace {
+
+constexpr int kMhThreads = 512;
+constexpr int kMhWaves = kMhThreads / kWave;
+constexpr int kMhRows = 32;              // clip rows per workgroup
+constexpr int kMhMaxH4 = 4;              // H <= 64 lanes * 4 * kMhMaxH4 = 1024 hidden columns
+
+__device__ __forceinline__ int mh_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+template <int ACT> __device__ __forceinline__ float act_f(float z) {          // 0 relu, 1 tanh, 2 sigmoid
+  if (ACT == 0) return fmaxf(z, 0.f);
+  if (ACT == 1) { const float e = fast_exp2(clampf(z, -44.f, 44.f) * k2Log2e); return 1.f - 2.f * fast_rcp(e + 1.f); }
+  return fast_rcp(1.f + fast_exp2(-z * kLog2e));
+}
+template <int ACT> __device__ __forceinline__ float act_d(float z, float a) {  // derivative given z and a = act(z)
+  if (ACT == 0) return z > 0.f ? 1.f : 0.f;
+  if (ACT == 1) return 1.f - a * a;
+  return a * (1.f - a);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(kMhThreads) void match_head_fwd_kernel(const float* __restrict__ y, const float* __restrict__ cs,
+                                                                    const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                    float* __restrict__ logit, int B, int T, int H) {
+  const int lane = threadIdx.x & 63, wv = mh_wave_id();
+  const int tiles = (T + kMhRows - 1) / kMhRows;
+  const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * kMhRows;
+  const int H4 = H / 4;
+  float4 c[kMhMaxH4], w[kMhMaxH4];
+#pragma unroll
+  for (int q = 0; q < kMhMaxH4; ++q) {
+    const int j = lane + 64 * q;
+    c[q] = j < H4 ? reinterpret_cast<const float4*>(cs + (size_t)b * H)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    w[q] = j < H4 ? reinterpret_cast<const float4*>(w2)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float bias = b2[0];
+#pragma unroll
+  for (int i = 0; i < kMhRows / kMhWaves; ++i) {
+    const int t = t0 + wv + kMhWaves * i;
+    if (t >= T) break;                                             // wave-uniform
+    const float4* row = reinterpret_cast<const float4*>(y + ((size_t)b * T + t) * H);
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < kMhMaxH4; ++q) {
+      const int j = lane + 64 * q;
+      if (j < H4) {
+        const float4 v = row[j];
+        acc += w[q].x * act_f<ACT>(v.x + c[q].x) + w[q].y * act_f<ACT>(v.y + c[q].y) + w[q].z * act_f<ACT>(v.z + c[q].z) +
+               w[q].w * act_f<ACT>(v.w + c[q].w);
+      }
+    }
+    acc = wave_allsum(acc);
+    if (lane == 0) logit[(size_t)b * T + t] = acc + bias;
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(kMhThreads) void match_head_bwd_kernel(const float* __restrict__ y, const float* __restrict__ cs,
+                                                                    const float* __restrict__ w2, const float* __restrict__ dl,
+                                                                    float* __restrict__ dy, float* __restrict__ dcs,
+                                                                    float* __restrict__ dw2, float* __restrict__ db2,
+                                                                    int B, int T, int H) {
+  __shared__ float fold[kMhWaves][256 * kMhMaxH4];                 // per wave: H partial sums (<= 1024 floats)
+  const int lane = threadIdx.x & 63, wv = mh_wave_id();
+  const int tiles = (T + kMhRows - 1) / kMhRows;
+  const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * kMhRows;
+  const int H4 = H / 4;
+  float4 c[kMhMaxH4], w[kMhMaxH4], sc[kMhMaxH4], sw[kMhMaxH4];
+#pragma unroll
+  for (int q = 0; q < kMhMaxH4; ++q) {
+    const int j = lane + 64 * q;
+    c[q] = j < H4 ? reinterpret_cast<const float4*>(cs + (size_t)b * H)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    w[q] = j < H4 ? reinterpret_cast<const float4*>(w2)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    sc[q] = make_float4(0.f, 0.f, 0.f, 0.f); sw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float sb = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMhRows / kMhWaves; ++i) {
+    const int t = t0 + wv + kMhWaves * i;
+    if (t >= T) break;
+    const size_t r = (size_t)b * T + t;
+    const float g = dl[r];
+    sb += g;
+    const float4* row = reinterpret_cast<const float4*>(y + r * H);
+    float4* drow = reinterpret_cast<float4*>(dy + r * H);
+#pragma unroll
+    for (int q = 0; q < kMhMaxH4; ++q) {
+      const int j = lane + 64 * q;
+      if (j < H4) {
+        const float4 v = row[j];
+        const float z[4] = {v.x + c[q].x, v.y + c[q].y, v.z + c[q].z, v.w + c[q].w};
+        const float ww[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
+        float d[4], a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] = act_f<ACT>(z[k]); d[k] = g * ww[k] * act_d<ACT>(z[k], a[k]); }
+        drow[j] = make_float4(d[0], d[1], d[2], d[3]);
+        sc[q].x += d[0]; sc[q].y += d[1]; sc[q].z += d[2]; sc[q].w += d[3];
+        sw[q].x += g * a[0]; sw[q].y += g * a[1]; sw[q].z += g * a[2]; sw[q].w += g * a[3];
+      }
+    }
+  }
+  // fold the waves' column sums, then one atomic per column and workgroup
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kMhMaxH4; ++q) {
+      const float4 v = pass == 0 ? sc[q] : sw[q];
+      reinterpret_cast<float4*>(&fold[wv][0])[lane + 64 * q] = v;
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += kMhThreads) {
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < kMhWaves; ++u) s += fold[u][col];
+      if (pass == 0) atomicAdd(dcs + (size_t)b * H + col, s); else atomicAdd(dw2 + col, s);
+    }
+  }
+  sb = (lane == 0) ? sb : 0.f;                                      // every lane of a wave carries the same row gradients
+  sb = wave_allsum(sb);
+  if (lane == 0) atomicAdd(db2, sb);
+}
+
+int mh_check(const char* fn, int B, int T, int H, int act) {
+  if (B <= 0 || T <= 0 || H <= 0) return set_error(TSG_E_SHAPE, "%s: non-positive dimension B=%d T=%d H=%d", fn, B, T, H);
+  if (H % 4 || H > 256 * kMhMaxH4) return set_error(TSG_E_SHAPE, "%s: H=%d must be a multiple of 4 and <= %d", fn, H, 256 * kMhMaxH4);
+  if (act < 0 || act > 2) return set_error(TSG_E_SHAPE, "%s: activation %d (0 relu, 1 tanh, 2 sigmoid)", fn, act);
+  return 0;
+}
+
+}  // namespace
+}  // namespace tsg
+
+using namespace tsg;
+
+extern "C" int tsg_match_head_fwd(const void* y, const void* cs, const void* w2, const void* b2, void* logits,
+                                  int B, int T, int H, int activation, void* stream) {
+  const char* fn = "tsg_match_head_fwd";
+  for (const void* p : {y, cs, w2, b2, (const void*)logits}) {
+    if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+    if (p != b2 && !aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
+  }
+  int rc = mh_check(fn, B, T, H, activation);
+  if (rc) return rc;
+  const int grid = B * cdiv(T, kMhRows);
+  auto st = static_cast<hipStream_t>(stream);
+  auto k = activation == 0 ? match_head_fwd_kernel<0> : activation == 1 ? match_head_fwd_kernel<1> : match_head_fwd_kernel<2>;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kMhThreads), 0, st, (const float*)y, (const float*)cs, (const float*)w2, (const float*)b2,
+                     (float*)logits, B, T, H);
+  return check_launch(fn);
+}
+
+extern "C" int tsg_match_head_bwd(const void* y, const void* cs, const void* w2, const void* dlogits, void* dy, void* dcs,
+                                  void* dw2, void* db2, int B, int T, int H, int activation, void* stream) {
+  const char* fn = "tsg_match_head_bwd";
+  for (const void* p : {y, cs, w2, dlogits, (const void*)dy, (const void*)dcs, (const void*)dw2, (const void*)db2}) {
+    if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+    if (p != db2 && !aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
+  }
+  int rc = mh_check(fn, B, T, H, activation);
+  if (rc) return rc;
+  auto st = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(dcs, 0, sizeof(float) * (size_t)B * H, st);
+  if (e == hipSuccess) e = hipMemsetAsync(dw2, 0, sizeof(float) * H, st);
+  if (e == hipSuccess) e = hipMemsetAsync(db2, 0, sizeof(float), st);
+  if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+  const int grid = B * cdiv(T, kMhRows);
+  auto k = activation == 0 ? match_head_bwd_kernel<0> : activation == 1 ? match_head_bwd_kernel<1> : match_head_bwd_kernel<2>;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kMhThreads), 0, st, (const float*)y, (const float*)cs, (const float*)w2,
+                     (const float*)dlogits, (float*)dy, (float*)dcs, (float*)dw2, (float*)db2, B, T, H);
+  return check_launch(fn);
+}

@@ -417,6 +417,44 @@ class _LinearHip(torch.autograd.Function):
         return dx, dw, db
 
 
+class _MatchHead(torch.autograd.Function):
+    """logits[b,t] = w2 . act(y[b,t,:] + cs[b,:]) + b2  (K5, csrc/match_head.hip)."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, y, cs, w2, b2, act):
+        require_device(y, cs, w2, b2)
+        y, cs, w2, b2 = _f32c(y), _f32c(cs), _f32c(w2).view(-1), _f32c(b2).view(-1)
+        B, T, H = y.shape
+        if cs.shape != (B, H) or w2.numel() != H or b2.numel() != 1:
+            raise ValueError(f"match_head: shape mismatch y{tuple(y.shape)} cs{tuple(cs.shape)} w2{tuple(w2.shape)} b2{tuple(b2.shape)}")
+        out = torch.empty(B, T, device=y.device, dtype=torch.float32)
+        _call("tsg_match_head_fwd", y, ptr(y), ptr(cs), ptr(w2), ptr(b2), ptr(out), B, T, H, int(act))
+        ctx.save_for_backward(y, cs, w2)
+        ctx.act = int(act)
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dl):
+        y, cs, w2 = ctx.saved_tensors
+        B, T, H = y.shape
+        dl = _f32c(dl)
+        dy = torch.empty_like(y)
+        dcs = torch.empty_like(cs); dw2 = torch.empty_like(w2); db2 = torch.empty(1, device=y.device, dtype=torch.float32)
+        _call("tsg_match_head_bwd", y, ptr(y), ptr(cs), ptr(w2), ptr(dl), ptr(dy), ptr(dcs), ptr(dw2), ptr(db2), B, T, H, ctx.act)
+        return dy, dcs, dw2, db2, None
+
+
+_ACTS = {"relu": 0, "tanh": 1, "sigmoid": 2}
+
+
+def match_head(y, cs, w2, b2, activation="relu"):
+    """Matching-head tail (include/tsg_hip.h, K5): y [B,T,H] video half of the first Linear, cs [B,H] query half + bias,
+    w2 [H] / b2 [1] the 1-output second Linear -> raw matching logits [B,T]."""
+    return _MatchHead.apply(y, cs, w2.reshape(-1), b2.reshape(-1), _ACTS[activation])
+
+
 class _GmdLosses(torch.autograd.Function):
     """The four GMD training losses (K4, csrc/losses.hip) -> (parts[4] = span, matching BCE, matching KL, order CE, all
     un-weighted; total = span + lam[0] BCE + lam[1] KL + lam[2] CE)."""
