@@ -563,8 +563,12 @@ class _BiLSTMLayer(torch.autograd.Function):
         h = W_hh.shape[2]
         if W_ih.shape != (8 * h, I) or W_hh.shape != (2, 4 * h, h) or bias.numel() != 8 * h:
             raise ValueError(f"bilstm: shape mismatch x{tuple(x.shape)} W_ih{tuple(W_ih.shape)} W_hh{tuple(W_hh.shape)}")
+        ctx.Ws = None
         if _GEMM_DTYPE is None:
             Gx, kbias = torch.addmm(bias, x.view(T * B, I), W_ih.t()), None   # [rows,2,4h]; bias in the GEMM epilogue
+        elif _GEMM_DTYPE == "f32s" and (T * B) % 4 == 0 and I % 4 == 0 and h % 4 == 0:
+            ctx.Ws = split_bf16x3(W_ih, 1, True)                              # [8h, 3I] (hi, lo, hi): kept for the backward's dX
+            Gx, kbias = torch.mm(split_bf16x3(x.view(T * B, I), 1, False), ctx.Ws.t(), out_dtype=torch.float32), bias
         else:
             Gx, kbias = _mm(x.view(T * B, I), W_ih.t()), bias                 # bias added inside the recurrence kernel
         out = torch.empty((B, T, 2 * h) if bm else (T, B, 2 * h), device=x.device, dtype=torch.float32)
@@ -627,7 +631,8 @@ class _BiLSTMLayer(torch.autograd.Function):
                 # dX = dG W_ih from the SAME planes: At viewed as [(gate column, plane), T*B] is the transposed left operand
                 # with the contraction ordered (column, plane); W_ih's (hi, lo, hi) planes in that order, K-contiguous, are a
                 # 24 MB permute of its split.  No second pass over dG (110 us per layer).
-                Wt = split_bf16x3(W_ih, 1, True).view(8 * h, 3, I).permute(2, 0, 1).reshape(I, 24 * h)
+                Ws = ctx.Ws if ctx.Ws is not None else split_bf16x3(W_ih, 1, True)
+                Wt = Ws.view(8 * h, 3, I).permute(2, 0, 1).reshape(I, 24 * h)
                 dx = torch.mm(At.view(24 * h, TB).t(), Wt.t(), out_dtype=torch.float32).view(x.shape)
             split_bf16x3_t(x2, 0, I, 0, True, Bt, 0, dup_row0=I + h)         # x planes, in both directions' batches
             split_bf16x3_t(o2, 0, h, shift, True, Bt, I, period)             # h_{t-1}, forward direction
