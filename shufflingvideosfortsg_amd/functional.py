@@ -638,8 +638,8 @@ class _BiLSTMLayer(torch.autograd.Function):
             split_bf16x3_t(o2, 0, h, shift, True, Bt, I, period)             # h_{t-1}, forward direction
             split_bf16x3_t(o2, h, h, -shift, True, Bt, 2 * I + h, period)    # h_{t+1}, reverse direction
             D = torch.bmm(At.view(2, 4 * h, 3 * TB), Bt.view(2, I + h, 3 * TB).transpose(1, 2), out_dtype=torch.float32)
-            dW_ih = D[:, :, :I].reshape(8 * h, I)
-            dW_hh = D[:, :, I:]
+            dW_ih = D[:, :, :I].contiguous().view(8 * h, I)                 # contiguous blocks: the per-parameter slices autograd
+            dW_hh = D[:, :, I:].contiguous()                                # cuts from them are taken over as they are (no clones)
         else:
             # the step whose partner is the zero state drops out, so both operands are plain strided VIEWS
             dW_ih = _mm(dGf.t(), x2)
