@@ -403,6 +403,23 @@ __device__ __forceinline__ unsigned xcc_id() {
 constexpr int kSyncGroupWord = 16;               // sync[16 + group] = XCD mask of exchange group (direction, batch slice)
 constexpr int kSyncBytes = TSG_LSTM_SYNC_BYTES;  // error word, arrival counter, debug / timing words, <= 256 group masks
 static_assert(kSyncBytes >= 4 * (kSyncGroupWord + 256), "group masks fit the sync workspace");
+// Workgroup barrier for the LDS hand-offs inside the step loops: release / acquire on the LDS address space only, so only
+// this wave's LDS operations are waited for (s_waitcnt lgkmcnt(0)).  __syncthreads() also fences GLOBAL memory (vmcnt(0) in
+// front of the barrier), which would put every load requested for the next step on the step's critical path.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// The launch's error word, read inside the poll loops (every 32nd retry).  Load and wait in ONE asm statement: as a compiler-
+// visible load its destination register stayed "pending" for the waitcnt pass across the loop, which then put a
+// conservative s_waitcnt vmcnt(0) in front of the first MFMA that reused the register -- a wait for the loads requested
+// for the next step, in the middle of the step.
+__device__ __forceinline__ unsigned err_word(const unsigned* sync) {
+  unsigned v;
+  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(sync) : "memory");
+  return v;
+}
 // A bounded wait expired: raise the launch's error word (what the other workgroups look at) and, when the caller registered
 // one (tsg_lstm_error_sink), the process-wide sink -- host-mapped memory the host can read without synchronising, so a
 // failed launch is reported by the next call instead of silently leaving invalid results.
@@ -473,8 +490,11 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
   float* Ht = Hl + kSlabFloats;                          // [16][kHLB] dwords), then Ht [16][33] = this step's h tile (16 rows x
   unsigned* Hhi = reinterpret_cast<unsigned*>(Hl);       // 32 units), gathered for whole-line stores
   unsigned* Hlo = Hhi + 16 * kHLB;
-  volatile unsigned* fail = reinterpret_cast<unsigned*>(Ht + 16 * 33);     // (region sized for UW = 32)     // raised by a wave whose bounded wait expired
-  if (threadIdx.x == 0) *fail = 0u;
+  // raised by a wave whose bounded wait expired.  A static __shared__ variable: through a pointer derived from the dynamic
+  // LDS block the compiler lost the address space and read the flag with a FLAT load, whose vmcnt(0) wait behind the barrier
+  // also waited for the loads requested for the next step.
+  __shared__ unsigned s_fail;
+  if (threadIdx.x == 0) s_fail = 0u;
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int uslices = h / UW, bslices = (B + 15) / 16;
   const int vidx = xcd_major_index(), group = vidx / uslices;     // exchange group = (direction, batch slice): its uslices
@@ -601,9 +621,9 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
           if (!raw) break;
           // the error word (a memory round trip) is looked at on every 32nd retry only; a wave that gives up also raises the
           // workgroup's LDS flag, which is what the other waves check after the barrier below
-          if ((++spins & 31) == 0 && (spins > (kSpinLimit >> 6) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+          if ((++spins & 31) == 0 && (spins > (kSpinLimit >> 6) || err_word(sync) != 0u)) {
             raise_error(sync, esink);
-            *fail = 1u;
+            __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
           }
         }
@@ -631,9 +651,9 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
           if (r < 16) *reinterpret_cast<f32x4*>(Hl + r * HLS + c4 * 4) = v[i];
         }
       }
-      __syncthreads();
+      lds_barrier();
       TSG_TICK(1)                                            // slab in LDS, workgroup met
-      if (*fail) return;                                     // a bounded wait expired in this workgroup
+      if (__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;     // a bounded wait expired in this workgroup
       if constexpr (SPLIT) {
         // B operand: k block j of row jb = 4 dwords at 16j + 4ku of each plane, one ds_read_b128 per plane, requested PFB
         // blocks ahead; three independent accumulator chains (hi*hi, hi*lo, lo*hi), the two small ones summed first
@@ -697,7 +717,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
       cprev = c;
       Ht[jb * HTS + at * 4 + ku] = go * tanh_f(c);
     }
-    __syncthreads();                                        // tile complete; the slab in LDS is free again
+    lds_barrier();                                        // tile complete; the slab in LDS is free again
     {
       const int row = tid / UW, col = tid % UW;
       if (b0 + row < B) store_x(out + seq_row(tt, b0 + row, B, T, bm) * 2 * h + d * h + us * UW + col, Ht[row * HTS + col], local);
@@ -759,8 +779,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
   unsigned* Dlo = Dhi + 16 * kDLB;
   float* Pl = Dl + kDlFloats;                     // [16][kPLS]  partial dh of all h units, gathered for whole-line stores
   float* Ql = Pl + 16 * kPLS;                     // [4][16][kQLS] sums of the polled blocks per producer group
-  volatile unsigned* fail = reinterpret_cast<unsigned*>(Ql + 4 * 16 * kQLS);   // raised by a wave whose bounded wait expired
-  if (threadIdx.x == 0) *fail = 0u;
+  __shared__ unsigned s_fail;                     // raised by a wave whose bounded wait expired (static: see the forward kernel)
+  if (threadIdx.x == 0) s_fail = 0u;
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int nus = h / 32, bslices = (B + 15) / 16;         // TW = h / 128 = 16-unit tiles per wave = float4 per thread
   const int vidx = xcd_major_index(), group = vidx / nus;   // exchange group = (direction, batch slice), see the forward kernel
@@ -825,8 +845,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float cc = 0.f, cpv = 0.f, dov = 0.f;
     if (live) {
-      // (requested here, in front of the poll; requesting them one step ahead, after the previous poll -- what the forward
-      // kernel does with its input gates -- measured 5.0 instead of 4.6 us per step)
+      // (requested here, in front of the poll.  With these operands L2-resident the step measures 3.8 instead of 4.6 us, but
+      // requesting them one step ahead, after the previous poll -- what the forward kernel does with its input gates --
+      // measured 4.8-5.6 us in every variant tried)
       const size_t sidx = (((size_t)tt * 2 + d) * B + b) * h + u;
       g4 = *reinterpret_cast<const float4*>(R + sidx * 4);
       cc = Cs[sidx];
@@ -857,9 +878,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
           if (((q[i][0] & q[i][1] & q[i][2] & q[i][3]) & 1u) != gen || ((q[i][0] | q[i][1] | q[i][2] | q[i][3]) & 1u) != gen) raw |= 1u << i;
         raw &= pending;
         if (!raw) break;
-        if ((++spins & 31) == 0 && (spins > (kSpinLimit >> 6) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        if ((++spins & 31) == 0 && (spins > (kSpinLimit >> 6) || err_word(sync) != 0u)) {
           raise_error(sync, esink);
-          *fail = 1u;                                        // (error word read on every 32nd retry only, see the forward kernel)
+          __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (error word read on every 32nd retry only)
           break;
         }
       }
@@ -869,8 +890,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
       for (int i = 0; i < 4; ++i)
         if (i < TW) sum += (f32x4){__uint_as_float(q[i][0]), __uint_as_float(q[i][1]), __uint_as_float(q[i][2]), __uint_as_float(q[i][3])};
       *reinterpret_cast<f32x4*>(Ql + (pg * 16 + pr) * kQLS + 4 * pc) = sum;
-      __syncthreads();
-      if (*fail) return;                                     // a bounded wait expired in this workgroup
+      lds_barrier();
+      if (__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;     // a bounded wait expired in this workgroup
 #pragma unroll
       for (int g = 0; g < 4; ++g) rec += Ql[(g * 16 + row) * kQLS + ul];
     }
@@ -902,17 +923,23 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
     }
     if (step > 0) TSG_TICK(1)                                // reduce + cell backward + dG / Dl stores issued
     if (step + 1 < T) {
-      __syncthreads();                                       // the dG tile is complete (and Ql is free again)
+      lds_barrier();                                       // the dG tile is complete (and Ql is free again)
       if (step > 0) TSG_TICK(4)                              // (timing builds: the wait at this barrier)
       f32x4 acc[TW];
 #pragma unroll
       for (int t = 0; t < TW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if constexpr (SPLIT) {
-        // per k block: hi*hi into acc, hi*lo and lo*hi into a second accumulator per tile (summed at the end); consecutive
-        // MFMAs always sit on different accumulators
-        f32x4 accc[TW];
+        // per k block: hi*hi, hi*lo and lo*hi; consecutive MFMAs always sit on different accumulators.  With >= 3 tiles per
+        // wave the three products of a tile share ONE accumulator (the tiles' round robin keeps dependent MFMAs >= 3 apart),
+        // which frees the 16 VGPRs the operands requested for the next step need (with a second accumulator set the kernel
+        // spilled a W_hh fragment to scratch and re-read it in front of an MFMA: 5.0 instead of 4.6 us per step); fewer tiles:
+        // a second accumulator per tile for the two small products
+        constexpr bool ONE = TW >= 3;
+        f32x4 accc[ONE ? 1 : TW];
+        if constexpr (!ONE) {
 #pragma unroll
-        for (int t = 0; t < TW; ++t) accc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int t = 0; t < TW; ++t) accc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         const unsigned* dr = Dhi + jb * kDLB + 4 * ku;
         u32x4 nh = *reinterpret_cast<const u32x4*>(dr), nl = *reinterpret_cast<const u32x4*>(dr + 16 * kDLB);
 #pragma unroll
@@ -924,13 +951,22 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
           }
 #pragma unroll
           for (int t = 0; t < TW; ++t) acc[t] = mfma_bf16(ahi[t][kb], vh, acc[t]);
+          if constexpr (ONE) {
 #pragma unroll
-          for (int t = 0; t < TW; ++t) accc[t] = mfma_bf16(ahi[t][kb], vl, accc[t]);
+            for (int t = 0; t < TW; ++t) acc[t] = mfma_bf16(ahi[t][kb], vl, acc[t]);
 #pragma unroll
-          for (int t = 0; t < TW; ++t) accc[t] = mfma_bf16(alo[t][kb], vh, accc[t]);
+            for (int t = 0; t < TW; ++t) acc[t] = mfma_bf16(alo[t][kb], vh, acc[t]);
+          } else {
+#pragma unroll
+            for (int t = 0; t < TW; ++t) accc[t] = mfma_bf16(ahi[t][kb], vl, accc[t]);
+#pragma unroll
+            for (int t = 0; t < TW; ++t) accc[t] = mfma_bf16(alo[t][kb], vh, accc[t]);
+          }
         }
+        if constexpr (!ONE) {
 #pragma unroll
-        for (int t = 0; t < TW; ++t) acc[t] += accc[t];
+          for (int t = 0; t < TW; ++t) acc[t] += accc[t];
+        }
       } else {
       const float* drow = Dl + jb * kDLS + 4 * ku;
       f32x4 bnext = *reinterpret_cast<const f32x4*>(drow);   // B fragment of step s8+1 requested before the MFMAs of step s8
@@ -947,7 +983,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
 #pragma unroll
       for (int t = 0; t < TW; ++t) *reinterpret_cast<f32x4*>(Pl + jb * kPLS + 16 * (wv * TW + t) + 4 * ku) = acc[t];
       if (step > 0) TSG_TICK(5)                              // (timing builds: MFMAs issued and their results written to LDS)
-      __syncthreads();
+      lds_barrier();
       if (step > 0) TSG_TICK(2)                              // MFMA + gather
       const unsigned gtag = ((unsigned)step >> 2) & 1u;      // generation of slot step%4, carried in the low mantissa bit
       for (int i = 0; i < TW; ++i) {
