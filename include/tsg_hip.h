@@ -142,6 +142,10 @@ int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* Whh, void* o
  * that launch's sync workspace is set as well).  NULL (default) disables it.  The Python host registers a pinned word and
  * checks it on every LSTM call, so a failed launch raises at the next call instead of passing silently.               */
 int tsg_lstm_error_sink(void* flag);
+/* Allow (default, TSG_LSTM_L2X) or forbid the exchange that stays inside one XCD's L2 (plain stores when a group's one-XCD
+ * placement is verified); forbidden = write-through stores always.  The Python host turns it off when its start-up self-test
+ * of the persistent kernels reports an expired wait.                                                                       */
+int tsg_lstm_set_l2_exchange(int on);
 
 /* backward of the recurrence: dOut [T,B,2h] (+ optional dHn [2,B,h] added at each direction's last step)
  * -> dG [T,B,2,4h] = dL/d(pre-activation gates); the caller derives dX, dW_ih, dW_hh, db from it with

@@ -1025,11 +1025,12 @@ static int persist_mode() {
   if (v == -2) { const char* e = getenv("TSG_LSTM_PERSIST"); v = e ? atoi(e) : -1; }
   return v;
 }
+static int g_l2x = -1;            // -1: not decided yet (TSG_LSTM_L2X, default on); tsg_lstm_set_l2_exchange overrides
 static int l2_exchange() {        // TSG_LSTM_L2X=0: always write-through exchange stores (A/B measurements)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TSG_LSTM_L2X"); v = e ? (atoi(e) != 0) : 1; }
-  return v;
+  if (g_l2x < 0) { const char* e = getenv("TSG_LSTM_L2X"); g_l2x = e ? (atoi(e) != 0) : 1; }
+  return g_l2x;
 }
+extern "C" int tsg_lstm_set_l2_exchange(int on) { g_l2x = on != 0; return 0; }
 static unsigned* g_error_sink = nullptr;
 extern "C" int tsg_lstm_error_sink(void* p) { g_error_sink = static_cast<unsigned*>(p); return 0; }
 static int launch_flags() {       // bit 0: L2-local exchange allowed; bit 1: inject a start-barrier timeout (tests)

@@ -59,11 +59,44 @@ def check_lstm_errors() -> None:
     if _lstm_sink is None:
         _lstm_sink = torch.zeros(1, dtype=torch.int32).pin_memory()
         check(load().tsg_lstm_error_sink(_lstm_sink.data_ptr()), "tsg_lstm_error_sink")
+        _lstm_selftest()
     elif int(_lstm_sink[0]) != 0:
         _lstm_sink[0] = 0
         raise LstmWaitExpired("a persistent LSTM kernel's bounded wait expired (workgroups not co-resident, e.g. the GPU is shared "
                               "with another process?): the recurrence outputs of that launch are invalid.  TSG_LSTM_PERSIST=0 "
                               "selects the launch-per-step kernels.")
+
+
+def _lstm_selftest() -> None:
+    """Once per process, before the first LSTM launch: a short persistent forward + backward at the full-chip grid
+    ([128, 8, 512], 256 workgroups) on scratch data, synchronised.  If a bounded wait expires with the L2-local exchange
+    allowed, the exchange falls back to write-through stores for the rest of the process (and the test is repeated); if it
+    expires again the persistent kernels cannot run here and LstmWaitExpired is raised."""
+    import warnings
+    lib = load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B, T, h = 128, 8, 512
+    st = torch.cuda.current_stream(dev).cuda_stream
+    Gx = torch.zeros(T, B, 2, 4 * h, device=dev); W = torch.zeros(2, 4 * h, h, device=dev)
+    out = torch.empty(T, B, 2 * h, device=dev); R = torch.empty(T, 2, B, h, 4, device=dev); Cs = torch.empty(T, 2, B, h, device=dev)
+    dG = torch.empty(T, B, 2, 4 * h, device=dev); dC = torch.empty(2, B, h, device=dev)
+    nb = int(lib.tsg_lstm_bwd_ws_bytes(B, T, h))
+    ws = torch.empty(nb // 4 + 4, device=dev)
+    for attempt in range(2):
+        sync = torch.empty(512, device=dev, dtype=torch.int32)
+        check(lib.tsg_lstm_fwd_bias(ptr(Gx), None, ptr(W), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, TSG_F32S, 0, st), "tsg_lstm_fwd_bias")
+        check(lib.tsg_lstm_bwd_ws_layout(ptr(W), ptr(R), ptr(Cs), ptr(out), None, ptr(dG), ptr(dC), ptr(ws), nb, None, B, T, h,
+                                         TSG_F32S, 0, st), "tsg_lstm_bwd_ws_layout")
+        torch.cuda.synchronize(dev)
+        if int(_lstm_sink[0]) == 0:
+            return
+        _lstm_sink[0] = 0
+        if attempt == 0:
+            warnings.warn("persistent LSTM self-test: a bounded wait expired with the L2-local exchange; falling back to "
+                          "write-through exchange stores for this process (TSG_LSTM_L2X=0)")
+            check(lib.tsg_lstm_set_l2_exchange(0), "tsg_lstm_set_l2_exchange")
+    raise LstmWaitExpired("persistent LSTM self-test failed twice: the persistent kernels cannot run on this device "
+                          "(is the GPU shared?).  TSG_LSTM_PERSIST=0 selects the launch-per-step kernels.")
 
 
 def _call(name: str, like: torch.Tensor, *args) -> None:
