@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the cross-modal matching hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: one rank per GPU over RCCL.  Either the caller launches the ranks (``python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N``: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or,
+when WORLD_SIZE is not set, this process starts them itself as CHILD processes -- before it has imported torch or touched
+a GPU -- relays rank 0's one JSON line and exits with the launcher's code.  A world size different from --gpus is an error.
 
 One "step" = one full training step of the grounding model over one synthetic batch of B=64
 clip-query pairs per GPU at [T_clip=128, T_word=20, d=1024] (BASELINE.json metric shape), fp32:
@@ -11,9 +16,10 @@ the QAVE baseline step.  Inputs are generated on the host and made resident in H
 region.  Weak scaling: per-GPU batch fixed, `value` = pairs of ALL ranks / max-over-ranks time.
 
 The one JSON line also carries
-  roofline     : the cross-attention kernel (K1 forward, tsg_scdm_attn_fwd): algorithmic bytes per
-                 launch / its mean duration measured with events on the launch stream INSIDE the timed
-                 steps, against the 8 TB/s HBM3E peak;
+  roofline     : the cross-attention kernel as the step launches it (K1 forward with the gate epilogue,
+                 tsg_scdm_gate_fwd; the plain tsg_scdm_attn_fwd for a model without the gate): algorithmic
+                 bytes per launch / its mean duration measured with events on the launch stream INSIDE the
+                 timed steps, against the 8 TB/s HBM3E peak;
   kernels      : the same for the other hot-path kernels (informational);
   cpu_baseline : the CPU oracle (oracle/tsg_oracle.py, a port of the reference's op graph) running
                  the same step on a bounded sample of the same workload on this host's cores.
@@ -26,11 +32,75 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="gmd", choices=["gmd", "qave"])
+    ap.add_argument("--B", type=int, default=64, help="clip-query pairs per GPU")
+    ap.add_argument("--T", type=int, default=128)
+    ap.add_argument("--N", type=int, default=20)
+    ap.add_argument("--d", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=32, help="pairs in the CPU-baseline sample (0 = skip); bounded to ~30 s")
+    ap.add_argument("--no-micro", action="store_true", help="skip the stand-alone K1 / K2 launches")
+    ap.add_argument("--dtype", default="f32s", choices=["f32", "bf16", "f32s"],
+                    help="precision mode of the GEMM-shaped glue (LSTM GEMMs and recurrence products, large projections); the hot-path "
+                         "HIP kernels are f32 in all of them.  "
+                         "f32s (default): split-precision bf16 MFMA products, hi*hi+hi*lo+lo*hi with fp32 accumulate -- error at the "
+                         "fp32 GEMM's level, the parity suite passes at the fp32 tolerances, and it is above the bf16 that BASELINE "
+                         "config 2 names; f32: rocBLAS fp32 GEMMs; bf16: bf16 operands, fp32 accumulate (~1e-3 from the reference)")
+    ap.add_argument("--predictor", default="mlp", choices=["mlp", "self_attn"],
+                    help="boundary head: mlp (reference default, K3) or self_attn (temporal self-attention, K2 in the step)")
+    ap.add_argument("--fwd-only", action="store_true",
+                    help="a step is the forward pass + losses under no_grad (BASELINE config 1 is forward-only); `value` is then "
+                         "forward pairs/s.  Without the flag the forward-only rate is a side measurement (`fwd_only`)")
+    ap.add_argument("--time-all", action="store_true", help="event-time every C-ABI launch (perturbs the step time)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the side measurements (other GEMM-operand modes, forward-only)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(a):
+    """--gpus N > 1 without a launcher environment: start N ranks as children of THIS process through
+    torch.distributed.run (rendezvous on 127.0.0.1, a free port), relay the one JSON line rank 0 prints and return the
+    launcher's exit code.  Nothing here imports torch or touches a GPU: a process that has initialised the GPU must never
+    be replaced or re-executed, and this parent never initialises it."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
+    print(f"[bench] starting {a.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if p.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(p.stdout)
+        print(f"[bench] launcher exit code {p.returncode}, {len(lines)} result lines", file=sys.stderr, flush=True)
+        return p.returncode or 1
+    got = json.loads(lines[0])
+    if got.get("n_gpus") != a.gpus or got.get("rccl_ranks") != a.gpus:
+        print(f"[bench] asked for {a.gpus} GPUs, result says n_gpus={got.get('n_gpus')} rccl_ranks={got.get('rccl_ranks')}",
+              file=sys.stderr, flush=True)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _a = parse_args()
+    if _a.gpus > 1:
+        sys.exit(spawn_ranks(_a))
+
+import torch                              # noqa: E402
+import torch.distributed as dist          # noqa: E402
 
 from shufflingvideosfortsg_amd import data, engine, functional  # noqa: E402
 from shufflingvideosfortsg_amd.dp import FlatGradAllReduce      # noqa: E402
@@ -154,59 +224,43 @@ def cpu_baseline(kind, params, T, N, sample_B):
             out = O.baseline_forward(sd, b["video"], b["query"], b["video_mask"])
             loss = O.span_ground_loss(out["start"], out["end"], b["gt"]["framestps"])
         loss.backward()
-    # The oracle's LSTM is a Python loop of small GEMMs: more than ~16 intra-op threads only adds
-    # fork/join overhead (with all 256 host threads of the GPU box one step takes many minutes).
-    cores = min(os.cpu_count() or 1, 16)
+    # The oracle's LSTM is a Python loop of small GEMMs: beyond ~32 intra-op threads the fork/join overhead dominates
+    # (with all 256 host threads of the GPU box one step takes many minutes), so the thread count is capped and stated.
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    log(f"cpu baseline: oracle {kind} step on {cores} threads")
-    step(1)                                   # warm-up
+    sB = max(1, min(16, sample_B))                         # pairs per CPU step
+    log(f"cpu baseline: oracle {kind} steps of {sB} pairs on {cores} of {os.cpu_count()} host threads")
+    step(2)                                   # warm-up
     t0 = time.time()
     done = 0
-    while done < sample_B and time.time() - t0 < 20.0:     # bounded: at most ~30 s of CPU work
-        step(2)
-        done += 2
+    while done < sample_B and time.time() - t0 < 30.0:     # bounded: about 10-30 s of CPU work
+        step(sB)
+        done += sB
     dt = time.time() - t0
     log(f"cpu baseline: {done} pairs in {dt:.1f} s")
     return {"value": round(done / dt, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{done // 2} {kind.upper()} train steps (fwd+losses+bwd, fp32) of 2 pairs at T={T},N={N},"
-                      f"d={2 * params['video_rnn_hiddendim']} by oracle/tsg_oracle.py on {cores} threads, {dt:.1f} s"}
+            "sample": f"{done // sB} {kind.upper()} train steps (fwd+losses+bwd, fp32) of {sB} pairs at T={T},N={N},"
+                      f"d={2 * params['video_rnn_hiddendim']} by oracle/tsg_oracle.py on {cores} of {os.cpu_count()} host threads, {dt:.1f} s"}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="gmd", choices=["gmd", "qave"])
-    ap.add_argument("--B", type=int, default=64, help="clip-query pairs per GPU")
-    ap.add_argument("--T", type=int, default=128)
-    ap.add_argument("--N", type=int, default=20)
-    ap.add_argument("--d", type=int, default=1024)
-    ap.add_argument("--cpu-sample", type=int, default=24, help="pairs in the CPU-baseline sample (0 = skip); bounded to ~20 s")
-    ap.add_argument("--no-micro", action="store_true", help="skip the stand-alone K2 launches")
-    ap.add_argument("--dtype", default="f32s", choices=["f32", "bf16", "f32s"],
-                    help="precision mode of the GEMM-shaped glue (LSTM GEMMs and recurrence products, large projections); the hot-path "
-                         "HIP kernels are f32 in all of them.  "
-                         "f32s (default): split-precision bf16 MFMA products, hi*hi+hi*lo+lo*hi with fp32 accumulate -- error at the "
-                         "fp32 GEMM's level, the parity suite passes at the fp32 tolerances, and it is above the bf16 that BASELINE "
-                         "config 2 names; f32: rocBLAS fp32 GEMMs; bf16: bf16 operands, fp32 accumulate (~1e-3 from the reference)")
-    ap.add_argument("--predictor", default="mlp", choices=["mlp", "self_attn"],
-                    help="boundary head: mlp (reference default, K3) or self_attn (temporal self-attention, K2 in the step)")
-    ap.add_argument("--time-all", action="store_true", help="event-time every C-ABI launch (perturbs the step time)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the side measurement in the other GEMM-operand mode")
-    a = ap.parse_args()
+    a = parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}, "
+                         f"or without a launcher environment (bench.py then starts its own ranks)")
+    if torch.cuda.device_count() < max(1, local + 1):          # counting devices does not initialise the GPU
+        raise SystemExit(f"bench.py needs an MI355X per rank: {torch.cuda.device_count()} visible, local rank {local} "
+                         "(the hot path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("TSG_FORCE_DIST") == "1"      # the latter: exercise the RCCL path on one GPU
     if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"RCCL world size {dist.get_world_size()} != --gpus {a.gpus}")
 
     params = engine.default_params(video_rnn_hiddendim=a.d // 2, sent_rnn_hiddendim=a.d // 2,
                                    video_len=a.T, sent_len=a.N, predictor=a.predictor)
@@ -222,17 +276,44 @@ def main():
 
     gdt = {"f32": None, "bf16": torch.bfloat16, "f32s": "f32s"}[a.dtype]
 
-    def step():
-        dp.zero_grad()
+    def forward():
         with engine.precision(gdt):
             if a.model == "gmd":
-                loss, _, _ = engine.gmd_step(model, batch, params)
-            else:
-                loss, _ = engine.baseline_step(model, batch)
+                return engine.gmd_step(model, batch, params)[0]
+            return engine.baseline_step(model, batch)[0]
+
+    def train_step():
+        dp.zero_grad()
+        loss = forward()
         loss.backward()
         dp.finish()
-        opt.step()
+        engine.optimizer_step(opt, loss)          # the update is skipped ON THE DEVICE if the loss is not finite (no sync)
         return loss
+
+    def fwd_step():
+        with torch.no_grad():
+            return forward()
+
+    step = fwd_step if a.fwd_only else train_step
+
+    def timed(fn, n):
+        """n calls bracketed by barrier + synchronize on both sides -> (max-over-ranks seconds, host enqueue seconds, last loss)"""
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            last = fn()
+        t_enq = time.perf_counter() - t0
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, t_enq, last
 
     log("batch resident; warm-up")
     for i in range(a.warmup):
@@ -242,23 +323,9 @@ def main():
     # event pairs around the hot-path kernel launches (K1 / K1g / K3; K2 when it is in the step) -- not around the LSTM and
     # operand-split launches, whose barrier packets would cost milliseconds per step (rocprof has their times)
     functional.kernel_timer.enable(only=None if a.time_all else ("tsg_scdm", "tsg_boundary", "tsg_mha"))
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    t_enq = time.perf_counter() - t0                      # host time to enqueue the K steps (== dt when the host is the limit)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, t_enq, loss = timed(step, a.steps)                # t_enq: host time to enqueue the K steps (== dt when the host is the limit)
     functional.kernel_timer.disable()
     log(f"timed {a.steps} steps in {dt:.3f} s (host enqueue {t_enq:.3f} s)")
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     if not torch.isfinite(loss):
         raise SystemExit("non-finite loss in the timed region")
     functional.check_lstm_errors()                        # a persistent LSTM launch whose bounded wait expired -> invalid run
@@ -277,31 +344,27 @@ def main():
         gdt = MODES[mode]
         for _ in range(2):
             step()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(a.steps):
-            loss2 = step()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
-        if use_dist:
-            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = float(t.item())
+        dt2, _, loss2 = timed(step, a.steps)
         alt.append({"dtype": mode, "value": round(a.B * world * a.steps / dt2, 2), "unit": "pairs/s",
                     "ms_per_step": round(dt2 / a.steps * 1e3, 3), "finite": bool(torch.isfinite(loss2)), "note": NOTES[mode]})
         log(f"alternate GEMM mode {mode}: {alt[-1]['ms_per_step']} ms/step")
     gdt = gdt_main
     functional.set_gemm_dtype(gdt_main)
+    fwd_only = None
+    if not a.fwd_only and not a.no_alt:                   # forward-only pairs/s, reported separately
+        for _ in range(2):
+            fwd_step()
+        dt3, _, loss3 = timed(fwd_step, a.steps)
+        fwd_only = {"value": round(a.B * world * a.steps / dt3, 2), "unit": "pairs/s", "ms_per_step": round(dt3 / a.steps * 1e3, 3),
+                    "finite": bool(torch.isfinite(loss3)), "note": "forward + losses under no_grad, same batch and mode as `value`"}
+        log(f"forward-only: {fwd_only['ms_per_step']} ms/step")
+    functional.check_lstm_errors()
 
     if rank == 0:
-        kt = functional.kernel_timer.summary()          # (name, dims) -> (mean us, launches)
+        kt = functional.kernel_timer.summary()          # (name, dims) -> (mean us, launches, median us)
         kern = {}
-        for (name, dims), (us, n) in sorted(kt.items()):
-            entry = {"mean_us": round(us, 2), "launches": n, "dims": list(dims)}
+        for (name, dims), (us, n, med) in sorted(kt.items()):
+            entry = {"mean_us": round(us, 2), "median_us": round(med, 2), "launches": n, "dims": list(dims)}
             key = {"tsg_scdm_attn_fwd": "scdm_fwd", "tsg_scdm_attn_bwd": "scdm_bwd",
                    "tsg_scdm_gate_fwd": "scdm_gate_fwd", "tsg_scdm_gate_bwd": "scdm_gate_bwd",
                    "tsg_boundary_score_fwd": "boundary_fwd", "tsg_boundary_score_bwd": "boundary_bwd"}.get(name)
@@ -330,16 +393,20 @@ def main():
                 "pairs_per_launch": k1B,
                 "alg_bytes_per_launch": k1.get("alg_bytes"), "mean_launch_us": k1.get("mean_us"),
                 "launches_timed": k1.get("launches")}
-        out = {"metric": "clip-query pairs/sec fwd+bwd at B=64,T=128,d=1024", "value": round(a.B * world * a.steps / dt, 2),
-               "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        what = "fwd-only" if a.fwd_only else "fwd+bwd"
+        wl = (f"{a.model}_forward: fwd+losses under no_grad, " if a.fwd_only else
+              f"{a.model}_train_step: fwd+losses+bwd+grad-allreduce+Adam, ")
+        out = {"metric": f"clip-query pairs/sec {what} at B={a.B},T={a.T},d={a.d}", "value": round(a.B * world * a.steps / dt, 2),
+               "unit": "pairs/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 1,
+               "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": f"{a.model}_train_step: fwd+losses+bwd+grad-allreduce+Adam, "
-                                      f"B={a.B}/GPU,T_clip={a.T},T_word={a.N},d={a.d}, i3d width 1024, GloVe 300"
+               "config": {"workload": wl + f"B={a.B}/GPU,T_clip={a.T},T_word={a.N},d={a.d}, i3d width 1024, GloVe 300"
                                       + ("" if a.predictor == "mlp" else f", boundary head {a.predictor}")
                                       + ("" if a.dtype == "f32" else "; " + NOTES[a.dtype]),
                           "global_batch": a.B * world, "parallelism": f"dp{world}", "grad_bytes": dp.grad_bytes},
-               "roofline": roof, "alt_gemm_modes": alt, "kernels": kern,
+               "roofline": roof, "alt_gemm_modes": alt, "fwd_only": fwd_only, "kernels": kern,
+               "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
                "cpu_baseline": cpu_baseline(a.model, params, a.T, a.N, a.cpu_sample) if (a.cpu_sample > 0 and world == 1) else None}
         os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
     if use_dist:

@@ -79,6 +79,22 @@ def make_optimizer(model, params):
     return torch.optim.Adam(ps, lr=params["lr"], weight_decay=params["weight_decay"], eps=1e-6, fused=fused)
 
 
+def optimizer_step(opt, loss):
+    """``opt.step()`` guarded on the DEVICE: a non-finite loss (a persistent LSTM launch whose bounded wait expired leaves
+    NaN sentinels in its output; an overflow) makes the fused Adam kernel skip the update -- its ``found_inf`` input, the
+    GradScaler mechanism -- so the parameters and the Adam moments are not corrupted by a step the host has already
+    enqueued.  No synchronisation; the host-side report follows at the next LSTM call / ``functional.check_lstm_errors()``.
+    With a non-fused optimizer (CPU tests) it is a plain ``opt.step()``."""
+    fused = any(g.get("fused") for g in opt.param_groups)
+    if fused:
+        opt.found_inf = (~torch.isfinite(loss.detach())).to(torch.float32).reshape(())
+    try:
+        opt.step()
+    finally:
+        if fused:
+            opt.found_inf = None
+
+
 def baseline_step(model, batch):
     """forward + span_ground_loss of one QAVE batch (train_baseline.py:120-134) -> (loss, span_prob)."""
     out = model(batch["video"], batch["query"], batch["video_mask"], batch["query_mask"])

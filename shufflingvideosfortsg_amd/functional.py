@@ -32,14 +32,13 @@ class _KernelTimer:
         self.on = False
 
     def summary(self):
-        """(name, dims) -> (mean microseconds, launches); dims = the integer shape arguments of the
-        call.  Synchronises on the recorded events."""
+        """(name, dims) -> (mean microseconds, launches, median microseconds); dims = the integer shape arguments of
+        the call.  Synchronises on the recorded events."""
         acc = {}
         for name, e0, e1, dims in self.records:
             e1.synchronize()
-            tot, n = acc.get((name, dims), (0.0, 0))
-            acc[(name, dims)] = (tot + e0.elapsed_time(e1) * 1e3, n + 1)
-        return {k: (tot / n, n) for k, (tot, n) in acc.items()}
+            acc.setdefault((name, dims), []).append(e0.elapsed_time(e1) * 1e3)
+        return {k: (sum(v) / len(v), len(v), sorted(v)[len(v) // 2]) for k, v in acc.items()}
 
 
 kernel_timer = _KernelTimer()
