@@ -9,11 +9,16 @@
  *   - all pointers are DEVICE pointers on the current HIP device, 16-byte aligned, row-major
  *     contiguous, batch-first; the caller owns every buffer (outputs and workspaces included);
  *     the library never allocates, frees or synchronises.
- *   - `dtype`: TSG_F32 (0) only in this revision; TSG_BF16 (1) is reserved.
+ *   - `dtype`: TSG_F32 (0) everywhere; TSG_F32S (2) additionally in the LSTM entry points (fp32 storage, split-precision
+ *     bf16 MFMA products; hidden sizes other than 128/256/384/512 compute in plain fp32 there); TSG_BF16 (1) is reserved.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); work is only enqueued.
  *   - return 0 on success; <0 = argument error (TSG_E_*); >0 = hipError_t from the launch.
  *     tsg_last_error() returns a thread-local message for the last non-zero return.
- *   - re-entrant; no global mutable state except a per-process device-property cache.
+ *   - thread-safe to call from one host thread per device.  Process-wide state, all of it atomic words: a per-(device, kernel)
+ *     co-residency cache, and the three LSTM switches set by tsg_lstm_error_sink / tsg_lstm_set_l2_exchange /
+ *     tsg_lstm_set_persist (initialised from TSG_LSTM_L2X / TSG_LSTM_PERSIST in the environment on first use).
+ *   - results are bitwise reproducible run to run except the sums formed with float atomics: dw of K1, dgbias of K1g, dcs / dw2 /
+ *     db2 of K5, the K4 loss accumulators and the LSTM's dbias (one atomic add per batch slice and column).
  */
 #ifndef TSG_HIP_H
 #define TSG_HIP_H
@@ -126,9 +131,11 @@ int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, cons
  *   Whh [2,4h,h];  out [T,B,2h] (forward half | reverse half);  saved for backward: R [T,2,B,h,4]
  *   (activated gates) and Cs [T,2,B,h] (cell states).  Limits: h % 4 == 0.
  * sync_ws: caller-owned workspace of TSG_LSTM_SYNC_BYTES bytes (may be NULL).  When given, T >= 8 (TSG_LSTM_PERSIST=0/1 in the
- *   environment: never / always), h % 32 == 0, h <= 512 and the grid fits the device, ONE persistent launch runs all T steps (W_hh stationary in
- *   registers; workgroups hand h_t over by polling the sentinel-marked `out` slab itself); word 0 of sync_ws is
- *   non-zero afterwards if a bounded wait expired (results then invalid).  Otherwise one launch per time step.   */
+ *   environment or tsg_lstm_set_persist: never / always), h % 32 == 0 and h <= 512, ONE persistent launch runs all T steps (W_hh stationary in
+ *   registers; workgroups hand h_t over by polling the sentinel-marked `out` slab itself); when the B rows need more workgroups
+ *   than can be co-resident (one per CU: B > 128 at h = 512 on 256 CUs) the rows -- independent sequences -- are processed as
+ *   consecutive persistent launches over balanced chunks of whole 16-row slices (B = 256 -> 2 x 128), never as step launches;
+ *   word 0 of sync_ws is non-zero afterwards if a bounded wait expired (results then invalid).  Otherwise one launch per time step.   */
 int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                  int B, int T, int h, int dtype, void* stream);
 /* Same, with the bias b_ih + b_hh [2,4h] added inside the kernel (bias may be NULL): for callers whose input GEMM has
@@ -146,6 +153,9 @@ int tsg_lstm_error_sink(void* flag);
  * placement is verified); forbidden = write-through stores always.  The Python host turns it off when its start-up self-test
  * of the persistent kernels reports an expired wait.                                                                       */
 int tsg_lstm_set_l2_exchange(int on);
+/* Persistent kernels: 0 = never (one launch per time step), 1 = whenever the shape allows, -1 = automatic (T >= 8; the
+ * default, or TSG_LSTM_PERSIST).  The Python host selects 0 when its start-up self-test fails in both exchange modes.  */
+int tsg_lstm_set_persist(int mode);
 
 /* backward of the recurrence: dOut [T,B,2h] (+ optional dHn [2,B,h] added at each direction's last step)
  * -> dG [T,B,2,4h] = dL/d(pre-activation gates); the caller derives dX, dW_ih, dW_hh, db from it with
@@ -158,7 +168,8 @@ int tsg_lstm_bwd(const void* WhhT, const void* R, const void* Cs, const void* dO
  * tsg_lstm_bwd_ws_bytes(B,T,h) bytes (0 = not available for this shape: h % 128 != 0 or h > 512), 16-byte aligned,
  * contents irrelevant.  One launch runs all T steps: workgroups exchange partial dh tiles through a 4-slot ring of
  * sentinel-marked, write-through 128-byte lines (no atomics or fences per step).  Falls back to tsg_lstm_bwd when ws is
- * NULL / too small, the grid does not fit the device or T < 8 (TSG_LSTM_PERSIST=0/1: never / always).            */
+ * NULL / too small or T < 8 (TSG_LSTM_PERSIST=0/1 or tsg_lstm_set_persist: never / always); rows beyond the co-resident
+ * grid are processed in chunks as in the forward.                                                                   */
 long long tsg_lstm_bwd_ws_bytes(int B, int T, int h);
 /* 1 when tsg_lstm_bwd_ws will take the persistent path for this shape and workspace size (then, and only then, it also
  * fills dbias [2,4h] = d(b_ih + b_hh), the sum of dG over time and batch, when dbias is non-NULL).                  */

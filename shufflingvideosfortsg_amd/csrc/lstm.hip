@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
                                                                         // NW = waves = A-tiles per workgroup (8: 32 units, one workgroup
                                                                         // per CU; 4: 16 units, two independent chains per CU)
     const float* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh, float* __restrict__ out,
-    float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int T, int h, int HLS, int flags, int bm, unsigned* __restrict__ esink) {
+    float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int Bs, int T, int h, int HLS, int flags, int bm, unsigned* __restrict__ esink) {
   constexpr int NT = 64 * NW, UW = 4 * NW, HTS = UW + 1;  // threads, units per workgroup, h-tile row stride
   constexpr int SV = 16 * (kPersistMaxH / 4) / NT;         // float4 of the 16-row slab per thread (4 / 8 at h = 512)
   extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice (SPLIT: two bf16 planes
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
     {
       const int row = tid / UW, col = tid % UW;              // the same whole-line pattern as the h stores of the step loop
       if (b0 + row < B)
-        for (int t = 0; t < T; ++t) store_sc1_u(out + seq_row(t, b0 + row, B, T, bm) * 2 * h + d * h + us * UW + col, kSentinel);
+        for (int t = 0; t < T; ++t) store_sc1_u(out + seq_row(t, b0 + row, Bs, T, bm) * 2 * h + d * h + us * UW + col, kSentinel);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
 #endif
   float gxn[4] = {0.f, 0.f, 0.f, 0.f};                     // input gates of the NEXT step (see the loop head)
   if (live) {
-    const float* g = Gx + (seq_row(d == 0 ? 0 : T - 1, b, B, T, bm) * 2 + d) * 4 * h + u;
+    const float* g = Gx + (seq_row(d == 0 ? 0 : T - 1, b, Bs, T, bm) * 2 + d) * 4 * h + u;
     gxn[0] = g[0]; gxn[1] = g[h]; gxn[2] = g[2 * h]; gxn[3] = g[3 * h];
   }
   for (int step = 0; step < T; ++step) {
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
       for (int k = 0; k < 4; ++k) gx[k] = gxn[k] + bi[k];
       if (live && step + 1 < T) {
         const int tn = d == 0 ? step + 1 : T - 2 - step;
-        const float* g = Gx + (seq_row(tn, b, B, T, bm) * 2 + d) * 4 * h + u;
+        const float* g = Gx + (seq_row(tn, b, Bs, T, bm) * 2 + d) * 4 * h + u;
         gxn[0] = g[0]; gxn[1] = g[h]; gxn[2] = g[2 * h]; gxn[3] = g[3 * h];
       }
     };
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
           const int idx = tid + i * NT, r = idx / nrow4, c4 = idx % nrow4;
           const bool ok = r < 16 && b0 + r < B;
           if (ok) pending |= 1u << i;
-          src[i] = out + seq_row(tp, ok ? b0 + r : b0, B, T, bm) * 2 * h + d * h + (ok ? c4 * 4 : 0);
+          src[i] = out + seq_row(tp, ok ? b0 + r : b0, Bs, T, bm) * 2 * h + d * h + (ok ? c4 * 4 : 0);
         }
         // (measured and dropped: two or three staggered copies of the poll in flight -- the extra slab traffic costs more
         // than the shorter retry saves, 13.7 vs 11.5 us per step)
@@ -720,10 +720,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
     lds_barrier();                                        // tile complete; the slab in LDS is free again
     {
       const int row = tid / UW, col = tid % UW;
-      if (b0 + row < B) store_x(out + seq_row(tt, b0 + row, B, T, bm) * 2 * h + d * h + us * UW + col, Ht[row * HTS + col], local);
+      if (b0 + row < B) store_x(out + seq_row(tt, b0 + row, Bs, T, bm) * 2 * h + d * h + us * UW + col, Ht[row * HTS + col], local);
     }
     if (live) {
-      const size_t s = (((size_t)tt * 2 + d) * B + b) * h + u;
+      const size_t s = (((size_t)tt * 2 + d) * Bs + b) * h + u;
       Cs[s] = c;
       *reinterpret_cast<float4*>(R + s * 4) = make_float4(gi, gf, gg, go);
     }
@@ -772,7 +772,7 @@ template <int TW, bool SPLIT>                     // TW = 16-unit tiles per wave
 __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPLIT: split-precision bf16 MFMA arithmetic
     const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
     const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG,
-    float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int T, int h, int flags, int bm, unsigned* __restrict__ esink) {
+    float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int Bs, int T, int h, int flags, int bm, unsigned* __restrict__ esink) {
   extern __shared__ __align__(16) float smem2[];
   float* Dl = smem2;                              // [16][kDLS]  this workgroup's dG tile, local column g*32 + ul
   unsigned* Dhi = reinterpret_cast<unsigned*>(Dl);          // (SPLIT: the same tile as two bf16 planes [16][kDLB] dwords)
@@ -848,12 +848,12 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
       // (requested here, in front of the poll.  With these operands L2-resident the step measures 3.8 instead of 4.6 us, but
       // requesting them one step ahead, after the previous poll -- what the forward kernel does with its input gates --
       // measured 4.8-5.6 us in every variant tried)
-      const size_t sidx = (((size_t)tt * 2 + d) * B + b) * h + u;
+      const size_t sidx = (((size_t)tt * 2 + d) * Bs + b) * h + u;
       g4 = *reinterpret_cast<const float4*>(R + sidx * 4);
       cc = Cs[sidx];
-      if (has_prev) cpv = Cs[(((size_t)tp * 2 + d) * B + b) * h + u];
-      dov = dOut[seq_row(tt, b, B, T, bm) * 2 * h + d * h + u];
-      if (step == 0 && dHn) dov += dHn[((size_t)d * B + b) * h + u];
+      if (has_prev) cpv = Cs[(((size_t)tp * 2 + d) * Bs + b) * h + u];
+      dov = dOut[seq_row(tt, b, Bs, T, bm) * 2 * h + d * h + u];
+      if (step == 0 && dHn) dov += dHn[((size_t)d * Bs + b) * h + u];
     }
     float rec = 0.f;
     if (step > 0) {
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
       dc_carry = dc * gf;
       const float dg[4] = {dc * gg * gi * (1.f - gi), dc * cpv * gf * (1.f - gf), dc * gi * (1.f - gg * gg), dh * tc * go * (1.f - go)};
       if (live) {
-        float* g = dG + (seq_row(tt, b, B, T, bm) * 2 + d) * K + u;
+        float* g = dG + (seq_row(tt, b, Bs, T, bm) * 2 + d) * K + u;
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) g[gate * h] = dg[gate];
       }
@@ -1016,23 +1016,58 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
 }  // namespace
 }  // namespace tsg
 
+#include <atomic>
+#include <mutex>
 using namespace tsg;
 
 // TSG_LSTM_PERSIST: unset = auto (persistent launch for sequences of >= 8 steps: 8.2 vs 17.3 us/step at
 // [B=128,T=128,h=512], 7.4 vs 11.3 us/step at [64,20,512]), 0 = never, 1 = whenever the grid fits.
+static std::atomic<int> g_persist{-2};   // -2: not decided yet (TSG_LSTM_PERSIST); tsg_lstm_set_persist overrides
 static int persist_mode() {
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("TSG_LSTM_PERSIST"); v = e ? atoi(e) : -1; }
+  int v = g_persist.load(std::memory_order_relaxed);
+  if (v == -2) { const char* e = getenv("TSG_LSTM_PERSIST"); v = e ? atoi(e) : -1; g_persist.store(v, std::memory_order_relaxed); }
   return v;
 }
-static int g_l2x = -1;            // -1: not decided yet (TSG_LSTM_L2X, default on); tsg_lstm_set_l2_exchange overrides
+extern "C" int tsg_lstm_set_persist(int mode) { g_persist.store(mode < 0 ? -1 : (mode != 0), std::memory_order_relaxed); return 0; }
+static std::atomic<int> g_l2x{-1};   // -1: not decided yet (TSG_LSTM_L2X, default on); tsg_lstm_set_l2_exchange overrides
 static int l2_exchange() {        // TSG_LSTM_L2X=0: always write-through exchange stores (A/B measurements)
-  if (g_l2x < 0) { const char* e = getenv("TSG_LSTM_L2X"); g_l2x = e ? (atoi(e) != 0) : 1; }
-  return g_l2x;
+  int v = g_l2x.load(std::memory_order_relaxed);
+  if (v < 0) { const char* e = getenv("TSG_LSTM_L2X"); v = e ? (atoi(e) != 0) : 1; g_l2x.store(v, std::memory_order_relaxed); }
+  return v;
 }
-extern "C" int tsg_lstm_set_l2_exchange(int on) { g_l2x = on != 0; return 0; }
-static unsigned* g_error_sink = nullptr;
-extern "C" int tsg_lstm_error_sink(void* p) { g_error_sink = static_cast<unsigned*>(p); return 0; }
+extern "C" int tsg_lstm_set_l2_exchange(int on) { g_l2x.store(on != 0, std::memory_order_relaxed); return 0; }
+static std::atomic<unsigned*> g_error_sink{nullptr};
+extern "C" int tsg_lstm_error_sink(void* p) { g_error_sink.store(static_cast<unsigned*>(p), std::memory_order_relaxed); return 0; }
+
+// Workgroups of a persistent kernel that can be co-resident: ONE per CU is counted (margin against over-reporting), cached
+// per (device, kernel slot).  0 = the kernel cannot run persistently here.
+static constexpr int kMaxDev = 16;
+template <class K>
+static int persist_capacity(int slot, K kern, int threads, size_t lds, int per_cu) {
+  static std::atomic<int> cache[kMaxDev][4];
+  static std::once_flag once;
+  std::call_once(once, [] { for (auto& d : cache) for (auto& c : d) c.store(-1); });
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 0;
+  int cap = cache[dev][slot].load(std::memory_order_relaxed);
+  if (cap >= 0) return cap;
+  int cus = 0, per = 0;
+  hipError_t e1 = allow_lds(kern, lds);
+  if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, threads, lds);
+  cap = (e1 == hipSuccess && per >= per_cu) ? cus * per_cu : 0;
+  cache[dev][slot].store(cap, std::memory_order_relaxed);
+  return cap;
+}
+// Rows per launch when the B rows of a layer need more workgroups than fit: balanced chunks of whole 16-row slices, each
+// with 2 * wgs_per_slice * slices <= cap workgroups.  0 = not even one slice fits.
+static int persist_chunk_rows(int B, int wgs_per_slice, int cap) {
+  const int max_slices = cap / (2 * wgs_per_slice);
+  if (max_slices <= 0) return 0;
+  const int slices = cdiv(B, 16);
+  const int chunks = cdiv(slices, max_slices);
+  return cdiv(slices, chunks) * 16;
+}
 static int launch_flags() {       // bit 0: L2-local exchange allowed; bit 1: inject a start-barrier timeout (tests)
   const char* e = getenv("TSG_LSTM_INJECT_TIMEOUT");
   return (l2_exchange() ? 1 : 0) | ((e && atoi(e) != 0) ? 2 : 0);
@@ -1062,7 +1097,6 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
     if (nw_env < 0) { const char* e = getenv("TSG_LSTM_NW"); nw_env = (e && atoi(e) == 4) ? 4 : 8; }
     const bool split = dtype == TSG_F32S;                  // other hidden sizes: the fp32 arithmetic (more accurate, slower)
     const int NW = (nw_env == 4 && h == 512 && split) ? 4 : 8;
-    const int grid = 2 * (h / (4 * NW)) * cdiv(B, 16);
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
     const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 33 + 4);
     static_assert(kSlabFloats >= 16 * (kPersistMaxH + 8), "slab region holds the fp32 slab too");
@@ -1072,22 +1106,21 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
             : h == 384 ? (split ? lstm_fwd_persist_kernel<24, true, 8> : lstm_fwd_persist_kernel<24, false, 8>)
             : h == 128 ? (split ? lstm_fwd_persist_kernel<8, true, 8> : lstm_fwd_persist_kernel<8, false, 8>)
             : lstm_fwd_persist_kernel<0, false, 8>;
-    static int capacity[2] = {-1, -1};                     // [NW == 4]
-    int& cap = capacity[NW == 4];
-    if (cap < 0) {
-      int dev = 0, cus = 0, per = 0;
-      hipError_t e1 = allow_lds(pk, plds);
-      if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
-      if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pk, 64 * NW, plds);
-      // count ONE workgroup per CU (two of the 4-wave ones): margin against over-reporting
-      cap = (e1 == hipSuccess) ? cus * (NW == 4 ? (per >= 2 ? 2 : 0) : (per > 0 ? 1 : 0)) : 0;
-    }
-    if (grid <= cap) {
-      hipError_t e = hipMemsetAsync(sync_ws, 0, kSyncBytes, st);
-      if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-      hipLaunchKernelGGL(pk, dim3(grid), dim3(64 * NW), plds, st, (const float*)Gx, (const float*)bias, (const float*)Whh, (float*)out,
-                         (float*)R, (float*)Cs, (unsigned*)sync_ws, B, T, h, HLS, launch_flags(), bm, g_error_sink);
+    const int cap = persist_capacity(NW == 4 ? 1 : 0, pk, 64 * NW, plds, NW == 4 ? 2 : 1);
+    // more rows than co-resident workgroups allow (B = 256 at h = 512: grid 512 on 256 CUs): the rows are independent, so the
+    // layer runs as consecutive launches over balanced row chunks (pointer offsets; Bs = B keeps the tensors' strides)
+    const int rows = persist_chunk_rows(B, h / (4 * NW), cap);
+    if (rows > 0) {
+      const size_t K8 = (size_t)8 * h, H2 = (size_t)2 * h;
+      for (int c0 = 0; c0 < B; c0 += rows) {
+        const int Bc = B - c0 < rows ? B - c0 : rows;
+        const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;              // first sequence row of the chunk
+        hipError_t e = hipMemsetAsync(sync_ws, 0, kSyncBytes, st);
+        if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+        hipLaunchKernelGGL(pk, dim3(2 * (h / (4 * NW)) * cdiv(Bc, 16)), dim3(64 * NW), plds, st, (const float*)Gx + seq * K8, (const float*)bias,
+                           (const float*)Whh, (float*)out + seq * H2, (float*)R + (size_t)c0 * h * 4, (float*)Cs + (size_t)c0 * h,
+                           (unsigned*)sync_ws, Bc, B, T, h, HLS, launch_flags(), bm, g_error_sink.load(std::memory_order_relaxed));
+      }
       return check_launch(fn);
     }
   }
@@ -1137,24 +1170,13 @@ extern "C" long long tsg_lstm_bwd_ws_bytes(int B, int T, int h) {
   return kSyncBytes + 4LL * 2 * bslices * nus * nus * 512 * (long long)sizeof(float);
 }
 
-static int bwd_persist_capacity(size_t plds) {
-  static int capacity = -1;
-  if (capacity < 0) {
-    int dev = 0, cus = 0, per = 0;
-    hipError_t e1 = allow_lds(lstm_bwd_persist2_kernel<4, false>, plds);
-    if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
-    if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, lstm_bwd_persist2_kernel<4, false>, kThreads, plds);
-    capacity = (e1 == hipSuccess) ? cus * (per > 0 ? 1 : 0) : 0;
-  }
-  return capacity;
-}
 static constexpr size_t kBwd2Lds = sizeof(float) * ((size_t)kDlFloats + 16 * kPLS + 4 * 16 * kQLS + 4);
 static_assert(kDlFloats >= 16 * kDLS, "dG tile region holds the fp32 tile too");
+static int bwd_persist_capacity() { return persist_capacity(2, lstm_bwd_persist2_kernel<4, false>, kThreads, kBwd2Lds, 1); }
 
 extern "C" int tsg_lstm_bwd_ws_persistent(int B, int T, int h, long long ws_bytes) {
   const long long need = tsg_lstm_bwd_ws_bytes(B, T, h);
-  return need > 0 && ws_bytes >= need && T > 1 && persist_wanted(T) && 2 * (h / 32) * cdiv(B, 16) <= bwd_persist_capacity(kBwd2Lds);
+  return need > 0 && ws_bytes >= need && T > 1 && persist_wanted(T) && persist_chunk_rows(B, h / 32, bwd_persist_capacity()) > 0;
 }
 
 extern "C" int tsg_lstm_bwd_ws(const void* WhhT, const void* R, const void* Cs, const void* dOut, const void* dHn,
@@ -1177,18 +1199,25 @@ extern "C" int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const voi
     int rc = lstm_check(fn, B, T, h, dtype);
     if (rc) return rc;
     auto st = static_cast<hipStream_t>(stream);
-    const int pgrid = 2 * (h / 32) * cdiv(B, 16);
-    hipError_t e = hipMemsetAsync(ws, 0, kSyncBytes, st);
-    if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, sizeof(float) * 8 * h, st);
+    hipError_t e = dbias ? hipMemsetAsync(dbias, 0, sizeof(float) * 8 * h, st) : hipSuccess;
     if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
     const bool split = dtype == TSG_F32S;
     auto pk = h == 512 ? (split ? lstm_bwd_persist2_kernel<4, true> : lstm_bwd_persist2_kernel<4, false>)
             : h == 384 ? (split ? lstm_bwd_persist2_kernel<3, true> : lstm_bwd_persist2_kernel<3, false>)
             : h == 256 ? (split ? lstm_bwd_persist2_kernel<2, true> : lstm_bwd_persist2_kernel<2, false>)
             : (split ? lstm_bwd_persist2_kernel<1, true> : lstm_bwd_persist2_kernel<1, false>);
-    hipLaunchKernelGGL(pk, dim3(pgrid), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT, (const float*)R,
-                       (const float*)Cs, (const float*)dOut, (const float*)dHn, (float*)dG, (float*)((char*)ws + kSyncBytes),
-                       (unsigned*)ws, (float*)dbias, B, T, h, launch_flags(), bm, g_error_sink);
+    const int rows = persist_chunk_rows(B, h / 32, bwd_persist_capacity());      // > 0 (tsg_lstm_bwd_ws_persistent)
+    const size_t K8 = (size_t)8 * h, H2 = (size_t)2 * h;
+    for (int c0 = 0; c0 < B; c0 += rows) {                   // row chunks as in the forward; the ring is reused, dbias accumulates
+      const int Bc = B - c0 < rows ? B - c0 : rows;
+      const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;
+      e = hipMemsetAsync(ws, 0, kSyncBytes, st);
+      if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+      hipLaunchKernelGGL(pk, dim3(2 * (h / 32) * cdiv(Bc, 16)), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT,
+                         (const float*)R + (size_t)c0 * h * 4, (const float*)Cs + (size_t)c0 * h, (const float*)dOut + seq * H2,
+                         dHn ? (const float*)dHn + (size_t)c0 * h : nullptr, (float*)dG + seq * K8, (float*)((char*)ws + kSyncBytes),
+                         (unsigned*)ws, (float*)dbias, Bc, B, T, h, launch_flags(), bm, g_error_sink.load(std::memory_order_relaxed));
+    }
     return check_launch(fn);
   }
   (void)need;

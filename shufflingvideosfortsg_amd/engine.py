@@ -104,14 +104,21 @@ def baseline_step(model, batch):
 def gmd_step(model, batch, params):
     """forward + the four GMD losses (train.py:131-165) -> (loss, parts, span_prob)."""
     gt, pgt = batch["gt"], batch["pseudo_gt"]
-    span, om, pm, od, pd = model(batch["query"], batch["query_mask"], batch["video"], batch["video_mask"],
-                                 batch["pseudo_video"], batch["video_mask"],
+    # the shuffled video's own mask (train.py:146-148 masks the pseudo stream with pseudo_video_mask).  gt_translate keeps
+    # nfeats and the moment length (data_augment.py:135-156), so its collate hands over the SAME mask; a batch from another
+    # augmentation (crop: aug_nfeats != raw_nfeats, data_augment.py:61,91) carries its own and takes the un-fused losses below
+    vm = batch["video_mask"]
+    pvm = batch.get("pseudo_video_mask", vm)
+    span, om, pm, od, pd = model(batch["query"], batch["query_mask"], batch["video"], vm,
+                                 batch["pseudo_video"], pvm,
                                  gt["temporal_labels"], gt["fore_masks"], gt["back_masks"],
                                  pgt["temporal_labels"], pgt["fore_masks"], pgt["back_masks"])
     fs, pfs = gt["framestps"], pgt["framestps"]
     if (om.is_cuda and isinstance(fs, torch.Tensor) and isinstance(pfs, torch.Tensor) and om.dim() == 2 and om.size(1) <= 2048
-            and od.dim() == 2 and od.size(1) == 2):
-        # K4: the four losses in one launch each way (csrc/losses.hip) instead of ~100 small torch launches
+            and od.dim() == 2 and od.size(1) == 2 and pvm is vm and batch.get("equal_moment_lengths", True)):
+        # K4: the four losses in one launch each way (csrc/losses.hip) instead of ~100 small torch launches.  K4 has ONE video
+        # mask (shared BCE denominator) and takes the KL slice length from the original span: exact for gt_translate pairs
+        # (same mask object, equal moment lengths -- a collate that cannot promise the latter sets equal_moment_lengths=False)
         from . import functional as TF
         lam = (params["loss_m1_lambda"], params["loss_m2_lambda"], params["loss_disc_lambda"])
         parts, total = TF.gmd_losses(span["start"], span["end"], om, pm, od, pd, fs, pfs, gt["temporal_labels"],
@@ -119,8 +126,8 @@ def gmd_step(model, batch, params):
         p = parts.detach()                                  # the parts are for logging; the gradient flows through `total`
         return total, (p[0], lam[0] * p[1], lam[1] * p[2], p[3]), span
     lg = L.span_ground_loss(span["start"], span["end"], gt["framestps"])
-    l1 = params["loss_m1_lambda"] * (L.BCE_loss(om, gt["temporal_labels"], batch["video_mask"])
-                                     + L.BCE_loss(pm, pgt["temporal_labels"], batch["video_mask"]))
+    l1 = params["loss_m1_lambda"] * (L.BCE_loss(om, gt["temporal_labels"], vm)
+                                     + L.BCE_loss(pm, pgt["temporal_labels"], pvm))
     l2 = params["loss_m2_lambda"] * L.matching_KL_divergence(masked_softmax(om, gt["temporal_labels"]),
                                                              masked_softmax(pm, pgt["temporal_labels"]),
                                                              gt["framestps"], pgt["framestps"])

@@ -70,7 +70,8 @@ def _lstm_selftest() -> None:
     """Once per process, before the first LSTM launch: a short persistent forward + backward at the full-chip grid
     ([128, 8, 512], 256 workgroups) on scratch data, synchronised.  If a bounded wait expires with the L2-local exchange
     allowed, the exchange falls back to write-through stores for the rest of the process (and the test is repeated); if it
-    expires again the persistent kernels cannot run here and LstmWaitExpired is raised."""
+    expires again the persistent kernels cannot run here (the GPU is shared?) and the process switches to the launch-per-step
+    kernels (tsg_lstm_set_persist(0), a warning): slower, but correct."""
     import warnings
     lib = load()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -94,8 +95,9 @@ def _lstm_selftest() -> None:
             warnings.warn("persistent LSTM self-test: a bounded wait expired with the L2-local exchange; falling back to "
                           "write-through exchange stores for this process (TSG_LSTM_L2X=0)")
             check(lib.tsg_lstm_set_l2_exchange(0), "tsg_lstm_set_l2_exchange")
-    raise LstmWaitExpired("persistent LSTM self-test failed twice: the persistent kernels cannot run on this device "
-                          "(is the GPU shared?).  TSG_LSTM_PERSIST=0 selects the launch-per-step kernels.")
+    warnings.warn("persistent LSTM self-test failed with both exchange modes: the persistent kernels cannot run on this device "
+                  "(is the GPU shared?); using the launch-per-step kernels for this process (TSG_LSTM_PERSIST=0)")
+    check(lib.tsg_lstm_set_persist(0), "tsg_lstm_set_persist")
 
 
 def _call(name: str, like: torch.Tensor, *args) -> None:
