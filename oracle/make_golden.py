@@ -447,7 +447,86 @@ def gen_config0():
          sentences=np.array([it[3] for it in items]))
 
 
+class _TupleIndex:
+    """what ``torch.stack((idx, col), 0).numpy()`` was to the torch the reference was written for: an index PAIR"""
+
+    def __init__(self, t):
+        self.t = t
+
+    def numpy(self):
+        return tuple(self.t[i] for i in range(self.t.shape[0]))
+
+
+class _TorchProxy:
+    """``torch`` as seen by the reference's loss.py, with ``stack`` returning the index-pair wrapper above so that the REAL
+    ``loss.span_pred`` (loss.py:53-70) runs unmodified on torch >= 2 (shim 4)."""
+
+    def __getattr__(self, k):
+        if k == "stack":
+            return lambda ts, dim=0: _TupleIndex(torch.stack(ts, dim=dim))
+        return getattr(torch, k)
+
+
+def _ref_span_pred(start, end):
+    real = ref_loss.torch
+    ref_loss.torch = _TorchProxy()
+    try:
+        return ref_loss.span_pred(start, end)
+    finally:
+        ref_loss.torch = real
+
+
+def gen_span_pred_cases():
+    """The reference's own span_pred on edge cases: random rows, exact ties (first maximum wins), rows whose probabilities are
+    exactly zero beyond a mask (the zero-filled lower triangle then takes part in the max), rounding-collapsed sums, T = 1."""
+    g = torch.Generator().manual_seed(42)
+    cases = {}
+    s = torch.softmax(torch.randn(6, 33, generator=g), 1); e = torch.softmax(torch.randn(6, 33, generator=g), 1)
+    cases["rand"] = (s, e)
+    s = torch.full((3, 8), 0.125); e = torch.full((3, 8), 0.125)                     # all ties
+    s[1, 5] = 0.25; e[1, 2] = 0.25; e[1, 6] = 0.25; s[2, 0] = 0.25; s[2, 7] = 0.25
+    cases["ties"] = (s, e)
+    s = torch.zeros(4, 12); e = torch.zeros(4, 12)                                    # masked tails: exact zeros
+    s[0, :5] = torch.softmax(torch.randn(5, generator=g), 0); e[0, :5] = torch.softmax(torch.randn(5, generator=g), 0)
+    s[1, 3] = 1.0; e[1, 1] = 1.0                                                      # end mass BEFORE the start
+    e[2, 0] = 1.0                                                                     # start all zero
+    cases["zeros"] = (s, e)                                                           # row 3: everything zero
+    s = torch.tensor([[1.0, 1.0, 0.5]]); e = torch.tensor([[3e-8, 5.9e-8, 6e-8]])     # fl(1 + e_j) collapses
+    cases["round"] = (s, e)
+    cases["t1"] = (torch.tensor([[0.7], [0.0]]), torch.tensor([[0.2], [0.0]]))
+    s = torch.softmax(torch.randn(2, 300, generator=g) * 3, 1); e = torch.softmax(torch.randn(2, 300, generator=g) * 3, 1)
+    cases["long"] = (s, e)
+    out = {}
+    for k, (s, e) in cases.items():
+        pred, score = _ref_span_pred(s, e)
+        p2, s2 = _span_pred_fixed(s, e) if k in ("rand", "long") else (pred, score)   # the tuple-index form agrees
+        assert torch.equal(pred, p2) and torch.equal(score, s2)
+        out.update({f"{k}.start": s, f"{k}.end": e, f"{k}.pred": pred, f"{k}.score": score})
+    save("span_pred_cases", **out)
+
+
+def gen_pool():
+    """Charades pair-mean pooling + zero pad + frame stamps (dataset/charades.py:177-196, generate_video_fts_data), called on
+    the real class's method with a stand-in ``self`` holding SAMPLE_LEN; float32 clip features as the i3d .npy files hold."""
+    from dataset.charades import CharadesVideoAugVideoPair as _C      # any class that defines generate_video_fts_data
+    rs = np.random.RandomState(5)
+    T, D = 12, 8
+    self_ = types.SimpleNamespace(SAMPLE_LEN=T)
+    raws, outs, nfs, fss, tss = [], [], [], [], []
+    for n, ts in ((7, (1.2, 3.9)), (8, (0.0, 2.0)), (1, (0.0, 0.4)), (24, (3.5, 30.0)), (31, (11.9, 12.0)), (23, (0.5, 11.2))):
+        raw = rs.randn(n, D).astype(np.float32)
+        o, fs, nf = _C.generate_video_fts_data(self_, raw, list(ts), 30.0)
+        raws.append(raw); outs.append(o[0]); nfs.append(nf); fss.append(fs); tss.append(ts)
+    save("pool", raw=np.concatenate(raws), offsets=np.cumsum([0] + [len(r) for r in raws]).astype(np.int64),
+         timestamps=np.array(tss, dtype=np.float64), out=np.stack(outs), nfeats=np.array(nfs, dtype=np.int64),
+         framestps=np.array(fss, dtype=np.int64), T=np.int64(T))
+
+
 if __name__ == "__main__":
     print("writing golden vectors to", os.path.normpath(OUT))
+    if len(sys.argv) > 1:                     # only the named generators, e.g. `make_golden.py gen_pool gen_span_pred_cases`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     gen_scdm(); gen_mha(); gen_posenc(); gen_mlp(); gen_selfattn_predictor(); gen_bilstm()
-    gen_qave_and_models(); gen_losses(); gen_aug(); gen_iou(); gen_config0()
+    gen_qave_and_models(); gen_losses(); gen_aug(); gen_iou(); gen_config0(); gen_span_pred_cases(); gen_pool()
