@@ -236,6 +236,34 @@ int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_shift, long
                        long long cols, long long ld_out, long long plane_stride, int right_operand, long long dup_offset,
                        void* stream);
 
+/* ---- Device-side input pipeline and span decoding (csrc/input_pipeline.hip) ---------------------------
+ * The reference does this per sample in numpy inside DataLoader workers; these entry points do it per batch on the GPU.
+ * Integer outputs are bit-exact with the reference.  int32 index tensors, fp32 features (dtype TSG_F32).
+ *
+ * tsg_pool_clips: CharadesDataSentence.generate_video_fts_data (dataset/charades.py:177-196).  raw [sum_b n_b, D] = the
+ *   batch's i3d clip features back to back, offsets [B+1] int64 (row offsets; n_b = offsets[b+1]-offsets[b]).
+ *   out [B,T,D]: row j = mean of clips 2j, 2j+1 (a lone last clip is copied), zero rows from nfeats[b] = min(ceil(n_b/2), T) on.
+ *   timestamps [B,2] double (seconds) -> framestps [B,2] = min(int(x), T-1) (charades.py:178); both NULL to skip.          */
+int tsg_pool_clips(const void* raw, const int64_t* offsets, const double* timestamps, void* out, int32_t* nfeats,
+                   int32_t* framestps, int B, int T, int D, int dtype, void* stream);
+/* tsg_sequence_masks: Sequence_mask (charades.py:12-18: ones on [max(0,st), min(et,T-1)] INCLUSIVE) for the four masks a
+ *   sample carries (charades.py:162-165, charades_pair_aug.py:96-107): video_mask = [0, nfeats], temporal_labels = [s, e],
+ *   fore_mask = [0, s], back_mask = [e, nfeats].  Each output is int32 [B,T]; any of them may be NULL.                      */
+int tsg_sequence_masks(const int32_t* nfeats, const int32_t* spans, int32_t* video_mask, int32_t* temporal_labels,
+                       int32_t* fore_mask, int32_t* back_mask, int B, int T, void* stream);
+/* tsg_moment_translate: the shuffling augmentation DataAugmentForTSG.gt_moment_translate (dataset/data_augment.py:135-156) as an
+ *   index gather: the ground-truth moment spans[b] = [s, e] is cut out of the first nfeats[b] clips, the gap closed and the
+ *   moment re-inserted in front of position cropin[b] of the gap-closed sequence; rows >= nfeats[b] become zero.  Moments of
+ *   length <= 1 or covering every clip: out[b] = video[b], span unchanged.  cropin NULL: the position is drawn uniformly from
+ *   [0, nfeats-len] by a counter-based hash of (seed, b) (the reference: unseeded random.randint, data_augment.py:149).
+ *   video, out [B,T,D] (out != video); new_spans [B,2] = [cropin, cropin+len-1].                                            */
+int tsg_moment_translate(const void* video, const int32_t* spans, const int32_t* nfeats, const int32_t* cropin,
+                         uint64_t seed, void* out, int32_t* new_spans, int B, int T, int D, int dtype, void* stream);
+/* tsg_span_pred: span_pred (grounding/loss.py:53-70): (i, j) = argmax of triu(start_i + end_j) -- the zero-filled lower
+ *   triangle takes part, the first maximum wins along j and then along i (torch.max).  start, end [B,T] fp32 ->
+ *   pred [B,2] int64 = (i, j), score [B] fp32 = the maximum.  T <= 16384.                                                   */
+int tsg_span_pred(const void* start, const void* end, int64_t* pred, void* score, int B, int T, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

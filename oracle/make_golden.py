@@ -491,7 +491,8 @@ def gen_span_pred_cases():
     s[1, 3] = 1.0; e[1, 1] = 1.0                                                      # end mass BEFORE the start
     e[2, 0] = 1.0                                                                     # start all zero
     cases["zeros"] = (s, e)                                                           # row 3: everything zero
-    s = torch.tensor([[1.0, 1.0, 0.5]]); e = torch.tensor([[3e-8, 5.9e-8, 6e-8]])     # fl(1 + e_j) collapses
+    s = torch.tensor([[1.0, 1.0, 0.5], [1.0, 0.25, 0.5]])                             # fl(1 + e_j) collapses: in row 1 all
+    e = torch.tensor([[3e-8, 5.9e-8, 6e-8], [6e-8, 7e-8, 8e-8]])                      # three sums are equal, the FIRST wins
     cases["round"] = (s, e)
     cases["t1"] = (torch.tensor([[0.7], [0.0]]), torch.tensor([[0.2], [0.0]]))
     s = torch.softmax(torch.randn(2, 300, generator=g) * 3, 1); e = torch.softmax(torch.randn(2, 300, generator=g) * 3, 1)
@@ -508,7 +509,7 @@ def gen_span_pred_cases():
 def gen_pool():
     """Charades pair-mean pooling + zero pad + frame stamps (dataset/charades.py:177-196, generate_video_fts_data), called on
     the real class's method with a stand-in ``self`` holding SAMPLE_LEN; float32 clip features as the i3d .npy files hold."""
-    from dataset.charades import CharadesVideoAugVideoPair as _C      # any class that defines generate_video_fts_data
+    from dataset.charades import CharadesDataSentence as _C          # the class that defines generate_video_fts_data
     rs = np.random.RandomState(5)
     T, D = 12, 8
     self_ = types.SimpleNamespace(SAMPLE_LEN=T)

@@ -44,6 +44,10 @@ _SIGNATURES = {
     "tsg_split_bf16x3": [_P, _P, c_longlong, c_longlong, c_longlong, c_longlong, _I, _P],
     "tsg_split_bf16x3_shift": [_P, c_longlong, c_longlong, c_longlong, _P, c_longlong, c_longlong, c_longlong, c_longlong, _I, _P],
     "tsg_split_bf16x3_t": [_P, c_longlong, c_longlong, c_longlong, _P, c_longlong, c_longlong, c_longlong, c_longlong, _I, c_longlong, _P],
+    "tsg_pool_clips": [_P] * 6 + [_I] * 4 + [_P],
+    "tsg_sequence_masks": [_P] * 6 + [_I] * 2 + [_P],
+    "tsg_moment_translate": [_P] * 4 + [c_uint64, _P, _P] + [_I] * 4 + [_P],
+    "tsg_span_pred": [_P] * 4 + [_I] * 3 + [_P],
     "tsg_mha_bwd": [_P] * 10 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
 }
 _RESTYPE = {"tsg_last_error": c_char_p, "tsg_lstm_bwd_ws_bytes": c_longlong}

@@ -66,6 +66,15 @@ def span_pred(start_prob, end_prob):
     """argmax_{i<=j}(start_i + end_j): the lower triangle is zero-filled and takes part in the max,
     first maximum wins (reference loss.py:53-70).  -> (int64 [B,2], score [B]) on the input device."""
     B, T = start_prob.shape
+    if start_prob.is_cuda and start_prob.dtype == torch.float32 and end_prob.dtype == torch.float32 and T <= 16384:
+        # one launch, one workgroup per pair (csrc/input_pipeline.hip: tsg_span_pred) instead of a [B,T,T] matrix and six ops
+        from . import _lib
+        from .functional import _call
+        s, e = start_prob.detach().contiguous(), end_prob.detach().contiguous()
+        pred = torch.empty(B, 2, device=s.device, dtype=torch.long)
+        score = torch.empty(B, device=s.device, dtype=torch.float32)
+        _call("tsg_span_pred", s, s.data_ptr(), e.data_ptr(), pred.data_ptr(), score.data_ptr(), B, T, _lib.TSG_F32)
+        return pred, score
     m = (start_prob.unsqueeze(2) + end_prob.unsqueeze(1)).triu(0)
     row_max, row_idx = m.max(dim=2)
     best, col = row_max.max(dim=1)
