@@ -168,11 +168,11 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
     A = torch.randn(B, T, d, device=dev); S = torch.randn(B, N, d, device=dev); w = torch.randn(d, device=dev) / sc
     V = torch.randn(B, N, d, device=dev); C = torch.empty(B, T, d, device=dev); P = torch.empty(B, T, N, device=dev)
     dC = torch.randn(B, T, d, device=dev); da, ds, dw, dV = torch.empty_like(A), torch.empty_like(S), torch.empty_like(w), torch.empty_like(V)
-    de = torch.empty(B, T, N, device=dev)
+    nb = int(lib.tsg_scdm_bwd_ws_bytes(B, T, N, d, d, 0)); ws = torch.empty(nb // 4 + 4, device=dev)
     run(f"tsg_scdm_attn_fwd[alone: {B},{T},{N},{d}]",
         lambda: lib.tsg_scdm_attn_fwd(ptr(A), ptr(S), ptr(w), ptr(V), ptr(C), ptr(P), B, T, N, d, d, TSG_F32, st), alg_bytes("scdm_fwd", B, T, N, d))
     run(f"tsg_scdm_attn_bwd[alone: {B},{T},{N},{d}]",
-        lambda: lib.tsg_scdm_attn_bwd(ptr(A), ptr(S), ptr(w), ptr(V), ptr(P), ptr(dC), ptr(da), ptr(ds), ptr(dw), ptr(dV), ptr(de),
+        lambda: lib.tsg_scdm_attn_bwd(ptr(A), ptr(S), ptr(w), ptr(V), ptr(P), ptr(dC), ptr(da), ptr(ds), ptr(dw), ptr(dV), ptr(ws), nb,
                                       B, T, N, d, d, TSG_F32, st), alg_bytes("scdm_bwd", B, T, N, d))
     for tag, Tk in (("cross", N), ("self", T)):
         Q = torch.randn(B, T, d, device=dev); K = torch.randn(B, Tk, d, device=dev); V = torch.randn(B, Tk, d, device=dev)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSG_VERSION 1
+#define TSG_VERSION 2   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points */
 #define TSG_F32 0
 #define TSG_BF16 1
 #define TSG_F32S 2   /* fp32 storage; the LSTM recurrence's W_hh products run as split-precision bf16 MFMAs
@@ -55,10 +55,14 @@ int tsg_scdm_attn_fwd(const void* a, const void* s, const void* w, const void* s
                       void* C, void* P, int B, int T, int N, int H, int Ds, int dtype, void* stream);
 
 /* backward of the above.  dC [B,T,Ds] -> da [B,T,H], ds [B,N,H], dw [H], dsent [B,N,Ds] (direct
- * path through C = P@sent only; the path through s = W_s(sent) is the caller's GEMM).
- * `de_ws` is a caller-owned workspace of B*T*N floats.  dw is fully overwritten.                */
+ * path through C = P@sent only; the path through s = W_s(sent) is the caller's GEMM).  One fused kernel: every input is
+ * read once and every output written once (workgroup = batch item x column part; the parts of an item exchange their
+ * partial <dC, sent> dot products -- T*N floats each -- through `ws`).  dw is fully overwritten.
+ * `ws`: caller-owned workspace of at least tsg_scdm_bwd_ws_bytes(B,T,N,H,Ds,gate) bytes, contents irrelevant.
+ * (TSG_K1_BWD=split in the environment selects the two-kernel path of revision 1, which moves dG / de through `ws`.)   */
+long long tsg_scdm_bwd_ws_bytes(int B, int T, int N, int H, int Ds, int gate);
 int tsg_scdm_attn_bwd(const void* a, const void* s, const void* w, const void* sent, const void* P,
-                      const void* dC, void* da, void* ds, void* dw, void* dsent, void* de_ws,
+                      const void* dC, void* da, void* ds, void* dw, void* dsent, void* ws, long long ws_bytes,
                       int B, int T, int N, int H, int Ds, int dtype, void* stream);
 
 /* ---- K1g: SCDM attention fused with the channel gate of rnn_recalibration_layer.forward
@@ -71,12 +75,11 @@ int tsg_scdm_gate_fwd(const void* a, const void* s, const void* w, const void* V
                       const void* r, void* out, void* P, int B, int T, int N, int H, int Ds, int dtype,
                       void* stream);
 
-/* backward: dout [B,T,Ds] -> da, ds, dw (as tsg_scdm_attn_bwd), dVW [B,N,Ds], dgbias [Ds], dr [B,T,Ds]
- * (gate path only: the path through a = W_a(r) is the caller's).  Workspaces: de_ws B*T*N floats,
- * dG_ws B*T*Ds floats.                                                                          */
+/* backward: dout [B,T,Ds] -> da, ds, dw (as tsg_scdm_attn_bwd), dVW [B,N,Ds], dgbias [Ds], dr [B,T,Ds]; `ws` as above
+ * (gate = 1 in tsg_scdm_bwd_ws_bytes).  dw and dgbias are fully overwritten.                                       */
 int tsg_scdm_gate_bwd(const void* a, const void* s, const void* w, const void* VW, const void* gbias,
                       const void* r, const void* P, const void* dout, void* da, void* ds, void* dw,
-                      void* dVW, void* dgbias, void* dr, void* de_ws, void* dG_ws,
+                      void* dVW, void* dgbias, void* dr, void* ws, long long ws_bytes,
                       int B, int T, int N, int H, int Ds, int dtype, void* stream);
 
 /* ---- K3: boundary-score head (VideoSentenceConcat + MLP_predictor.forward,
@@ -149,6 +152,7 @@ int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* Whh, void* o
  * that launch's sync workspace is set as well).  NULL (default) disables it.  The Python host registers a pinned word and
  * checks it on every LSTM call, so a failed launch raises at the next call instead of passing silently.               */
 int tsg_lstm_error_sink(void* flag);
+int tsg_error_sink(void* flag);          /* the same sink under its general name: the K1 backward's bounded exchange wait reports there too */
 /* Allow (default, TSG_LSTM_L2X) or forbid the exchange that stays inside one XCD's L2 (plain stores when a group's one-XCD
  * placement is verified); forbidden = write-through stores always.  The Python host turns it off when its start-up self-test
  * of the persistent kernels reports an expired wait.                                                                       */

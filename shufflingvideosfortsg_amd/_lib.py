@@ -20,9 +20,11 @@ _SIGNATURES = {
     "tsg_version": [],
     "tsg_last_error": [],
     "tsg_scdm_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "tsg_scdm_attn_bwd": [_P] * 11 + [_I] * 6 + [_P],
+    "tsg_scdm_attn_bwd": [_P] * 11 + [c_longlong] + [_I] * 6 + [_P],
+    "tsg_scdm_bwd_ws_bytes": [_I] * 6,
+    "tsg_error_sink": [_P],
     "tsg_scdm_gate_fwd": [_P] * 8 + [_I] * 6 + [_P],
-    "tsg_scdm_gate_bwd": [_P] * 16 + [_I] * 6 + [_P],
+    "tsg_scdm_gate_bwd": [_P] * 15 + [c_longlong] + [_I] * 6 + [_P],
     "tsg_boundary_score_fwd": [_P] * 9 + [_I] * 4 + [_P],
     "tsg_boundary_score_bwd": [_P] * 17 + [_I] * 4 + [_P],
     "tsg_mha_fwd": [_P] * 7 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
@@ -50,7 +52,7 @@ _SIGNATURES = {
     "tsg_span_pred": [_P] * 4 + [_I] * 3 + [_P],
     "tsg_mha_bwd": [_P] * 10 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
 }
-_RESTYPE = {"tsg_last_error": c_char_p, "tsg_lstm_bwd_ws_bytes": c_longlong}
+_RESTYPE = {"tsg_last_error": c_char_p, "tsg_lstm_bwd_ws_bytes": c_longlong, "tsg_scdm_bwd_ws_bytes": c_longlong}
 
 
 class TsgLibraryError(RuntimeError):
@@ -75,8 +77,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)            # AttributeError here = header / library mismatch
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, c_int)
-    if lib.tsg_version() != 1:
-        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 1 expected by the Python host code")
+    if lib.tsg_version() != 2:
+        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 2 expected by the Python host code")
     _lib = lib
     return lib
 

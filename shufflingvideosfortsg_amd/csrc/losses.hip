@@ -172,7 +172,7 @@ extern "C" int tsg_gmd_losses_fwd(const void* ps, const void* pe, const void* om
   int rc = loss_check(fn, B, T);
   if (rc) return rc;
   auto st = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(ws, 0, 32, st);
+  hipError_t e = zero_async(ws, 32, st);
   if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
   hipLaunchKernelGGL(gmd_losses_fwd_kernel, dim3(B), dim3(kLossThreads), sizeof(float) * 2 * T, st, (const float*)ps, (const float*)pe,
                      (const float*)om, (const float*)pm, (const float*)od, (const float*)pd, (const long long*)fs,

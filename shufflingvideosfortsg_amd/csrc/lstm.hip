@@ -1036,8 +1036,6 @@ static int l2_exchange() {        // TSG_LSTM_L2X=0: always write-through exchan
   return v;
 }
 extern "C" int tsg_lstm_set_l2_exchange(int on) { g_l2x.store(on != 0, std::memory_order_relaxed); return 0; }
-static std::atomic<unsigned*> g_error_sink{nullptr};
-extern "C" int tsg_lstm_error_sink(void* p) { g_error_sink.store(static_cast<unsigned*>(p), std::memory_order_relaxed); return 0; }
 
 // Workgroups of a persistent kernel that can be co-resident: ONE per CU is counted (margin against over-reporting), cached
 // per (device, kernel slot).  0 = the kernel cannot run persistently here.
@@ -1115,11 +1113,11 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
       for (int c0 = 0; c0 < B; c0 += rows) {
         const int Bc = B - c0 < rows ? B - c0 : rows;
         const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;              // first sequence row of the chunk
-        hipError_t e = hipMemsetAsync(sync_ws, 0, kSyncBytes, st);
+        hipError_t e = zero_async(sync_ws, kSyncBytes, st);
         if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
         hipLaunchKernelGGL(pk, dim3(2 * (h / (4 * NW)) * cdiv(Bc, 16)), dim3(64 * NW), plds, st, (const float*)Gx + seq * K8, (const float*)bias,
                            (const float*)Whh, (float*)out + seq * H2, (float*)R + (size_t)c0 * h * 4, (float*)Cs + (size_t)c0 * h,
-                           (unsigned*)sync_ws, Bc, B, T, h, HLS, launch_flags(), bm, g_error_sink.load(std::memory_order_relaxed));
+                           (unsigned*)sync_ws, Bc, B, T, h, HLS, launch_flags(), bm, error_sink());
       }
       return check_launch(fn);
     }
@@ -1199,7 +1197,7 @@ extern "C" int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const voi
     int rc = lstm_check(fn, B, T, h, dtype);
     if (rc) return rc;
     auto st = static_cast<hipStream_t>(stream);
-    hipError_t e = dbias ? hipMemsetAsync(dbias, 0, sizeof(float) * 8 * h, st) : hipSuccess;
+    hipError_t e = dbias ? zero_async(dbias, sizeof(float) * 8 * h, st) : hipSuccess;
     if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
     const bool split = dtype == TSG_F32S;
     auto pk = h == 512 ? (split ? lstm_bwd_persist2_kernel<4, true> : lstm_bwd_persist2_kernel<4, false>)
@@ -1211,12 +1209,12 @@ extern "C" int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const voi
     for (int c0 = 0; c0 < B; c0 += rows) {                   // row chunks as in the forward; the ring is reused, dbias accumulates
       const int Bc = B - c0 < rows ? B - c0 : rows;
       const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;
-      e = hipMemsetAsync(ws, 0, kSyncBytes, st);
+      e = zero_async(ws, kSyncBytes, st);
       if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
       hipLaunchKernelGGL(pk, dim3(2 * (h / 32) * cdiv(Bc, 16)), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT,
                          (const float*)R + (size_t)c0 * h * 4, (const float*)Cs + (size_t)c0 * h, (const float*)dOut + seq * H2,
                          dHn ? (const float*)dHn + (size_t)c0 * h : nullptr, (float*)dG + seq * K8, (float*)((char*)ws + kSyncBytes),
-                         (unsigned*)ws, (float*)dbias, Bc, B, T, h, launch_flags(), bm, g_error_sink.load(std::memory_order_relaxed));
+                         (unsigned*)ws, (float*)dbias, Bc, B, T, h, launch_flags(), bm, error_sink());
     }
     return check_launch(fn);
   }

@@ -199,9 +199,9 @@ extern "C" int tsg_match_head_bwd(const void* y, const void* cs, const void* w2,
   int rc = mh_check(fn, B, T, H, activation);
   if (rc) return rc;
   auto st = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(dcs, 0, sizeof(float) * (size_t)B * H, st);
-  if (e == hipSuccess) e = hipMemsetAsync(dw2, 0, sizeof(float) * H, st);
-  if (e == hipSuccess) e = hipMemsetAsync(db2, 0, sizeof(float), st);
+  hipError_t e = zero_async(dcs, sizeof(float) * (size_t)B * H, st);
+  if (e == hipSuccess) e = zero_async(dw2, sizeof(float) * H, st);
+  if (e == hipSuccess) e = zero_async(db2, sizeof(float), st);
   if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
   const int grid = B * cdiv(T, kMhRows);
   auto k = activation == 0 ? match_head_bwd_kernel<0> : activation == 1 ? match_head_bwd_kernel<1> : match_head_bwd_kernel<2>;

@@ -775,8 +775,8 @@ extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O,
   if (!(scale > 0.f)) return set_error(TSG_E_SHAPE, "%s: scale must be positive", fn);
   auto st = static_cast<hipStream_t>(stream);
   const size_t map_bytes = sizeof(float) * (size_t)B * Tq * Tk;
-  if (A_sum) { hipError_t e = hipMemsetAsync(A_sum, 0, map_bytes, st); if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e)); }
-  if (S_sum) { hipError_t e = hipMemsetAsync(S_sum, 0, map_bytes, st); if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e)); }
+  if (A_sum) { hipError_t e = zero_async(A_sum, map_bytes, st); if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e)); }
+  if (S_sum) { hipError_t e = zero_async(S_sum, map_bytes, st); if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e)); }
   const int dh = d_key / n_heads, dvh = d_value / n_heads;
   if (!A_sum && !S_sum && dh <= DHMAX && dvh <= DHMAX) {            // MFMA path
     const int KS = roundup(dh, 64) + 2, VS = roundup(dvh, 32) + 4, qblocks = cdiv(Tq, QB);

@@ -785,6 +785,378 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// backward, fused (default): ONE kernel; every input is read once and every output written once
+// (the two-kernel path above moves dG and de through HBM: 1.38x the algorithmic traffic).
+//
+// Workgroup = (batch item b, column part pt), 8 waves.  The columns (of Ds in the row phase, of H in the column
+// phase) are cut into slices of SW = 64*CPL; the part owns SP consecutive slices, wave (sw, rq) owns slice sw of
+// them and the clip rows rq, rq+RS, rq+2RS, ... (RS = 8/SP row splits).  All T rows of the item stay with the
+// workgroup, so the T-sums (ds, dVW) never leave it:
+//   row phase   per row t, columns of the wave:  G = P[t,:] VW + bias, sg = sigmoid(G), dr = dout*sg (stored),
+//               dG = dout*r*sg*(1-sg);  dVW += P[t,:]^T dG;  dbias += dG;  partial dP[t,n] = <dG, VW[n,:]> over the
+//               wave's columns (swap reduction), folded over the part's slices in LDS  (GATE = false: dG = dC)
+//   exchange    the dot products need ALL columns: the `parts` workgroups of an item publish their partial dP
+//               ([T][NP] floats, agent-scope stores), meet on a counter and each sums the partials in part order
+//               (deterministic).  de = P (dP - <P,dP>) -> LDS.  Co-dispatched neighbours (consecutive block ids),
+//               bounded spin; 10 KiB per workgroup instead of the 1 MiB dG round trip.
+//   column phase per row t, columns k of the wave: r = 1/(Ea Es[n]+1), q = r - r^2:
+//               da[t,k] = 4w Σ_n de q (stored), ds[n,k] += de q, dw[k] += de r      (5 VALU + 1 rcp per element)
+//   end         row splits folded through LDS in fixed order; ds, dVW stored; dw, dbias: one atomic per column.
+// ------------------------------------------------------------------------------------------
+constexpr int kFusedThreads = 512, kFusedWaves = kFusedThreads / kWave;
+constexpr int kFusedSub = 32;                  // rows per dP folding round
+constexpr int kFusedPF = 4;                    // rows in flight per wave
+constexpr unsigned kXchSpinLimit = 1u << 22;   // bounded wait on the neighbours (~seconds); expiry sets the error sink
+template <int NP> constexpr int fused_cpl() { return NP <= 20 ? 2 : 1; }
+
+struct FusedPlan { int parts, SP, grid; size_t lds; long long ws_bytes; bool ok; };
+
+template <int NP>
+FusedPlan fused_plan(int B, int T, int N, int H, int Ds) {
+  constexpr int SW = kWave * fused_cpl<NP>();
+  FusedPlan p{};
+  int S = cdiv(H, SW) > cdiv(Ds, SW) ? cdiv(H, SW) : cdiv(Ds, SW), S2 = 1;
+  while (S2 < S) S2 <<= 1;
+  int parts = 1;
+  while (parts < S2 && ((long)B * parts < 256 || S2 / parts > kFusedWaves)) parts <<= 1;
+  p.parts = parts; p.SP = S2 / parts; p.grid = B * parts;
+  const int RS = kFusedWaves / p.SP;
+  const size_t part_f = (size_t)p.SP * kFusedSub * (NP + 1), red_f = (size_t)(RS - 1) * p.SP * NP * SW;
+  p.lds = sizeof(float) * ((size_t)2 * T * NP + (part_f > red_f ? part_f : red_f));
+  p.ws_bytes = (long long)sizeof(float) * ((long long)B * parts * T * NP + roundup(B, 4));
+  p.ok = p.SP <= kFusedWaves && p.lds <= (size_t)kLdsBytes - 1024;
+  return p;
+}
+
+template <int NP, bool GATE>
+__global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
+    const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w, const float* __restrict__ V,
+    const float* __restrict__ P, const float* __restrict__ dC, const float* __restrict__ gr, const float* __restrict__ gbias,
+    float* __restrict__ da, float* __restrict__ ds, float* __restrict__ dw, float* __restrict__ dV, float* __restrict__ dbias,
+    float* __restrict__ drout, float* xch, unsigned* __restrict__ cnt, unsigned* __restrict__ esink,
+    int B, int T, int N, int H, int Ds, int parts, int SP, int dbg) {
+  constexpr int CPL = fused_cpl<NP>(), SW = kWave * CPL;
+  extern __shared__ __align__(16) float lds[];
+  float* Pl = lds;                              // [T][NP]  P rows, zero beyond N
+  float* De = Pl + (size_t)T * NP;              // [T][NP]  partial dP -> de
+  float* part = De + (size_t)T * NP;            // [SP][kFusedSub][NP+1] per-slice partial dP of a folding round; later the
+  float* red = part;                            // [RS-1][SP][NP][SW] row-split partials of the T-sums
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+  const int bid = xcd_remap(blockIdx.x, gridDim.x, parts);
+  const int b = bid / parts, pt = bid % parts;
+  const int RS = kFusedWaves / SP, sw = wv % SP, rq = wv / SP;
+  const int col = (pt * SP + sw) * SW + lane * CPL;
+  const bool jok = col < Ds, kok = col < H;
+  const size_t rowDs = (size_t)b * T * Ds + (jok ? col : 0), rowH = (size_t)b * T * H + (kok ? col : 0);
+  const int nrows = rq < T ? (T - rq + RS - 1) / RS : 0;          // this wave's rows: t = rq + RS*i
+
+  for (int idx = tid; idx < T * NP; idx += kFusedThreads) {
+    const int r = idx / NP, n = idx % NP;
+    Pl[idx] = n < N ? P[((size_t)b * T + r) * N + n] : 0.f;
+  }
+
+  // ---------------- row phase ------------------------------------------------------------------
+  {
+    float vreg[NP][CPL], dvacc[NP][CPL], gsum[CPL], gb[CPL];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { vreg[n][c] = 0.f; dvacc[n][c] = 0.f; }
+      if (n < N && jok) ld_cols<CPL>(V + ((size_t)b * N + n) * Ds + col, vreg[n]);
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { gsum[c] = 0.f; gb[c] = (GATE && col + c < Ds) ? gbias[col + c] : 0.f; }
+    float gring[kFusedPF][CPL], rring[kFusedPF][CPL];
+#pragma unroll
+    for (int u = 0; u < kFusedPF; ++u) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { gring[u][c] = 0.f; rring[u][c] = 0.f; }
+      if (u < nrows && jok) {
+        ld_cols<CPL>(dC + rowDs + (size_t)(rq + RS * u) * Ds, gring[u]);
+        if (GATE) ld_cols<CPL>(gr + rowDs + (size_t)(rq + RS * u) * Ds, rring[u]);
+      }
+    }
+    const int q4 = lane >> 4, nq = ((q4 & 1) << 1) | (q4 >> 1);
+    const int per_sub = kFusedSub / RS;                           // this wave's rows per folding round (RS divides 32)
+    __syncthreads();                                              // Pl staged
+    for (int sb0 = 0, i0 = 0; sb0 < T; sb0 += kFusedSub, i0 += per_sub) {
+#pragma unroll 1
+      for (int ib = 0; ib < per_sub; ib += kFusedPF) {
+#pragma unroll
+        for (int u = 0; u < kFusedPF; ++u) {
+          const int i = i0 + ib + u, t = rq + RS * i;
+          if (ib + u < per_sub && i < nrows && !TSG_SKIP(16)) {    // wave-uniform
+            float g[CPL], rr[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) { g[c] = gring[u][c]; rr[c] = rring[u][c]; }
+            const int inx = i + kFusedPF;                         // same ring slot, kFusedPF rows ahead (per_sub % PF == 0 or tail)
+            if (inx < nrows && jok) {
+              ld_cols<CPL>(dC + rowDs + (size_t)(rq + RS * inx) * Ds, gring[u]);
+              if (GATE) ld_cols<CPL>(gr + rowDs + (size_t)(rq + RS * inx) * Ds, rring[u]);
+            }
+            const float* prow = Pl + t * NP;
+            if (GATE) {
+              float G[CPL];
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) G[c] = gb[c];
+#pragma unroll
+              for (int n4 = 0; n4 < NP; n4 += 4) {
+                const float4 p4 = *reinterpret_cast<const float4*>(prow + n4);
+                const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                  for (int c = 0; c < CPL; ++c) G[c] = fmaf(pp[j], vreg[n4 + j][c], G[c]);
+              }
+              float drv[CPL];
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) {
+                const float sg = fast_rcp(1.f + fast_exp2(-G[c] * kLog2e));
+                drv[c] = g[c] * sg;
+                g[c] = g[c] * rr[c] * sg * (1.f - sg);             // dG: from here on "dC"
+              }
+              if (jok) st_cols<CPL>(drout + rowDs + (size_t)t * Ds, drv);
+            }
+            float dp[NP];
+#pragma unroll
+            for (int n4 = 0; n4 < NP; n4 += 4) {
+              const float4 p4 = *reinterpret_cast<const float4*>(prow + n4);
+              const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                  dvacc[n4 + j][c] = fmaf(pp[j], g[c], dvacc[n4 + j][c]);
+                  acc = fmaf(g[c], vreg[n4 + j][c], acc);
+                }
+                dp[n4 + j] = acc;
+              }
+            }
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) gsum[c] += g[c];
+            float z[NP / 4];
+            if (TSG_SKIP(128)) {
+#pragma unroll
+              for (int j = 0; j < NP / 4; ++j) z[j] = dp[j];
+            } else {
+              wave_transpose_sum<NP>(dp, z);
+            }
+            if ((lane & 15) == 0) {
+#pragma unroll
+              for (int j = 0; j < NP / 4; ++j) part[(sw * kFusedSub + (t - sb0)) * (NP + 1) + 4 * j + nq] = z[j];
+            }
+          }
+        }
+      }
+      lds_barrier();
+      const int sbn = T - sb0 < kFusedSub ? T - sb0 : kFusedSub;
+      for (int idx = tid; idx < sbn * NP; idx += kFusedThreads) {
+        const int r = idx / NP, n = idx % NP;
+        float sum = 0.f;
+        for (int c = 0; c < SP; ++c) sum += part[(c * kFusedSub + r) * (NP + 1) + n];
+        De[(sb0 + r) * NP + n] = sum;
+      }
+      lds_barrier();
+    }
+    // T-sums of the row phase: dVW and the gate bias gradient.  Row splits rq > 0 hand theirs to rq = 0 through LDS.
+    for (int q = 1; q < RS; ++q) {
+      if (rq == q) {
+#pragma unroll
+        for (int n = 0; n < NP; ++n) st_cols<CPL>(red + (((size_t)(q - 1) * SP + sw) * NP + n) * SW + lane * CPL, dvacc[n]);
+      }
+    }
+    lds_barrier();
+    if (rq == 0) {
+      for (int q = 1; q < RS; ++q) {
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+          float o[CPL];
+          ld_cols<CPL>(red + (((size_t)(q - 1) * SP + sw) * NP + n) * SW + lane * CPL, o);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) dvacc[n][c] += o[c];
+        }
+      }
+      if (jok) {
+#pragma unroll
+        for (int n = 0; n < NP; ++n)
+          if (n < N) st_cols<CPL>(dV + ((size_t)b * N + n) * Ds + col, dvacc[n]);
+      }
+    }
+    if (GATE) {                                                    // dbias: fold the row splits with a second round
+      lds_barrier();
+      if (rq > 0) st_cols<CPL>(red + ((size_t)(rq - 1) * SP + sw) * SW + lane * CPL, gsum);
+      lds_barrier();
+      if (rq == 0 && jok) {
+        for (int q = 1; q < RS; ++q) {
+          float o[CPL];
+          ld_cols<CPL>(red + ((size_t)(q - 1) * SP + sw) * SW + lane * CPL, o);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) gsum[c] += o[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+          if (col + c < Ds && !TSG_SKIP(256)) atomicAdd(dbias + col + c, gsum[c]);
+      }
+    }
+  }
+
+  // ---------------- exchange: dP over ALL columns, then de -------------------------------------
+  if (parts > 1) {
+    float* mine = xch + ((size_t)b * parts + pt) * T * NP;
+    for (int idx = tid; idx < T * NP; idx += kFusedThreads)
+      __hip_atomic_store(mine + idx, De[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      __hip_atomic_fetch_add(cnt + b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while (!TSG_SKIP(64) && __hip_atomic_load(cnt + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)parts) {
+        if (++spins > kXchSpinLimit) {
+          if (esink) __hip_atomic_store(esink, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      __threadfence();
+    }
+    __syncthreads();
+    // every part's partial in part order (deterministic).  Plain loads: thread 0's agent-scope acquire followed by the
+    // workgroup barrier orders them after the neighbours' published stores, and they can be issued back to back (atomic
+    // loads are kept in program order by the compiler: one memory round trip each, ~40 in a row).
+    for (int idx = tid; idx < T * NP; idx += kFusedThreads) {
+      float v = 0.f;
+      for (int p = 0; p < parts; ++p) v += xch[((size_t)b * parts + p) * T * NP + idx];
+      De[idx] = v;
+    }
+    __syncthreads();
+  } else {
+    __syncthreads();
+  }
+  for (int r = tid; r < T; r += kFusedThreads) {
+    float dp[NP], dot = 0.f;
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+      dp[n] = De[r * NP + n];
+      dot = fmaf(Pl[r * NP + n], dp[n], dot);
+    }
+#pragma unroll
+    for (int n = 0; n < NP; ++n) De[r * NP + n] = Pl[r * NP + n] * (dp[n] - dot);      // 0 for padded words (P = 0)
+  }
+  __syncthreads();
+
+  // ---------------- column phase -----------------------------------------------------------------
+  {
+    float es[NP][CPL], dsacc[NP][CPL], dwacc[CPL], w4[CPL];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { es[n][c] = 0.f; dsacc[n][c] = 0.f; }
+      if (n < N && kok) ld_cols<CPL>(s + ((size_t)b * N + n) * H + col, es[n]);
+      exp2_cols<CPL>(es[n]);
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { dwacc[c] = 0.f; w4[c] = (col + c < H) ? 4.f * w[col + c] : 0.f; }
+    float aring[kFusedPF][CPL];
+#pragma unroll
+    for (int u = 0; u < kFusedPF; ++u) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) aring[u][c] = 0.f;
+      if (u < nrows && kok) ld_cols<CPL>(a + rowH + (size_t)(rq + RS * u) * H, aring[u]);
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < nrows; i0 += kFusedPF) {
+#pragma unroll
+      for (int u = 0; u < kFusedPF; ++u) {
+        const int i = i0 + u, t = rq + RS * i;
+        if (i < nrows && !TSG_SKIP(32)) {                           // wave-uniform
+          float ea[CPL], dasum[CPL];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) { ea[c] = aring[u][c]; dasum[c] = 0.f; }
+          const int inx = i + kFusedPF;
+          if (inx < nrows && kok) ld_cols<CPL>(a + rowH + (size_t)(rq + RS * inx) * H, aring[u]);
+          exp2_cols<CPL>(ea);
+          const float* drow = De + t * NP;
+#pragma unroll
+          for (int n4 = 0; n4 < NP; n4 += 4) {
+            const float4 d4 = *reinterpret_cast<const float4*>(drow + n4);   // broadcast
+            const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) {
+                const float r = fast_rcp(fmaf(ea[c], es[n4 + j][c], 1.f));
+                const float q = fmaf(-r, r, r);
+                dsacc[n4 + j][c] = fmaf(dd[j], q, dsacc[n4 + j][c]);
+                dasum[c] = fmaf(dd[j], q, dasum[c]);
+                dwacc[c] = fmaf(dd[j], r, dwacc[c]);
+              }
+          }
+          if (kok) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) dasum[c] *= w4[c];
+            st_cols<CPL>(da + rowH + (size_t)t * H, dasum);
+          }
+        }
+      }
+    }
+    // T-sums of the column phase
+    __syncthreads();                                               // De no longer read; `red` overlays `part` only, but keep order simple
+    for (int q = 1; q < RS; ++q) {
+      if (rq == q) {
+#pragma unroll
+        for (int n = 0; n < NP; ++n) st_cols<CPL>(red + (((size_t)(q - 1) * SP + sw) * NP + n) * SW + lane * CPL, dsacc[n]);
+      }
+    }
+    lds_barrier();
+    if (rq == 0) {
+      for (int q = 1; q < RS; ++q) {
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+          float o[CPL];
+          ld_cols<CPL>(red + (((size_t)(q - 1) * SP + sw) * NP + n) * SW + lane * CPL, o);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) dsacc[n][c] += o[c];
+        }
+      }
+      if (kok) {
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+          if (n < N) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) dsacc[n][c] *= w4[c];
+            st_cols<CPL>(ds + ((size_t)b * N + n) * H + col, dsacc[n]);
+          }
+        }
+      }
+    }
+    lds_barrier();
+    if (rq > 0) st_cols<CPL>(red + ((size_t)(rq - 1) * SP + sw) * SW + lane * CPL, dwacc);
+    lds_barrier();
+    if (rq == 0 && kok) {
+      for (int q = 1; q < RS; ++q) {
+        float o[CPL];
+        ld_cols<CPL>(red + ((size_t)(q - 1) * SP + sw) * SW + lane * CPL, o);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) dwacc[c] += o[c];
+      }
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+        if (col + c < H && !TSG_SKIP(256)) atomicAdd(dw + col + c, -2.f * dwacc[c]);
+    }
+  }
+}
+
+// zero up to three small accumulator blocks with ONE launch (dw, dbias, the exchange counters)
+__global__ void zero3_kernel(unsigned* p0, int n0, unsigned* p1, int n1, unsigned* p2, int n2) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1 + n2; i += gridDim.x * blockDim.x) {
+    if (i < n0) p0[i] = 0u;
+    else if (i < n0 + n1) p1[i - n0] = 0u;
+    else p2[i - n0 - n1] = 0u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
 
@@ -817,17 +1189,16 @@ int launch_fwd(const float* a, const float* s, const float* w, const float* V, f
   return check_launch("scdm_attn_fwd");
 }
 
-// GATE: V = VW, dC = dout; extra outputs dbias [Ds], dr [B,T,Ds]; dG_ws [B,T,Ds] workspace.
+// Two-kernel path (kept for shapes whose P / de tiles do not fit the fused kernel's LDS, and for A/B timing with
+// TSG_K1_BWD=split).  GATE: V = VW, dC = dout; extra outputs dbias [Ds], dr [B,T,Ds]; dG_ws [B,T,Ds] workspace.
 template <int NP, bool GATE>
-int launch_bwd(const float* a, const float* s, const float* w, const float* V, const float* P,
+int launch_bwd_split(const float* a, const float* s, const float* w, const float* V, const float* P,
                const float* dC, float* da, float* ds, float* dw, float* dV, float* de,
                const float* gr, const float* gbias, float* dbias, float* dr, float* dG_ws,
                int B, int T, int N, int H, int Ds, hipStream_t st) {
   if (Ds > (NP <= 20 ? 2048 : 1024))
     return set_error(TSG_E_SHAPE, "scdm_attn_bwd: Ds=%d (max %d at N=%d) not supported", Ds, NP <= 20 ? 2048 : 1024, N);
-  hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * H, st);
-  if (e == hipSuccess && GATE) e = hipMemsetAsync(dbias, 0, sizeof(float) * Ds, st);
-  if (e != hipSuccess) return set_error((int)e, "scdm_attn_bwd: memset: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(zero3_kernel, dim3(4), dim3(256), 0, st, (unsigned*)dw, H, (unsigned*)dbias, GATE ? Ds : 0, (unsigned*)nullptr, 0);
   const int tiles = cdiv(T, 32);
   hipLaunchKernelGGL((scdm_bwd_rows_kernel<NP, GATE>), dim3(B * tiles), dim3(kFwdThreads), 0, st, V, P, dC, de, gr, gbias,
                      dG_ws, dr, B, T, N, Ds, tiles);
@@ -839,6 +1210,46 @@ int launch_bwd(const float* a, const float* s, const float* w, const float* V, c
   hipLaunchKernelGGL(scdm_bwd_cols_kernel<NP>, dim3(B * slices), dim3(kColThreads), rows_lds, st, a, s, w, P, GATE ? dG_ws : dC, de,
                      da, ds, dw, dV, GATE ? dbias : nullptr, B, T, N, H, Ds, hslices, slices);
   return check_launch("scdm_attn_bwd(cols)");
+}
+
+static bool want_split() {
+  static const bool v = [] { const char* e = getenv("TSG_K1_BWD"); return e && e[0] == 's'; }();
+  return v;
+}
+
+inline long long split_ws_bytes(int B, int T, int N, int Ds, bool gate) {
+  return (long long)sizeof(float) * ((long long)B * T * roundup(N, 4) + (gate ? (long long)B * T * Ds : 0));
+}
+
+template <int NP, bool GATE>
+int launch_bwd(const float* a, const float* s, const float* w, const float* V, const float* P,
+               const float* dC, float* da, float* ds, float* dw, float* dV, const float* gr, const float* gbias,
+               float* dbias, float* dr, void* ws, long long ws_bytes, int B, int T, int N, int H, int Ds, hipStream_t st) {
+  const char* fn = GATE ? "tsg_scdm_gate_bwd" : "tsg_scdm_attn_bwd";
+  if (Ds > (NP <= 20 ? 2048 : 1024))
+    return set_error(TSG_E_SHAPE, "%s: Ds=%d (max %d at N=%d) not supported", fn, Ds, NP <= 20 ? 2048 : 1024, N);
+  const FusedPlan pl = fused_plan<NP>(B, T, N, H, Ds);
+  if (pl.ok && !want_split()) {
+    if (ws_bytes < pl.ws_bytes) return set_error(TSG_E_SHAPE, "%s: workspace of %lld B < %lld B (tsg_scdm_bwd_ws_bytes)", fn, ws_bytes, pl.ws_bytes);
+    float* xch = static_cast<float*>(ws);
+    unsigned* cnt = reinterpret_cast<unsigned*>(xch + (size_t)B * pl.parts * T * NP);
+    hipLaunchKernelGGL(zero3_kernel, dim3(4), dim3(256), 0, st, (unsigned*)dw, H, (unsigned*)dbias, GATE ? Ds : 0, cnt, B);
+    auto kern = scdm_bwd_fused_kernel<NP, GATE>;
+    static thread_local size_t allowed = 0;     // per instantiation
+    if (pl.lds > allowed) {
+      hipError_t e = allow_lds(kern, pl.lds);
+      if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute(%zu): %s", fn, pl.lds, hipGetErrorString(e));
+      allowed = pl.lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kFusedThreads), pl.lds, st, a, s, w, V, P, dC, gr, gbias, da, ds, dw, dV, dbias, dr,
+                       xch, cnt, error_sink(), B, T, N, H, Ds, pl.parts, pl.SP, ablate_mask());
+    return check_launch(fn);
+  }
+  if (ws_bytes < split_ws_bytes(B, T, N, Ds, GATE))
+    return set_error(TSG_E_SHAPE, "%s: workspace of %lld B < %lld B (tsg_scdm_bwd_ws_bytes)", fn, ws_bytes, split_ws_bytes(B, T, N, Ds, GATE));
+  float* de = static_cast<float*>(ws);
+  float* dG = de + (size_t)B * T * roundup(N, 4);
+  return launch_bwd_split<NP, GATE>(a, s, w, V, P, dC, da, ds, dw, dV, de, gr, gbias, dbias, dr, GATE ? dG : nullptr, B, T, N, H, Ds, st);
 }
 
 int check_common(const char* fn, std::initializer_list<const void*> ptrs, int B, int T, int N, int H, int Ds, int dtype) {
@@ -881,16 +1292,34 @@ extern "C" int tsg_scdm_attn_fwd(const void* a, const void* s, const void* w, co
                                              (float*)C, (float*)P, nullptr, nullptr, B, T, N, H, Ds, st)));
 }
 
+extern "C" long long tsg_scdm_bwd_ws_bytes(int B, int T, int N, int H, int Ds, int gate) {
+  if (B <= 0 || T <= 0 || N <= 0 || N > 32 || H <= 0 || Ds <= 0) return 0;
+  const int np = roundup(N, 4);
+  const long long split = split_ws_bytes(B, T, N, Ds, gate != 0);
+  long long fused = 0;
+  switch (np) {
+    case 4: fused = fused_plan<4>(B, T, N, H, Ds).ws_bytes; break;
+    case 8: fused = fused_plan<8>(B, T, N, H, Ds).ws_bytes; break;
+    case 12: fused = fused_plan<12>(B, T, N, H, Ds).ws_bytes; break;
+    case 16: fused = fused_plan<16>(B, T, N, H, Ds).ws_bytes; break;
+    case 20: fused = fused_plan<20>(B, T, N, H, Ds).ws_bytes; break;
+    case 24: fused = fused_plan<24>(B, T, N, H, Ds).ws_bytes; break;
+    case 28: fused = fused_plan<28>(B, T, N, H, Ds).ws_bytes; break;
+    default: fused = fused_plan<32>(B, T, N, H, Ds).ws_bytes; break;
+  }
+  return fused > split ? fused : split;       // either path can run in it
+}
+
 extern "C" int tsg_scdm_attn_bwd(const void* a, const void* s, const void* w, const void* sent,
                                  const void* P, const void* dC, void* da, void* ds, void* dw, void* dsent,
-                                 void* de_ws, int B, int T, int N, int H, int Ds, int dtype, void* stream) {
-  int rc = check_common("tsg_scdm_attn_bwd", {a, s, w, sent, P, dC, da, ds, dw, dsent, de_ws}, B, T, N, H, Ds, dtype);
+                                 void* ws, long long ws_bytes, int B, int T, int N, int H, int Ds, int dtype, void* stream) {
+  int rc = check_common("tsg_scdm_attn_bwd", {a, s, w, sent, P, dC, da, ds, dw, dsent, ws}, B, T, N, H, Ds, dtype);
   if (rc) return rc;
   const int np = roundup(N, 4);
   auto st = static_cast<hipStream_t>(stream);
   TSG_DISPATCH_NP(np, (launch_bwd<NP, false>((const float*)a, (const float*)s, (const float*)w, (const float*)sent,
                                              (const float*)P, (const float*)dC, (float*)da, (float*)ds, (float*)dw,
-                                             (float*)dsent, (float*)de_ws, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                             (float*)dsent, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
                                              B, T, N, H, Ds, st)));
 }
 
@@ -907,15 +1336,15 @@ extern "C" int tsg_scdm_gate_fwd(const void* a, const void* s, const void* w, co
 
 extern "C" int tsg_scdm_gate_bwd(const void* a, const void* s, const void* w, const void* VW, const void* gbias,
                                  const void* r, const void* P, const void* dout, void* da, void* ds, void* dw,
-                                 void* dVW, void* dgbias, void* dr, void* de_ws, void* dG_ws,
+                                 void* dVW, void* dgbias, void* dr, void* ws, long long ws_bytes,
                                  int B, int T, int N, int H, int Ds, int dtype, void* stream) {
-  int rc = check_common("tsg_scdm_gate_bwd", {a, s, w, VW, gbias, r, P, dout, da, ds, dw, dVW, dgbias, dr, de_ws, dG_ws},
+  int rc = check_common("tsg_scdm_gate_bwd", {a, s, w, VW, gbias, r, P, dout, da, ds, dw, dVW, dgbias, dr, ws},
                         B, T, N, H, Ds, dtype);
   if (rc) return rc;
   const int np = roundup(N, 4);
   auto st = static_cast<hipStream_t>(stream);
   TSG_DISPATCH_NP(np, (launch_bwd<NP, true>((const float*)a, (const float*)s, (const float*)w, (const float*)VW,
                                             (const float*)P, (const float*)dout, (float*)da, (float*)ds, (float*)dw,
-                                            (float*)dVW, (float*)de_ws, (const float*)r, (const float*)gbias,
-                                            (float*)dgbias, (float*)dr, (float*)dG_ws, B, T, N, H, Ds, st)));
+                                            (float*)dVW, (const float*)r, (const float*)gbias,
+                                            (float*)dgbias, (float*)dr, ws, ws_bytes, B, T, N, H, Ds, st)));
 }

@@ -17,6 +17,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 // ---- host side ---------------------------------------------------------------------------
 int set_error(int code, const char* fmt, ...);   // stores a thread-local message, returns code
 int check_launch(const char* what);              // hipGetLastError() -> 0 or positive hipError_t
+unsigned* error_sink();                          // the registered error sink (tsg_error_sink), or nullptr
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -84,6 +85,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks, int group) {
   const int round = bid / per_round, r = bid % per_round;
   const int xcd = r % 8, slot = r / 8;         // slot-th block this XCD receives in the round
   return round * per_round + xcd * group + slot;
+}
+
+// Zero-fill of a small accumulator / sync block as an ordinary kernel node.  (hipMemsetAsync is avoided on purpose: the
+// library's launches must behave identically when the caller's stream is being captured into a HIP graph and replayed, and a
+// plain kernel is the one node type every capture / replay path treats as ordered, re-executed work.)
+static __global__ void zero_words_kernel(unsigned* __restrict__ p, size_t words) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+inline hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {      // p 4-byte aligned, bytes a multiple of 4
+  const size_t words = bytes / 4;
+  if (words == 0) return hipSuccess;
+  const int blocks = (int)((words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, st, static_cast<unsigned*>(p), words);
+  return hipGetLastError();
 }
 
 #endif  // __HIPCC__

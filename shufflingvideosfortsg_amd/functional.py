@@ -57,7 +57,7 @@ def check_lstm_errors() -> None:
     global _lstm_sink
     if _lstm_sink is None:
         _lstm_sink = torch.zeros(1, dtype=torch.int32).pin_memory()
-        check(load().tsg_lstm_error_sink(_lstm_sink.data_ptr()), "tsg_lstm_error_sink")
+        check(load().tsg_error_sink(_lstm_sink.data_ptr()), "tsg_error_sink")
         _lstm_selftest()
     elif int(_lstm_sink[0]) != 0:
         _lstm_sink[0] = 0
@@ -243,9 +243,10 @@ class _ScdmAttn(torch.autograd.Function):
         _, N, Ds = sent.shape
         da = torch.empty_like(a); ds = torch.empty_like(s)
         dw = torch.empty_like(w); dsent = torch.empty_like(sent)
-        de = torch.empty(B, T, N, device=a.device, dtype=torch.float32)
+        nb = int(load().tsg_scdm_bwd_ws_bytes(B, T, N, H, Ds, 0))
+        ws = torch.empty(nb // 4 + 4, device=a.device, dtype=torch.float32)
         _call("tsg_scdm_attn_bwd", a, ptr(a), ptr(s), ptr(w), ptr(sent), ptr(P), ptr(dC), ptr(da), ptr(ds),
-                                       ptr(dw), ptr(dsent), ptr(de), B, T, N, H, Ds, TSG_F32)
+                                       ptr(dw), ptr(dsent), ptr(ws), nb, B, T, N, H, Ds, TSG_F32)
         return da, ds, dw, dsent
 
 
@@ -283,10 +284,10 @@ class _ScdmGate(torch.autograd.Function):
         _, N, Ds = VW.shape
         da = torch.empty_like(a); ds = torch.empty_like(s); dw = torch.empty_like(w)
         dVW = torch.empty_like(VW); dgb = torch.empty_like(gbias); dr = torch.empty_like(r)
-        de = torch.empty(B, T, N, device=a.device, dtype=torch.float32)
-        dG = torch.empty(B, T, Ds, device=a.device, dtype=torch.float32)
+        nb = int(load().tsg_scdm_bwd_ws_bytes(B, T, N, H, Ds, 1))
+        ws = torch.empty(nb // 4 + 4, device=a.device, dtype=torch.float32)
         _call("tsg_scdm_gate_bwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(r), ptr(P), ptr(dout),
-              ptr(da), ptr(ds), ptr(dw), ptr(dVW), ptr(dgb), ptr(dr), ptr(de), ptr(dG), B, T, N, H, Ds, TSG_F32)
+              ptr(da), ptr(ds), ptr(dw), ptr(dVW), ptr(dgb), ptr(dr), ptr(ws), nb, B, T, N, H, Ds, TSG_F32)
         return da, ds, dw, dVW, dgb, dr
 
 

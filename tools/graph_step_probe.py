@@ -8,13 +8,15 @@ import torch
 from shufflingvideosfortsg_amd import data, engine, functional as TF
 
 B, T, N, d = 64, 128, 20, 1024
-params = engine.default_params(video_rnn_hiddendim=d // 2, sent_rnn_hiddendim=d // 2, video_len=T, sent_len=N)
+DROP = float(os.environ.get("PROBE_DROPOUT", "0.0"))
+params = engine.default_params(video_rnn_hiddendim=d // 2, sent_rnn_hiddendim=d // 2, video_len=T, sent_len=N, dropout=DROP)
 dev = torch.device("cuda", 0)
 
 
 def build():
     torch.manual_seed(0)
     model = engine.build_model("gmd", params).to(dev).train()
+    model.tod.dropout.p = DROP if DROP > 0 else 0.0
     ps = list(model.parameters())
     opt = torch.optim.Adam(ps, lr=params["lr"], weight_decay=params["weight_decay"], eps=1e-6, fused=True, capturable=True)
     return model, opt
@@ -79,8 +81,12 @@ print("captured: graph A (fwd+bwd) and graph B (Adam)")
 def replay():
     gA.replay(); gB.replay(); return loss_static
 lg = []
-for _ in range(6):
+for i in range(6):
     replay(); lg.append(float(loss_static))
+    try:
+        TF.check_lstm_errors()
+    except TF.LstmWaitExpired as e:
+        print(f"replay {i}: LSTM wait expired")
 print("eager  losses:", [round(x, 5) for x in le])
 print("graph  losses:", [round(x, 5) for x in lg])
 ms, enq, _ = timeit(replay)
