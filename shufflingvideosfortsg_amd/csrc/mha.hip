@@ -231,14 +231,14 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 
 // Batched tile staging: every thread first REQUESTS its NV float4 (rows x cols4 float4 per row, zero fill
 // outside the matrix), then writes them to LDS -- one round trip instead of NV dependent ones.
-template <int NV>
+template <int NV, int NT = 256>
 struct TileStage {
   float4 v[NV];
   __device__ __forceinline__ void load(const float* __restrict__ src, int ld, int row0, int rows_total, int rows,
                                        int cols, int cols4) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = threadIdx.x + i * kMfmaThreads;
+      const int idx = threadIdx.x + i * NT;
       const int r = idx / cols4, c = (idx % cols4) * 4;
       v[i] = (r < rows && row0 + r < rows_total && c < cols) ? *reinterpret_cast<const float4*>(src + (size_t)(row0 + r) * ld + c)
                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -248,7 +248,7 @@ struct TileStage {
   __device__ __forceinline__ void store(float* __restrict__ dst, int stride, int rows, int cols4) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = threadIdx.x + i * kMfmaThreads;
+      const int idx = threadIdx.x + i * NT;
       const int r = idx / cols4, c = (idx % cols4) * 4;
       if (r < rows && c + 4 <= stride) {                 // the padded row (zeros beyond the head width)
         *reinterpret_cast<float2*>(dst + r * stride + c) = make_float2(v[i].x, v[i].y);
@@ -385,6 +385,151 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(2,
   for (int idx = tid; idx < QB * (dvh / 4); idx += kMfmaThreads) {
     const int r = idx / (dvh / 4), c = (idx % (dvh / 4)) * 4;
     const int qq = qb * QB + r;
+    if (qq < Tq)
+      *reinterpret_cast<float4*>(O + ((size_t)b * Tq + qq) * dv + hd * dvh + c) = *reinterpret_cast<const float4*>(Ol + r * VS + c);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, MFMA path for WIDE heads (128 < head width <= 256: Self_Attention_predictor at d = 1024 has 2d/8 = 256 channels
+// per head, SpanPredictor.py:244-266).  Keeping a 256-wide Q fragment and a 256-wide O accumulator per lane as the kernel
+// above does would take one wave per SIMD and still spill, so the head's channels are SPLIT OVER THE WAVES instead (as in
+// the backward): workgroup = (b, head, 64 queries), 8 waves = 2 query tiles x 4 channel quarters.  Per 32-key block wave
+// (qt, cw) forms the partial S^T = K Q^T over its 64 channels (32 MFMAs), the four quarters meet in LDS, every wave
+// rebuilds the full tile and the (replicated) online softmax, and accumulates O^T = V^T P^T for ITS 64 output channels.
+// Per wave: 32 registers of Q fragments, 32 of O accumulators -- two waves per SIMD with room to spare.
+// ------------------------------------------------------------------------------------------
+constexpr int kWideThreads = 512;
+constexpr int QBW = 64;           // queries per workgroup
+constexpr int DHW = 256;          // max head width
+
+template <bool DROP>
+__global__ __launch_bounds__(kWideThreads) void mha_fwd_mfma_wide_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    float* __restrict__ O, float* __restrict__ LSE,
+    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int qblocks, int KS, int VS, DropCfg dc) {
+  extern __shared__ __align__(16) float lds[];
+  float* Kl = lds;                         // [32][KS]   KS = 258 (= 2 mod 64: conflict-free b64 A reads), zero beyond dh
+  float* Vl = lds + 32 * KS;               // [32][VS]   zero beyond dvh
+  float* X = Vl + 32 * VS;                 // [2 query tiles][4 quarters][16][64] partial S^T
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qt = wv >> 2, cw = wv & 3;     // query tile, channel quarter
+  const int hd = blockIdx.x % H;
+  const int qb = (blockIdx.x / H) % qblocks, b = blockIdx.x / (H * qblocks);
+  const int dh = dk / H, dvh = dv / H;
+  const int jq = lane & 31, kk = lane >> 5;
+  const int q = qb * QBW + qt * 32 + jq;   // this lane's query
+  const float* Qb = Q + (size_t)b * Tq * dk + hd * dh;
+  const float* Kb = K + (size_t)b * Tk * dk + hd * dh;
+  const float* Vb = V + (size_t)b * Tk * dv + hd * dvh;
+  const int c0 = cw * 64;                  // this wave's channels (of Q/K for the scores, of V/O for the output)
+  const int ksteps = c0 < dh ? ((dh - c0 < 64 ? dh - c0 : 64) + 3) / 4 : 0;      // MFMA pairs over my score channels
+  const int ctiles = c0 < dvh ? ((dvh - c0 < 64 ? dvh - c0 : 64) + 31) / 32 : 0; // my 32-channel output tiles (0..2)
+
+  TileStage<32 * (DHW / 4) / kWideThreads, kWideThreads> ks, vs;                  // 4 float4 per thread each
+  ks.load(Kb, dk, 0, Tk, 32, dh, DHW / 4);
+  vs.load(Vb, dv, 0, Tk, 32, dvh, DHW / 4);
+
+  float2 qf[16];                           // Q fragments of my 64 channels: B operand of S^T = K Q^T
+  {
+    float* Ql = lds;                       // [64][KS] = 66 KB, aliased with Kl / Vl / X (98 KB)
+    TileStage<QBW * (DHW / 4) / kWideThreads, kWideThreads> qs;                   // 8 float4 per thread
+    qs.load(Qb, dk, qb * QBW, Tq, QBW, dh, DHW / 4);
+    qs.store(Ql, KS, QBW, DHW / 4);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      qf[s] = (s < ksteps) ? *reinterpret_cast<const float2*>(Ql + (qt * 32 + jq) * KS + c0 + 4 * s + 2 * kk) : make_float2(0.f, 0.f);
+    __syncthreads();
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+  float m_run = kNegBig, l_run = 0.f;
+
+  for (int k0 = 0; k0 < Tk; k0 += 32) {
+    ks.store(Kl, KS, 32, DHW / 4);
+    vs.store(Vl, VS, 32, DHW / 4);
+    __syncthreads();
+    if (k0 + 32 < Tk) {
+      ks.load(Kb, dk, k0 + 32, Tk, 32, dh, DHW / 4);
+      vs.load(Vb, dv, k0 + 32, Tk, 32, dvh, DHW / 4);
+    }
+    // partial S^T over my channels: rows = keys rho(r) + 4 kk, column = this lane's query
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    const float* krow = Kl + jq * KS + c0 + 2 * kk;      // A operand: K[key = lane&31][channel pair]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s < ksteps) {                                   // wave-uniform
+        const float2 a = *reinterpret_cast<const float2*>(krow + 4 * s);
+        st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[s].x, st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[s].y, st, 0, 0, 0);
+      }
+    }
+    float* Xq = X + qt * 4 * 16 * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Xq[(cw * 16 + r) * 64 + lane] = st[r];
+    __syncthreads();
+    float mb = kNegBig;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = (Xq[(0 * 16 + r) * 64 + lane] + Xq[(1 * 16 + r) * 64 + lane]) + (Xq[(2 * 16 + r) * 64 + lane] + Xq[(3 * 16 + r) * 64 + lane]);
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (causal && key > q) v -= 1e10f;
+      v *= inv_scale;
+      v = (key < Tk) ? v : kNegBig;
+      st[r] = v;
+      mb = fmaxf(mb, v);
+    }
+    const float m_new = fmaxf(m_run, xhalf_max(mb));
+    const float alpha = __expf(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = (st[r] > kNegBig) ? __expf(st[r] - m_new) : 0.f;
+      st[r] = DROP ? p * drop_scale(dc, b, H, hd, Tq, q, Tk, k0 + (r & 3) + 8 * (r >> 2) + 4 * kk) : p;
+      ps += p;
+    }
+    l_run = l_run * alpha + xhalf_sum(ps);
+    m_run = m_new;
+    // O^T += V^T P^T for my output channels: A operand V[key = rho(r) + 4 kk][channel], B operand = st[r]
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      if (ct < ctiles) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float a = Vl[((r & 3) + 8 * (r >> 2) + 4 * kk) * VS + c0 + ct * 32 + jq];
+          o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, st[r], o[ct], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: O[q][c] = o / l ; transpose through LDS for coalesced row stores
+  float* Ol = lds;                                       // [64][VS]
+  const float inv = 1.f / l_run;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+    if (ct < ctiles) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (c < dvh) Ol[(qt * 32 + jq) * VS + c] = o[ct][r] * inv;
+      }
+    }
+  if (cw == 0 && kk == 0 && q < Tq) LSE[((size_t)b * H + hd) * Tq + q] = m_run + __logf(l_run);
+  __syncthreads();
+  for (int idx = tid; idx < QBW * (dvh / 4); idx += kWideThreads) {
+    const int r = idx / (dvh / 4), c = (idx % (dvh / 4)) * 4;
+    const int qq = qb * QBW + r;
     if (qq < Tq)
       *reinterpret_cast<float4*>(O + ((size_t)b * Tq + qq) * dv + hd * dvh + c) = *reinterpret_cast<const float4*>(Ol + r * VS + c);
   }
@@ -733,6 +878,174 @@ __global__ __launch_bounds__(kMfmaThreads) void mha_bwd_mfma_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward, MFMA path for WIDE heads (128 < head width <= 256).  Same scheme as above with TWO 32-channel tiles per
+// wave (wave w owns channels [64w, 64w+64) of every product).  Four [32][258] operand tiles do not fit the LDS next to
+// the exchange buffer, so the V rows of the key block -- only ever the B operand of dP = dO V^T, 16 channel pairs per
+// lane -- are held in registers for the length of the key block (32 VGPRs; one wave per SIMD has 512).
+// ------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ __launch_bounds__(kMfmaThreads) void mha_bwd_mfma_wide_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ delta,
+    float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
+    int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int KS, int VS2, DropCfg dc) {
+  // LDS: Kl [32][KS], Ql [32][KS], Gl (dO; V while its fragments are read) [32][VS2]  (strides = 2 mod 64: b64 A/B reads),
+  //      X [2][4 waves][16][64] partial S / dP, dSl [32][66], lsel [32], dl [32]
+  extern __shared__ __align__(16) float lds[];
+  float* Kl = lds; float* Ql = Kl + 32 * KS; float* Gl = Ql + 32 * KS;
+  float* X = Gl + 32 * VS2; float* dSl = X + 2 * 4 * 16 * 64; float* lsel = dSl + 32 * 66; float* dl = lsel + 32;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / H, hd = blockIdx.x % H;
+  const int dh = dk / H, dvh = dv / H;
+  const int jl = lane & 31, kk = lane >> 5;
+  const float* Qb = Q + (size_t)b * Tq * dk + hd * dh;
+  const float* Kb = K + (size_t)b * Tk * dk + hd * dh;
+  const float* Vb = V + (size_t)b * Tk * dv + hd * dvh;
+  const float* Gb = dO + (size_t)b * Tq * dv + hd * dvh;
+  float* dQb = dQ + (size_t)b * Tq * dk + hd * dh;
+  float* dKb = dK + (size_t)b * Tk * dk + hd * dh;
+  float* dVb = dV + (size_t)b * Tk * dv + hd * dvh;
+  const float* lse = LSE + ((size_t)b * H + hd) * Tq;
+  const float* dlt = delta + ((size_t)b * H + hd) * Tq;
+  const int c0 = wv * 64;                                  // this wave's 64 channels = two 32-channel tiles
+  const int kw = c0 < dh ? (dh - c0 < 64 ? dh - c0 : 64) : 0, vw = c0 < dvh ? (dvh - c0 < 64 ? dvh - c0 : 64) : 0;
+  const int ks_steps = (kw + 3) / 4, vs_steps = (vw + 3) / 4;       // paired MFMA steps over my channels (<= 16)
+  const int ktiles = (kw + 31) / 32, vtiles = (vw + 31) / 32;       // my 32-channel tiles (0..2)
+
+  TileStage<32 * (DHW / 4) / kMfmaThreads> t0, t1;          // 8 float4 per thread each
+  for (int k0 = 0; k0 < Tk; k0 += 32) {
+    __syncthreads();
+    t0.load(Kb, dk, k0, Tk, 32, dh, DHW / 4); t1.load(Vb, dv, k0, Tk, 32, dvh, DHW / 4);
+    t0.store(Kl, KS, 32, DHW / 4); t1.store(Gl, VS2, 32, DHW / 4);
+    // Q / dO tiles: the next tile's rows are requested while the current tile is in the MFMAs
+    t0.load(Qb, dk, 0, Tq, 32, dh, DHW / 4); t1.load(Gb, dv, 0, Tq, 32, dvh, DHW / 4);
+    __syncthreads();
+    float2 vf[16];                                         // V[key = jl][my channel pairs]: B operand of dP
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      vf[s] = (s < vs_steps) ? *reinterpret_cast<const float2*>(Gl + jl * VS2 + c0 + 4 * s + 2 * kk) : make_float2(0.f, 0.f);
+    f32x16 dkt[2], dvt[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dkt[ct][r] = 0.f; dvt[ct][r] = 0.f; }
+
+    float lse_n = (tid < 32 && tid < Tq) ? lse[tid] : 0.f, dl_n = (tid < 32 && tid < Tq) ? dlt[tid] : 0.f;
+    for (int q0 = 0; q0 < Tq; q0 += 32) {
+      __syncthreads();                                     // previous tile's readers (and the V fragment reads) are done
+      t0.store(Ql, KS, 32, DHW / 4); t1.store(Gl, VS2, 32, DHW / 4);
+      if (tid < 32) { lsel[tid] = lse_n; dl[tid] = dl_n; }
+      __syncthreads();
+      if (q0 + 32 < Tq) {
+        t0.load(Qb, dk, q0 + 32, Tq, 32, dh, DHW / 4); t1.load(Gb, dv, q0 + 32, Tq, 32, dvh, DHW / 4);
+        if (tid < 32) { lse_n = (q0 + 32 + tid < Tq) ? lse[q0 + 32 + tid] : 0.f; dl_n = (q0 + 32 + tid < Tq) ? dlt[q0 + 32 + tid] : 0.f; }
+      }
+
+      // partial S = Q K^T and dP = dO V^T over this wave's 64 channels (A: rows = queries, B: cols = keys)
+      f32x16 sp, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sp[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        if (s < ks_steps) {
+          const float2 a = *reinterpret_cast<const float2*>(Ql + jl * KS + c0 + 4 * s + 2 * kk);
+          const float2 bb = *reinterpret_cast<const float2*>(Kl + jl * KS + c0 + 4 * s + 2 * kk);
+          sp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, sp, 0, 0, 0);
+          sp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, sp, 0, 0, 0);
+        }
+        if (s < vs_steps) {
+          const float2 a = *reinterpret_cast<const float2*>(Gl + jl * VS2 + c0 + 4 * s + 2 * kk);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, vf[s].x, dp, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, vf[s].y, dp, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { X[((0 * 4 + wv) * 16 + r) * 64 + lane] = sp[r]; X[((1 * 4 + wv) * 16 + r) * 64 + lane] = dp[r]; }
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      // full S, dP (every wave), then P and dS in the accumulator layout: row q = rho(r,kk), col key = jl
+      f32x16 pm, ds;
+      const int key = k0 + jl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sv = 0.f, dpv = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sv += X[((0 * 4 + u) * 16 + r) * 64 + lane]; dpv += X[((1 * 4 + u) * 16 + r) * 64 + lane]; }
+        const int ql = rho(r, kk), q = q0 + ql;
+        if (causal && key > q) sv -= 1e10f;
+        sv *= inv_scale;
+        const float p = (key < Tk && q < Tq) ? __expf(sv - lsel[ql]) : 0.f;
+        const float mk = DROP ? drop_scale(dc, b, H, hd, Tq, q, Tk, key) : 1.f;
+        pm[r] = p * mk;
+        ds[r] = p * (dpv * mk - dl[ql]) * inv_scale;
+      }
+      if (wv == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dSl[rho(r, kk) * 66 + jl] = ds[r];
+      }
+      __syncthreads();
+
+      // dV^T[c][key] += dO^T[c][q] P[q][key];  dK^T[c][key] += Q^T[c][q] dS[q][key]   (sum over the 32 queries)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        __builtin_amdgcn_sched_barrier(0);                 // one channel tile at a time (the A reads of the next stay behind)
+        if (ct < vtiles) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dvt[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(Gl[rho(r, kk) * VS2 + c0 + 32 * ct + jl], pm[r], dvt[ct], 0, 0, 0);
+        }
+        if (ct < ktiles) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dkt[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ql[rho(r, kk) * KS + c0 + 32 * ct + jl], ds[r], dkt[ct], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          // dQ[q][c] (+)= dS[q][key] K[key][c]: A = dS rows from LDS, B = K[key pair][my channel]
+          f32x16 dq;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const float2 a = *reinterpret_cast<const float2*>(dSl + jl * 66 + 4 * s + 2 * kk);
+            dq = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, Kl[(4 * s + 2 * kk) * KS + c0 + 32 * ct + jl], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, Kl[(4 * s + 2 * kk + 1) * KS + c0 + 32 * ct + jl], dq, 0, 0, 0);
+          }
+          if (c0 + 32 * ct + jl < dh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int q = q0 + rho(r, kk);
+              if (q < Tq) {
+                float* dst = dQb + (size_t)q * dk + c0 + 32 * ct + jl;
+                *dst = (k0 > 0 ? *dst : 0.f) + dq[r];     // same lane wrote it for the previous key block
+              }
+            }
+          }
+        }
+      }
+    }
+    // dK / dV rows of this key block: accumulators are [channel rows][key on lane] -> transpose through LDS
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (ct < ktiles) Ql[jl * KS + c0 + 32 * ct + rho(r, kk)] = dkt[ct][r];
+        if (ct < vtiles) Gl[jl * VS2 + c0 + 32 * ct + rho(r, kk)] = dvt[ct][r];
+      }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * (dh / 4); idx += kMfmaThreads) {
+      const int r = idx / (dh / 4), c = (idx % (dh / 4)) * 4;
+      if (k0 + r < Tk)
+        *reinterpret_cast<float4*>(dKb + (size_t)(k0 + r) * dk + c) = make_float4(Ql[r * KS + c], Ql[r * KS + c + 1], Ql[r * KS + c + 2], Ql[r * KS + c + 3]);
+    }
+    for (int idx = tid; idx < 32 * (dvh / 4); idx += kMfmaThreads) {
+      const int r = idx / (dvh / 4), c = (idx % (dvh / 4)) * 4;
+      if (k0 + r < Tk)
+        *reinterpret_cast<float4*>(dVb + (size_t)(k0 + r) * dv + c) = make_float4(Gl[r * VS2 + c], Gl[r * VS2 + c + 1], Gl[r * VS2 + c + 2], Gl[r * VS2 + c + 3]);
+    }
+  }
+}
+
 int check(const char* fn, int B, int Tq, int Tk, int dk, int dv, int H, int dtype) {
   if (dtype != TSG_F32) return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (fp32 only)", fn, dtype);
   if (B <= 0 || Tq <= 0 || Tk <= 0 || dk <= 0 || dv <= 0 || H <= 0)
@@ -796,6 +1109,20 @@ extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O,
                        qblocks, KS, VS, dc);
     return check_launch(fn);
   }
+  if (!A_sum && !S_sum && dh <= DHW && dvh <= DHW) {                // MFMA path for wide heads (channels split over the waves)
+    const int KS = DHW + 2, VS = DHW + 4, qblocks = cdiv(Tq, QBW);
+    size_t lds = sizeof(float) * ((size_t)32 * (KS + VS) + 2 * 4 * 16 * 64);
+    const size_t qstage = sizeof(float) * (size_t)QBW * KS, ostage = sizeof(float) * (size_t)QBW * VS;
+    if (qstage > lds) lds = qstage;
+    if (ostage > lds) lds = ostage;
+    auto kern = dc.thresh ? mha_fwd_mfma_wide_kernel<true> : mha_fwd_mfma_wide_kernel<false>;
+    hipError_t e = allow_lds(kern, lds);
+    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(B * qblocks * n_heads), dim3(kWideThreads), lds, st, (const float*)Q, (const float*)K,
+                       (const float*)V, (float*)O, (float*)lse, B, Tq, Tk, d_key, d_value, n_heads, 1.f / scale, causal,
+                       qblocks, KS, VS, dc);
+    return check_launch(fn);
+  }
   const int qtiles = cdiv(Tq, TQ);
   hipLaunchKernelGGL(mha_fwd_kernel, dim3(B * qtiles), dim3(kThreads), 0, st, (const float*)Q, (const float*)K,
                      (const float*)V, (float*)O, (float*)A_sum, (float*)S_sum, (float*)lse, B, Tq, Tk, d_key, d_value,
@@ -833,6 +1160,22 @@ extern "C" int tsg_mha_bwd(const void* Q, const void* K, const void* V, const vo
       hipError_t e = allow_lds(kern, lds);
       if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
     }
+    hipLaunchKernelGGL(kern, dim3(B * n_heads), dim3(kMfmaThreads), lds, st, (const float*)Q, (const float*)K, (const float*)V,
+                       (const float*)dO, (const float*)lse, (const float*)delta_ws, (float*)dQ, (float*)dK, (float*)dV,
+                       B, Tq, Tk, d_key, d_value, n_heads, 1.f / scale, causal, KS, VS2, dc);
+    return check_launch(fn);
+  }
+  if (delta_ws && dh <= DHW && dvh <= DHW) {                        // MFMA path for wide heads
+    auto st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mha_bwd_delta_kernel, dim3(cdiv(B * Tq, 4)), dim3(256), 0, st, (const float*)O, (const float*)dO,
+                       (float*)delta_ws, B, Tq, d_value, n_heads);
+    rc = check_launch(fn);
+    if (rc) return rc;
+    const int KS = DHW + 2, VS2 = DHW + 2;
+    const size_t lds = sizeof(float) * ((size_t)32 * (2 * KS + VS2) + 2 * 4 * 16 * 64 + 32 * 66 + 64);
+    auto kern = dc.thresh ? mha_bwd_mfma_wide_kernel<true> : mha_bwd_mfma_wide_kernel<false>;
+    hipError_t e = allow_lds(kern, lds);
+    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
     hipLaunchKernelGGL(kern, dim3(B * n_heads), dim3(kMfmaThreads), lds, st, (const float*)Q, (const float*)K, (const float*)V,
                        (const float*)dO, (const float*)lse, (const float*)delta_ws, (float*)dQ, (float*)dK, (float*)dV,
                        B, Tq, Tk, d_key, d_value, n_heads, 1.f / scale, causal, KS, VS2, dc);

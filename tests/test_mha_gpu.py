@@ -19,7 +19,11 @@ TOL = dict(atol=1e-4, rtol=1e-4)
     (2, 128, 20, 1024, 1024, 8, False), # north-star shape, cross (B reduced)
     (1, 128, 128, 1024, 1024, 8, False),  # temporal self-attention over 128 clips
     (1, 70, 70, 256, 128, 2, True),     # ragged T, d_value != d_key, head width 128/64, causal
-    (1, 40, 33, 640, 640, 2, False),    # head width 320 (> one 128-channel chunk)
+    (1, 40, 33, 640, 640, 2, False),    # head width 320 (> 256: VALU kernels)
+    (2, 128, 128, 2048, 2048, 8, False),  # head width 256 (Self_Attention_predictor at d=1024): wide MFMA kernels, Tk = 128
+    (1, 96, 512, 512, 512, 2, False),   # head width 256, Tk = 512 (config 4), ragged query tile
+    (1, 70, 70, 384, 256, 2, True),     # head widths 192 / 128 on the wide kernels, causal, ragged
+    (2, 33, 20, 1024, 1024, 4, False),  # head width 256, cross attention (Tk = 20)
 ])
 def test_mha_parity(B, Tq, Tk, d, dv, h, causal):
     from shufflingvideosfortsg_amd import functional as F

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from shufflingvideosfortsg_amd import _lib
 from shufflingvideosfortsg_amd._lib import ptr, TSG_F32
-B, T, d, heads = 64, 128, 1024, 8
+B, T, heads = 64, 128, 8
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 lib = _lib.load(); dev = "cuda"; st = torch.cuda.current_stream().cuda_stream
 def timeit(fn):
@@ -24,4 +25,4 @@ for tag, Tk in (("cross", 20), ("self", 128)):
     f = timeit(lambda: lib.tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), None, None, ptr(lse), B, T, Tk, d, d, heads, sc, 0, 0.0, 0, 0, TSG_F32, st))
     b = timeit(lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d, heads, sc, 0, 0.0, 0, 0, TSG_F32, st))
     fb = B * (2 * T + 2 * Tk) * d * 4; bb = B * (4 * T + 4 * Tk) * d * 4
-    print(f"{tag}: fwd {f:.1f} us ({fb/f/1e3/8000*100:.1f}% of 8 TB/s)   bwd {b:.1f} us ({bb/b/1e3/8000*100:.1f}%)")
+    print(f"d={d} h{heads} {tag}: fwd {f:.1f} us ({fb/f/1e3/8000*100:.1f}% of 8 TB/s)   bwd {b:.1f} us ({bb/b/1e3/8000*100:.1f}%)")
