@@ -13,7 +13,7 @@ A = torch.randn(B, T, d, device=dev); S = torch.randn(B, N, d, device=dev); w = 
 P = torch.softmax(torch.randn(B, T, N, device=dev), -1); VW = torch.randn(B, N, d, device=dev); gb = torch.randn(d, device=dev)
 r = torch.randn(B, T, d, device=dev); dC = torch.randn(B, T, d, device=dev)
 da = torch.empty_like(A); ds = torch.empty_like(S); dw = torch.empty_like(w); dVW = torch.empty_like(VW); dgb = torch.empty_like(gb)
-dr = torch.empty_like(r); dG = torch.empty_like(r); de = torch.empty(B, T, N, device=dev)
+dr = torch.empty_like(r); nb = int(lib.tsg_scdm_bwd_ws_bytes(B, T, N, d, d, 1)); ws = torch.empty(nb // 4 + 4, device=dev)
 for _ in range(n):
-    lib.tsg_scdm_gate_bwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(gb), ptr(r), ptr(P), ptr(dC), ptr(da), ptr(ds), ptr(dw), ptr(dVW), ptr(dgb), ptr(dr), ptr(de), ptr(dG), B, T, N, d, d, TSG_F32, st)
+    lib.tsg_scdm_gate_bwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(gb), ptr(r), ptr(P), ptr(dC), ptr(da), ptr(ds), ptr(dw), ptr(dVW), ptr(dgb), ptr(dr), ptr(ws), nb, B, T, N, d, d, TSG_F32, st)
 torch.cuda.synchronize()
