@@ -59,6 +59,9 @@ def parse_args(argv=None):
     ap.add_argument("--fwd-only", action="store_true",
                     help="a step is the forward pass + losses under no_grad (BASELINE config 1 is forward-only); `value` is then "
                          "forward pairs/s.  Without the flag the forward-only rate is a side measurement (`fwd_only`)")
+    ap.add_argument("--graph", action="store_true",
+                    help="the graph-replay side measurement (`graph_replay`: the same step replayed from HIP graphs, "
+                         "engine.GraphedTrainStep) runs by default on one GPU only; with this flag also when N > 1")
     ap.add_argument("--time-all", action="store_true", help="event-time every C-ABI launch (perturbs the step time)")
     ap.add_argument("--no-alt", action="store_true", help="skip the side measurements (other GEMM-operand modes, forward-only)")
     return ap.parse_args(argv)
@@ -189,19 +192,22 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
 
 
 def pmc_traffic(kernel, B, T, N, d, launch_B=None):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes, see
+    profiles/r2/k1_pmc_traffic.json; profiles/r1 for the shapes only measured there); None when no pass exists for this shape."""
     launch_B = launch_B or B
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
-    profiles/r1/k1_pmc_traffic.json); None when no pass exists for this shape."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1", "k1_pmc_traffic.json")) as f:
-            j = json.load(f)
-        if j["shape"] == {"B": B, "T": T, "N": N, "d": d, "dtype": "f32"}:
+    for rnd in ("r2", "r1"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "k1_pmc_traffic.json")) as f:
+                j = json.load(f)
+            if j["shape"] != {"B": B, "T": T, "N": N, "d": d, "dtype": "f32"}:
+                continue
             exact = j["kernels"].get(f"{kernel}@B{launch_B}")          # a pass at the launch's own pair count, if committed
             if exact:
                 return exact["hbm_bytes_per_launch"]
-            return int(j["kernels"][kernel]["hbm_bytes_per_launch"] * launch_B / B)
-    except (OSError, KeyError, ValueError):
-        pass
+            if kernel in j["kernels"]:
+                return int(j["kernels"][kernel]["hbm_bytes_per_launch"] * launch_B / B)
+        except (OSError, KeyError, ValueError):
+            pass
     return None
 
 
@@ -359,6 +365,24 @@ def main():
                     "finite": bool(torch.isfinite(loss3)), "note": "forward + losses under no_grad, same batch and mode as `value`"}
         log(f"forward-only: {fwd_only['ms_per_step']} ms/step")
     functional.check_lstm_errors()
+    graph_replay = None
+    if not a.fwd_only and not a.no_alt and (world == 1 or a.graph) and not (a.predictor == "self_attn" and params["dropout"] > 0):
+        # the same train step replayed from two HIP graphs (forward+backward | Adam), gradient exchange eager in between
+        try:
+            opt_g = engine.make_optimizer(model, params, capturable=True)
+            gstep = engine.GraphedTrainStep(model, opt_g, lambda m, b: forward(), batch, dp=dp)
+            for _ in range(2):
+                gstep()
+            dt4, enq4, loss4 = timed(gstep, a.steps)
+            functional.check_lstm_errors()
+            graph_replay = {"value": round(a.B * world * a.steps / dt4, 2), "unit": "pairs/s", "ms_per_step": round(dt4 / a.steps * 1e3, 3),
+                            "host_enqueue_ms_per_step": round(enq4 / a.steps * 1e3, 3), "finite": bool(torch.isfinite(loss4)),
+                            "note": "same step, same mode, replayed from two HIP graphs (forward+losses+backward | guarded Adam), "
+                                    "gradient exchange eager between them (engine.GraphedTrainStep)"}
+            log(f"graph replay: {graph_replay['ms_per_step']} ms/step, host enqueue {graph_replay['host_enqueue_ms_per_step']} ms/step")
+        except Exception as e:                                # noqa: BLE001  (a side measurement must not take the result down)
+            graph_replay = {"error": f"{type(e).__name__}: {e}"[:300]}
+            log(f"graph replay failed: {graph_replay['error']}")
 
     if rank == 0:
         kt = functional.kernel_timer.summary()          # (name, dims) -> (mean us, launches, median us)
@@ -405,7 +429,7 @@ def main():
                                       + ("" if a.predictor == "mlp" else f", boundary head {a.predictor}")
                                       + ("" if a.dtype == "f32" else "; " + NOTES[a.dtype]),
                           "global_batch": a.B * world, "parallelism": f"dp{world}", "grad_bytes": dp.grad_bytes},
-               "roofline": roof, "alt_gemm_modes": alt, "fwd_only": fwd_only, "kernels": kern,
+               "roofline": roof, "alt_gemm_modes": alt, "fwd_only": fwd_only, "graph_replay": graph_replay, "kernels": kern,
                "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
                "cpu_baseline": cpu_baseline(a.model, params, a.T, a.N, a.cpu_sample) if (a.cpu_sample > 0 and world == 1) else None}
         os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())

@@ -125,6 +125,28 @@ class FlatGradAllReduce:
         if not self._avg:
             self.flat.div_(self.world)
 
+    # -- graph-replay protocol (engine.GraphedTrainStep) ---------------------------------------
+    def adopt(self, grads):
+        """Called once after the backward has been captured: ``grads`` are the graph's static gradient tensors (in
+        ``self.params`` order).  Gathers and exchanges them once and leaves ``.grad`` of every parameter pointing into the flat
+        buffer, which is what the captured optimizer update then reads on every replay."""
+        self.exchange_static(grads)
+
+    def exchange_static(self, grads):
+        """static gradient tensors -> flat buffer (one multi-tensor copy; zeros where there is no gradient), ONE all-reduce of the
+        whole buffer (the backward has finished: nothing to overlap with), ``.grad`` re-pointed at the flat views."""
+        have = [(self._view[id(p)], g) for p, g in zip(self.params, grads) if g is not None]
+        none = [self._view[id(p)] for p, g in zip(self.params, grads) if g is None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if none:
+            torch._foreach_zero_(none)
+        dist.all_reduce(self.flat, op=self._op, group=self.group)
+        if not self._avg:
+            self.flat.div_(self.world)
+        for p in self.params:
+            p.grad = self._view[id(p)]
+
     @property
     def grad_bytes(self) -> int:
         return self._numel * self._esize

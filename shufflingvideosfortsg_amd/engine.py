@@ -71,12 +71,14 @@ def precision(gemm_dtype=None):
     return torch.autocast("cuda", dtype=gemm_dtype)
 
 
-def make_optimizer(model, params):
+def make_optimizer(model, params, capturable=False):
     """Adam(lr, L2 weight decay, eps=1e-6) as the reference builds it (train.py:367-371); on a GPU the single-pass
-    fused implementation of the same update (one kernel over all parameters instead of ~7 foreach passes)."""
+    fused implementation of the same update (one kernel over all parameters instead of ~7 foreach passes).
+    ``capturable``: step counters on the device, so that the update can be part of a HIP graph (GraphedTrainStep)."""
     ps = list(model.parameters())
     fused = bool(ps) and all(p.is_cuda for p in ps)
-    return torch.optim.Adam(ps, lr=params["lr"], weight_decay=params["weight_decay"], eps=1e-6, fused=fused)
+    return torch.optim.Adam(ps, lr=params["lr"], weight_decay=params["weight_decay"], eps=1e-6, fused=fused,
+                            capturable=bool(capturable and fused))
 
 
 def optimizer_step(opt, loss):
@@ -93,6 +95,65 @@ def optimizer_step(opt, loss):
     finally:
         if fused:
             opt.found_inf = None
+
+
+class GraphedTrainStep:
+    """One training step as two HIP graphs: A = forward + losses + backward, B = the (guarded) Adam update, with the
+    gradient exchange of ``dp`` (FlatGradAllReduce; may be inactive) run eagerly between them.  The step's ~390 kernel
+    launches -- the C-ABI kernels, their zero-fill nodes, autograd's glue, the fused Adam -- are enqueued by two
+    ``hipGraphLaunch`` calls: host time per step drops from ~12 ms to ~0.2 ms (tools/graph_step_probe.py), which is what keeps
+    eight ranks on one host from queueing behind their Python threads.  The reference has no counterpart (eager PyTorch 1.x).
+
+    ``step_fn(model, batch) -> loss`` must be capture-safe: static shapes, no host synchronisation, device-resident batch (the
+    caller refreshes the batch by copying into the SAME tensors).  ``opt`` must come from ``make_optimizer(capturable=True)``.
+    Dropout draws fresh masks on every replay (torch's graph-safe Philox offsets); the in-kernel attention dropout of K2 takes
+    its offset on the host and would repeat its mask, so a model with ``MultiHead`` dropout > 0 must not be trained through this.
+    """
+
+    def __init__(self, model, opt, step_fn, batch, dp=None, warmup=3):
+        from . import functional as TF
+        self.model, self.opt, self.dp, self.batch = model, opt, dp, batch
+        if dp is not None and dp.overlap:
+            raise ValueError("GraphedTrainStep: the gradient exchange must run after the backward (FlatGradAllReduce(overlap=False))")
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # eager warm-up on the capture stream: lazy initialisation happens here
+            for _ in range(warmup):
+                self._zero()
+                loss = step_fn(model, batch)
+                loss.backward()
+                if dp is not None:
+                    dp.finish()
+                optimizer_step(opt, loss)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        TF.check_lstm_errors()
+        self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self._zero()
+        with torch.cuda.graph(self.graph_a):
+            self._zero()
+            self.loss = step_fn(model, batch)
+            self.loss.backward()
+        self.grads = [p.grad for p in self.params]          # the graph's static gradient tensors (None: no gradient)
+        if dp is not None and dp.active:
+            dp.adopt(self.grads)                            # gather + exchange once: .grad now points into the flat buffer
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            optimizer_step(opt, self.loss)
+
+    def _zero(self):
+        for p in self.params:
+            p.grad = None
+        if self.dp is not None:
+            self.dp.zero_grad()
+
+    def __call__(self):
+        """Replay one step on the current batch tensors -> the (static) loss tensor of this step."""
+        self.graph_a.replay()
+        if self.dp is not None and self.dp.active:
+            self.dp.exchange_static(self.grads)
+        self.graph_b.replay()
+        return self.loss
 
 
 def baseline_step(model, batch):

@@ -322,3 +322,55 @@ def test_baseline_with_self_attention_predictor_trains():
         o1 = m(b["video"], b["query"], b["video_mask"], None)["start"]
         o2 = m(b["video"], b["query"], b["video_mask"], None)["start"]
     assert torch.equal(o1, o2)
+
+
+def test_graphed_train_step_matches_eager():
+    """engine.GraphedTrainStep: the GMD train step captured into HIP graphs (C-ABI kernels, their zero-fill nodes, autograd, the
+    fused Adam with device-side step counters) and replayed reproduces the eager steps' loss trajectory (dropout off: no RNG),
+    with the persistent LSTM error sink clean, and picks up new data written into the static batch tensors."""
+    from shufflingvideosfortsg_amd import data, engine, functional as TF
+    params = engine.default_params(video_rnn_hiddendim=128, sent_rnn_hiddendim=128, mlp_hidden_dim=64, m_pred_hidden=128, dropout=0.0,
+                                   video_feature_dim=256, video_len=32, sent_len=15)
+
+    def build():
+        torch.manual_seed(0)
+        m = engine.build_model("gmd", params).cuda().train()
+        m.tod.dropout.p = 0.0
+        return m, engine.make_optimizer(m, params, capturable=True)
+    batch = data.synthetic_batch(32, 32, 15, video_dim=256, seed=3, pair=True, device="cuda")
+    other = data.synthetic_batch(32, 32, 15, video_dim=256, seed=4, pair=True, device="cuda")
+    step_fn = lambda m, b: engine.gmd_step(m, b, params)[0]
+    engine.precision("f32s")
+    try:
+        m, opt = build()
+        eager = []
+        for i in range(7):
+            b = batch if i < 5 else other
+            for p in m.parameters():
+                p.grad = None
+            loss = step_fn(m, b)
+            loss.backward()
+            engine.optimizer_step(opt, loss)
+            eager.append(float(loss))
+        m, opt = build()
+        live = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items() if not isinstance(v, dict)}
+        for gt in ("gt", "pseudo_gt"):
+            live[gt] = {k: v.clone() for k, v in batch[gt].items()}
+        g = engine.GraphedTrainStep(m, opt, step_fn, live, warmup=3)      # 3 eager warm-up steps + 2 replays = eager steps 0..4
+        got = list(eager[:3])
+        for i in range(3, 7):
+            if i == 5:                                                     # new data into the SAME tensors
+                for k, v in other.items():
+                    if isinstance(v, torch.Tensor):
+                        live[k].copy_(v)
+                for gt in ("gt", "pseudo_gt"):
+                    for k, v in other[gt].items():
+                        live[gt][k].copy_(v)
+            got.append(float(g()))
+        torch.cuda.synchronize()
+        TF.check_lstm_errors()
+    finally:
+        engine.precision(None)
+    for a, b in zip(got, eager):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (got, eager)
+    assert abs(got[3] - eager[3]) <= 1e-4 * max(1.0, abs(eager[3]))
