@@ -59,9 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--fwd-only", action="store_true",
                     help="a step is the forward pass + losses under no_grad (BASELINE config 1 is forward-only); `value` is then "
                          "forward pairs/s.  Without the flag the forward-only rate is a side measurement (`fwd_only`)")
-    ap.add_argument("--graph", action="store_true",
-                    help="the graph-replay side measurement (`graph_replay`: the same step replayed from HIP graphs, "
-                         "engine.GraphedTrainStep) runs by default on one GPU only; with this flag also when N > 1")
+    ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)     # child mode of the graph_replay measurement
     ap.add_argument("--time-all", action="store_true", help="event-time every C-ABI launch (perturbs the step time)")
     ap.add_argument("--no-alt", action="store_true", help="skip the side measurements (other GEMM-operand modes, forward-only)")
     return ap.parse_args(argv)
@@ -321,6 +319,20 @@ def main():
             dt = float(t.item())
         return dt, t_enq, last
 
+    if a.graph_only:
+        opt_g = engine.make_optimizer(model, params, capturable=True)
+        gstep = engine.GraphedTrainStep(model, opt_g, lambda m, b: forward(), batch, dp=dp)
+        for _ in range(3):
+            gstep()
+        dt4, enq4, loss4 = timed(gstep, a.steps)
+        functional.check_lstm_errors()
+        out = {"graph_replay": {"value": round(a.B * world * a.steps / dt4, 2), "unit": "pairs/s", "ms_per_step": round(dt4 / a.steps * 1e3, 3),
+                                "host_enqueue_ms_per_step": round(enq4 / a.steps * 1e3, 3), "finite": bool(torch.isfinite(loss4)),
+                                "note": "same step and mode replayed from two HIP graphs (forward+losses+backward | guarded Adam), gradient "
+                                        "exchange eager between them (engine.GraphedTrainStep); measured in a child process"}}
+        os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
+        return
+
     log("batch resident; warm-up")
     for i in range(a.warmup):
         step()
@@ -366,23 +378,20 @@ def main():
         log(f"forward-only: {fwd_only['ms_per_step']} ms/step")
     functional.check_lstm_errors()
     graph_replay = None
-    if not a.fwd_only and not a.no_alt and (world == 1 or a.graph) and not (a.predictor == "self_attn" and params["dropout"] > 0):
-        # the same train step replayed from two HIP graphs (forward+backward | Adam), gradient exchange eager in between
+    if not a.fwd_only and not a.no_alt and world == 1 and not (a.predictor == "self_attn" and params["dropout"] > 0):
+        # the same train step replayed from two HIP graphs (engine.GraphedTrainStep), measured in a CHILD process started from
+        # this one (a fresh capture state; a failure there cannot take this result down).  One GPU only: the child shares it.
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(a.steps), "--model", a.model, "--B", str(a.B),
+               "--T", str(a.T), "--N", str(a.N), "--d", str(a.d), "--dtype", a.dtype, "--predictor", a.predictor]
         try:
-            opt_g = engine.make_optimizer(model, params, capturable=True)
-            gstep = engine.GraphedTrainStep(model, opt_g, lambda m, b: forward(), batch, dp=dp)
-            for _ in range(2):
-                gstep()
-            dt4, enq4, loss4 = timed(gstep, a.steps)
-            functional.check_lstm_errors()
-            graph_replay = {"value": round(a.B * world * a.steps / dt4, 2), "unit": "pairs/s", "ms_per_step": round(dt4 / a.steps * 1e3, 3),
-                            "host_enqueue_ms_per_step": round(enq4 / a.steps * 1e3, 3), "finite": bool(torch.isfinite(loss4)),
-                            "note": "same step, same mode, replayed from two HIP graphs (forward+losses+backward | guarded Adam), "
-                                    "gradient exchange eager between them (engine.GraphedTrainStep)"}
-            log(f"graph replay: {graph_replay['ms_per_step']} ms/step, host enqueue {graph_replay['host_enqueue_ms_per_step']} ms/step")
-        except Exception as e:                                # noqa: BLE001  (a side measurement must not take the result down)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                               env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"graph_replay"')]
+            graph_replay = json.loads(lines[-1])["graph_replay"] if lines else {"error": f"child exit code {r.returncode}: {r.stderr[-300:]}"}
+        except Exception as e:                                # noqa: BLE001
             graph_replay = {"error": f"{type(e).__name__}: {e}"[:300]}
-            log(f"graph replay failed: {graph_replay['error']}")
+        log(f"graph replay: {graph_replay}")
 
     if rank == 0:
         kt = functional.kernel_timer.summary()          # (name, dims) -> (mean us, launches, median us)
