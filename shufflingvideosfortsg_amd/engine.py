@@ -131,14 +131,16 @@ class GraphedTrainStep:
         TF.check_lstm_errors()
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         self._zero()
-        with torch.cuda.graph(self.graph_a):
+        # capture on the warm-up stream: autograd's AccumulateGrad nodes were created there, and a capture on another stream
+        # would record cross-stream event nodes into the graph (a forked graph: hipGraphLaunch then enqueues node by node)
+        with torch.cuda.graph(self.graph_a, stream=side):
             self._zero()
             self.loss = step_fn(model, batch)
             self.loss.backward()
         self.grads = [p.grad for p in self.params]          # the graph's static gradient tensors (None: no gradient)
         if dp is not None and dp.active:
             dp.adopt(self.grads)                            # gather + exchange once: .grad now points into the flat buffer
-        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=side):
             optimizer_step(opt, self.loss)
 
     def _zero(self):
