@@ -33,7 +33,9 @@
 //                dsent[n,j] = sum_t P[t,n] dC[t,j]
 //              Es for the slice lives in registers (NP*4 per lane); de / P rows are wave-uniform.
 #include "tsg_common.h"
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace tsg {
 namespace {
@@ -815,11 +817,15 @@ constexpr int kFusedPF = TSG_FUSED_PF;         // rows in flight per wave
 constexpr unsigned kXchSpinLimit = 1u << 22;   // bounded wait on the neighbours (~seconds); expiry sets the error sink
 template <int NP> constexpr int fused_cpl() { return NP <= 20 ? 2 : 1; }
 
-struct FusedPlan { int parts, SP, grid; size_t lds; long long ws_bytes; bool ok; };
+struct FusedPlan { int parts, SP, grid; size_t lds; long long ws_bytes; bool ok; bool mrow; size_t lds_mrow; };
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMrowWk = 32 * 33;               // floats of a wave's scratch block (dG transpose tile, then its dP tile)
 
-template <int NP>
+// MROW = true: the variant with the row phase on the matrix pipe; its waves own 64-column slices (two 32-column MFMA
+// tiles: 32 accumulator registers for dVW instead of 64 -- with 128-column slices the gate variant spilled 110 registers).
+template <int NP, bool MROW>
 FusedPlan fused_plan(int B, int T, int N, int H, int Ds) {
-  constexpr int SW = kWave * fused_cpl<NP>();
+  constexpr int SW = MROW ? kWave : kWave * fused_cpl<NP>();
   FusedPlan p{};
   int S = cdiv(H, SW) > cdiv(Ds, SW) ? cdiv(H, SW) : cdiv(Ds, SW), S2 = 1;
   while (S2 < S) S2 <<= 1;
@@ -828,25 +834,38 @@ FusedPlan fused_plan(int B, int T, int N, int H, int Ds) {
   p.parts = parts; p.SP = S2 / parts; p.grid = B * parts;
   const int RS = kFusedWaves / p.SP;
   const size_t part_f = (size_t)p.SP * kFusedSub * (NP + 1), red_f = (size_t)(RS - 1) * p.SP * NP * SW;
-  p.lds = sizeof(float) * ((size_t)2 * T * NP + (part_f > red_f ? part_f : red_f));
   p.ws_bytes = (long long)sizeof(float) * ((long long)B * parts * T * NP + roundup(B, 4));
-  p.ok = p.SP <= kFusedWaves && p.lds <= (size_t)kLdsBytes - 1024;
+  if (!MROW) {
+    p.lds = sizeof(float) * ((size_t)2 * T * NP + (part_f > red_f ? part_f : red_f));
+    p.ok = p.SP <= kFusedWaves && p.lds <= (size_t)kLdsBytes - 1024;
+    p.mrow = false; p.lds_mrow = 0;
+    return p;
+  }
+  // P / de tiles padded to 32 rows, a scratch block and the VW slice [NP][SW+4] per wave (the row-split partials of the
+  // column phase and of dVW overlay the VW slices at the end)
+  const size_t t32 = (size_t)roundup(T, 32), vw_f = (size_t)kFusedWaves * NP * (SW + 4);
+  const size_t red_m = (size_t)(RS - 1) * p.SP * (SW / 32) * 1024;                       // dVW accumulator tiles of the row splits
+  const size_t tail = vw_f > red_f ? (vw_f > red_m ? vw_f : red_m) : (red_f > red_m ? red_f : red_m);
+  p.lds = p.lds_mrow = sizeof(float) * (2 * t32 * NP + (size_t)kFusedWaves * kMrowWk + tail);
+  p.ok = p.mrow = p.SP <= kFusedWaves && p.lds <= (size_t)kLdsBytes - 1024;
   return p;
 }
 
-template <int NP, bool GATE>
+// MROW: the row phase on the matrix pipe (see the block comment inside).
+template <int NP, bool GATE, bool MROW>
 __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
     const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w, const float* __restrict__ V,
     const float* __restrict__ P, const float* __restrict__ dC, const float* __restrict__ gr, const float* __restrict__ gbias,
     float* __restrict__ da, float* __restrict__ ds, float* __restrict__ dw, float* __restrict__ dV, float* __restrict__ dbias,
     float* __restrict__ drout, float* xch, unsigned* __restrict__ cnt, unsigned* __restrict__ esink,
     int B, int T, int N, int H, int Ds, int parts, int SP, int dbg) {
-  constexpr int CPL = fused_cpl<NP>(), SW = kWave * CPL;
+  constexpr int CPL = MROW ? 1 : fused_cpl<NP>(), SW = kWave * CPL;
   extern __shared__ __align__(16) float lds[];
-  float* Pl = lds;                              // [T][NP]  P rows, zero beyond N
-  float* De = Pl + (size_t)T * NP;              // [T][NP]  partial dP -> de
-  float* part = De + (size_t)T * NP;            // [SP][kFusedSub][NP+1] per-slice partial dP of a folding round; later the
-  float* red = part;                            // [RS-1][SP][NP][SW] row-split partials of the T-sums
+  const int TL = MROW ? ((T + 31) & ~31) : T;   // rows of the P / de tiles in LDS (MROW: padded to whole 32-row MFMA tiles)
+  float* Pl = lds;                              // [TL][NP]  P rows, zero beyond N (and beyond T)
+  float* De = Pl + (size_t)TL * NP;             // [TL][NP]  partial dP -> de
+  float* part = De + (size_t)TL * NP;           // [SP][kFusedSub][NP+1] per-slice partial dP of a folding round; later the
+  float* red = MROW ? part + kFusedWaves * kMrowWk : part;   // [RS-1][SP][NP][SW] row-split partials of the T-sums
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
   const int bid = xcd_remap(blockIdx.x, gridDim.x, parts);
   const int b = bid / parts, pt = bid % parts;
@@ -856,13 +875,184 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
   const size_t rowDs = (size_t)b * T * Ds + (jok ? col : 0), rowH = (size_t)b * T * H + (kok ? col : 0);
   const int nrows = rq < T ? (T - rq + RS - 1) / RS : 0;          // this wave's rows: t = rq + RS*i
 
-  for (int idx = tid; idx < T * NP; idx += kFusedThreads) {
+  for (int idx = tid; idx < TL * NP; idx += kFusedThreads) {
     const int r = idx / NP, n = idx % NP;
-    Pl[idx] = n < N ? P[((size_t)b * T + r) * N + n] : 0.f;
+    Pl[idx] = (n < N && r < T) ? P[((size_t)b * T + r) * N + n] : 0.f;
   }
 
   // ---------------- row phase ------------------------------------------------------------------
-  {
+  if constexpr (MROW) {
+    // The row phase is three small GEMMs per 32-row tile and 32-column tile of the wave's slice -- G = P VW (K = N words),
+    // dVW += P^T dG (K = rows) and dP += dG VW^T (K = columns) -- i.e. 3 T N Ds multiply-adds per pair, as much VALU work as
+    // the column phase when done with FMAs plus a 64-lane reduction per row.  Here they run as v_mfma_f32_32x32x2_f32
+    // (exact fp32), 42 per (row tile, column tile):
+    //   G    : A = P[t = lane&31][n = 2s + kk] (LDS), B = VW[n][j = lane&31] (the wave's slice in LDS)  -> D: column j on the
+    //          lane, 16 rows t = rho(v, kk) in registers.  dout / r are loaded and dr is stored in that layout (one dword per
+    //          lane: 128 contiguous bytes per half wave); sigmoid, dr and dG are formed element-wise in it.
+    //   dVW  : dG's ROW index is the contraction index, so the accumulator tile is the B operand as it stands (no lane
+    //          movement); A = P^T[n = lane&31][t = rho(v, kk)] from LDS.  Accumulates over the wave's row tiles.
+    //   dP   : contracts over dG's COLUMN (lane) index: the tile goes through a 32 x 33 LDS block once and comes back as the
+    //          A operand [t = lane&31][j = 2s + kk]; B = VW^T.  The MFMA does the reduction the VALU version needs the swap /
+    //          DPP ladder for; the wave's dP tile lands in the same block for the fold over the slices.
+    constexpr int CTW = SW / 32, VS = SW + 4;
+    float* Wk = part;                                               // [8][kMrowWk]
+    float* myW = Wk + wv * kMrowWk;
+    float* myV = Wk + kFusedWaves * kMrowWk + wv * NP * VS;          // [NP][VS]  VW[b, :, slice] (zero beyond N / Ds)
+    const int jl = lane & 31, kk = lane >> 5;
+    const int colw = (pt * SP + sw) * SW;
+    for (int idx = lane; idx < NP * (SW / 4); idx += kWave) {
+      const int n = idx / (SW / 4), c4 = (idx % (SW / 4)) * 4;
+      float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N && colw + c4 < Ds) v4 = *reinterpret_cast<const float4*>(V + ((size_t)b * N + n) * Ds + colw + c4);
+      *reinterpret_cast<float4*>(myV + n * VS + c4) = v4;
+    }
+    f32x16 dvw[CTW];
+    float gsum[CTW], gb[CTW];
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) dvw[ct][v] = 0.f;
+      gsum[ct] = 0.f;
+      gb[ct] = (GATE && colw + 32 * ct + jl < Ds) ? gbias[colw + 32 * ct + jl] : 0.f;
+    }
+    __syncthreads();                                               // Pl and the VW slices staged
+    for (int r0 = 0; r0 < TL; r0 += 32 * RS) {
+      const int t0 = r0 + 32 * rq;                                 // this wave's row tile of the round
+      if (t0 < TL && !TSG_SKIP(16)) {                              // wave-uniform
+        // every read below is UNCONDITIONAL on a clamped address and masked by a select afterwards: a conditional read
+        // becomes an exec-masked branch per element and a wait in front of every MFMA
+        const int jn = jl < NP ? jl : 0;
+        const float nmask = jl < NP ? 1.f : 0.f;
+        f32x16 dpacc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) dpacc[v] = 0.f;
+        // RAG = false: all 32 rows of the tile exist (row v of this lane sits rho(v) * Ds elements behind its first: a constant
+        // times a wave-uniform stride, no per-row registers); RAG = true: the last, partial tile (rows clamped and masked)
+        auto run_tile = [&](auto rag_tag) {
+          constexpr bool RAG = decltype(rag_tag)::value;
+          float pa[NP / 2], ptt[16];
+#pragma unroll
+          for (int s2 = 0; s2 < NP / 2; ++s2) pa[s2] = Pl[(t0 + jl) * NP + 2 * s2 + kk];
+#pragma unroll
+          for (int v = 0; v < 16; ++v) ptt[v] = Pl[(t0 + (v & 3) + 8 * (v >> 2) + 4 * kk) * NP + jn] * nmask;
+          const int tfirst = t0 + 4 * kk;
+#pragma unroll
+          for (int ct = 0; ct < CTW; ++ct) {
+            const int col = colw + 32 * ct + jl;
+            const bool cok = col < Ds;
+            const float cmask = cok ? 1.f : 0.f;
+            const size_t base = ((size_t)b * T + (RAG ? 0 : tfirst)) * Ds + (cok ? col : 0);
+            const float* gp = dC + base;
+            const float* rp = gr + base;
+            float* op = drout + base;
+            auto ro = [&](int v) -> size_t {                        // element offset of row v from the base
+              const int dt = (v & 3) + 8 * (v >> 2);
+              if (!RAG) return (size_t)dt * Ds;
+              const int t = tfirst + dt;
+              return (size_t)(t < T ? t : T - 1) * Ds;
+            };
+            auto live = [&](int v) -> bool { return !RAG || tfirst + (v & 3) + 8 * (v >> 2) < T; };
+            float g[16], rr[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) g[v] = gp[ro(v)];
+            if (GATE) {
+#pragma unroll
+              for (int v = 0; v < 16; ++v) rr[v] = rp[ro(v)];
+            }
+            float vb[NP / 2];
+#pragma unroll
+            for (int s2 = 0; s2 < NP / 2; ++s2) vb[s2] = myV[(2 * s2 + kk) * VS + 32 * ct + jl];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) g[v] = live(v) ? g[v] * cmask : 0.f;
+            if (GATE) {
+              f32x16 G;
+#pragma unroll
+              for (int v = 0; v < 16; ++v) G[v] = 0.f;
+#pragma unroll
+              for (int s2 = 0; s2 < NP / 2; ++s2) G = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s2], vb[s2], G, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int v = 0; v < 16; ++v) {
+                const float sg = fast_rcp(1.f + fast_exp2(-(G[v] + gb[ct]) * kLog2e));
+                const float drv = g[v] * sg;
+                if (cok && live(v)) op[ro(v)] = drv;
+                g[v] = g[v] * rr[v] * sg * (1.f - sg);             // dG: from here on "dC" (g is 0 outside the matrix)
+              }
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) gsum[ct] += g[v];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) myW[((v & 3) + 8 * (v >> 2) + 4 * kk) * 33 + jl] = g[v];
+            __builtin_amdgcn_sched_barrier(0);                     // the operand reads below stay below (registers)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) dvw[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ptt[v], g[v], dvw[ct], 0, 0, 0);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {                       // four operand pairs at a time: reads fly under the MFMAs before them
+              float av[4], vt[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                av[u] = myW[jl * 33 + 2 * (4 * q4 + u) + kk];
+                vt[u] = myV[jn * VS + 32 * ct + 2 * (4 * q4 + u) + kk] * nmask;
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], vt[u], dpacc, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);                     // one column tile's operands at a time (registers)
+          }
+        };
+        if (t0 + 32 <= T) run_tile(std::false_type{}); else run_tile(std::true_type{});
+        if (jl < NP) {                                             // dP tile [t][n]: column n on the lane
+#pragma unroll
+          for (int v = 0; v < 16; ++v) myW[((v & 3) + 8 * (v >> 2) + 4 * kk) * (NP + 1) + jl] = dpacc[v];
+        }
+      }
+      lds_barrier();
+      for (int idx = tid; idx < 32 * RS * NP; idx += kFusedThreads) {
+        const int row = idx / NP, n = idx % NP, t = r0 + row;
+        if (t < TL) {
+          float sum = 0.f;
+          for (int c = 0; c < SP; ++c) sum += Wk[((row >> 5) * SP + c) * kMrowWk + (row & 31) * (NP + 1) + n];
+          De[t * NP + n] = sum;
+        }
+      }
+      lds_barrier();
+    }
+    // T-sums of the row phase.  The accumulator tiles hold dVW[n = rho(v, kk)][column jl]; row splits rq > 0 hand theirs to
+    // rq = 0 through LDS (over the VW slices, which are dead now), in fixed order.
+    float* redm = Wk + kFusedWaves * kMrowWk;                      // [RS-1][SP][CTW][16][64]
+    for (int q = 1; q < RS; ++q) {
+      if (rq == q) {
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) redm[((((size_t)(q - 1) * SP + sw) * CTW + ct) * 16 + v) * 64 + lane] = dvw[ct][v];
+      }
+    }
+    lds_barrier();
+    if (rq == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct) {
+        const int col = colw + 32 * ct + jl;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          float acc = dvw[ct][v];
+          for (int q = 1; q < RS; ++q) acc += redm[((((size_t)(q - 1) * SP + sw) * CTW + ct) * 16 + v) * 64 + lane];
+          const int n = (v & 3) + 8 * (v >> 2) + 4 * kk;
+          if (n < N && col < Ds) dV[((size_t)b * N + n) * Ds + col] = acc;
+        }
+      }
+    }
+    if (GATE) {                                                    // dbias: the two half waves hold different rows of a column
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct) {
+        const float gs = gsum[ct] + __shfl_xor(gsum[ct], 32, 64);
+        const int col = colw + 32 * ct + jl;
+        if (kk == 0 && col < Ds && !TSG_SKIP(256)) atomicAdd(dbias + col, gs);
+      }
+    }
+    lds_barrier();                                                 // redm is read; the column phase may overlay it
+  } else {
     float vreg[NP][CPL], dvacc[NP][CPL], gsum[CPL], gb[CPL];
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
@@ -1234,18 +1424,24 @@ int launch_bwd(const float* a, const float* s, const float* w, const float* V, c
   const char* fn = GATE ? "tsg_scdm_gate_bwd" : "tsg_scdm_attn_bwd";
   if (Ds > (NP <= 20 ? 2048 : 1024))
     return set_error(TSG_E_SHAPE, "%s: Ds=%d (max %d at N=%d) not supported", fn, Ds, NP <= 20 ? 2048 : 1024, N);
-  const FusedPlan pl = fused_plan<NP>(B, T, N, H, Ds);
+  static const bool valu_rows = [] { const char* e = getenv("TSG_K1_BWD"); return e && e[0] == 'v'; }();   // A/B: row phase on the VALU
+  const FusedPlan pm = fused_plan<NP, true>(B, T, N, H, Ds), pv = fused_plan<NP, false>(B, T, N, H, Ds);
+  // the MFMA row phase pays when its 64-column slices do not force more column parts per item than the 128-column
+  // slices of the VALU variant would need (measured at [., 128, 20, 1024]: 128 pairs 183 vs 188 us gate-fused, 132 vs 158 us
+  // plain; 256 pairs -- 2 parts instead of 1 -- 355 vs 326 us)
+  const bool mrow = pm.ok && !valu_rows && (!pv.ok || pm.parts <= pv.parts);
+  const FusedPlan& pl = mrow ? pm : pv;
   if (pl.ok && !want_split()) {
     if (ws_bytes < pl.ws_bytes) return set_error(TSG_E_SHAPE, "%s: workspace of %lld B < %lld B (tsg_scdm_bwd_ws_bytes)", fn, ws_bytes, pl.ws_bytes);
     float* xch = static_cast<float*>(ws);
     unsigned* cnt = reinterpret_cast<unsigned*>(xch + (size_t)B * pl.parts * T * NP);
     hipLaunchKernelGGL(zero3_kernel, dim3(4), dim3(256), 0, st, (unsigned*)dw, H, (unsigned*)dbias, GATE ? Ds : 0, cnt, B);
-    auto kern = scdm_bwd_fused_kernel<NP, GATE>;
-    static thread_local size_t allowed = 0;     // per instantiation
-    if (pl.lds > allowed) {
+    auto kern = mrow ? scdm_bwd_fused_kernel<NP, GATE, true> : scdm_bwd_fused_kernel<NP, GATE, false>;
+    static thread_local size_t allowed[2] = {0, 0};     // per instantiation
+    if (pl.lds > allowed[mrow]) {
       hipError_t e = allow_lds(kern, pl.lds);
       if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute(%zu): %s", fn, pl.lds, hipGetErrorString(e));
-      allowed = pl.lds;
+      allowed[mrow] = pl.lds;
     }
     hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kFusedThreads), pl.lds, st, a, s, w, V, P, dC, gr, gbias, da, ds, dw, dV, dbias, dr,
                        xch, cnt, error_sink(), B, T, N, H, Ds, pl.parts, pl.SP, ablate_mask());
@@ -1304,14 +1500,14 @@ extern "C" long long tsg_scdm_bwd_ws_bytes(int B, int T, int N, int H, int Ds, i
   const long long split = split_ws_bytes(B, T, N, Ds, gate != 0);
   long long fused = 0;
   switch (np) {
-    case 4: fused = fused_plan<4>(B, T, N, H, Ds).ws_bytes; break;
-    case 8: fused = fused_plan<8>(B, T, N, H, Ds).ws_bytes; break;
-    case 12: fused = fused_plan<12>(B, T, N, H, Ds).ws_bytes; break;
-    case 16: fused = fused_plan<16>(B, T, N, H, Ds).ws_bytes; break;
-    case 20: fused = fused_plan<20>(B, T, N, H, Ds).ws_bytes; break;
-    case 24: fused = fused_plan<24>(B, T, N, H, Ds).ws_bytes; break;
-    case 28: fused = fused_plan<28>(B, T, N, H, Ds).ws_bytes; break;
-    default: fused = fused_plan<32>(B, T, N, H, Ds).ws_bytes; break;
+    case 4: fused = std::max(fused_plan<4, true>(B, T, N, H, Ds).ws_bytes, fused_plan<4, false>(B, T, N, H, Ds).ws_bytes); break;
+    case 8: fused = std::max(fused_plan<8, true>(B, T, N, H, Ds).ws_bytes, fused_plan<8, false>(B, T, N, H, Ds).ws_bytes); break;
+    case 12: fused = std::max(fused_plan<12, true>(B, T, N, H, Ds).ws_bytes, fused_plan<12, false>(B, T, N, H, Ds).ws_bytes); break;
+    case 16: fused = std::max(fused_plan<16, true>(B, T, N, H, Ds).ws_bytes, fused_plan<16, false>(B, T, N, H, Ds).ws_bytes); break;
+    case 20: fused = std::max(fused_plan<20, true>(B, T, N, H, Ds).ws_bytes, fused_plan<20, false>(B, T, N, H, Ds).ws_bytes); break;
+    case 24: fused = std::max(fused_plan<24, true>(B, T, N, H, Ds).ws_bytes, fused_plan<24, false>(B, T, N, H, Ds).ws_bytes); break;
+    case 28: fused = std::max(fused_plan<28, true>(B, T, N, H, Ds).ws_bytes, fused_plan<28, false>(B, T, N, H, Ds).ws_bytes); break;
+    default: fused = std::max(fused_plan<32, true>(B, T, N, H, Ds).ws_bytes, fused_plan<32, false>(B, T, N, H, Ds).ws_bytes); break;
   }
   return fused > split ? fused : split;       // either path can run in it
 }
