@@ -56,15 +56,10 @@ class rnn_recalibration_layer(nn.Module):
             VW = TF.linear(word_feat, self.sent_linear.weight)
             a, s = att.projections(rnn_output, word_feat)
             return TF.scdm_gate(a, s, att.w.weight, VW, self.sent_linear.bias, rnn_output)
-        C = self.attention(rnn_output, word_feat)
-        channel_attn = self.sent_linear(C)
-        if self.ca_activ in ['sigmoid']:
-            channel_attn = torch.sigmoid(channel_attn)
-        elif self.ca_activ in ['relu']:
-            channel_attn = torch.relu(channel_attn)
-        elif self.ca_activ in ['tanh']:
-            channel_attn = torch.tanh(channel_attn)
-        return rnn_output * channel_attn
+        # un-fused tail (another attention class, or a word width sent_linear was not built for)
+        acts = {'sigmoid': torch.sigmoid, 'relu': torch.relu, 'tanh': torch.tanh}
+        channel_attn = self.sent_linear(self.attention(rnn_output, word_feat))
+        return rnn_output * acts.get(self.ca_activ, lambda x: x)(channel_attn)
 
 
 class QueryAwareEncoder(nn.Module):
