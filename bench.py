@@ -394,8 +394,6 @@ def main():
             except Exception as e:                                # noqa: BLE001
                 return {"error": f"{type(e).__name__}: {e}"[:300]}
         graph_replay = graph_child(a.dtype)
-        if a.dtype != "bf16":                                  # the eager bf16 step is bound by the host's 12 ms of launches: its GPU time
-            graph_replay["bf16"] = graph_child("bf16")         # only shows in the replay (side number, ~1e-3 from the fp32 reference)
         log(f"graph replay: {graph_replay}")
 
     if rank == 0:
