@@ -43,11 +43,22 @@ def _worker(rank, world, port, overlap, bucket_mb, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(100 + rank)              # different init per rank: broadcast must fix it
     model = Tiny()
-    dp = FlatGradAllReduce(model, bucket_mb=bucket_mb, overlap=overlap)
+    static = overlap == "static"               # the graph-replay protocol: static gradient tensors, exchange_static()
+    dp = FlatGradAllReduce(model, bucket_mb=bucket_mb, overlap=False if static else overlap)
     local = shard_batch(_batch(), rank, world)
     dp.zero_grad()
     _loss(model, local).backward()
-    dp.finish()
+    if static:
+        grads = [p.grad for p in dp.params]    # what a captured backward leaves behind (None: no gradient)
+        dp.adopt(grads)
+        views = [p.grad for p in dp.params]
+        for g in grads:                        # a "replay": the same tensors are rewritten, the exchange runs again
+            if g is not None:
+                g.mul_(1.0)
+        dp.exchange_static(grads)
+        assert all(a is b or a.data_ptr() == b.data_ptr() for a, b in zip(views, (p.grad for p in dp.params)))
+    else:
+        dp.finish()
     if rank == 0:
         # numpy (pickled by value): tensors would travel as shared-memory fds that die with the worker
         out.put({k: p.grad.numpy().copy() for k, p in model.named_parameters()})
@@ -56,7 +67,7 @@ def _worker(rank, world, port, overlap, bucket_mb, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,bucket_mb", [(True, 0.0002), (False, 32.0)])
+@pytest.mark.parametrize("overlap,bucket_mb", [(True, 0.0002), (False, 32.0), ("static", 32.0)])
 def test_flat_allreduce_matches_single_process(overlap, bucket_mb):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
