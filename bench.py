@@ -378,7 +378,7 @@ def main():
         log(f"forward-only: {fwd_only['ms_per_step']} ms/step")
     functional.check_lstm_errors()
     graph_replay = None
-    if not a.fwd_only and not a.no_alt and world == 1 and not (a.predictor == "self_attn" and params["dropout"] > 0):
+    if not a.fwd_only and not a.no_alt and world == 1:
         # the same train step replayed from two HIP graphs (engine.GraphedTrainStep), measured in a CHILD process started from
         # this one (a fresh capture state; a failure there cannot take this result down).  One GPU only: the child shares it.
         import subprocess

@@ -126,6 +126,16 @@ int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, cons
                 int n_heads, float scale, int causal, float p_drop, uint64_t seed, uint64_t offset, int dtype,
                 void* stream);
 
+/* Same two entry points with (seed, offset) read by the kernels from DEVICE memory: rng_dev -> two uint64 words, [0] = seed,
+ * [1] = offset.  For launches captured into a HIP graph: the replays advance the offset with a captured add, so every replay
+ * draws a fresh mask and the backward of the same replay regenerates it.                                                    */
+int tsg_mha_fwd_rng(const void* Q, const void* K, const void* V, void* O, void* A_sum, void* S_sum, void* lse,
+                    int B, int Tq, int Tk, int d_key, int d_value, int n_heads, float scale, int causal,
+                    float p_drop, const void* rng_dev, int dtype, void* stream);
+int tsg_mha_bwd_rng(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* lse,
+                    void* dQ, void* dK, void* dV, void* delta_ws, int B, int Tq, int Tk, int d_key, int d_value,
+                    int n_heads, float scale, int causal, float p_drop, const void* rng_dev, int dtype, void* stream);
+
 /* ---- Adjacent glue: bidirectional LSTM recurrence (BiLSTM.forward networks/RNN.py:34-48 = one layer of
  * nn.LSTM(bidirectional), zero initial state).  Sequence tensors are TIME-MAJOR here.  The caller computes
  * the input projections of all steps and both directions with one GEMM:

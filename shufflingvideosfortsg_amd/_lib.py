@@ -28,6 +28,8 @@ _SIGNATURES = {
     "tsg_boundary_score_fwd": [_P] * 9 + [_I] * 4 + [_P],
     "tsg_boundary_score_bwd": [_P] * 17 + [_I] * 4 + [_P],
     "tsg_mha_fwd": [_P] * 7 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
+    "tsg_mha_fwd_rng": [_P] * 7 + [_I] * 6 + [c_float, _I, c_float, _P, _I, _P],
+    "tsg_mha_bwd_rng": [_P] * 10 + [_I] * 6 + [c_float, _I, c_float, _P, _I, _P],
     "tsg_lstm_fwd": [_P] * 6 + [_I] * 4 + [_P],
     "tsg_lstm_error_sink": [_P],
     "tsg_lstm_set_l2_exchange": [_I],

@@ -35,7 +35,16 @@ constexpr float kNegBig = -3.0e38f;
 // un-dropped softmax).  Counter-based: the keep decision of element (b, head, q, key) is a hash of its index and
 // of (seed, offset), so forward and backward regenerate the same mask and nothing is stored.  thresh = p * 2^32
 // (0 = no dropout), inv_keep = 1/(1-p).
-struct DropCfg { unsigned thresh; float inv_keep; unsigned k0, k1; };
+struct DropCfg { unsigned thresh; float inv_keep; unsigned k0, k1; const unsigned long long* rng; };
+// rng != NULL: (seed, offset) live in DEVICE memory ([0] = seed, [1] = offset) and the keys are derived in the kernel -- the
+// launch can then sit in a captured HIP graph whose replays advance the offset with a captured add (tsg_mha_fwd_rng).
+__device__ __forceinline__ void drop_resolve(DropCfg& dc) {
+  if (dc.rng) {
+    const unsigned long long seed = dc.rng[0], off = dc.rng[1];
+    dc.k0 = (unsigned)seed ^ ((unsigned)off * 0x9E3779B1u);
+    dc.k1 = (unsigned)(seed >> 32) ^ ((unsigned)(off >> 32) * 0x85EBCA77u + 0x165667B1u);
+  }
+}
 __device__ __forceinline__ unsigned mix32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
@@ -98,6 +107,7 @@ __global__ __launch_bounds__(kThreads) void mha_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, float* __restrict__ Asum, float* __restrict__ Ssum, float* __restrict__ LSE,
     int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int qtiles, DropCfg dc) {
+  drop_resolve(dc);
   __shared__ __align__(16) float Qs[TQ * LS];
   __shared__ __align__(16) float Ks[KB * LS];      // K chunk, then reused for the V chunk
   __shared__ __align__(16) float Ps[TQ * PS];
@@ -265,6 +275,7 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(2,
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, float* __restrict__ LSE,
     int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int qblocks, int KS, int VS, DropCfg dc) {
+  drop_resolve(dc);
   extern __shared__ __align__(16) float lds[];
   float* Kl = lds;                         // [32][KS]   KS = roundup(dh,64)+2  (conflict-free b64 A reads)
   float* Vl = lds + 32 * KS;               // [32][VS]   VS = roundup(dvh,32)+4, zero beyond dvh
@@ -408,6 +419,7 @@ __global__ __launch_bounds__(kWideThreads) void mha_fwd_mfma_wide_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, float* __restrict__ LSE,
     int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int qblocks, int KS, int VS, DropCfg dc) {
+  drop_resolve(dc);
   extern __shared__ __align__(16) float lds[];
   float* Kl = lds;                         // [32][KS]   KS = 258 (= 2 mod 64: conflict-free b64 A reads), zero beyond dh
   float* Vl = lds + 32 * KS;               // [32][VS]   zero beyond dvh
@@ -550,6 +562,7 @@ __global__ __launch_bounds__(kThreads) void mha_bwd_kernel(
     const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ LSE,
     float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
     int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, DropCfg dc) {
+  drop_resolve(dc);
   __shared__ __align__(16) float Xs[TQ * LS];      // Q or dO tile chunk
   __shared__ __align__(16) float Ys[KB * LS];      // K or V block chunk
   __shared__ __align__(16) float Ps[TQ * PS];      // P tile   [q][n]
@@ -735,6 +748,7 @@ __global__ __launch_bounds__(kMfmaThreads) void mha_bwd_mfma_kernel(
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ delta,
     float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
     int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int KS, int VS2, DropCfg dc) {
+  drop_resolve(dc);
   // LDS: Kl [32][KS], Vl [32][VS2], Ql [32][KS], Gl (dO) [32][VS2]  (strides = 2 mod 64: b64 A/B reads),
   //      X [2][4 waves][16][64] partial S / dP, dSl [32][66], lsel [32], dl [32]
   extern __shared__ __align__(16) float lds[];
@@ -890,6 +904,7 @@ __global__ __launch_bounds__(kMfmaThreads) void mha_bwd_mfma_wide_kernel(
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ delta,
     float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
     int B, int Tq, int Tk, int dk, int dv, int H, float inv_scale, int causal, int KS, int VS2, DropCfg dc) {
+  drop_resolve(dc);
   // LDS: Kl [32][KS], Ql [32][KS], Gl (dO; V while its fragments are read) [32][VS2]  (strides = 2 mod 64: b64 A/B reads),
   //      X [2][4 waves][16][64] partial S / dP, dSl [32][66], lsel [32], dl [32]
   extern __shared__ __align__(16) float lds[];
@@ -1062,7 +1077,8 @@ int check(const char* fn, int B, int Tq, int Tk, int dk, int dv, int H, int dtyp
 
 using namespace tsg;
 
-static int make_drop(const char* fn, float p_drop, uint64_t seed, uint64_t offset, tsg::DropCfg* dc) {
+static int make_drop(const char* fn, float p_drop, uint64_t seed, uint64_t offset, const void* rng_dev, tsg::DropCfg* dc) {
+  dc->rng = static_cast<const unsigned long long*>(rng_dev);
   if (!(p_drop >= 0.f) || p_drop >= 1.f) return tsg::set_error(TSG_E_SHAPE, "%s: dropout probability %g outside [0, 1)", fn, p_drop);
   const double t = (double)p_drop * 4294967296.0;
   dc->thresh = p_drop > 0.f ? (unsigned)(t < 1.0 ? 1.0 : (t > 4294967295.0 ? 4294967295.0 : t)) : 0u;
@@ -1072,9 +1088,9 @@ static int make_drop(const char* fn, float p_drop, uint64_t seed, uint64_t offse
   return 0;
 }
 
-extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O, void* A_sum, void* S_sum, void* lse,
-                           int B, int Tq, int Tk, int d_key, int d_value, int n_heads, float scale, int causal,
-                           float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream) {
+static int mha_fwd_impl(const void* Q, const void* K, const void* V, void* O, void* A_sum, void* S_sum, void* lse,
+                        int B, int Tq, int Tk, int d_key, int d_value, int n_heads, float scale, int causal,
+                        float p_drop, uint64_t seed, uint64_t offset, const void* rng_dev, int dtype, void* stream) {
   const char* fn = "tsg_mha_fwd";
   for (const void* p : {Q, K, V, (const void*)O, (const void*)lse}) {
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
@@ -1083,7 +1099,7 @@ extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O,
   int rc = check(fn, B, Tq, Tk, d_key, d_value, n_heads, dtype);
   if (rc) return rc;
   DropCfg dc;
-  rc = make_drop(fn, p_drop, seed, offset, &dc);
+  rc = make_drop(fn, p_drop, seed, offset, rng_dev, &dc);
   if (rc) return rc;
   if (!(scale > 0.f)) return set_error(TSG_E_SHAPE, "%s: scale must be positive", fn);
   auto st = static_cast<hipStream_t>(stream);
@@ -1130,10 +1146,22 @@ extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O,
   return check_launch(fn);
 }
 
-extern "C" int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* lse,
-                           void* dQ, void* dK, void* dV, void* delta_ws, int B, int Tq, int Tk, int d_key, int d_value,
-                           int n_heads, float scale, int causal, float p_drop, uint64_t seed, uint64_t offset, int dtype,
-                           void* stream) {
+extern "C" int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O, void* A_sum, void* S_sum, void* lse,
+                           int B, int Tq, int Tk, int d_key, int d_value, int n_heads, float scale, int causal,
+                           float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream) {
+  return mha_fwd_impl(Q, K, V, O, A_sum, S_sum, lse, B, Tq, Tk, d_key, d_value, n_heads, scale, causal, p_drop, seed, offset, nullptr, dtype, stream);
+}
+extern "C" int tsg_mha_fwd_rng(const void* Q, const void* K, const void* V, void* O, void* A_sum, void* S_sum, void* lse,
+                               int B, int Tq, int Tk, int d_key, int d_value, int n_heads, float scale, int causal,
+                               float p_drop, const void* rng_dev, int dtype, void* stream) {
+  if (p_drop > 0.f && !rng_dev) return set_error(TSG_E_NULL, "tsg_mha_fwd_rng: rng_dev is NULL");
+  return mha_fwd_impl(Q, K, V, O, A_sum, S_sum, lse, B, Tq, Tk, d_key, d_value, n_heads, scale, causal, p_drop, 0, 0, rng_dev, dtype, stream);
+}
+
+static int mha_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* lse,
+                        void* dQ, void* dK, void* dV, void* delta_ws, int B, int Tq, int Tk, int d_key, int d_value,
+                        int n_heads, float scale, int causal, float p_drop, uint64_t seed, uint64_t offset, const void* rng_dev,
+                        int dtype, void* stream) {
   const char* fn = "tsg_mha_bwd";
   for (const void* p : {Q, K, V, O, dO, lse, (const void*)dQ, (const void*)dK, (const void*)dV}) {
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
@@ -1142,7 +1170,7 @@ extern "C" int tsg_mha_bwd(const void* Q, const void* K, const void* V, const vo
   int rc = check(fn, B, Tq, Tk, d_key, d_value, n_heads, dtype);
   if (rc) return rc;
   DropCfg dc;
-  rc = make_drop(fn, p_drop, seed, offset, &dc);
+  rc = make_drop(fn, p_drop, seed, offset, rng_dev, &dc);
   if (rc) return rc;
   const int dh = d_key / n_heads, dvh = d_value / n_heads;
   if (delta_ws && dh <= DHMAX && dvh <= DHMAX) {                    // MFMA path
@@ -1186,4 +1214,19 @@ extern "C" int tsg_mha_bwd(const void* Q, const void* K, const void* V, const vo
                      (const float*)lse, (float*)dQ, (float*)dK, (float*)dV, B, Tq, Tk, d_key, d_value, n_heads,
                      1.f / scale, causal, dc);
   return check_launch(fn);
+}
+
+extern "C" int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* lse,
+                           void* dQ, void* dK, void* dV, void* delta_ws, int B, int Tq, int Tk, int d_key, int d_value,
+                           int n_heads, float scale, int causal, float p_drop, uint64_t seed, uint64_t offset, int dtype,
+                           void* stream) {
+  return mha_bwd_impl(Q, K, V, O, dO, lse, dQ, dK, dV, delta_ws, B, Tq, Tk, d_key, d_value, n_heads, scale, causal, p_drop, seed, offset,
+                      nullptr, dtype, stream);
+}
+extern "C" int tsg_mha_bwd_rng(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* lse,
+                               void* dQ, void* dK, void* dV, void* delta_ws, int B, int Tq, int Tk, int d_key, int d_value,
+                               int n_heads, float scale, int causal, float p_drop, const void* rng_dev, int dtype, void* stream) {
+  if (p_drop > 0.f && !rng_dev) return set_error(TSG_E_NULL, "tsg_mha_bwd_rng: rng_dev is NULL");
+  return mha_bwd_impl(Q, K, V, O, dO, lse, dQ, dK, dV, delta_ws, B, Tq, Tk, d_key, d_value, n_heads, scale, causal, p_drop, 0, 0, rng_dev,
+                      dtype, stream);
 }

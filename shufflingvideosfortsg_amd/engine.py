@@ -106,8 +106,8 @@ class GraphedTrainStep:
 
     ``step_fn(model, batch) -> loss`` must be capture-safe: static shapes, no host synchronisation, device-resident batch (the
     caller refreshes the batch by copying into the SAME tensors).  ``opt`` must come from ``make_optimizer(capturable=True)``.
-    Dropout draws fresh masks on every replay (torch's graph-safe Philox offsets); the in-kernel attention dropout of K2 takes
-    its offset on the host and would repeat its mask, so a model with ``MultiHead`` dropout > 0 must not be trained through this.
+    Dropout draws fresh masks on every replay: torch's graph-safe Philox offsets for ``F.dropout``, and for the in-kernel attention
+    dropout of K2 a device-resident (seed, offset) pair whose increment is part of the graph (``functional.mha_graph_rng``).
     """
 
     def __init__(self, model, opt, step_fn, batch, dp=None, warmup=3):
@@ -116,6 +116,7 @@ class GraphedTrainStep:
         if dp is not None and dp.overlap:
             raise ValueError("GraphedTrainStep: the gradient exchange must run after the backward (FlatGradAllReduce(overlap=False))")
         self.params = [p for p in model.parameters() if p.requires_grad]
+        TF.mha_graph_rng(next(model.parameters()).device)   # K2 dropout state, created outside the capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # eager warm-up on the capture stream: lazy initialisation happens here

@@ -357,7 +357,7 @@ class _MHA(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, Q, K, V, n_heads, scale, causal, want_maps, p_drop=0.0, seed=0, offset=0):
+    def forward(ctx, Q, K, V, n_heads, scale, causal, want_maps, p_drop=0.0, seed=0, offset=0, rng=None):
         require_device(Q, K, V)
         Q, K, V = _f32c(Q), _f32c(K), _f32c(V)
         B, Tq, dk = Q.shape
@@ -370,12 +370,16 @@ class _MHA(torch.autograd.Function):
         lse = torch.empty(B, n_heads, Tq, device=Q.device, dtype=torch.float32)
         A = torch.empty(B, Tq, Tk, device=Q.device, dtype=torch.float32) if want_maps else None
         S = torch.empty(B, Tq, Tk, device=Q.device, dtype=torch.float32) if want_maps else None
-        _call("tsg_mha_fwd", Q, ptr(Q), ptr(K), ptr(V), ptr(O), ptr(A) if want_maps else None,
-                                 ptr(S) if want_maps else None, ptr(lse), B, Tq, Tk, dk, dv, int(n_heads),
-                                 float(scale), int(bool(causal)), float(p_drop), int(seed), int(offset), TSG_F32)
-        ctx.save_for_backward(Q, K, V, O, lse)
+        head = (ptr(Q), ptr(K), ptr(V), ptr(O), ptr(A) if want_maps else None, ptr(S) if want_maps else None, ptr(lse), B, Tq, Tk, dk, dv,
+                int(n_heads), float(scale), int(bool(causal)), float(p_drop))
+        if rng is not None:                                         # (seed, offset) in device memory: graph-capture safe
+            _call("tsg_mha_fwd_rng", Q, *head, ptr(rng), TSG_F32)
+        else:
+            _call("tsg_mha_fwd", Q, *head, int(seed), int(offset), TSG_F32)
+        ctx.save_for_backward(Q, K, V, O, lse, *([rng] if rng is not None else []))
         ctx.cfg = (int(n_heads), float(scale), int(bool(causal)))
         ctx.drop = (float(p_drop), int(seed), int(offset))          # the backward regenerates the same mask
+        ctx.has_rng = rng is not None
         ctx.set_materialize_grads(False)                            # no zero tensors for the non-differentiable maps' grads
         if want_maps:
             ctx.mark_non_differentiable(A, S)
@@ -385,7 +389,8 @@ class _MHA(torch.autograd.Function):
     @staticmethod
     @_bwd
     def backward(ctx, dO, _dA, _dS):
-        Q, K, V, O, lse = ctx.saved_tensors
+        Q, K, V, O, lse = ctx.saved_tensors[:5]
+        rng = ctx.saved_tensors[5] if ctx.has_rng else None
         n_heads, scale, causal = ctx.cfg
         p_drop, seed, offset = ctx.drop
         dO = _f32c(dO) if dO is not None else torch.zeros_like(O)
@@ -393,9 +398,16 @@ class _MHA(torch.autograd.Function):
         _, Tk, dv = V.shape
         dQ = torch.empty_like(Q); dK = torch.empty_like(K); dV = torch.empty_like(V)
         delta = torch.empty_like(lse)
-        _call("tsg_mha_bwd", Q, ptr(Q), ptr(K), ptr(V), ptr(O), ptr(dO), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(delta),
-                                 B, Tq, Tk, dk, dv, n_heads, scale, causal, p_drop, seed, offset, TSG_F32)
-        return dQ, dK, dV, None, None, None, None, None, None, None
+        head = (ptr(Q), ptr(K), ptr(V), ptr(O), ptr(dO), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(delta), B, Tq, Tk, dk, dv, n_heads, scale,
+                causal, p_drop)
+        if rng is not None:
+            _call("tsg_mha_bwd_rng", Q, *head, ptr(rng), TSG_F32)
+        else:
+            _call("tsg_mha_bwd", Q, *head, seed, offset, TSG_F32)
+        return dQ, dK, dV, None, None, None, None, None, None, None, None
+
+
+_mha_rng_state = {}        # device -> int64 [2] tensor (seed, offset): the dropout counter of captured launches
 
 
 def mha(Q, K, V, n_heads, scale, causal=False, return_maps=False, p_drop=0.0):
@@ -403,13 +415,34 @@ def mha(Q, K, V, n_heads, scale, causal=False, return_maps=False, p_drop=0.0):
     Returns O, or (O, A_sum, S_sum) with ``return_maps`` (S_sum is the un-dropped softmax, as in the reference).
     ``p_drop`` > 0 applies attention dropout inside the kernel (out = dropout(softmax) V, attention.py:53-54): the mask
     is a counter-based hash of (seed, offset, element index); seed = torch.initial_seed(), offset drawn from torch's CPU
-    generator, so ``torch.manual_seed`` makes it reproducible and every call gets a fresh mask."""
+    generator, so ``torch.manual_seed`` makes it reproducible and every call gets a fresh mask.  While the stream is being
+    captured into a HIP graph the (seed, offset) pair lives in device memory instead: the captured increment of the offset
+    makes every REPLAY draw a fresh mask (a host-side offset would be frozen into the graph)."""
     seed = offset = 0
+    rng = None
     if p_drop > 0.0:
         seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-        offset = int(torch.randint(0, 2 ** 62, (1,)).item())
-    O, A, S = _MHA.apply(Q, K, V, n_heads, scale, causal, return_maps, float(p_drop), seed, offset)
+        if Q.is_cuda and torch.cuda.is_current_stream_capturing():
+            st = _mha_rng_state.get(Q.device)
+            if st is None:
+                raise RuntimeError("mha: attention dropout under graph capture needs functional.mha_graph_rng(device) called before the "
+                                   "capture (engine.GraphedTrainStep does)")
+            st[1] += 1                                              # captured: advances on every replay
+            rng = st.clone()                                        # this call's (seed, offset), shared by forward and backward
+        else:
+            offset = int(torch.randint(0, 2 ** 62, (1,)).item())
+    O, A, S = _MHA.apply(Q, K, V, n_heads, scale, causal, return_maps, float(p_drop), seed, offset, rng)
     return (O, A, S) if return_maps else O
+
+
+def mha_graph_rng(device):
+    """Create (outside any capture) the device-resident (seed, offset) state the in-kernel attention dropout uses while a HIP
+    graph is being captured / replayed on ``device``."""
+    device = torch.device(device)
+    if device not in _mha_rng_state:
+        seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
+        _mha_rng_state[device] = torch.tensor([seed, int(torch.randint(0, 2 ** 40, (1,)).item())], dtype=torch.int64, device=device)
+    return _mha_rng_state[device]
 
 
 class _LinearHip(torch.autograd.Function):

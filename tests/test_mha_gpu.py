@@ -142,3 +142,39 @@ def test_multihead_module_dropout_modes():
     assert not torch.equal(t1, t2) and torch.equal(t1, t3) and not torch.allclose(t1, e1)
     t1.sum().backward()
     assert torch.isfinite(x.grad).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_attention_dropout_under_graph_capture():
+    """K2's in-kernel dropout inside a captured HIP graph: (seed, offset) live in device memory (tsg_mha_fwd_rng / _bwd_rng) and
+    the captured increment of the offset gives every REPLAY a fresh mask; forward and backward of one replay share it, and the
+    result equals the host-offset entry points called with the same (seed, offset)."""
+    from shufflingvideosfortsg_amd import functional as F
+    torch.manual_seed(5)
+    B, T, d, h, p = 2, 64, 256, 4, 0.3
+    Q = torch.randn(B, T, d, device="cuda", requires_grad=True); K = torch.randn(B, T, d, device="cuda", requires_grad=True)
+    V = torch.randn(B, T, d, device="cuda", requires_grad=True); gO = torch.randn(B, T, d, device="cuda")
+    st = F.mha_graph_rng(Q.device)
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):                                     # warm-up (eager path: host offsets)
+            o = F.mha(Q, K, V, h, math.sqrt(d), p_drop=p); o.backward(gO)
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    Q.grad = K.grad = V.grad = None
+    with torch.cuda.graph(g, stream=side):
+        out = F.mha(Q, K, V, h, math.sqrt(d), p_drop=p)
+        out.backward(gO)
+    res = []
+    for _ in range(3):
+        g.replay(); torch.cuda.synchronize()
+        seed, off = (int(x) for x in st.tolist())
+        ref = F._MHA.apply(Q.detach(), K.detach(), V.detach(), h, math.sqrt(d), False, False, p, seed, off, None)[0]
+        assert torch.equal(out, ref), "replayed output differs from the host-offset kernel at the same (seed, offset)"
+        # backward of the replay used the same mask: compare with an eager backward at that offset
+        Qe, Ke, Ve = (t.detach().clone().requires_grad_(True) for t in (Q, K, V))
+        F._MHA.apply(Qe, Ke, Ve, h, math.sqrt(d), False, False, p, seed, off, None)[0].backward(gO)
+        assert torch.equal(Q.grad, Qe.grad) and torch.equal(V.grad, Ve.grad)
+        res.append(out.clone())
+    assert not torch.equal(res[0], res[1]) and not torch.equal(res[1], res[2]), "replays repeated the dropout mask"
+    zeros = (res[0] == 0).float().mean().item()
+    assert zeros < 0.05                                        # dropout acts on the softmax, not on the output elements
