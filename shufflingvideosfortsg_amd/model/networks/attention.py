@@ -23,12 +23,21 @@ def positional_encodings_like(x: torch.Tensor, t: torch.Tensor = None) -> torch.
     sin(pos / 10000^(c/D)), odd -> cos(pos / 10000^((c-1)/D)).  Built in one shot on x's device
     (the reference fills it channel by channel in a Python loop); same float32 operand types."""
     T, D = x.size(1), x.size(2)
+    key = (T, D, x.device)
+    if t is None and key in _PE_CACHE:                     # the table depends on (T, D) only: built once per shape and device (a host
+        return _PE_CACHE[key]                              # list -> device copy on every call is also illegal under graph capture)
     pos = torch.arange(0, T, device=x.device).float() if t is None else t
     c = torch.arange(D)
     div = torch.tensor([10000 ** (float(ci - (ci % 2)) / D) for ci in c.tolist()], dtype=torch.float32, device=x.device)
     ang = pos[:, None] / div[None, :]
     even = (c % 2 == 0).to(x.device)
-    return torch.where(even[None, :], torch.sin(ang), torch.cos(ang))
+    pe = torch.where(even[None, :], torch.sin(ang), torch.cos(ang))
+    if t is None:
+        _PE_CACHE[key] = pe
+    return pe
+
+
+_PE_CACHE = {}
 
 
 def masked_softmax(vec, mask, dim=1, epsilon=1e-4):
