@@ -595,7 +595,20 @@ class _LinearSplit(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         dy2 = _f32c(dy).view(-1, w.shape[0])
         dx = _mm(dy2, w).view(*dy.shape[:-1], w.shape[1]) if ctx.needs_input_grad[0] else None
-        dw = dy2.t() @ x2 if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            M, (N, K) = x2.shape[0], w.shape
+            if _GEMM_DTYPE == "f32s" and N * K >= 2048 * 2048 and M % 16 == 0 and N % 4 == 0 and K % 4 == 0:
+                # a LARGE weight gradient (the 2048 x 2048 projections of the self-attention head: 69 GFLOP each, 0.49 ms as an
+                # fp32 GEMM) as a split-precision GEMM over the row contraction: both operands K-contiguous from the transposing
+                # split, as in the LSTM weight gradients
+                At = torch.empty(N, 3 * M, device=x2.device, dtype=torch.bfloat16)
+                Bt = torch.empty(K, 3 * M, device=x2.device, dtype=torch.bfloat16)
+                split_bf16x3_t(dy2, 0, N, 0, False, At)
+                split_bf16x3_t(x2, 0, K, 0, True, Bt)
+                dw = torch.mm(At, Bt.t(), out_dtype=torch.float32)
+            else:
+                dw = dy2.t() @ x2
         db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 

@@ -130,3 +130,23 @@ def test_linear_split_precision_matches_fp32():
     for got, want in [(y, ref), (dx, gx), (dw, gw), (db, gb)]:
         err = (got.double() - want).abs().max().item() / want.abs().max().item()
         assert err < 2e-5, err
+
+
+def test_linear_split_large_weight_gradient_vs_float64():
+    """functional.linear in the split-precision mode at the self-attention head's projection shape ([8192, 2048] x [2048, 2048]):
+    forward, input gradient AND the weight gradient (a split-precision GEMM over the 8192-row contraction from the transposing
+    split) stay at the fp32 GEMM's error level vs float64."""
+    torch.manual_seed(9)
+    M, K, N = 8192, 2048, 2048
+    x = (torch.randn(M, K, device="cuda") * 0.5).requires_grad_(True); w = (torch.randn(N, K, device="cuda") / K ** 0.5).requires_grad_(True)
+    gy = torch.randn(M, N, device="cuda") * 0.1
+    TF.set_gemm_dtype("f32s")
+    try:
+        y = TF.linear(x, w)
+        y.backward(gy)
+    finally:
+        TF.set_gemm_dtype(None)
+    xd, wd, gd = x.detach().double(), w.detach().double(), gy.double()
+    for got, ref, name in ((y.detach(), xd @ wd.t(), "y"), (x.grad, gd @ wd, "dx"), (w.grad, gd.t() @ xd, "dw")):
+        err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-5, (name, err)
