@@ -845,7 +845,9 @@ FusedPlan fused_plan(int B, int T, int N, int H, int Ds) {
   // column phase and of dVW overlay the VW slices at the end)
   const size_t t32 = (size_t)roundup(T, 32), vw_f = (size_t)kFusedWaves * NP * (SW + 4);
   const size_t red_m = (size_t)(RS - 1) * p.SP * (SW / 32) * 1024;                       // dVW accumulator tiles of the row splits
-  const size_t tail = vw_f > red_f ? (vw_f > red_m ? vw_f : red_m) : (red_f > red_m ? red_f : red_m);
+  const size_t red_c = (fused_cpl<NP>() == 2 && p.SP % 2 == 0) ? (size_t)(2 * RS - 1) * (p.SP / 2) * NP * 2 * kWave : 0;   // column phase regrouped
+  size_t tail = vw_f > red_f ? (vw_f > red_m ? vw_f : red_m) : (red_f > red_m ? red_f : red_m);
+  if (red_c > tail) tail = red_c;
   p.lds = p.lds_mrow = sizeof(float) * (2 * t32 * NP + (size_t)kFusedWaves * kMrowWk + tail);
   p.ok = p.mrow = p.SP <= kFusedWaves && p.lds <= (size_t)kLdsBytes - 1024;
   return p;
@@ -1242,7 +1244,16 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
   __syncthreads();
 
   // ---------------- column phase -----------------------------------------------------------------
-  {
+  // Generic in the columns per lane: the MFMA-row variant works on 64-column slices in its row phase (two MFMA tiles per wave), but
+  // its column phase is the VALU loop of the other variant and amortises its per-row overhead (exponential of the a row, de broadcast,
+  // da store, loop control) better over 2 columns per lane: the waves regroup as SP/2 slices of 128 columns x twice the row splits.
+  auto column_phase = [&](auto cpl_tag, const int SP, const int RS) {
+    constexpr int CPL = decltype(cpl_tag)::value, SW = kWave * CPL;
+    const int sw = wv % SP, rq = wv / SP;
+    const int col = (pt * SP + sw) * SW + lane * CPL;
+    const bool kok = col < H;
+    const size_t rowH = (size_t)b * T * H + (kok ? col : 0);
+    const int nrows = rq < T ? (T - rq + RS - 1) / RS : 0;          // this wave's rows: t = rq + RS*i
     float es[NP][CPL], dsacc[NP][CPL], dwacc[CPL], w4[CPL];
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
@@ -1340,6 +1351,12 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
       for (int c = 0; c < CPL; ++c)
         if (col + c < H && !TSG_SKIP(256)) atomicAdd(dw + col + c, -2.f * dwacc[c]);
     }
+  };
+  if constexpr (MROW && fused_cpl<NP>() == 2) {
+    if (SP % 2 == 0) column_phase(std::integral_constant<int, 2>{}, SP / 2, 2 * RS);
+    else column_phase(std::integral_constant<int, 1>{}, SP, RS);
+  } else {
+    column_phase(std::integral_constant<int, CPL>{}, SP, RS);
   }
 }
 
