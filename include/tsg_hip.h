@@ -261,7 +261,7 @@ int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_shift, long
 int tsg_pool_clips(const void* raw, const int64_t* offsets, const double* timestamps, void* out, int32_t* nfeats,
                    int32_t* framestps, int B, int T, int D, int dtype, void* stream);
 /* tsg_sequence_masks: Sequence_mask (charades.py:12-18: ones on [max(0,st), min(et,T-1)] INCLUSIVE) for the four masks a
- *   sample carries (charades.py:162-165, charades_pair_aug.py:96-107): video_mask = [0, nfeats], temporal_labels = [s, e],
+ *   sample carries (charades.py:167-170, charades_pair_aug.py:96-107): video_mask = [0, nfeats], temporal_labels = [s, e],
  *   fore_mask = [0, s], back_mask = [e, nfeats].  Each output is int32 [B,T]; any of them may be NULL.                      */
 int tsg_sequence_masks(const int32_t* nfeats, const int32_t* spans, int32_t* video_mask, int32_t* temporal_labels,
                        int32_t* fore_mask, int32_t* back_mask, int B, int T, void* stream);

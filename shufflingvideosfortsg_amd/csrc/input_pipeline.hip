@@ -6,7 +6,7 @@
 //   tsg_pool_clips        adjacent-pair mean pooling of the raw i3d clips + zero pad + nfeats + frame stamps
 //                         (CharadesDataSentence.generate_video_fts_data, dataset/charades.py:177-196)
 //   tsg_sequence_masks    video / temporal / fore / back masks from (nfeats, span)
-//                         (Sequence_mask, charades.py:12-18, as combined at charades.py:162-170 / charades_pair_aug.py:96-107)
+//                         (Sequence_mask, charades.py:12-18, as combined at charades.py:167-170 / charades_pair_aug.py:96-107)
 //   tsg_moment_translate  the shuffling augmentation as an index gather (DataAugmentForTSG.gt_moment_translate,
 //                         dataset/data_augment.py:135-156), insert position given or drawn from a counter-based hash
 //   tsg_span_pred         argmax_{i,j} of the zero-filled upper-triangular start_i + end_j matrix, first maximum wins
@@ -145,10 +145,10 @@ __global__ __launch_bounds__(kThreads) void sequence_masks_kernel(
   if (idx >= B * T) return;
   const int b = idx / T, t = idx % T;
   const int nf = nfeats[b], s = spans[2 * b], e = spans[2 * b + 1];
-  if (vm) vm[idx] = seq_mask(t, 0, nf, T);                    // video_mask     = [0, nfeats]   (charades.py:162)
-  if (tl) tl[idx] = seq_mask(t, s, e, T);                     // temporal_labels = framestamps  (:163)
-  if (fm) fm[idx] = seq_mask(t, 0, s, T);                     // fore_mask      = [0, start]    (:164)
-  if (bm) bm[idx] = seq_mask(t, e, nf, T);                    // back_mask      = [end, nfeats] (:165)
+  if (vm) vm[idx] = seq_mask(t, 0, nf, T);                    // video_mask     = [0, nfeats]   (charades.py:167)
+  if (tl) tl[idx] = seq_mask(t, s, e, T);                     // temporal_labels = framestamps  (:168)
+  if (fm) fm[idx] = seq_mask(t, 0, s, T);                     // fore_mask      = [0, start]    (:169)
+  if (bm) bm[idx] = seq_mask(t, e, nf, T);                    // back_mask      = [end, nfeats] (:170)
 }
 
 // span_pred: row i of the matrix is m[i][j] = j >= i ? fl(start_i + end_j) : 0 (triu zero-fills the lower triangle, which

@@ -118,7 +118,7 @@ def pool_clips_device(raw, offsets, T, timestamps=None):
 
 def sequence_masks_device(nfeats, spans, T):
     """-> dict(video_mask, temporal_labels, fore_masks, back_masks), each int32 [B,T] (Sequence_mask as combined at
-    charades.py:162-165) from device tensors nfeats [B] and spans [B,2]."""
+    charades.py:167-170) from device tensors nfeats [B] and spans [B,2]."""
     from . import _lib
     from .functional import _call
     _lib.require_device(nfeats, spans)
