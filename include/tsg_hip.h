@@ -250,6 +250,27 @@ int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_shift, long
                        long long cols, long long ld_out, long long plane_stride, int right_operand, long long dup_offset,
                        void* stream);
 
+/* ---- Weight-gradient products in the split-precision mode, operands converted on load (csrc/wgrad_split.hip) ----------------
+ * The dW = dY^T X products autograd forms for the path's Linears (networks/attention.py:105-106,113-114,
+ * components/SpanPredictor.py:62-72, components/DistributionAlign.py:88-94) and for nn.LSTM's W_ih / W_hh (networks/RNN.py:31,42):
+ *     C[g][n][k] = sum_{m < M} A[m][g*a_group_stride + n] * Bg[m][k],      g < groups (1 or 2), n < N, k < K0 + K1,
+ *     Bg[m][k] = B0[m][k]                                                  for k <  K0   (row stride ldb0),
+ *              = B1[m - s_g][g*b1_group_stride + (k - K0)]  or 0           for k >= K0   (row stride ldb1; s_0 = shift, s_1 = -shift;
+ *                0 when row m - s_g is outside [0, M) or, with period > 0, outside m's own run of `period` rows -- the h_{t-1} /
+ *                h_{t+1} operand of dW_hh read from the LSTM output, as in tsg_split_bf16x3_shift).
+ * fp32 row-major operands (row strides lda / ldb0 / ldb1 / ldc floats), fp32 output C[g] at C + g*c_group_stride.  Arithmetic:
+ * every operand element x is split into hi = rne_bf16(x), lo = rne_bf16(x - hi) and hi*hi + hi*lo + lo*hi is accumulated in
+ * fp32 on the bf16 MFMA -- the "f32s" arithmetic of tsg_split_bf16x3 + a bf16 GEMM, without operand planes in memory.  (Unlike
+ * tsg_split_bf16x3 an infinite element leaves a NaN, not an inf, in the result.)
+ * Limits: M % 32 == 0, N % 256 == 0, K0 % 128 == 0, K1 % 128 == 0, strides % 4 == 0, pointers 16-byte aligned.
+ * ws: scratch of tsg_wgrad_f32s_ws_bytes(...) bytes (0: may be NULL) -- partial tiles of the row ranges the contraction is cut
+ * into, added in a fixed order by a second launch: results are run-to-run identical.                                        */
+long long tsg_wgrad_f32s_ws_bytes(long long M, int N, int K0, int K1, int groups);
+int tsg_wgrad_f32s(const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
+                   const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift, long long period,
+                   void* C, long long ldc, long long c_group_stride, void* ws, long long ws_bytes,
+                   long long M, int N, int groups, void* stream);
+
 /* ---- Device-side input pipeline and span decoding (csrc/input_pipeline.hip) ---------------------------
  * The reference does this per sample in numpy inside DataLoader workers; these entry points do it per batch on the GPU.
  * Integer outputs are bit-exact with the reference.  int32 index tensors, fp32 features (dtype TSG_F32).

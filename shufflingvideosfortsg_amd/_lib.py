@@ -25,6 +25,9 @@ _SIGNATURES = {
     "tsg_error_sink": [_P],
     "tsg_scdm_gate_fwd": [_P] * 8 + [_I] * 6 + [_P],
     "tsg_scdm_gate_bwd": [_P] * 15 + [c_longlong] + [_I] * 6 + [_P],
+    "tsg_wgrad_f32s_ws_bytes": [c_longlong] + [_I] * 4,
+    "tsg_wgrad_f32s": [_P, c_longlong, c_longlong, _P, c_longlong, _I, _P, c_longlong, c_longlong, _I, c_longlong, c_longlong,
+                       _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _I, _I, _P],
     "tsg_boundary_score_fwd": [_P] * 9 + [_I] * 4 + [_P],
     "tsg_boundary_score_bwd": [_P] * 17 + [_I] * 4 + [_P],
     "tsg_mha_fwd": [_P] * 7 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
@@ -54,7 +57,8 @@ _SIGNATURES = {
     "tsg_span_pred": [_P] * 4 + [_I] * 3 + [_P],
     "tsg_mha_bwd": [_P] * 10 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
 }
-_RESTYPE = {"tsg_last_error": c_char_p, "tsg_lstm_bwd_ws_bytes": c_longlong, "tsg_scdm_bwd_ws_bytes": c_longlong}
+_RESTYPE = {"tsg_last_error": c_char_p, "tsg_lstm_bwd_ws_bytes": c_longlong, "tsg_scdm_bwd_ws_bytes": c_longlong,
+             "tsg_wgrad_f32s_ws_bytes": c_longlong}
 
 
 class TsgLibraryError(RuntimeError):

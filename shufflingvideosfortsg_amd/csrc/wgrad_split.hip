@@ -1,0 +1,389 @@
+// Weight-gradient products of the path in the split-precision mode ("f32s"), operands converted ON LOAD:
+//     C[g][n][k] = sum_m A[m][g*a_gs + n] * B_g[m][k]            (dW = dY^T X: contraction over the T*B rows)
+// Reference sites: the weight gradients autograd forms for the path's Linears (networks/attention.py:105-106,113-114,
+// components/SpanPredictor.py:62-72, components/DistributionAlign.py:88-94) and for nn.LSTM's W_ih / W_hh (networks/RNN.py:31,42).
+//
+// Why a hand-written kernel here: the output is small (<= 2048 x 1536) and the contraction long (16384 rows), and BOTH operands
+// are stored contraction-major (the contraction index is the row of a row-major fp32 matrix).  The library path needs a
+// transposing operand pass per operand (fp32 read, three bf16 planes written, read again by the GEMM) and then runs a shape its
+// bf16 kernels are slow at (few output tiles); its fp32 GEMM is at the fp32 MFMA peak but that peak is 16x lower.  This kernel
+// reads the fp32 rows once, splits every element into hi = rne_bf16(x), lo = rne_bf16(x - hi) in registers, transposes through
+// LDS into m-contiguous bf16 fragments and accumulates  hi*hi + hi*lo + lo*hi  on v_mfma_f32_32x32x16_bf16 (fp32 accumulate):
+// the arithmetic of the split-precision GEMMs around it (split_bf16.hip), without the operand planes ever touching HBM.
+//
+// Workgroup = 512 threads = 8 waves (4 along n x 2 along k), output tile 256 (n) x 128 (k), each wave 64 x 64 = 2 x 2 MFMA tiles
+// (64 accumulator registers).  The contraction is walked in chunks of 32 rows: the next chunk's rows are requested (6 float4 per
+// thread) before the current chunk's 24 MFMAs per wave, converted after them and written to the other LDS buffer; one barrier
+// per chunk.  Per MFMA gap: 2/3 of a ds_read_b128 and ~13 cycles of conversion VALU (the MFMA holds the issue port for 8 of its
+// 32), so the loop is MFMA-paced.  LDS image per operand plane: [column][32 m] bf16 on an 80-byte pitch -- conflict-free for the
+// b128 fragment reads (16 lanes = 16 distinct bank quads) and for the transposing writes (lanes run along m first).
+// Long contraction, few tiles: the rows are cut into `splits` ranges, one per workgroup; partial tiles go to a workspace and a
+// second kernel adds them in split order (deterministic).  Workgroups of one split are neighbours in XCD-major order, so an XCD's
+// L2 streams one row range of A and B once.
+// B can have two column segments: [0,K0) from B0, [K0,K0+K1) from B1 with a ROW SHIFT (source row m - shift, zeros outside the
+// row's sequence; group 1 uses -shift): the h_{t-1} / h_{t+1} operand of dW_hh straight from the LSTM output, no shifted copy.
+#include "tsg_common.h"
+#include <cstdlib>
+
+namespace tsg {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 32;                                  // rows of the contraction per chunk
+constexpr int P = 20;                                   // LDS pitch of one column in dwords: 16 (32 bf16 rows) + 4
+
+struct WgradArgs {
+  const float* A; long lda; long a_gs;
+  const float* B0; long ldb0; int K0;
+  const float* B1; long ldb1; long b1_gs; int K1; long shift; long period;
+  float* C; long ldc; long c_gs;                        // output (splits == 1) ...
+  float* ws;                                            // ... or partials [splits][groups][N][K0+K1]
+  long M; int N; int groups; int splits; int cps;       // cps = chunks (of 32 rows) per split
+};
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // (rne(a), rne(b)) packed, a in the low half
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pk_bf16(a, b);
+  lo = pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+__device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ int xcd_major(int bid, int g) {               // position when the grid is ordered by (XCD, arrival)
+  const int x = bid & 7, s = bid >> 3;
+  return x * (g >> 3) + min(x, g & 7) + s;
+}
+// source row of B's shifted segment exists?  32-bit arithmetic (M < 2^31, checked on the host)
+__device__ __forceinline__ bool row_ok(unsigned r, int shift, unsigned rows, unsigned period) {
+  if (period > 0) { const int t = (int)(r % period) - shift; return t >= 0 && t < (int)period; }
+  const long q = (long)r - shift;
+  return q >= 0 && q < (long)rows;
+}
+
+// Geometry of one kernel variant: WN x WK waves, each a 64 x 64 output block.
+template <int WN, int WK>
+struct Geo {
+  static constexpr int TN = 64 * WN, TK = 64 * WK, NT = 64 * WN * WK;
+  static constexpr int RA = 8 * TN / NT, RB = 8 * TK / NT;               // operand rows per thread and chunk (float4 each): 2 or 4
+  static constexpr int kPlaneA = TN * P, kPlaneB = TK * P;               // dwords per LDS plane
+  static constexpr int kBuf = 2 * kPlaneA + 2 * kPlaneB;                 // A_hi, A_lo, B_hi, B_lo
+  static constexpr size_t kLds = sizeof(unsigned) * 2 * kBuf;            // double-buffered
+  static_assert((RA == 2 || RA == 4) && (RB == 2 || RB == 4), "thread roles");
+};
+
+// a thread's rows of one operand tile: row group mg (4 rows), column quad c4, and for 2-row roles which half of the group
+template <int R, int W>
+struct Role {
+  int mg, c4, sub;
+  // lane bits [1:0] = column quad within a 64-byte segment, [4:2] = row group, [5..] = further segments: four neighbouring lanes
+  // read 64 contiguous bytes (one L1 tag lookup per lane quad -- with the lanes running along the rows first every lane was its
+  // own lookup: 64 per load instruction, and the L1 pipe, not the MFMA, set the pace), and the transposing LDS writes of one
+  // instruction still spread over all banks: column offset 80 dwords = 16 banks per quad step, 2 dwords per row group.
+  __device__ __forceinline__ explicit Role(int tid)
+      : mg((tid >> 2) & 7), c4((tid & 3) + 4 * ((tid >> 5) % (W / 16))), sub((tid >> 5) / (W / 16)) {}
+  __device__ __forceinline__ int row0() const { return 4 * mg + R * sub; }
+  // split the R x 4 block and write it m-contiguous: column 4*c4 + j, dwords (4*mg + R*sub) / 2 ..
+  __device__ __forceinline__ void write(const float4 (&v)[R], unsigned* hi, unsigned* lo) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float e[R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) e[i] = j == 0 ? v[i].x : j == 1 ? v[i].y : j == 2 ? v[i].z : v[i].w;
+      const int o = (4 * c4 + j) * P + 2 * mg + (R == 2 ? sub : 0);
+      if constexpr (R == 4) {
+        unsigned h0, l0, h1, l1;
+        split_pair(e[0], e[1], h0, l0);
+        split_pair(e[2], e[3], h1, l1);
+        *reinterpret_cast<uint2*>(hi + o) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(lo + o) = make_uint2(l0, l1);
+      } else {
+        unsigned h, l;
+        split_pair(e[0], e[1], h, l);
+        hi[o] = h; lo[o] = l;
+      }
+    }
+  }
+};
+
+template <int WN, int WK, bool SHIFTED>
+__device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, int split, int g, int n0, int k0) {
+  using G = Geo<WN, WK>;
+  constexpr bool NT_SKEW = WN * WK == 8;                  // two waves per SIMD inside one workgroup
+  struct Staged { float4 a[G::RA]; float4 b[G::RB]; };    // one chunk's operand rows of a thread, in flight / waiting for the split
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int K = a.K0 + a.K1;
+  const long chunks = a.M / BM;
+  const long c_begin = (long)split * a.cps;
+  const int nc = (int)(min(chunks, c_begin + a.cps) - c_begin);          // chunks of this row range (may be <= 0)
+
+  // load roles (see Role)
+  const Role<G::RA, G::TN> ra(tid);
+  const Role<G::RB, G::TK> rb(tid);
+  const bool seg1 = k0 >= a.K0;
+  const long ldb = seg1 ? a.ldb1 : a.ldb0;
+  const int shift = SHIFTED ? (int)(g ? -a.shift : a.shift) : 0;
+  const unsigned brow0 = (unsigned)(c_begin * BM) + rb.row0();
+  const float* pa = a.A + g * a.a_gs + n0 + 4 * ra.c4 + (c_begin * BM + ra.row0()) * a.lda;
+  const float* pb = (seg1 ? a.B1 + g * a.b1_gs + (k0 - a.K0) : a.B0 + k0) + 4 * rb.c4 + ((long)brow0 - shift) * ldb;
+
+  auto request = [&](Staged& r, int c) {                   // chunk c of the range (clamped: the tail re-requests the last chunk)
+    c = min(c, nc - 1);
+    const float* qa = pa + (long)c * BM * a.lda;
+    const float* qb = pb + (long)c * BM * ldb;
+#pragma unroll
+    for (int i = 0; i < G::RA; ++i) r.a[i] = *reinterpret_cast<const float4*>(qa + i * a.lda);
+#pragma unroll
+    for (int i = 0; i < G::RB; ++i) {
+      if (SHIFTED) {
+        r.b[i] = row_ok(brow0 + (unsigned)c * BM + i, shift, (unsigned)a.M, (unsigned)a.period)
+                     ? *reinterpret_cast<const float4*>(qb + i * ldb) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        r.b[i] = *reinterpret_cast<const float4*>(qb + i * ldb);
+      }
+    }
+  };
+  auto stage = [&](const Staged& r, int buf) {             // registers -> split -> LDS planes of buffer `buf`
+    unsigned* Ahi = lds + buf * G::kBuf; unsigned* Alo = Ahi + G::kPlaneA;
+    unsigned* Bhi = Alo + G::kPlaneA;    unsigned* Blo = Bhi + G::kPlaneB;
+    ra.write(r.a, Ahi, Alo);
+    rb.write(r.b, Bhi, Blo);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  const int wn = wv / WK, wk = wv % WK, r = lane & 31, hh = lane >> 5;
+  const int ao = (64 * wn + r) * P + 4 * hh, bo = (64 * wk + r) * P + 4 * hh;
+  auto compute = [&](int buf) {                            // 2 m-steps x (8 fragment reads, 12 MFMAs)
+    const unsigned* Ahi = lds + buf * G::kBuf; const unsigned* Alo = Ahi + G::kPlaneA;
+    const unsigned* Bhi = Alo + G::kPlaneA;    const unsigned* Blo = Bhi + G::kPlaneB;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      u32x4 fa_h[2], fa_l[2], fb_h[2], fb_l[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa_h[t] = *reinterpret_cast<const u32x4*>(Ahi + ao + 32 * t * P + 8 * ms);
+        fa_l[t] = *reinterpret_cast<const u32x4*>(Alo + ao + 32 * t * P + 8 * ms);
+        fb_h[t] = *reinterpret_cast<const u32x4*>(Bhi + bo + 32 * t * P + 8 * ms);
+        fb_l[t] = *reinterpret_cast<const u32x4*>(Blo + bo + 32 * t * P + 8 * ms);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = mfma(fa_h[i], fb_h[j], acc[i][j]);
+          acc[i][j] = mfma(fa_h[i], fb_l[j], acc[i][j]);
+          acc[i][j] = mfma(fa_l[i], fb_h[j], acc[i][j]);
+        }
+    }
+  };
+
+#ifdef TSG_WGRAD_TIMING
+  unsigned long long tph[4] = {0, 0, 0, 0}, tm0 = __builtin_amdgcn_s_memtime(), tm1 = 0;
+#define TSG_TICK(i) { tm1 = __builtin_amdgcn_s_memtime(); tph[i] += tm1 - tm0; tm0 = tm1; }
+#else
+#define TSG_TICK(i) {}
+#endif
+  if (nc > 0) {
+    // two chunks in flight: the rows requested at the top of an iteration are split and written to LDS at the end of the NEXT
+    // one (an L2 round trip under load is longer than one chunk's 24 MFMAs per wave).  No conditionals in the loop: the tail
+    // re-requests the last chunk and stages it into a buffer nobody reads any more.
+    Staged s0, s1;
+    request(s0, 0);
+    request(s1, 1);
+    stage(s0, 0);
+    __syncthreads();
+    // The two waves that share a SIMD (w and w + 4) take the two halves of an iteration -- 24 MFMAs on the current buffer, the
+    // split of the next chunk into the other buffer -- in OPPOSITE order: between two barriers all waves are in the same
+    // iteration, and with the same order everywhere the matrix pipe idles while both waves convert (measured: MFMA busy 30 %,
+    // the iteration took MFMA time + VALU time).
+    if (NT_SKEW && ((wv >> 2) & 1)) {
+      for (int c = 0; c + 1 < nc; c += 2) {
+        request(s0, c + 2); TSG_TICK(0)
+        stage(s1, 1); TSG_TICK(2)
+        compute(0); TSG_TICK(1)
+        __syncthreads(); TSG_TICK(3)
+        request(s1, c + 3); TSG_TICK(0)
+        stage(s0, 0); TSG_TICK(2)
+        compute(1); TSG_TICK(1)
+        __syncthreads(); TSG_TICK(3)
+      }
+    } else {
+      for (int c = 0; c + 1 < nc; c += 2) {
+        request(s0, c + 2); TSG_TICK(0)
+        compute(0); TSG_TICK(1)
+        stage(s1, 1); TSG_TICK(2)
+        __syncthreads(); TSG_TICK(3)
+        request(s1, c + 3); TSG_TICK(0)
+        compute(1); TSG_TICK(1)
+        stage(s0, 0); TSG_TICK(2)
+        __syncthreads(); TSG_TICK(3)
+      }
+    }
+    if (nc & 1) compute(0);
+  }
+
+  // epilogue: accumulator (row = n, column = k on the lanes) -> C or this split's partial tile
+  float* out = a.splits == 1 ? a.C + g * a.c_gs : a.ws + ((size_t)split * a.groups + g) * (size_t)a.N * K;
+  const long ldo = a.splits == 1 ? a.ldc : K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int n = n0 + 64 * wn + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * hh;
+        const int k = k0 + 64 * wk + 32 * j + r;
+        out[(size_t)n * ldo + k] = acc[i][j][q];
+      }
+#ifdef TSG_WGRAD_TIMING
+  __syncthreads();
+  if (blockIdx.x == 0 && lane == 0)                        // cycles per chunk and phase: request, compute, stage, barrier
+    for (int i = 0; i < 4; ++i) a.C[wv * 4 + i] = (float)(tph[i] / (unsigned long long)max(nc, 1));
+#endif
+}
+
+template <int WN, int WK>
+__global__ __launch_bounds__(64 * WN * WK) void wgrad_split_kernel(const WgradArgs a) {
+  extern __shared__ __align__(16) unsigned lds[];
+  using G = Geo<WN, WK>;
+  const int K = a.K0 + a.K1, tiles_k = K / G::TK, tpg = (a.N / G::TN) * tiles_k, tps = tpg * a.groups;
+  const int v = xcd_major(blockIdx.x, gridDim.x);
+  const int split = v / tps, rem = v % tps, g = rem / tpg, tile = rem % tpg;
+  const int n0 = (tile / tiles_k) * G::TN, k0 = (tile % tiles_k) * G::TK;
+  if (k0 >= a.K0 && a.shift != 0) wgrad_tile<WN, WK, true>(a, lds, split, g, n0, k0);      // workgroup-uniform
+  else wgrad_tile<WN, WK, false>(a, lds, split, g, n0, k0);
+}
+
+// C[g][n][k] = sum_s ws[s][g][n][k], float4 per thread
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc, long c_gs,
+                                                           int N, int K, int groups, int splits) {
+  const long per = (long)N * K / 4, total = per * groups;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int g = (int)(i / per);
+    const long e = (i % per) * 4, n = e / K, k = e % K;
+    float4 s = *reinterpret_cast<const float4*>(ws + (size_t)g * N * K + e);
+    for (int p = 1; p < splits; ++p) {
+      const float4 t = *reinterpret_cast<const float4*>(ws + ((size_t)p * groups + g) * (size_t)N * K + e);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    *reinterpret_cast<float4*>(C + g * c_gs + n * ldc + k) = s;
+  }
+}
+
+// Kernel variant.  0: 4 x 2 waves, 256 x 128 tile, one workgroup per CU (LDS 120 KiB); 1: 2 x 2 waves, 128 x 128 tile, two
+// workgroups per CU (80 KiB each) whose phases drift apart, so one converts while the other multiplies.  TSG_WGRAD_CFG selects.
+int variant() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TSG_WGRAD_CFG"); v = e ? atoi(e) : 1; if (v < 0 || v > 1) v = 1; }
+  return v;
+}
+struct Plan { int tn, tk, slots, tiles, splits; long long ws; };
+
+// number of row ranges: the smallest power of two (<= 16, >= 4 chunks per range) that minimises the number of full-chip rounds
+// per unit of work
+int choose_splits(long chunks, int tiles, int slots) {
+  int best = 1; double best_cost = 1e30;
+  for (int s = 1; s <= 16; s *= 2) {
+    if (chunks / s < 4 && s > 1) break;
+    const double rounds = (double)((tiles * s + slots - 1) / slots);
+    const double cost = rounds / s + (s > 1 ? 0.02 : 0.0) + 0.002 * s;      // + the reduce pass / prologue per workgroup
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+
+int check_args(const char* fn, long long M, int N, int K0, int K1, int groups) {
+  if (M <= 0 || N <= 0 || K0 < 0 || K1 < 0 || K0 + K1 <= 0 || groups < 1 || groups > 2)
+    return set_error(TSG_E_SHAPE, "%s: M=%lld N=%d K0=%d K1=%d groups=%d", fn, M, N, K0, K1, groups);
+  if (M % BM || N % 256 || K0 % 128 || K1 % 128)
+    return set_error(TSG_E_SHAPE, "%s: needs M %% %d == 0, N %% 256 == 0, K0 and K1 %% 128 == 0 (M=%lld N=%d K0=%d K1=%d)", fn, BM,
+                     M, N, K0, K1);
+  return 0;
+}
+
+Plan make_plan(long long M, int N, int K, int groups) {
+  Plan p;
+  const int v = variant();
+  p.tn = v == 0 ? 256 : 128; p.tk = 128; p.slots = v == 0 ? 256 : 512;
+  p.tiles = groups * (N / p.tn) * (K / p.tk);
+  p.splits = choose_splits(M / BM, p.tiles, p.slots);
+  p.ws = p.splits == 1 ? 0 : (long long)sizeof(float) * p.splits * groups * N * K;
+  return p;
+}
+
+template <int WN, int WK>
+int launch(const char* fn, const WgradArgs& a, int grid, hipStream_t st) {
+  using G = Geo<WN, WK>;
+  static bool lds_ok = false;
+  if (!lds_ok) {
+    hipError_t e = allow_lds(wgrad_split_kernel<WN, WK>, G::kLds);
+    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+    lds_ok = true;
+  }
+  hipLaunchKernelGGL((wgrad_split_kernel<WN, WK>), dim3(grid), dim3(G::NT), G::kLds, st, a);
+  return check_launch(fn);
+}
+
+}  // namespace
+}  // namespace tsg
+
+using namespace tsg;
+
+extern "C" long long tsg_wgrad_f32s_ws_bytes(long long M, int N, int K0, int K1, int groups) {
+  if (check_args("tsg_wgrad_f32s_ws_bytes", M, N, K0, K1, groups)) return -1;
+  return make_plan(M, N, K0 + K1, groups).ws;
+}
+
+extern "C" int tsg_wgrad_f32s(const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
+                              const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift,
+                              long long period, void* C, long long ldc, long long c_group_stride, void* ws, long long ws_bytes,
+                              long long M, int N, int groups, void* stream) {
+  const char* fn = "tsg_wgrad_f32s";
+  int rc = check_args(fn, M, N, K0, K1, groups);
+  if (rc) return rc;
+  if (!A || !C || (K0 > 0 && !B0) || (K1 > 0 && !B1)) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+  const int K = K0 + K1;
+  if ((lda & 3) || (ldb0 & 3) || (ldb1 & 3) || (ldc & 3) || (a_group_stride & 3) || (b1_group_stride & 3) || (c_group_stride & 3) ||
+      lda < (groups - 1) * a_group_stride + N || (K0 > 0 && ldb0 < K0) || (K1 > 0 && ldb1 < (groups - 1) * b1_group_stride + K1) ||
+      ldc < K || period < 0)
+    return set_error(TSG_E_SHAPE, "%s: leading dimensions / group strides must be multiples of 4 and cover the operands", fn);
+  if (period > 0 && M % period) return set_error(TSG_E_SHAPE, "%s: M=%lld is not a multiple of period=%lld", fn, M, period);
+  if (M >= (1LL << 31) || shift >= (1LL << 31) || shift <= -(1LL << 31) || period >= (1LL << 31))
+    return set_error(TSG_E_SHAPE, "%s: M, shift and period must fit 31 bits", fn);
+  if (!aligned16(A) || !aligned16(C) || (B0 && !aligned16(B0)) || (B1 && !aligned16(B1)))
+    return set_error(TSG_E_ALIGN, "%s: operands must be 16-byte aligned", fn);
+  const Plan p = make_plan(M, N, K, groups);
+  if (p.ws > 0 && (!ws || ws_bytes < p.ws || !aligned16(ws)))
+    return set_error(TSG_E_SHAPE, "%s: workspace of %lld bytes (16-byte aligned) required, got %lld", fn, p.ws, ws_bytes);
+  auto st = static_cast<hipStream_t>(stream);
+  const long chunks = M / BM;
+  WgradArgs a;
+  a.A = (const float*)A; a.lda = lda; a.a_gs = a_group_stride;
+  a.B0 = (const float*)B0; a.ldb0 = ldb0; a.K0 = K0;
+  a.B1 = (const float*)B1; a.ldb1 = ldb1; a.b1_gs = b1_group_stride; a.K1 = K1; a.shift = shift; a.period = period;
+  a.C = (float*)C; a.ldc = ldc; a.c_gs = c_group_stride; a.ws = (float*)ws;
+  a.M = M; a.N = N; a.groups = groups; a.splits = p.splits; a.cps = (int)((chunks + p.splits - 1) / p.splits);
+  rc = p.tn == 256 ? launch<4, 2>(fn, a, p.tiles * p.splits, st) : launch<2, 2>(fn, a, p.tiles * p.splits, st);
+#ifdef TSG_WGRAD_TIMING
+  return rc;
+#endif
+  if (rc || p.splits == 1) return rc;
+  const long total = (long)groups * N * K / 4;
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)ws, (float*)C, (long)ldc, (long)c_group_stride,
+                     N, K, groups, p.splits);
+  return check_launch(fn);
+}

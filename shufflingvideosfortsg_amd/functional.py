@@ -184,6 +184,42 @@ def split_bf16x3_t(x: torch.Tensor, col0: int, cols: int, row_shift: int, right:
     return out
 
 
+def wgrad_f32s_ok(M: int, N: int, K0: int, K1: int = 0) -> bool:
+    """Shapes tsg_wgrad_f32s takes (include/tsg_hip.h)."""
+    return M > 0 and M % 32 == 0 and N > 0 and N % 256 == 0 and K0 % 128 == 0 and K1 % 128 == 0 and K0 + K1 > 0
+
+
+def _rows2d(t: torch.Tensor) -> torch.Tensor:
+    """fp32 2-D operand whose rows are contiguous (a column slice of a row-major matrix is taken as it is)."""
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise TypeError(f"fp32 matrix expected, got {t.dtype} {tuple(t.shape)}")
+    return t if t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 else t.contiguous()
+
+
+def wgrad_f32s(A: torch.Tensor, B0: torch.Tensor, N: int = None, groups: int = 1, a_group_stride: int = 0,
+               B1: torch.Tensor = None, K1: int = 0, b1_group_stride: int = 0, shift: int = 0, period: int = 0) -> torch.Tensor:
+    """C[g] = A[:, g*a_group_stride : +N]^T @ [B0 | B1[rows shifted by -+shift, g*b1_group_stride : +K1]] -> [groups, N, K0+K1]:
+    the weight-gradient product in split precision with the operands converted on load (tsg_wgrad_f32s, include/tsg_hip.h).
+    A [M, >= N], B0 [M, K0], B1 [M, >= K1] are fp32 matrices with contiguous rows (column slices are fine)."""
+    require_device(A, B0, B1)
+    A, B0 = _rows2d(A), _rows2d(B0)
+    B1 = _rows2d(B1) if B1 is not None else None
+    M, K0 = B0.shape
+    N = A.shape[1] if N is None else N
+    if A.shape[0] != M or (B1 is not None and B1.shape[0] != M) or (B1 is None) != (K1 == 0):
+        raise ValueError("wgrad_f32s: operand rows differ")
+    K = K0 + K1
+    C = torch.empty(groups, N, K, device=A.device, dtype=torch.float32)
+    nb = int(load().tsg_wgrad_f32s_ws_bytes(M, N, K0, K1, groups))
+    if nb < 0:
+        raise ValueError(f"wgrad_f32s: unsupported shape M={M} N={N} K0={K0} K1={K1} groups={groups}")
+    ws = torch.empty(nb, device=A.device, dtype=torch.uint8) if nb else None
+    _call("tsg_wgrad_f32s", A, ptr(A), A.stride(0), a_group_stride, ptr(B0), B0.stride(0), K0,
+          ptr(B1) if B1 is not None else None, B1.stride(0) if B1 is not None else 0, b1_group_stride, K1, shift, period,
+          ptr(C), K, N * K, ptr(ws) if ws is not None else None, nb, M, N, groups)
+    return C
+
+
 def _split_operand(m: torch.Tensor, k_dim: int, right: bool) -> torch.Tensor:
     """Split a (possibly transposed-view) fp32 matrix without materialising the transpose."""
     if m.is_contiguous():
@@ -573,10 +609,14 @@ def gmd_losses(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, lam=(1.0, 1.0, 1.0)
     return _GmdLosses.apply(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, lam)
 
 
+_WGRAD_KERNEL = os.environ.get("TSG_WGRAD", "1") != "0"      # A/B switch: 0 = library GEMMs for the weight gradients
+
+
 class _LinearSplit(torch.autograd.Function):
-    """y = x w^T (+ b) with the two large GEMMs (forward, input gradient) in the split-precision mode; the weight
-    gradient dY^T x has a small output and a T*B-long contraction, which the library's fp32 GEMM handles at the fp32 MFMA
-    peak and its bf16 one does not, so it stays an fp32 GEMM."""
+    """y = x w^T (+ b) with the two large GEMMs (forward, input gradient) in the split-precision mode on the library's bf16
+    kernels; the weight gradient dY^T x has a small output and a T*B-long contraction over the ROWS of both operands, a shape
+    the library is slow at in bf16 (and 16x below the bf16 peak in fp32): tsg_wgrad_f32s (csrc/wgrad_split.hip) where its
+    tile constraints hold, the fp32 GEMM otherwise."""
 
     @staticmethod
     @_fwd
@@ -598,7 +638,12 @@ class _LinearSplit(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             M, (N, K) = x2.shape[0], w.shape
-            if _GEMM_DTYPE == "f32s" and N * K >= 2048 * 2048 and M % 16 == 0 and N % 4 == 0 and K % 4 == 0:
+            if _GEMM_DTYPE == "f32s" and _WGRAD_KERNEL and wgrad_f32s_ok(M, N, K):
+                # dY^T X in the same split-precision arithmetic by the hand-written kernel that converts the fp32 rows on load:
+                # 132 us at [1024 x 16384] x [16384 x 1024] against 290 us for the fp32 library GEMM and 340 us for operand planes
+                # + the library's bf16 GEMM (tools/wgrad_time.py)
+                dw = wgrad_f32s(dy2, x2)[0]
+            elif _GEMM_DTYPE == "f32s" and N * K >= 2048 * 2048 and M % 16 == 0 and N % 4 == 0 and K % 4 == 0:
                 # a LARGE weight gradient (the 2048 x 2048 projections of the self-attention head: 69 GFLOP each, 0.49 ms as an
                 # fp32 GEMM) as a split-precision GEMM over the row contraction: both operands K-contiguous from the transposing
                 # split, as in the LSTM weight gradients

@@ -1,0 +1,101 @@
+"""tsg_wgrad_f32s (csrc/wgrad_split.hip): dW = dY^T [X | shifted H] in split precision, operands converted on load --
+vs a float64 product of the same operands (fp32-GEMM-level error), vs the library split-GEMM path it replaces, the shifted
+second segment in both sequence layouts, strided operands, determinism and the argument checks."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(c, ref):
+    return float((c.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (32, 256, 128),            # one chunk, one tile, no split
+    (2560, 1024, 1024),        # word-side projections: 8 row ranges of 10 chunks
+    (16384, 1024, 1024),       # W_a at the north-star shape
+    (8192, 512, 1024),         # boundary head W1 (video half)
+    (4128, 256, 384),          # ragged row ranges (129 chunks)
+])
+def test_wgrad_matches_float64(M, N, K):
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, N, generator=g).cuda()
+    B = torch.randn(M, K, generator=g).cuda()
+    C = F.wgrad_f32s(A, B)
+    assert C.shape == (1, N, K)
+    ref = A.double().t() @ B.double()
+    assert _rel(C[0], ref) < 1e-5                       # fp32 rocBLAS on the same product: 1.4e-6 .. 6.4e-6 of max|C|
+    assert torch.equal(C, F.wgrad_f32s(A, B))           # fixed summation order
+
+
+def test_wgrad_wide_dynamic_range_and_zero_rows():
+    """lo planes matter: operands whose hi*hi product alone is off by 2^-9; zero rows contribute nothing."""
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 1024, 256, 256
+    A = (torch.randn(M, N, generator=g) * torch.logspace(-3, 3, M)[:, None]).cuda()
+    B = (1.0 + 1e-3 * torch.randn(M, K, generator=g)).cuda()
+    A[100:164] = 0
+    ref = A.double().t() @ B.double()
+    assert _rel(F.wgrad_f32s(A, B)[0], ref) < 1e-5
+    hi_only = A.bfloat16().float().double().t() @ B.bfloat16().float().double()
+    assert _rel(hi_only, ref) > 1e-4                    # a plain bf16 product is NOT good enough here
+
+
+@pytest.mark.parametrize("bm", [True, False])
+def test_wgrad_lstm_operands(bm):
+    """Two groups (directions), B = [x | h_{t-1}] / [x | h_{t+1}] read from `out` with a row shift: equals the explicitly
+    shifted construction, in the batch-major (period T, shift 1) and time-major (shift B) layouts."""
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    Bn, T, I, h = 8, 16, 128, 128
+    TB = Bn * T
+    dG = torch.randn(TB, 8 * h, generator=g).cuda()
+    x = torch.randn(TB, I, generator=g).cuda()
+    out = torch.randn(TB, 2 * h, generator=g).cuda()
+    shift, period = (1, T) if bm else (Bn, 0)
+    D = F.wgrad_f32s(dG, x, N=4 * h, groups=2, a_group_stride=4 * h, B1=out, K1=h, b1_group_stride=h, shift=shift, period=period)
+    assert D.shape == (2, 4 * h, I + h)
+    o3 = out.view(Bn, T, 2 * h) if bm else out.view(T, Bn, 2 * h)
+    prev, nxt = torch.zeros_like(o3), torch.zeros_like(o3)
+    if bm:
+        prev[:, 1:] = o3[:, :-1]; nxt[:, :-1] = o3[:, 1:]
+    else:
+        prev[1:] = o3[:-1]; nxt[:-1] = o3[1:]
+    for d, hs in ((0, prev.reshape(TB, 2 * h)[:, :h]), (1, nxt.reshape(TB, 2 * h)[:, h:])):
+        ref = dG[:, d * 4 * h:(d + 1) * 4 * h].double().t() @ torch.cat([x, hs], 1).double()
+        assert _rel(D[d], ref) < 1e-5, d
+
+
+def test_wgrad_strided_operands_and_library_path():
+    """Column slices of wider matrices go in without copies; the result agrees with split planes + library bf16 GEMM (the
+    same arithmetic in another summation order) to fp32 rounding."""
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 2048, 256, 256
+    Aw = torch.randn(M, 3 * N, generator=g).cuda()
+    Bw = torch.randn(M, 2 * K, generator=g).cuda()
+    A, B = Aw[:, N:2 * N], Bw[:, K:]
+    C = F.wgrad_f32s(A, B)[0]
+    At = torch.empty(N, 3 * M, device="cuda", dtype=torch.bfloat16)
+    Bt = torch.empty(K, 3 * M, device="cuda", dtype=torch.bfloat16)
+    F.split_bf16x3_t(Aw, N, N, 0, False, At)
+    F.split_bf16x3_t(Bw, K, K, 0, True, Bt)
+    lib = torch.mm(At, Bt.t(), out_dtype=torch.float32)
+    ref = A.double().t() @ B.double()
+    assert _rel(C, ref) < 1e-5 and _rel(lib, ref) < 1e-5
+    torch.testing.assert_close(C, lib, atol=2e-5 * float(ref.abs().max()), rtol=0)
+
+
+def test_wgrad_argument_checks():
+    from shufflingvideosfortsg_amd import functional as F
+    A, B = torch.zeros(64, 256, device="cuda"), torch.zeros(64, 128, device="cuda")
+    assert F.wgrad_f32s_ok(64, 256, 128) and not F.wgrad_f32s_ok(48, 256, 128) and not F.wgrad_f32s_ok(64, 128, 128)
+    with pytest.raises(ValueError):
+        F.wgrad_f32s(A[:48], B[:48])
+    with pytest.raises(ValueError):
+        F.wgrad_f32s(A[:, :128], B)
+    with pytest.raises(RuntimeError):
+        F.wgrad_f32s(A.cpu(), B.cpu())
