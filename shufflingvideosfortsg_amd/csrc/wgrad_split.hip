@@ -12,11 +12,19 @@
 // the arithmetic of the split-precision GEMMs around it (split_bf16.hip), without the operand planes ever touching HBM.
 //
 // Workgroup = 512 threads = 8 waves (4 along n x 2 along k), output tile 256 (n) x 128 (k), each wave 64 x 64 = 2 x 2 MFMA tiles
-// (64 accumulator registers).  The contraction is walked in chunks of 32 rows: the next chunk's rows are requested (6 float4 per
-// thread) before the current chunk's 24 MFMAs per wave, converted after them and written to the other LDS buffer; one barrier
-// per chunk.  Per MFMA gap: 2/3 of a ds_read_b128 and ~13 cycles of conversion VALU (the MFMA holds the issue port for 8 of its
-// 32), so the loop is MFMA-paced.  LDS image per operand plane: [column][32 m] bf16 on an 80-byte pitch -- conflict-free for the
-// b128 fragment reads (16 lanes = 16 distinct bank quads) and for the transposing writes (lanes run along m first).
+// (64 accumulator registers).  The contraction is walked in chunks of 32 rows; per chunk and wave: 24 MFMAs on the current LDS
+// buffer, 6 float4 row requests TWO chunks ahead (an L2 round trip under load is longer than one chunk), and the split of the next
+// chunk's rows (requested an iteration ago) into the other LDS buffer; one barrier per chunk.  The three are independent and are laid
+// out as ONE interleaved instruction stream (sched_group_barrier: after every MFMA a fragment read / a load / an LDS write and 3-4
+// conversion instructions), so a wave hides its own memory and VALU work in the 24 of 32 cycles an MFMA leaves the issue port free.
+// Loads: four neighbouring lanes read 64 contiguous bytes of a row (one L1 tag lookup per lane quad; lanes running along the rows
+// cost 64 lookups per instruction and made the L1 pipe the bottleneck: 3 900 -> 3 000 cycles per chunk), then the lanes run along
+// the rows, which keeps the transposing LDS writes conflict-free.  LDS image per operand plane: [column][32 m] bf16 on an 80-byte
+// pitch -- conflict-free for the b128 fragment reads (16 lanes = 16 distinct bank quads).
+// Where the time goes at [1024 x 16384] x [16384 x 1024] (ablation builds -DTSG_WGRAD_ABL, tools/wgrad_abl.py): 111 us by events =
+// 26 us fixed (launches, 32 MB of partial tiles out and back, the reduce) + 65 us for fragment reads + MFMAs alone (41 us at the
+// 2.5 PFLOP/s peak: LDS fragment traffic, 128 KiB per chunk and CU, is the co-bottleneck) + 20 us of loads and conversion that
+// still do not overlap.  Against it: 290 us for the library's fp32 GEMM, 340 us for operand planes + its bf16 GEMM.
 // Long contraction, few tiles: the rows are cut into `splits` ranges, one per workgroup; partial tiles go to a workspace and a
 // second kernel adds them in split order (deterministic).  Workgroups of one split are neighbours in XCD-major order, so an XCD's
 // L2 streams one row range of A and B once.
@@ -115,7 +123,6 @@ struct Role {
 template <int WN, int WK, bool SHIFTED>
 __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, int split, int g, int n0, int k0) {
   using G = Geo<WN, WK>;
-  constexpr bool NT_SKEW = WN * WK == 8;                  // two waves per SIMD inside one workgroup
   struct Staged { float4 a[G::RA]; float4 b[G::RB]; };    // one chunk's operand rows of a thread, in flight / waiting for the split
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int K = a.K0 + a.K1;
@@ -196,6 +203,29 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
 #else
 #define TSG_TICK(i) {}
 #endif
+  auto interleave = [&]() {
+#ifndef TSG_WGRAD_NO_SGB
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                    // fragments of the first m-step
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                                        // MFMAs 0-7: the second m-step's fragments
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {                                        // MFMAs 8-13: the requests two chunks ahead
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {                                       // MFMAs 14-23: the next chunk's planes go to LDS
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
+#endif
+  };
   if (nc > 0) {
     // two chunks in flight: the rows requested at the top of an iteration are split and written to LDS at the end of the NEXT
     // one (an L2 round trip under load is longer than one chunk's 24 MFMAs per wave).  No conditionals in the loop: the tail
@@ -205,32 +235,30 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
     request(s1, 1);
     stage(s0, 0);
     __syncthreads();
-    // The two waves that share a SIMD (w and w + 4) take the two halves of an iteration -- 24 MFMAs on the current buffer, the
-    // split of the next chunk into the other buffer -- in OPPOSITE order: between two barriers all waves are in the same
-    // iteration, and with the same order everywhere the matrix pipe idles while both waves convert (measured: MFMA busy 30 %,
-    // the iteration took MFMA time + VALU time).
-    if (NT_SKEW && ((wv >> 2) & 1)) {
-      for (int c = 0; c + 1 < nc; c += 2) {
-        request(s0, c + 2); TSG_TICK(0)
-        stage(s1, 1); TSG_TICK(2)
-        compute(0); TSG_TICK(1)
-        __syncthreads(); TSG_TICK(3)
-        request(s1, c + 3); TSG_TICK(0)
-        stage(s0, 0); TSG_TICK(2)
-        compute(1); TSG_TICK(1)
-        __syncthreads(); TSG_TICK(3)
-      }
-    } else {
-      for (int c = 0; c + 1 < nc; c += 2) {
-        request(s0, c + 2); TSG_TICK(0)
-        compute(0); TSG_TICK(1)
-        stage(s1, 1); TSG_TICK(2)
-        __syncthreads(); TSG_TICK(3)
-        request(s1, c + 3); TSG_TICK(0)
-        compute(1); TSG_TICK(1)
-        stage(s0, 0); TSG_TICK(2)
-        __syncthreads(); TSG_TICK(3)
-      }
+    // One basic block per chunk: 24 MFMAs on the current buffer, the requests two chunks ahead and the split of the next chunk
+    // into the other buffer are independent, and sched_group_barrier lays them out as ONE interleaved stream -- after every
+    // MFMA (8 issue cycles of its 32) a fragment read / a load / an LDS write and 3-4 conversion instructions -- so that a wave
+    // hides its own memory and VALU work under its own MFMAs.  (With the three pieces one after the other the two waves of a
+    // SIMD, which meet at every barrier, were in the same phase at the same time: MFMA time + VALU time + L1 issue time per
+    // chunk, matrix pipe 30 % busy.)
+#ifndef TSG_WGRAD_ABL
+#define TSG_WGRAD_ABL 0
+#endif
+#define ABL_REQ(x) { if (!(TSG_WGRAD_ABL & 2)) { x; } }
+#define ABL_CMP(x) { if (!(TSG_WGRAD_ABL & 8)) { x; } }
+#define ABL_STG(x) { if (!(TSG_WGRAD_ABL & 4)) { x; } }
+#define ABL_BAR() { if (!(TSG_WGRAD_ABL & 1)) __syncthreads(); }
+    for (int c = 0; c + 1 < nc; c += 2) {
+      ABL_REQ(request(s0, c + 2)) TSG_TICK(0)
+      ABL_CMP(compute(0)) TSG_TICK(1)
+      ABL_STG(stage(s1, 1)) TSG_TICK(2)
+      interleave();
+      ABL_BAR() TSG_TICK(3)
+      ABL_REQ(request(s1, c + 3)) TSG_TICK(0)
+      ABL_CMP(compute(1)) TSG_TICK(1)
+      ABL_STG(stage(s0, 0)) TSG_TICK(2)
+      interleave();
+      ABL_BAR() TSG_TICK(3)
     }
     if (nc & 1) compute(0);
   }
@@ -283,11 +311,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-// Kernel variant.  0: 4 x 2 waves, 256 x 128 tile, one workgroup per CU (LDS 120 KiB); 1: 2 x 2 waves, 128 x 128 tile, two
-// workgroups per CU (80 KiB each) whose phases drift apart, so one converts while the other multiplies.  TSG_WGRAD_CFG selects.
+// Kernel variant.  0 (default): 4 x 2 waves, 256 x 128 tile, one workgroup per CU (LDS 120 KiB); 1: 2 x 2 waves, 128 x 128 tile,
+// two workgroups per CU (80 KiB each: tools/ubench/lds_occupancy.hip -- 2 x 81 920 B is the most two workgroups can hold).
+// Measured at [1024 x 16384] x [16384 x 1024]: 121.6 us vs 134.8 us -- the smaller tile moves a third more operand bytes through
+// L1 and LDS per MFMA and converts a third more elements.  TSG_WGRAD_CFG selects (A/B).
 int variant() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("TSG_WGRAD_CFG"); v = e ? atoi(e) : 1; if (v < 0 || v > 1) v = 1; }
+  if (v < 0) { const char* e = getenv("TSG_WGRAD_CFG"); v = e ? atoi(e) : 0; if (v < 0 || v > 1) v = 0; }
   return v;
 }
 struct Plan { int tn, tk, slots, tiles, splits; long long ws; };
