@@ -107,6 +107,7 @@ from shufflingvideosfortsg_amd import data, engine, functional  # noqa: E402
 from shufflingvideosfortsg_amd.dp import FlatGradAllReduce      # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; no sparsity)
 _T0 = time.time()
 
 
@@ -186,6 +187,19 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
             lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d,
                                     heads, sc, 0, 0.0, 0, 0, TSG_F32, st),
             B * (4 * T + 4 * Tk) * d * e)          # read Q,K,V,O,dO ; write dQ,dK,dV
+    # the hand-written weight-gradient GEMM (csrc/wgrad_split.hip) at the step's three shapes: MFMA-bound, so its roofline is the
+    # dense bf16 MFMA peak; flops = the bf16 matrix work it issues (3 products per fp32 product)
+    for (M, Nn, Kk) in ((2 * B * T, d, d), (2 * B * N, d, d), (B * T, 512, d)):
+        if M % 32 or Nn % 256 or Kk % 128:
+            continue
+        Aw = torch.randn(M, Nn, device=dev); Bw = torch.randn(M, Kk, device=dev); Cw = torch.empty(Nn, Kk, device=dev)
+        nbw = int(lib.tsg_wgrad_f32s_ws_bytes(M, Nn, Kk, 0, 1)); wsw = torch.empty(max(nbw, 16), device=dev, dtype=torch.uint8)
+        name = f"tsg_wgrad_f32s[{Nn}x{M} . {M}x{Kk}]"
+        run(name, lambda: lib.tsg_wgrad_f32s(ptr(Aw), Nn, 0, ptr(Bw), Kk, Kk, None, 0, 0, 0, 0, 0, ptr(Cw), Kk, 0, ptr(wsw), nbw, M, Nn, 1, st),
+            (M * (Nn + Kk) + Nn * Kk) * e)
+        fl = 3 * 2.0 * M * Nn * Kk
+        out[name].update(bound="mfma", mfma_flops=fl, achieved_TFLOPs=round(fl / out[name]["mean_us"] / 1e6, 1),
+                         mfma_frac=round(fl / out[name]["mean_us"] / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4))
     return out
 
 
@@ -302,6 +316,9 @@ def main():
 
     def timed(fn, n):
         """n calls bracketed by barrier + synchronize on both sides -> (max-over-ranks seconds, host enqueue seconds, last loss)"""
+        import gc
+        gc.collect()
+        gc.disable()                                      # no cyclic-GC pauses of the host inside a timed region
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -309,6 +326,7 @@ def main():
         for _ in range(n):
             last = fn()
         t_enq = time.perf_counter() - t0
+        gc.enable()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -343,7 +361,9 @@ def main():
     functional.kernel_timer.enable(only=None if a.time_all else ("tsg_scdm", "tsg_boundary", "tsg_mha"))
     dt, t_enq, loss = timed(step, a.steps)                # t_enq: host time to enqueue the K steps (== dt when the host is the limit)
     functional.kernel_timer.disable()
-    log(f"timed {a.steps} steps in {dt:.3f} s (host enqueue {t_enq:.3f} s)")
+    ms_ = torch.cuda.memory_stats()
+    log(f"timed {a.steps} steps in {dt:.3f} s (host enqueue {t_enq:.3f} s); device allocs {ms_.get('num_device_alloc')} frees {ms_.get('num_device_free')} "
+        f"reserved {ms_.get('reserved_bytes.all.current', 0) / 2**30:.1f} GiB")
     if not torch.isfinite(loss):
         raise SystemExit("non-finite loss in the timed region")
     functional.check_lstm_errors()                        # a persistent LSTM launch whose bounded wait expired -> invalid run
@@ -370,9 +390,13 @@ def main():
     functional.set_gemm_dtype(gdt_main)
     fwd_only = None
     if not a.fwd_only and not a.no_alt:                   # forward-only pairs/s, reported separately
-        for _ in range(2):
-            fwd_step()
-        dt3, _, loss3 = timed(fwd_step, a.steps)
+        for _ in range(max(a.warmup, 2)):                 # the first no_grad passes after training steps run host-bound (allocator
+            fwd_step()                                    # re-fit: 8.7 instead of 3.5 ms of host time per step); not part of the rate
+        torch.cuda.synchronize()
+        dt3, enq3, loss3 = timed(fwd_step, a.steps)
+        ms_ = torch.cuda.memory_stats()
+        log(f"forward-only: host enqueue {enq3 / a.steps * 1e3:.3f} ms/step; device allocs {ms_.get('num_device_alloc')} frees {ms_.get('num_device_free')} "
+            f"reserved {ms_.get('reserved_bytes.all.current', 0) / 2**30:.1f} GiB retries {ms_.get('num_alloc_retries')}")
         fwd_only = {"value": round(a.B * world * a.steps / dt3, 2), "unit": "pairs/s", "ms_per_step": round(dt3 / a.steps * 1e3, 3),
                     "finite": bool(torch.isfinite(loss3)), "note": "forward + losses under no_grad, same batch and mode as `value`"}
         log(f"forward-only: {fwd_only['ms_per_step']} ms/step")

@@ -17,7 +17,7 @@ def timeit(fn, n=30):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-for (M, N, K) in [(16384, 1024, 1024), (2560, 1024, 1024), (8192, 512, 1024)]:
+for (M, N, K) in [(16384, 1024, 1024), (2560, 1024, 1024), (8192, 512, 1024), (16384, 2048, 2048), (8192, 2048, 2048), (16384, 256, 1024)]:
     A, B = torch.randn(M, N, device="cuda"), torch.randn(M, K, device="cuda")
     t_new = timeit(lambda: F.wgrad_f32s(A, B))
     t_f32 = timeit(lambda: A.t() @ B)
