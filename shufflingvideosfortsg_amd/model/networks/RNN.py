@@ -12,7 +12,29 @@ import torch.nn.functional as F
 from ... import functional as TF
 
 
+class _Joined(torch.autograd.Function):
+    """Two parameters that are ADJACENT views of one buffer -> the buffer viewed as their concatenation along dim 0 (``stack``:
+    as a new leading axis), without a copy; the gradient goes back as the two halves (views of it).  Replaces the
+    ``torch.cat`` / ``torch.stack`` of the forward and reverse ``nn.LSTM`` weights every layer call (16 MB of copies and
+    five launches per layer and step)."""
+
+    @staticmethod
+    def forward(ctx, pf, pr, base, stack):
+        ctx.n0 = pf.shape[0]
+        ctx.stack = stack
+        shape = (2,) + tuple(pf.shape) if stack else (2 * pf.shape[0],) + tuple(pf.shape[1:])
+        return base.detach().view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.stack:
+            return g[0], g[1], None, None
+        return g[:ctx.n0], g[ctx.n0:], None, None
+
+
 class BiLSTM(nn.Module):
+    _PARTS = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+
     def __init__(self, input_size, hidden_size, num_layers, dropout=0.5):
         super().__init__()
         self.hidden_size = hidden_size
@@ -20,17 +42,39 @@ class BiLSTM(nn.Module):
         self.lstm = nn.LSTM(input_size, hidden_size, num_layers, batch_first=True, bidirectional=True, dropout=dropout)
         # "hip" (default on GPU tensors) | "miopen" = torch.nn.LSTM, kept for A/B timing
         self.backend = os.environ.get("TSG_LSTM", "hip")
+        self._join = os.environ.get("TSG_LSTM_JOIN", "1") != "0"      # A/B switch: 0 = torch.cat / torch.stack every call
+        self._fused = {}                          # (layer, part) -> buffer holding the forward and the reverse parameter back to back
+
+    def _joined(self, k, part, stack=False):
+        """[forward; reverse] parameter ``part`` of layer k as ONE tensor.  The two nn.Parameters keep their identity, names and
+        shapes (state_dict, optimizer, gradient exchange see nothing); their ``.data`` are re-pointed once at the two halves of
+        a shared buffer, and re-pointed again whenever something replaced them (``.to()``, ``flatten_parameters()``, a deep
+        copy): checked by address on every call."""
+        L = self.lstm
+        pf, pr = getattr(L, f"{part}_l{k}"), getattr(L, f"{part}_l{k}_reverse")
+        if not self._join:
+            return (torch.stack if stack else torch.cat)([pf, pr], 0)
+        base = self._fused.get((k, part))
+        n, es = pf.numel(), pf.element_size()
+        if (base is None or base.device != pf.device or base.dtype != pf.dtype or pf.data_ptr() != base.data_ptr()
+                or pr.data_ptr() != base.data_ptr() + n * es or not pf.is_contiguous() or not pr.is_contiguous()):
+            if torch.cuda.is_available() and pf.is_cuda and torch.cuda.is_current_stream_capturing():
+                return (torch.stack if stack else torch.cat)([pf, pr], 0)      # never re-point under a graph capture
+            with torch.no_grad():
+                base = torch.cat([pf.detach().reshape(-1), pr.detach().reshape(-1)])
+                pf.data = base[:n].view(pf.shape)
+                pr.data = base[n:].view(pr.shape)
+            self._fused[(k, part)] = base
+        return _Joined.apply(pf, pr, base, stack)
 
     def _hip_forward(self, x):
         L, p = self.lstm, self.lstm.dropout
         bm = os.environ.get("TSG_LSTM_LAYOUT", "bm") != "tm"   # default: batch-major throughout, the kernels index [B,T,..]
         inp, hn, cn = (x if bm else x.transpose(0, 1).contiguous()), [], []     # directly; "tm" = transposed copies (A/B timing)
         for k in range(self.num_layers):
-            g = lambda n: getattr(L, f"{n}_l{k}")
-            gr = lambda n: getattr(L, f"{n}_l{k}_reverse")
-            W_ih = torch.cat([g("weight_ih"), gr("weight_ih")], 0)
-            bias = torch.cat([g("bias_ih") + g("bias_hh"), gr("bias_ih") + gr("bias_hh")])
-            W_hh = torch.stack([g("weight_hh"), gr("weight_hh")])
+            W_ih = self._joined(k, "weight_ih")                              # [8h, I]   (forward rows, then reverse)
+            bias = self._joined(k, "bias_ih") + self._joined(k, "bias_hh")    # [8h]
+            W_hh = self._joined(k, "weight_hh", stack=True)                  # [2, 4h, h]
             out, Cs = TF.bilstm_layer(inp, W_ih, bias, W_hh, batch_major=bm)
             h = self.hidden_size
             hn += [out[:, -1, :h], out[:, 0, h:]] if bm else [out[-1, :, :h], out[0, :, h:]]

@@ -242,7 +242,9 @@ def test_full_size_properties():
     g1 = torch.autograd.grad(C, (ad, sd, wd, vd), gC, retain_graph=True)
     g2 = torch.autograd.grad(C, (ad, sd, wd, vd), 2 * gC)
     for x, y in zip(g1, g2):                                                                 # backward is linear in dC
-        torch.testing.assert_close(2 * x, y, atol=1e-5, rtol=1e-4)
+        # dw sums B*T*N terms per column through float atomics (arrival order differs between the two launches): compare
+        # against the tensor's scale rather than element by element
+        torch.testing.assert_close(2 * x, y, atol=1e-5 + 2e-5 * float(y.abs().max()), rtol=1e-4)
     C0, P0 = O.scdm_core(a[:2], s[:2], w, sent[:2])
     torch.testing.assert_close(C[:2].detach().cpu(), C0, **TOL)
     torch.testing.assert_close(P[:2].detach().cpu(), P0, **TOL)
