@@ -262,3 +262,46 @@ def test_persistent_lstm_timeout_is_reported():
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and "raised ok" in r.stdout and "recovered ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_bilstm_joined_parameters_are_zero_copy_and_survive_repointing():
+    """The forward / reverse nn.LSTM parameters are adjacent views of one buffer (no torch.cat per call): same outputs and
+    parameter gradients as the concatenating path, bit for bit; the join is rebuilt after .to() / flatten_parameters() / a
+    deep copy replaced the parameter storage; the optimizer's in-place updates are seen; state_dict keys are nn.LSTM's."""
+    import copy
+    from shufflingvideosfortsg_amd.model.networks.RNN import BiLSTM
+    torch.manual_seed(3)
+    m = BiLSTM(24, 16, 2, dropout=0.0).cuda()
+    ref = copy.deepcopy(m); ref._join = False
+    x = torch.randn(5, 9, 24, device="cuda")
+    g = torch.randn(5, 9, 32, device="cuda")
+
+    def run(mod):
+        for p in mod.parameters():
+            p.grad = None
+        out, hn, cn = mod(x)
+        (out * g).sum().backward()
+        return out.detach().clone(), hn.detach().clone(), {n: p.grad.clone() for n, p in mod.named_parameters()}
+
+    o0, h0, g0 = run(ref)
+    for attempt in ("first", "again", "after flatten_parameters", "after deepcopy", "after cpu round trip"):
+        if attempt == "after flatten_parameters":
+            m.lstm.flatten_parameters()
+        elif attempt == "after deepcopy":
+            m = copy.deepcopy(m)
+        elif attempt == "after cpu round trip":
+            m = m.cpu().cuda()
+        o1, h1, g1 = run(m)
+        assert torch.equal(o0, o1) and torch.equal(h0, h1), attempt
+        assert set(g0) == set(g1) and all(torch.equal(g0[n], g1[n]) for n in g0), attempt
+        L = m.lstm
+        for part in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            pf, pr = getattr(L, f"{part}_l1"), getattr(L, f"{part}_l1_reverse")
+            assert pr.data_ptr() == pf.data_ptr() + pf.numel() * 4, (attempt, part)       # adjacent: the join is a view
+    assert sorted(m.state_dict()) == sorted(ref.state_dict())
+    opt_a, opt_b = torch.optim.SGD(m.parameters(), lr=0.1), torch.optim.SGD(ref.parameters(), lr=0.1)
+    run(m); run(ref)
+    opt_a.step(); opt_b.step()
+    o1, _, _ = run(m)
+    o2, _, _ = run(ref)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o0)
