@@ -187,6 +187,11 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
             lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d,
                                     heads, sc, 0, 0.0, 0, 0, TSG_F32, st),
             B * (4 * T + 4 * Tk) * d * e)          # read Q,K,V,O,dO ; write dQ,dK,dV
+        if Tk > 32:                                # the split-precision backward (dtype TSG_F32S: what the "f32s" mode launches)
+            run(f"tsg_mha_bwd[{tag}, f32s: {B},{T},{Tk},{d},h{heads}]",
+                lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d,
+                                        heads, sc, 0, 0.0, 0, 0, 2, st),
+                B * (4 * T + 4 * Tk) * d * e)
     # the hand-written weight-gradient GEMM (csrc/wgrad_split.hip) at the step's three shapes: MFMA-bound, so its roofline is the
     # dense bf16 MFMA peak; flops = the bf16 matrix work it issues (3 products per fp32 product)
     for (M, Nn, Kk) in ((2 * B * T, d, d), (2 * B * N, d, d), (B * T, 512, d)):

@@ -9,8 +9,9 @@
  *   - all pointers are DEVICE pointers on the current HIP device, 16-byte aligned, row-major
  *     contiguous, batch-first; the caller owns every buffer (outputs and workspaces included);
  *     the library never allocates, frees or synchronises.
- *   - `dtype`: TSG_F32 (0) everywhere; TSG_F32S (2) additionally in the LSTM entry points (fp32 storage, split-precision
- *     bf16 MFMA products; hidden sizes other than 128/256/384/512 compute in plain fp32 there); TSG_BF16 (1) is reserved.
+ *   - `dtype`: TSG_F32 (0) everywhere; TSG_F32S (2) additionally in the LSTM entry points and in tsg_mha_bwd (fp32 storage,
+ *     split-precision bf16 MFMA products; LSTM hidden sizes other than 128/256/384/512 and attention shapes outside the ones
+ *     named at tsg_mha_bwd compute in plain fp32); TSG_BF16 (1) is reserved.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); work is only enqueued.
  *   - return 0 on success; <0 = argument error (TSG_E_*); >0 = hipError_t from the launch.
  *     tsg_last_error() returns a thread-local message for the last non-zero return.
@@ -120,7 +121,11 @@ int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O, void* A_su
                 float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream);
 
 /* backward: dO [B,Tq,d_value] -> dQ, dK, dV (fully overwritten; no atomics, deterministic).
- * delta_ws: caller-owned workspace of B*n_heads*Tq floats (NULL selects the slower non-MFMA kernel). */
+ * delta_ws: caller-owned workspace of B*n_heads*Tq floats (NULL selects the slower non-MFMA kernel).
+ * dtype TSG_F32: exact fp32 products.  TSG_F32S (fp32 storage): the five products of the backward as split-precision bf16 MFMA
+ * products (x = hi + lo, hi*hi + hi*lo + lo*hi, fp32 accumulate -- fp32-GEMM-level error) in two kernels (dK/dV, dQ), where
+ * d_key == d_value, the head width is 32 / 64 / 96 / 128 and Tk > 32; otherwise the exact kernels run.  tsg_mha_fwd treats
+ * TSG_F32S as TSG_F32.                                                                                                       */
 int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* lse,
                 void* dQ, void* dK, void* dV, void* delta_ws, int B, int Tq, int Tk, int d_key, int d_value,
                 int n_heads, float scale, int causal, float p_drop, uint64_t seed, uint64_t offset, int dtype,

@@ -18,6 +18,7 @@
 // workgroup -- no atomics, bitwise reproducible.  For each 32-key block the dK/dV accumulators live
 // in registers while the query tiles stream through LDS; P is recomputed from LSE.
 #include "tsg_common.h"
+#include <cstdlib>
 
 namespace tsg {
 namespace {
@@ -1061,8 +1062,388 @@ __global__ __launch_bounds__(kMfmaThreads) void mha_bwd_mfma_wide_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward in SPLIT PRECISION (dtype TSG_F32S; head widths 32 / 64 / 96 / 128, d_key == d_value): the five products of the
+// attention backward on the bf16 MFMA -- every fp32 operand x as hi = rne_bf16(x), lo = rne_bf16(x - hi), each product as
+// hi*hi + hi*lo + lo*hi with fp32 accumulation (v_mfma_f32_32x32x16_bf16: 5.3x fewer matrix cycles than the exact-fp32
+// 32x32x2 form; the arithmetic of the split-precision GEMMs and of the LSTM recurrence around it).  With the matrix time out
+// of the way the kernel is organised around NOT moving data instead:
+//   * TWO kernels, each the only writer of its outputs -- (A) dK, dV: workgroup = (b, head, 128 keys), wave = 32 keys;
+//     (B) dQ: workgroup = (b, head, 128 queries), wave = 32 queries.  S and dP are recomputed in both (cheap now); there is
+//     no global read-modify-write of dQ per (query tile, key block) and no cross-wave exchange of partial S / dP tiles.
+//   * the wave's OWN rows (K, V in A; Q, dO in B) are B-operand fragments held in registers for the whole kernel; the rows it
+//     streams past (Q, dO tiles in A; K, V tiles in B) are staged once per tile in LDS as bf16 planes in the two layouts the
+//     products need: row-major (contraction over channels) and transposed (contraction over the tile's rows).
+//   * P and dS never leave the registers: S is formed with the wave's rows on the LANES (A: S[q][key], B: S^T[key][q]), so
+//     its accumulator registers -- 16 tile rows rho(r, hh) per lane -- are, packed to bf16 pairs, exactly the operand of the
+//     next product whose contraction runs over the tile's rows in that same permuted order (the transposed planes are read
+//     in the matching 4-row runs).
+// LDS is double-buffered (the next tile's rows are requested before the MFMAs of the current one and split afterwards); one
+// barrier per tile.  delta = <dO, O> comes from the same pre-pass as the fp32 kernels; dropout / causal masks as there.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // (rne(a), rne(b)) packed, a in the low half
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v){a, b}, bf16x2v));
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pk_bf16(a, b);
+  lo = pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4v& hi, u32x4v& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) split_pair(v[2 * i], v[2 * i + 1], h[i], l[i]);
+  hi = (u32x4v){h[0], h[1], h[2], h[3]};
+  lo = (u32x4v){l[0], l[1], l[2], l[3]};
+}
+__device__ __forceinline__ f32x16 mfma_bf(u32x4v a, u32x4v b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, a), __builtin_bit_cast(bf16x8v, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma3(u32x4v ah, u32x4v al, u32x4v bh, u32x4v bl, f32x16 c) {
+  c = mfma_bf(ah, bh, c);
+  c = mfma_bf(ah, bl, c);
+  return mfma_bf(al, bh, c);
+}
+
+// One staged [32 rows x 32*DT channels] fp32 tile as bf16 planes in LDS.  Row-major planes R (pitch PR dwords per row: the
+// b128 fragment reads of 16 lanes hit 16 distinct bank quads for DT = 1..4) and, when TR, transposed planes T (pitch 20 dwords
+// per channel: 32 rows + 4).  256 threads: lane bits [1:0] = channel quad inside a 64-byte segment, [4:2] = group of 4 rows,
+// the rest = further segments -- 64-byte global reads per lane quad and conflict-free transposing writes (csrc/wgrad_split.hip).
+template <int DT, bool TR>
+struct SplitTile {
+  static constexpr int PR = 16 * DT + 4, PT = 20;
+  static constexpr int kRow = 32 * PR, kCol = 32 * DT * PT;                 // dwords per plane
+  static constexpr int kDwords = 2 * kRow + (TR ? 2 * kCol : 0);            // [R hi][R lo][T hi][T lo]
+  float4 v[4];
+  const float* p0;                                                       // this thread's first row of tile 0
+  int mg, c4, ld;
+  bool on;
+  // src: the matrix (row stride ld_ floats) with the head's first channel already applied
+  __device__ __forceinline__ SplitTile(const float* __restrict__ src, int ld_) {
+    const int tid = threadIdx.x;
+    mg = (tid >> 2) & 7; c4 = (tid & 3) + 4 * (tid >> 5); on = tid < 64 * DT; ld = ld_;
+    p0 = src + (size_t)(4 * mg) * ld + 4 * c4;
+  }
+  // rows [row0, row0+32), zero fill beyond rows_total
+  __device__ __forceinline__ void request(int row0, int rows_total) {
+    const float* p = p0 + (size_t)row0 * ld;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v[i] = (on && row0 + 4 * mg + i < rows_total) ? *reinterpret_cast<const float4*>(p + i * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ void stage(unsigned* __restrict__ base) const {
+    if (!on) return;
+    unsigned* Rh = base; unsigned* Rl = Rh + kRow;
+    const float e[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
+                           {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned h0, l0, h1, l1;
+      split_pair(e[i][0], e[i][1], h0, l0);
+      split_pair(e[i][2], e[i][3], h1, l1);
+      *reinterpret_cast<uint2*>(Rh + (4 * mg + i) * PR + 2 * c4) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(Rl + (4 * mg + i) * PR + 2 * c4) = make_uint2(l0, l1);
+    }
+    if (TR) {
+      unsigned* Th = Rl + kRow; unsigned* Tl = Th + kCol;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned h0, l0, h1, l1;
+        split_pair(e[0][j], e[1][j], h0, l0);
+        split_pair(e[2][j], e[3][j], h1, l1);
+        *reinterpret_cast<uint2*>(Th + (4 * c4 + j) * PT + 2 * mg) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(Tl + (4 * c4 + j) * PT + 2 * mg) = make_uint2(l0, l1);
+      }
+    }
+  }
+  // A operand, rows = the tile's rows, contraction = channels [16 ks, 16 ks + 16)
+  static __device__ __forceinline__ void row_frag(const unsigned* __restrict__ base, int ks, int jl, int hh, u32x4v& hi, u32x4v& lo) {
+    hi = *reinterpret_cast<const u32x4v*>(base + jl * PR + 8 * ks + 4 * hh);
+    lo = *reinterpret_cast<const u32x4v*>(base + kRow + jl * PR + 8 * ks + 4 * hh);
+  }
+  // operand whose contraction runs over the tile's rows in accumulator order: slot (hh, j) of step s <-> row rho(8 s + j, hh),
+  // i.e. the 4-row runs 16 s + 4 hh .. +3 and 16 s + 8 + 4 hh .. +3; lane = channel 32 ct + jl
+  static __device__ __forceinline__ void col_frag(const unsigned* __restrict__ base, int ct, int s, int jl, int hh, u32x4v& hi, u32x4v& lo) {
+    const unsigned* Th = base + 2 * kRow + (32 * ct + jl) * PT + 8 * s + 2 * hh;
+    const uint2 a = *reinterpret_cast<const uint2*>(Th), b = *reinterpret_cast<const uint2*>(Th + 4);
+    const uint2 c = *reinterpret_cast<const uint2*>(Th + kCol), d = *reinterpret_cast<const uint2*>(Th + kCol + 4);
+    hi = (u32x4v){a.x, a.y, b.x, b.y};
+    lo = (u32x4v){c.x, c.y, d.x, d.y};
+  }
+};
+
+// The workgroup's own 128 rows (wave w: rows row0 + 32 w .. +31) as B-operand fragments over the channels -- lane (jl, hh) holds
+// channels 16 ks + 8 hh .. +7 of row 32 w + jl for every step ks.  Through LDS: the rows are read as 64-byte lane-quad segments
+// and split once (a direct per-lane read is 64 separate 16-byte L1 lookups per instruction); `scratch` holds 4 row-major tiles.
+template <int DT>
+__device__ __forceinline__ void own_rows(const float* __restrict__ src, int ld, int row0, int rows_total, unsigned* __restrict__ scratch,
+                                         u32x4v (&hi)[2 * DT], u32x4v (&lo)[2 * DT]) {
+  using SR = SplitTile<DT, false>;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, jl = lane & 31, hh = lane >> 5;
+  SR t0(src, ld), t1(src, ld), t2(src, ld), t3(src, ld);              // all 16 float4 of the thread in flight together
+  t0.request(row0, rows_total); t1.request(row0 + 32, rows_total); t2.request(row0 + 64, rows_total); t3.request(row0 + 96, rows_total);
+  t0.stage(scratch); t1.stage(scratch + SR::kDwords); t2.stage(scratch + 2 * SR::kDwords); t3.stage(scratch + 3 * SR::kDwords);
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 2 * DT; ++ks) SR::row_frag(scratch + wv * SR::kDwords, ks, jl, hh, hi[ks], lo[ks]);
+  __syncthreads();
+}
+
+// (A) dK, dV.  grid = B * H * ceil(Tk / 128); wave w owns keys kb + 32 w .. +31.
+template <int DT, bool DROP>
+__global__ __launch_bounds__(256) void mha_bwd_split_dkv_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
+    const float* __restrict__ LSE, const float* __restrict__ delta, float* __restrict__ dK, float* __restrict__ dV,
+    int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
+  drop_resolve(dc);
+#ifdef TSG_K2_TIMING
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm0 = __builtin_amdgcn_s_memtime(), tm1 = 0;
+#define K2_TICK(i) { tm1 = __builtin_amdgcn_s_memtime(); tph[i] += tm1 - tm0; tm0 = tm1; }
+#else
+#define K2_TICK(i) {}
+#endif
+  using ST = SplitTile<DT, true>;
+  extern __shared__ __align__(16) unsigned lds_u[];                      // [2 buffers][Q tile | dO tile] + lse / delta rows
+  constexpr int kBuf = 2 * ST::kDwords;
+  float* rows = reinterpret_cast<float*>(lds_u + 2 * kBuf);              // [2][2][32]: lse, delta of the tile's queries
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hh = lane >> 5;
+  const int kblocks = (Tk + 127) / 128;
+  const int b = blockIdx.x / (H * kblocks), hd = (blockIdx.x / kblocks) % H, kb = (blockIdx.x % kblocks) * 128;
+  const float* Qb = Q + (size_t)b * Tq * dk + hd * 32 * DT;
+  const float* Gb = dO + (size_t)b * Tq * dk + hd * 32 * DT;
+  const float* lse = LSE + ((size_t)b * H + hd) * Tq;
+  const float* dlt = delta + ((size_t)b * H + hd) * Tq;
+  const int key = kb + 32 * wv + jl;                                     // this lane's key (the S / dP column)
+
+  ST tq(Qb, dk), tg(Gb, dk);
+  float lse_n = 0.f, dl_n = 0.f;
+  auto request = [&](int q0) {
+    tq.request(q0, Tq); tg.request(q0, Tq);
+    if (tid < 32) { lse_n = q0 + tid < Tq ? lse[q0 + tid] : 0.f; dl_n = q0 + tid < Tq ? dlt[q0 + tid] : 0.f; }
+  };
+  auto stage = [&](int buf) {
+    tq.stage(lds_u + buf * kBuf); tg.stage(lds_u + buf * kBuf + ST::kDwords);
+    if (tid < 32) { rows[(buf * 2 + 0) * 32 + tid] = lse_n; rows[(buf * 2 + 1) * 32 + tid] = dl_n; }
+  };
+  request(0);                                                            // in flight together with the workgroup's own K / V rows
+  u32x4v kh[2 * DT], kl[2 * DT], vh[2 * DT], vl[2 * DT];
+  own_rows<DT>(K + (size_t)b * Tk * dk + hd * 32 * DT, dk, kb, Tk, lds_u, kh, kl);
+  own_rows<DT>(V + (size_t)b * Tk * dk + hd * 32 * DT, dk, kb, Tk, lds_u, vh, vl);
+  f32x16 dkt[DT], dvt[DT];
+#pragma unroll
+  for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[ct][r] = 0.f; dvt[ct][r] = 0.f; }
+  stage(0);
+  __syncthreads();
+  K2_TICK(0)
+  const int ntiles = (Tq + 31) / 32;
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1, q0 = 32 * t;
+    request(min(q0 + 32, 32 * (ntiles - 1)));                            // the last iteration re-requests its own tile (unused)
+    K2_TICK(1)
+    const unsigned* Qt = lds_u + buf * kBuf; const unsigned* Gt = Qt + ST::kDwords;
+    // S = Q K^T, dP = dO V^T over the head's channels: rows = the tile's queries, columns = this wave's keys
+    f32x16 sp, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sp[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 2 * DT; ++ks) {
+      u32x4v ah, al;
+      ST::row_frag(Qt, ks, jl, hh, ah, al);
+      sp = mfma3(ah, al, kh[ks], kl[ks], sp);
+      ST::row_frag(Gt, ks, jl, hh, ah, al);
+      dp = mfma3(ah, al, vh[ks], vl[ks], dp);
+    }
+    K2_TICK(2)
+    // P (dropout-scaled) and dS in the accumulator layout: register r <-> query rho(r, hh)
+    float pm[16], ds[16], lsev[16], dlv[16];
+    const float* lsel = rows + (buf * 2 + 0) * 32; const float* dl = rows + (buf * 2 + 1) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                        // rho(4 i + j, hh) = 8 i + 4 hh + j: four b128 reads each, one wait
+      const float4 a = *reinterpret_cast<const float4*>(lsel + 8 * i + 4 * hh), c = *reinterpret_cast<const float4*>(dl + 8 * i + 4 * hh);
+      lsev[4 * i] = a.x; lsev[4 * i + 1] = a.y; lsev[4 * i + 2] = a.z; lsev[4 * i + 3] = a.w;
+      dlv[4 * i] = c.x; dlv[4 * i + 1] = c.y; dlv[4 * i + 2] = c.z; dlv[4 * i + 3] = c.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = q0 + rho(r, hh);
+      float sv = sp[r];
+      if (causal && key > q) sv -= 1e10f;
+      sv *= inv_scale;
+      const float p = (key < Tk && q < Tq) ? __expf(sv - lsev[r]) : 0.f;
+      const float mk = DROP ? drop_scale(dc, b, H, hd, Tq, q, Tk, key) : 1.f;
+      pm[r] = p * mk;
+      ds[r] = p * (dp[r] * mk - dlv[r]) * inv_scale;
+    }
+    K2_TICK(3)
+    // dV[key][c] += sum_q P[q][key] dO[q][c];  dK[key][c] += sum_q dS[q][key] Q[q][c]   (A = the registers above, B = transposed planes)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4v ph, pl, sh, sl;
+      const float pa[8] = {pm[8 * s], pm[8 * s + 1], pm[8 * s + 2], pm[8 * s + 3], pm[8 * s + 4], pm[8 * s + 5], pm[8 * s + 6], pm[8 * s + 7]};
+      const float sa[8] = {ds[8 * s], ds[8 * s + 1], ds[8 * s + 2], ds[8 * s + 3], ds[8 * s + 4], ds[8 * s + 5], ds[8 * s + 6], ds[8 * s + 7]};
+      split8(pa, ph, pl);
+      split8(sa, sh, sl);
+#pragma unroll
+      for (int ct = 0; ct < DT; ++ct) {
+        u32x4v bh, bl;
+        ST::col_frag(Gt, ct, s, jl, hh, bh, bl);
+        dvt[ct] = mfma3(ph, pl, bh, bl, dvt[ct]);
+        ST::col_frag(Qt, ct, s, jl, hh, bh, bl);
+        dkt[ct] = mfma3(sh, sl, bh, bl, dkt[ct]);
+      }
+    }
+    K2_TICK(4)
+    stage(buf ^ 1);
+    K2_TICK(5)
+    __syncthreads();
+    K2_TICK(6)
+  }
+  // accumulators: rows = keys rho(r, hh) of this wave, column = channel 32 ct + jl: 128-byte row segments
+  float* dKb = dK + (size_t)b * Tk * dk + hd * 32 * DT;
+  float* dVb = dV + (size_t)b * Tk * dk + hd * 32 * DT;
+#pragma unroll
+  for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = kb + 32 * wv + rho(r, hh);
+      if (k < Tk) {
+        dKb[(size_t)k * dk + 32 * ct + jl] = dkt[ct][r];
+        dVb[(size_t)k * dk + 32 * ct + jl] = dvt[ct][r];
+      }
+    }
+#ifdef TSG_K2_TIMING
+  K2_TICK(7)
+  __syncthreads();
+  if (blockIdx.x == 0 && lane == 0)
+    for (int i = 0; i < 8; ++i) dK[wv * 8 + i] = (float)tph[i];
+#endif
+}
+
+// (B) dQ.  grid = B * H * ceil(Tq / 128); wave w owns queries qb + 32 w .. +31.
+template <int DT, bool DROP>
+__global__ __launch_bounds__(256) void mha_bwd_split_dq_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
+    const float* __restrict__ LSE, const float* __restrict__ delta, float* __restrict__ dQ,
+    int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
+  drop_resolve(dc);
+  using SK = SplitTile<DT, true>;                                        // K tile: row-major + transposed planes
+  using SV = SplitTile<DT, false>;                                       // V tile: row-major planes only
+  extern __shared__ __align__(16) unsigned lds_u[];
+  constexpr int kBuf = SK::kDwords + SV::kDwords;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hh = lane >> 5;
+  const int qblocks = (Tq + 127) / 128;
+  const int b = blockIdx.x / (H * qblocks), hd = (blockIdx.x / qblocks) % H, qb = (blockIdx.x % qblocks) * 128;
+  const float* Kb = K + (size_t)b * Tk * dk + hd * 32 * DT;
+  const float* Vb = V + (size_t)b * Tk * dk + hd * 32 * DT;
+  const int q = qb + 32 * wv + jl;                                       // this lane's query (the S^T / dP^T column)
+  const float lse_q = q < Tq ? LSE[((size_t)b * H + hd) * Tq + q] : 0.f;
+  const float dl_q = q < Tq ? delta[((size_t)b * H + hd) * Tq + q] : 0.f;
+
+  SK tk(Kb, dk); SV tv(Vb, dk);
+  auto request = [&](int k0) { tk.request(k0, Tk); tv.request(k0, Tk); };
+  auto stage = [&](int buf) { tk.stage(lds_u + buf * kBuf); tv.stage(lds_u + buf * kBuf + SK::kDwords); };
+  request(0);
+  u32x4v qh[2 * DT], ql[2 * DT], gh[2 * DT], gl[2 * DT];
+  own_rows<DT>(Q + (size_t)b * Tq * dk + hd * 32 * DT, dk, qb, Tq, lds_u, qh, ql);
+  own_rows<DT>(dO + (size_t)b * Tq * dk + hd * 32 * DT, dk, qb, Tq, lds_u, gh, gl);
+  f32x16 dqt[DT];
+#pragma unroll
+  for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqt[ct][r] = 0.f;
+  stage(0);
+  __syncthreads();
+  const int ntiles = (Tk + 31) / 32;
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1, k0 = 32 * t;
+    request(min(k0 + 32, 32 * (ntiles - 1)));
+    const unsigned* Kt = lds_u + buf * kBuf; const unsigned* Vt = Kt + SK::kDwords;
+    // S^T = K Q^T, dP^T = V dO^T: rows = the tile's keys, columns = this wave's queries
+    f32x16 sp, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sp[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 2 * DT; ++ks) {
+      u32x4v ah, al;
+      SK::row_frag(Kt, ks, jl, hh, ah, al);
+      sp = mfma3(ah, al, qh[ks], ql[ks], sp);
+      SV::row_frag(Vt, ks, jl, hh, ah, al);
+      dp = mfma3(ah, al, gh[ks], gl[ks], dp);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + rho(r, hh);
+      float sv = sp[r];
+      if (causal && key > q) sv -= 1e10f;
+      sv *= inv_scale;
+      const float p = (key < Tk && q < Tq) ? __expf(sv - lse_q) : 0.f;
+      const float mk = DROP ? drop_scale(dc, b, H, hd, Tq, q, Tk, key) : 1.f;
+      ds[r] = p * (dp[r] * mk - dl_q) * inv_scale;
+    }
+    // dQ^T[c][q] += sum_key K^T[c][key] dS^T[key][q]   (A = transposed K planes, B = the registers above)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4v sh, sl;
+      const float sa[8] = {ds[8 * s], ds[8 * s + 1], ds[8 * s + 2], ds[8 * s + 3], ds[8 * s + 4], ds[8 * s + 5], ds[8 * s + 6], ds[8 * s + 7]};
+      split8(sa, sh, sl);
+#pragma unroll
+      for (int ct = 0; ct < DT; ++ct) {
+        u32x4v ah, al;
+        SK::col_frag(Kt, ct, s, jl, hh, ah, al);
+        dqt[ct] = mfma3(ah, al, sh, sl, dqt[ct]);
+      }
+    }
+    stage(buf ^ 1);
+    __syncthreads();
+  }
+  // dQ^T accumulators (rows = channels 32 ct + rho(r, hh), column = this lane's query) -> the wave's [32][dh] block in LDS -> rows out
+  constexpr int OP = 32 * DT + 4;                                        // floats per query row
+  float* Ol = reinterpret_cast<float*>(lds_u) + wv * 32 * OP;
+#pragma unroll
+  for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ol[jl * OP + 32 * ct + rho(r, hh)] = dqt[ct][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                 // the block is private to this wave
+  __builtin_amdgcn_wave_barrier();
+  float* dQb = dQ + (size_t)b * Tq * dk + hd * 32 * DT;
+  for (int idx = lane; idx < 32 * 8 * DT; idx += 64) {
+    const int r = idx / (8 * DT), c = (idx % (8 * DT)) * 4;
+    const int qq = qb + 32 * wv + r;
+    if (qq < Tq) *reinterpret_cast<float4*>(dQb + (size_t)qq * dk + c) = *reinterpret_cast<const float4*>(Ol + r * OP + c);
+  }
+}
+
+template <int DT, bool DROP>
+int launch_bwd_split(const char* fn, const float* Q, const float* K, const float* V, const float* dO, const float* lse,
+                     const float* delta, float* dQ, float* dK, float* dV, int B, int Tq, int Tk, int dk, int H, float inv_scale,
+                     int causal, const DropCfg& dc, hipStream_t st) {
+  using ST = SplitTile<DT, true>;
+  using SV = SplitTile<DT, false>;
+  const size_t lds_a = sizeof(unsigned) * (size_t)(2 * 2 * ST::kDwords) + sizeof(float) * 128;
+  size_t lds_b = sizeof(unsigned) * (size_t)(2 * (ST::kDwords + SV::kDwords));
+  const size_t out_b = sizeof(float) * 4 * 32 * (32 * DT + 4);
+  if (out_b > lds_b) lds_b = out_b;
+  auto ka = mha_bwd_split_dkv_kernel<DT, DROP>;
+  auto kq = mha_bwd_split_dq_kernel<DT, DROP>;
+  hipError_t e = allow_lds(ka, lds_a);
+  if (e == hipSuccess) e = allow_lds(kq, lds_b);
+  if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+  hipLaunchKernelGGL(ka, dim3(B * H * cdiv(Tk, 128)), dim3(256), lds_a, st, Q, K, V, dO, lse, delta, dK, dV, B, Tq, Tk, dk, H, inv_scale, causal, dc);
+  int rc = check_launch(fn);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kq, dim3(B * H * cdiv(Tq, 128)), dim3(256), lds_b, st, Q, K, V, dO, lse, delta, dQ, B, Tq, Tk, dk, H, inv_scale, causal, dc);
+  return check_launch(fn);
+}
+
 int check(const char* fn, int B, int Tq, int Tk, int dk, int dv, int H, int dtype) {
-  if (dtype != TSG_F32) return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (fp32 only)", fn, dtype);
+  if (dtype != TSG_F32 && dtype != TSG_F32S) return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32 or TSG_F32S)", fn, dtype);
   if (B <= 0 || Tq <= 0 || Tk <= 0 || dk <= 0 || dv <= 0 || H <= 0)
     return set_error(TSG_E_SHAPE, "%s: non-positive dimension B=%d Tq=%d Tk=%d dk=%d dv=%d heads=%d", fn, B, Tq, Tk, dk, dv, H);
   if (dk % H || dv % H) return set_error(TSG_E_SHAPE, "%s: d_key=%d / d_value=%d not divisible by n_heads=%d", fn, dk, dv, H);
@@ -1173,6 +1554,30 @@ static int mha_bwd_impl(const void* Q, const void* K, const void* V, const void*
   rc = make_drop(fn, p_drop, seed, offset, rng_dev, &dc);
   if (rc) return rc;
   const int dh = d_key / n_heads, dvh = d_value / n_heads;
+  static int split_on = -1;                                         // TSG_MHA_SPLIT=0: exact-fp32 kernels also for TSG_F32S (A/B)
+  if (split_on < 0) { const char* e = getenv("TSG_MHA_SPLIT"); split_on = e ? atoi(e) : 1; }
+  // split-precision path; not for a single short key tile (Tk = 20 cross attention: 89 vs 85 us, three of four waves hold no keys)
+  if (dtype == TSG_F32S && split_on && delta_ws && dh == dvh && dh % 32 == 0 && dh <= 128 && Tk > 32) {
+    auto st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mha_bwd_delta_kernel, dim3(cdiv(B * Tq, 4)), dim3(256), 0, st, (const float*)O, (const float*)dO,
+                       (float*)delta_ws, B, Tq, d_value, n_heads);
+    rc = check_launch(fn);
+    if (rc) return rc;
+    const float* q = (const float*)Q; const float* k = (const float*)K; const float* v = (const float*)V; const float* g = (const float*)dO;
+    const float* l = (const float*)lse; const float* dl = (const float*)delta_ws;
+    float* dq = (float*)dQ; float* dk_ = (float*)dK; float* dv_ = (float*)dV;
+    const float is = 1.f / scale;
+#define TSG_SPLIT_CASE(DT) \
+    return dc.thresh ? launch_bwd_split<DT, true>(fn, q, k, v, g, l, dl, dq, dk_, dv_, B, Tq, Tk, d_key, n_heads, is, causal, dc, st) \
+                     : launch_bwd_split<DT, false>(fn, q, k, v, g, l, dl, dq, dk_, dv_, B, Tq, Tk, d_key, n_heads, is, causal, dc, st)
+    switch (dh / 32) {
+      case 1: TSG_SPLIT_CASE(1);
+      case 2: TSG_SPLIT_CASE(2);
+      case 3: TSG_SPLIT_CASE(3);
+      default: TSG_SPLIT_CASE(4);
+    }
+#undef TSG_SPLIT_CASE
+  }
   if (delta_ws && dh <= DHMAX && dvh <= DHMAX) {                    // MFMA path
     auto st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(mha_bwd_delta_kernel, dim3(cdiv(B * Tq, 4)), dim3(256), 0, st, (const float*)O, (const float*)dO,

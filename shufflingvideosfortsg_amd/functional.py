@@ -416,6 +416,9 @@ class _MHA(torch.autograd.Function):
         ctx.cfg = (int(n_heads), float(scale), int(bool(causal)))
         ctx.drop = (float(p_drop), int(seed), int(offset))          # the backward regenerates the same mask
         ctx.has_rng = rng is not None
+        # in the split-precision GEMM mode the backward's five products run on the bf16 MFMA as hi/lo products as well
+        # (TSG_F32S: include/tsg_hip.h, K2); the forward (and its lse) stays exact fp32
+        ctx.bwd_dtype = TSG_F32S if _GEMM_DTYPE == "f32s" else TSG_F32
         ctx.set_materialize_grads(False)                            # no zero tensors for the non-differentiable maps' grads
         if want_maps:
             ctx.mark_non_differentiable(A, S)
@@ -437,9 +440,9 @@ class _MHA(torch.autograd.Function):
         head = (ptr(Q), ptr(K), ptr(V), ptr(O), ptr(dO), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(delta), B, Tq, Tk, dk, dv, n_heads, scale,
                 causal, p_drop)
         if rng is not None:
-            _call("tsg_mha_bwd_rng", Q, *head, ptr(rng), TSG_F32)
+            _call("tsg_mha_bwd_rng", Q, *head, ptr(rng), ctx.bwd_dtype)
         else:
-            _call("tsg_mha_bwd", Q, *head, seed, offset, TSG_F32)
+            _call("tsg_mha_bwd", Q, *head, seed, offset, ctx.bwd_dtype)
         return dQ, dK, dV, None, None, None, None, None, None, None, None
 
 

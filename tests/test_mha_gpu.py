@@ -178,3 +178,51 @@ def test_attention_dropout_under_graph_capture():
     assert not torch.equal(res[0], res[1]) and not torch.equal(res[1], res[2]), "replays repeated the dropout mask"
     zeros = (res[0] == 0).float().mean().item()
     assert zeros < 0.05                                        # dropout acts on the softmax, not on the output elements
+
+
+@pytest.mark.parametrize("B,Tq,Tk,d,h,causal,p", [
+    (2, 128, 128, 1024, 8, False, 0.0),   # temporal self-attention at the north-star width: head width 128
+    (2, 128, 20, 1024, 8, False, 0.0),    # cross attention, Tk = 20 (one ragged key tile)
+    (1, 70, 70, 256, 2, True, 0.0),       # ragged tiles, causal
+    (2, 33, 45, 256, 8, False, 0.0),      # head width 32
+    (1, 300, 257, 192, 2, False, 0.0),    # head width 96, several 128-row blocks, ragged
+    (2, 64, 64, 512, 8, False, 0.3),      # head width 64, attention dropout (mask regenerated from the counters)
+    (1, 512, 512, 1024, 8, True, 0.1),    # config-4 length, causal + dropout
+])
+def test_mha_split_precision_backward(B, Tq, Tk, d, h, causal, p):
+    """dtype TSG_F32S (the 'f32s' GEMM mode): the backward's products as bf16 hi/lo products on the MFMA, two kernels.  Same
+    gradients as the exact-fp32 kernels to fp32-GEMM-level error, and -- without dropout -- as float64 autograd of the formula."""
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(Tq + Tk)
+    Q, K, V = (torch.randn(B, n, d, generator=g).cuda() for n in (Tq, Tk, Tk))
+    gO = torch.randn(B, Tq, d, generator=g).cuda()
+
+    def grads(mode):
+        F.set_gemm_dtype(mode)
+        try:
+            q, k, v = (t.clone().requires_grad_(True) for t in (Q, K, V))
+            torch.manual_seed(5)                                 # the same dropout (seed, offset) in both runs
+            o = F.mha(q, k, v, h, math.sqrt(d), causal, p_drop=p)
+            o.backward(gO)
+            return o.detach(), [t.grad for t in (q, k, v)]
+        finally:
+            F.set_gemm_dtype(None)
+
+    o_s, g_s = grads("f32s")
+    o_e, g_e = grads(None)
+    assert torch.equal(o_s, o_e)                                 # the forward is the exact-fp32 kernel in both modes
+    for a, b_, name in zip(g_s, g_e, "QKV"):
+        scale = float(b_.abs().max())
+        torch.testing.assert_close(a, b_, atol=2e-5 * scale + 1e-7, rtol=1e-4, msg=lambda m, n=name: f"d{n} vs fp32 kernels: {m}")
+    if p == 0.0:
+        q, k, v = (t.double().requires_grad_(True) for t in (Q, K, V))
+        dh = d // h
+        qh, kh, vh = (t.view(B, -1, h, dh).transpose(1, 2) for t in (q, k, v))
+        a = qh @ kh.transpose(-1, -2)
+        if causal:
+            a = a - 1e10 * torch.triu(torch.ones(Tk, Tk, device="cuda", dtype=torch.float64), 1)
+        o = (torch.softmax(a / math.sqrt(d), -1) @ vh).transpose(1, 2).reshape(B, Tq, d)
+        o.backward(gO.double())
+        for a_, t, name in zip(g_s, (q, k, v), "QKV"):
+            scale = float(t.grad.abs().max())
+            assert float((a_.double() - t.grad).abs().max()) < 2e-5 * scale + 1e-7, name
