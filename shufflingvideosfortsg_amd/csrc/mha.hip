@@ -1113,11 +1113,12 @@ __device__ __forceinline__ f32x16 mfma3(u32x4v ah, u32x4v al, u32x4v bh, u32x4v 
 // b128 fragment reads of 16 lanes hit 16 distinct bank quads for DT = 1..4) and, when TR, transposed planes T (pitch 20 dwords
 // per channel: 32 rows + 4).  256 threads: lane bits [1:0] = channel quad inside a 64-byte segment, [4:2] = group of 4 rows,
 // the rest = further segments -- 64-byte global reads per lane quad and conflict-free transposing writes (csrc/wgrad_split.hip).
-template <int DT, bool TR>
+template <int DT, bool TR, bool ROW = true>
 struct SplitTile {
   static constexpr int PR = 16 * DT + 4, PT = 20;
   static constexpr int kRow = 32 * PR, kCol = 32 * DT * PT;                 // dwords per plane
-  static constexpr int kDwords = 2 * kRow + (TR ? 2 * kCol : 0);            // [R hi][R lo][T hi][T lo]
+  static constexpr int kT0 = ROW ? 2 * kRow : 0;                            // first dword of the transposed planes
+  static constexpr int kDwords = kT0 + (TR ? 2 * kCol : 0);                 // [R hi][R lo][T hi][T lo]
   float4 v[4];
   const float* p0;                                                       // this thread's first row of tile 0
   int mg, c4, ld;
@@ -1137,19 +1138,21 @@ struct SplitTile {
   }
   __device__ __forceinline__ void stage(unsigned* __restrict__ base) const {
     if (!on) return;
-    unsigned* Rh = base; unsigned* Rl = Rh + kRow;
     const float e[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
                            {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
+    if (ROW) {
+      unsigned* Rh = base; unsigned* Rl = Rh + kRow;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      unsigned h0, l0, h1, l1;
-      split_pair(e[i][0], e[i][1], h0, l0);
-      split_pair(e[i][2], e[i][3], h1, l1);
-      *reinterpret_cast<uint2*>(Rh + (4 * mg + i) * PR + 2 * c4) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(Rl + (4 * mg + i) * PR + 2 * c4) = make_uint2(l0, l1);
+      for (int i = 0; i < 4; ++i) {
+        unsigned h0, l0, h1, l1;
+        split_pair(e[i][0], e[i][1], h0, l0);
+        split_pair(e[i][2], e[i][3], h1, l1);
+        *reinterpret_cast<uint2*>(Rh + (4 * mg + i) * PR + 2 * c4) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(Rl + (4 * mg + i) * PR + 2 * c4) = make_uint2(l0, l1);
+      }
     }
     if (TR) {
-      unsigned* Th = Rl + kRow; unsigned* Tl = Th + kCol;
+      unsigned* Th = base + kT0; unsigned* Tl = Th + kCol;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         unsigned h0, l0, h1, l1;
@@ -1168,7 +1171,7 @@ struct SplitTile {
   // operand whose contraction runs over the tile's rows in accumulator order: slot (hh, j) of step s <-> row rho(8 s + j, hh),
   // i.e. the 4-row runs 16 s + 4 hh .. +3 and 16 s + 8 + 4 hh .. +3; lane = channel 32 ct + jl
   static __device__ __forceinline__ void col_frag(const unsigned* __restrict__ base, int ct, int s, int jl, int hh, u32x4v& hi, u32x4v& lo) {
-    const unsigned* Th = base + 2 * kRow + (32 * ct + jl) * PT + 8 * s + 2 * hh;
+    const unsigned* Th = base + kT0 + (32 * ct + jl) * PT + 8 * s + 2 * hh;
     const uint2 a = *reinterpret_cast<const uint2*>(Th), b = *reinterpret_cast<const uint2*>(Th + 4);
     const uint2 c = *reinterpret_cast<const uint2*>(Th + kCol), d = *reinterpret_cast<const uint2*>(Th + kCol + 4);
     hi = (u32x4v){a.x, a.y, b.x, b.y};
@@ -1420,6 +1423,128 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dq_kernel(
   }
 }
 
+// Forward in split precision (dtype TSG_F32S, no A_forward side outputs; same shapes as the backward): the dQ kernel's structure with
+// an online softmax.  Workgroup = (b, head, 128 queries), wave = 32 queries held as B-operand fragments; per 32-key tile
+// S^T = K Q^T (rows = keys in the accumulator registers, column = the lane's query), running max / sum per query (16 registers
+// + one exchange with lane ^ 32, which holds the other 16 keys of the same query), O^T[c][q] += V^T[c][key] P^T[key][q] with the
+// P^T registers as the B operand and the transposed V planes as A.  O leaves through LDS as whole rows.
+template <int DT, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mha_fwd_split_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, float* __restrict__ O,
+    float* __restrict__ LSE, int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
+  drop_resolve(dc);
+  using SK = SplitTile<DT, false>;                                       // K tile: row-major planes
+  using SV = SplitTile<DT, true, false>;                                 // V tile: transposed planes only
+  extern __shared__ __align__(16) unsigned lds_u[];
+  constexpr int kBuf = SK::kDwords + SV::kDwords;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hh = lane >> 5;
+  const int qblocks = (Tq + 127) / 128;
+  const int b = blockIdx.x / (H * qblocks), hd = (blockIdx.x / qblocks) % H, qb = (blockIdx.x % qblocks) * 128;
+  const int q = qb + 32 * wv + jl;
+  SK tk(K + (size_t)b * Tk * dk + hd * 32 * DT, dk); SV tv(V + (size_t)b * Tk * dk + hd * 32 * DT, dk);
+  auto request = [&](int k0) { tk.request(k0, Tk); tv.request(k0, Tk); };
+  auto stage = [&](int buf) { tk.stage(lds_u + buf * kBuf); tv.stage(lds_u + buf * kBuf + SK::kDwords); };
+  request(0);
+  u32x4v qh[2 * DT], ql[2 * DT];
+  own_rows<DT>(Q + (size_t)b * Tq * dk + hd * 32 * DT, dk, qb, Tq, lds_u, qh, ql);
+  f32x16 ot[DT];
+#pragma unroll
+  for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[ct][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;                                  // l_run: this lane's 16 keys per tile only (pair-summed at the end)
+  stage(0);
+  __syncthreads();
+  const int ntiles = (Tk + 31) / 32;
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1, k0 = 32 * t;
+    request(min(k0 + 32, 32 * (ntiles - 1)));
+    const unsigned* Kt = lds_u + buf * kBuf; const unsigned* Vt = Kt + SK::kDwords;
+    f32x16 sp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sp[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2 * DT; ++ks) {
+      u32x4v ah, al;
+      SK::row_frag(Kt, ks, jl, hh, ah, al);
+      sp = mfma3(ah, al, qh[ks], ql[ks], sp);
+    }
+    float sv[16], mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + rho(r, hh);
+      float x = sp[r];
+      if (causal && key > q) x -= 1e10f;
+      x = key < Tk ? x * inv_scale : -INFINITY;
+      sv[r] = x;
+      mx = fmaxf(mx, x);
+    }
+    mx = xhalf_max(mx);                                                  // both lanes of a query agree on the tile maximum
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);                           // 0 on the first tile (m_run = -inf, m_new finite: key k0 is valid)
+    m_run = m_new;
+    float pm[16], ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(sv[r] - m_new);
+      ls += p;
+      pm[r] = DROP ? p * drop_scale(dc, b, H, hd, Tq, q, Tk, k0 + rho(r, hh)) : p;
+    }
+    l_run = l_run * alpha + ls;
+#pragma unroll
+    for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[ct][r] *= alpha;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4v ph, pl;
+      const float pa[8] = {pm[8 * s], pm[8 * s + 1], pm[8 * s + 2], pm[8 * s + 3], pm[8 * s + 4], pm[8 * s + 5], pm[8 * s + 6], pm[8 * s + 7]};
+      split8(pa, ph, pl);
+#pragma unroll
+      for (int ct = 0; ct < DT; ++ct) {
+        u32x4v ah, al;
+        SV::col_frag(Vt, ct, s, jl, hh, ah, al);
+        ot[ct] = mfma3(ah, al, ph, pl, ot[ct]);
+      }
+    }
+    stage(buf ^ 1);
+    __syncthreads();
+  }
+  const float l_tot = xhalf_sum(l_run);
+  const float inv_l = 1.f / l_tot;
+  if (hh == 0 && q < Tq) LSE[((size_t)b * H + hd) * Tq + q] = m_run + __logf(l_tot);
+  constexpr int OP = 32 * DT + 4;
+  float* Ol = reinterpret_cast<float*>(lds_u) + wv * 32 * OP;
+#pragma unroll
+  for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ol[jl * OP + 32 * ct + rho(r, hh)] = ot[ct][r] * inv_l;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float* Ob = O + (size_t)b * Tq * dk + hd * 32 * DT;
+  for (int idx = lane; idx < 32 * 8 * DT; idx += 64) {
+    const int r = idx / (8 * DT), c = (idx % (8 * DT)) * 4;
+    const int qq = qb + 32 * wv + r;
+    if (qq < Tq) *reinterpret_cast<float4*>(Ob + (size_t)qq * dk + c) = *reinterpret_cast<const float4*>(Ol + r * OP + c);
+  }
+}
+
+template <int DT, bool DROP>
+int launch_fwd_split(const char* fn, const float* Q, const float* K, const float* V, float* O, float* lse, int B, int Tq, int Tk, int dk,
+                     int H, float inv_scale, int causal, const DropCfg& dc, hipStream_t st) {
+  using SK = SplitTile<DT, false>;
+  using SV = SplitTile<DT, true, false>;
+  size_t lds = sizeof(unsigned) * (size_t)(2 * (SK::kDwords + SV::kDwords));
+  const size_t own = sizeof(unsigned) * (size_t)(4 * SK::kDwords), outb = sizeof(float) * 4 * 32 * (32 * DT + 4);
+  if (own > lds) lds = own;
+  if (outb > lds) lds = outb;
+  auto kf = mha_fwd_split_kernel<DT, DROP>;
+  hipError_t e = allow_lds(kf, lds);
+  if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+  hipLaunchKernelGGL(kf, dim3(B * H * cdiv(Tq, 128)), dim3(256), lds, st, Q, K, V, O, lse, B, Tq, Tk, dk, H, inv_scale, causal, dc);
+  return check_launch(fn);
+}
+
 template <int DT, bool DROP>
 int launch_bwd_split(const char* fn, const float* Q, const float* K, const float* V, const float* dO, const float* lse,
                      const float* delta, float* dQ, float* dK, float* dV, int B, int Tq, int Tk, int dk, int H, float inv_scale,
@@ -1488,6 +1613,22 @@ static int mha_fwd_impl(const void* Q, const void* K, const void* V, void* O, vo
   if (A_sum) { hipError_t e = zero_async(A_sum, map_bytes, st); if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e)); }
   if (S_sum) { hipError_t e = zero_async(S_sum, map_bytes, st); if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e)); }
   const int dh = d_key / n_heads, dvh = d_value / n_heads;
+  static int split_on = -1;                                         // TSG_MHA_SPLIT=0: exact-fp32 kernels also for TSG_F32S (A/B)
+  if (split_on < 0) { const char* e = getenv("TSG_MHA_SPLIT"); split_on = e ? atoi(e) : 1; }
+  if (dtype == TSG_F32S && split_on && !A_sum && !S_sum && dh == dvh && dh % 32 == 0 && dh <= 128 && Tk > 32) {     // split precision
+    const float* q = (const float*)Q; const float* k = (const float*)K; const float* v = (const float*)V;
+    const float is = 1.f / scale;
+#define TSG_SPLIT_CASE(DT) \
+    return dc.thresh ? launch_fwd_split<DT, true>(fn, q, k, v, (float*)O, (float*)lse, B, Tq, Tk, d_key, n_heads, is, causal, dc, st) \
+                     : launch_fwd_split<DT, false>(fn, q, k, v, (float*)O, (float*)lse, B, Tq, Tk, d_key, n_heads, is, causal, dc, st)
+    switch (dh / 32) {
+      case 1: TSG_SPLIT_CASE(1);
+      case 2: TSG_SPLIT_CASE(2);
+      case 3: TSG_SPLIT_CASE(3);
+      default: TSG_SPLIT_CASE(4);
+    }
+#undef TSG_SPLIT_CASE
+  }
   if (!A_sum && !S_sum && dh <= DHMAX && dvh <= DHMAX) {            // MFMA path
     const int KS = roundup(dh, 64) + 2, VS = roundup(dvh, 32) + 4, qblocks = cdiv(Tq, QB);
     size_t lds = sizeof(float) * (size_t)32 * (KS + VS);

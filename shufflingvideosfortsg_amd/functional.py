@@ -408,17 +408,18 @@ class _MHA(torch.autograd.Function):
         S = torch.empty(B, Tq, Tk, device=Q.device, dtype=torch.float32) if want_maps else None
         head = (ptr(Q), ptr(K), ptr(V), ptr(O), ptr(A) if want_maps else None, ptr(S) if want_maps else None, ptr(lse), B, Tq, Tk, dk, dv,
                 int(n_heads), float(scale), int(bool(causal)), float(p_drop))
+        # in the split-precision GEMM mode the attention products run on the bf16 MFMA as hi/lo products as well (TSG_F32S:
+        # include/tsg_hip.h, K2; shapes the split kernels do not cover, and the A_forward maps, run the exact kernels)
+        dt = TSG_F32S if _GEMM_DTYPE == "f32s" else TSG_F32
         if rng is not None:                                         # (seed, offset) in device memory: graph-capture safe
-            _call("tsg_mha_fwd_rng", Q, *head, ptr(rng), TSG_F32)
+            _call("tsg_mha_fwd_rng", Q, *head, ptr(rng), dt)
         else:
-            _call("tsg_mha_fwd", Q, *head, int(seed), int(offset), TSG_F32)
+            _call("tsg_mha_fwd", Q, *head, int(seed), int(offset), dt)
         ctx.save_for_backward(Q, K, V, O, lse, *([rng] if rng is not None else []))
         ctx.cfg = (int(n_heads), float(scale), int(bool(causal)))
         ctx.drop = (float(p_drop), int(seed), int(offset))          # the backward regenerates the same mask
         ctx.has_rng = rng is not None
-        # in the split-precision GEMM mode the backward's five products run on the bf16 MFMA as hi/lo products as well
-        # (TSG_F32S: include/tsg_hip.h, K2); the forward (and its lse) stays exact fp32
-        ctx.bwd_dtype = TSG_F32S if _GEMM_DTYPE == "f32s" else TSG_F32
+        ctx.bwd_dtype = dt
         ctx.set_materialize_grads(False)                            # no zero tensors for the non-differentiable maps' grads
         if want_maps:
             ctx.mark_non_differentiable(A, S)

@@ -13,6 +13,19 @@ for (B, T, Tk, d, h) in [(64, 128, 128, 1024, 8), (64, 128, 20, 1024, 8), (64, 1
     dQ, dK, dV, dlt = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V), torch.empty_like(lse)
     sc = math.sqrt(d)
     lib.tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), None, None, ptr(lse), B, T, Tk, d, d, h, sc, 0, 0.0, 0, 0, TSG_F32, st)
+    fres = []
+    for dt in (TSG_F32, TSG_F32S):
+        fn = lambda: lib.tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), None, None, ptr(lse), B, T, Tk, d, d, h, sc, 0, 0.0, 0, 0, dt, st)
+        for _ in range(3):
+            assert fn() == 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            fn()
+        e1.record(); e1.synchronize()
+        fres.append(e0.elapsed_time(e1) * 1e3 / 30)
+    fby = B * (2 * T + 2 * Tk) * d * 4
+    print(f"[{B},{T},{Tk},{d},h{h}] forward : fp32 kernels {fres[0]:7.1f} us, split-precision {fres[1]:7.1f} us = {fby / fres[1] / 1e3 / 8000:.3f} of the HBM roofline")
     res = []
     for dt in (TSG_F32, TSG_F32S):
         fn = lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d, h, sc, 0, 0.0, 0, 0, dt, st)
@@ -25,4 +38,4 @@ for (B, T, Tk, d, h) in [(64, 128, 128, 1024, 8), (64, 128, 20, 1024, 8), (64, 1
         e1.record(); e1.synchronize()
         res.append(e0.elapsed_time(e1) * 1e3 / 30)
     by = B * (4 * T + 4 * Tk) * d * 4
-    print(f"[{B},{T},{Tk},{d},h{h}]: fp32 kernels {res[0]:7.1f} us, split-precision {res[1]:7.1f} us = {by / res[1] / 1e3 / 8000:.3f} of the HBM roofline")
+    print(f"[{B},{T},{Tk},{d},h{h}] backward: fp32 kernels {res[0]:7.1f} us, split-precision {res[1]:7.1f} us = {by / res[1] / 1e3 / 8000:.3f} of the HBM roofline")
