@@ -1615,7 +1615,7 @@ static int mha_fwd_impl(const void* Q, const void* K, const void* V, void* O, vo
   const int dh = d_key / n_heads, dvh = d_value / n_heads;
   static int split_on = -1;                                         // TSG_MHA_SPLIT=0: exact-fp32 kernels also for TSG_F32S (A/B)
   if (split_on < 0) { const char* e = getenv("TSG_MHA_SPLIT"); split_on = e ? atoi(e) : 1; }
-  if (dtype == TSG_F32S && split_on && !A_sum && !S_sum && dh == dvh && dh % 32 == 0 && dh <= 128 && Tk > 32) {     // split precision
+  if (dtype == TSG_F32S && split_on && !A_sum && !S_sum && dh == dvh && dh % 32 == 0 && dh <= 128) {     // split precision
     const float* q = (const float*)Q; const float* k = (const float*)K; const float* v = (const float*)V;
     const float is = 1.f / scale;
 #define TSG_SPLIT_CASE(DT) \
