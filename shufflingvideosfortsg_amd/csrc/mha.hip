@@ -1180,20 +1180,69 @@ struct SplitTile {
 };
 
 // The workgroup's own 128 rows (wave w: rows row0 + 32 w .. +31) as B-operand fragments over the channels -- lane (jl, hh) holds
-// channels 16 ks + 8 hh .. +7 of row 32 w + jl for every step ks.  Through LDS: the rows are read as 64-byte lane-quad segments
-// and split once (a direct per-lane read is 64 separate 16-byte L1 lookups per instruction); `scratch` holds 4 row-major tiles.
+// channels 16 ks + 8 hh .. +7 of row 32 w + jl for every step ks.  Every lane reads its 32-byte pieces itself; staging the rows
+// through LDS as lane-quad segments instead (one L1 lookup per lane quad rather than per lane) measured the same (31.3 vs 31.1 us
+// forward, 121.7 vs 123.3 us backward): this phase waits for HBM, not for the L1 pipe.
 template <int DT>
-__device__ __forceinline__ void own_rows(const float* __restrict__ src, int ld, int row0, int rows_total, unsigned* __restrict__ scratch,
+__device__ __forceinline__ void own_rows(const float* __restrict__ src, int ld, int row0, int rows_total,
                                          u32x4v (&hi)[2 * DT], u32x4v (&lo)[2 * DT]) {
-  using SR = SplitTile<DT, false>;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, jl = lane & 31, hh = lane >> 5;
-  SR t0(src, ld), t1(src, ld), t2(src, ld), t3(src, ld);              // all 16 float4 of the thread in flight together
-  t0.request(row0, rows_total); t1.request(row0 + 32, rows_total); t2.request(row0 + 64, rows_total); t3.request(row0 + 96, rows_total);
-  t0.stage(scratch); t1.stage(scratch + SR::kDwords); t2.stage(scratch + 2 * SR::kDwords); t3.stage(scratch + 3 * SR::kDwords);
-  __syncthreads();
+  const int row = row0 + 32 * wv + jl;
+  float4 x[2 * DT], y[2 * DT];
 #pragma unroll
-  for (int ks = 0; ks < 2 * DT; ++ks) SR::row_frag(scratch + wv * SR::kDwords, ks, jl, hh, hi[ks], lo[ks]);
-  __syncthreads();
+  for (int ks = 0; ks < 2 * DT; ++ks) {
+    x[ks] = y[ks] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows_total) {
+      x[ks] = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 16 * ks + 8 * hh);
+      y[ks] = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 16 * ks + 8 * hh + 4);
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < 2 * DT; ++ks) {
+    const float e[8] = {x[ks].x, x[ks].y, x[ks].z, x[ks].w, y[ks].x, y[ks].y, y[ks].z, y[ks].w};
+    split8(e, hi[ks], lo[ks]);
+  }
+}
+
+// own_rows of dO that also returns this lane's part of delta[row] = <dO[row], O[row]> over the head's channels (the lane's 8-channel
+// pieces; lane ^ 32 holds the others): the delta pre-pass folded into the kernel that reads dO anyway.
+template <int DT>
+__device__ __forceinline__ float own_rows_delta(const float* __restrict__ src, const float* __restrict__ osrc, int ld, int row0, int rows_total,
+                                                u32x4v (&hi)[2 * DT], u32x4v (&lo)[2 * DT]) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, jl = lane & 31, hh = lane >> 5;
+  const int row = row0 + 32 * wv + jl;
+  float4 x[2 * DT], y[2 * DT];
+  float acc = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2 * DT; ++ks) {
+    x[ks] = y[ks] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows_total) {
+      x[ks] = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 16 * ks + 8 * hh);
+      y[ks] = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 16 * ks + 8 * hh + 4);
+      const float4 ox = *reinterpret_cast<const float4*>(osrc + (size_t)row * ld + 16 * ks + 8 * hh);
+      const float4 oy = *reinterpret_cast<const float4*>(osrc + (size_t)row * ld + 16 * ks + 8 * hh + 4);
+      acc = fmaf(x[ks].x, ox.x, fmaf(x[ks].y, ox.y, fmaf(x[ks].z, ox.z, fmaf(x[ks].w, ox.w, acc))));
+      acc = fmaf(y[ks].x, oy.x, fmaf(y[ks].y, oy.y, fmaf(y[ks].z, oy.z, fmaf(y[ks].w, oy.w, acc))));
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < 2 * DT; ++ks) {
+    const float e[8] = {x[ks].x, x[ks].y, x[ks].z, x[ks].w, y[ks].x, y[ks].y, y[ks].z, y[ks].w};
+    split8(e, hi[ks], lo[ks]);
+  }
+  return acc;
+}
+
+// Operand whose contraction runs over the wave's own 32 rows in accumulator order (slot (hh, j) of step s <-> row rho(8 s + j, hh)),
+// gathered from global memory: lane = channel c.  For a fixed j the 32 lanes of a half read 128 contiguous bytes of one row.
+__device__ __forceinline__ void gather_frag(const float* __restrict__ rows, int ld, int valid, int s, int hh, int c, u32x4v& hi, u32x4v& lo) {
+  float e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = rho(8 * s + j, hh);
+    e[j] = r < valid ? rows[(size_t)r * ld + c] : 0.f;
+  }
+  split8(e, hi, lo);
 }
 
 // (A) dK, dV.  grid = B * H * ceil(Tk / 128); wave w owns keys kb + 32 w .. +31.
@@ -1234,8 +1283,8 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dkv_kernel(
   };
   request(0);                                                            // in flight together with the workgroup's own K / V rows
   u32x4v kh[2 * DT], kl[2 * DT], vh[2 * DT], vl[2 * DT];
-  own_rows<DT>(K + (size_t)b * Tk * dk + hd * 32 * DT, dk, kb, Tk, lds_u, kh, kl);
-  own_rows<DT>(V + (size_t)b * Tk * dk + hd * 32 * DT, dk, kb, Tk, lds_u, vh, vl);
+  own_rows<DT>(K + (size_t)b * Tk * dk + hd * 32 * DT, dk, kb, Tk, kh, kl);
+  own_rows<DT>(V + (size_t)b * Tk * dk + hd * 32 * DT, dk, kb, Tk, vh, vl);
   f32x16 dkt[DT], dvt[DT];
 #pragma unroll
   for (int ct = 0; ct < DT; ++ct)
@@ -1332,7 +1381,7 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dkv_kernel(
 template <int DT, bool DROP>
 __global__ __launch_bounds__(256) void mha_bwd_split_dq_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
-    const float* __restrict__ LSE, const float* __restrict__ delta, float* __restrict__ dQ,
+    const float* __restrict__ LSE, const float* __restrict__ O, float* __restrict__ delta, float* __restrict__ dQ,
     int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
   drop_resolve(dc);
   using SK = SplitTile<DT, true>;                                        // K tile: row-major + transposed planes
@@ -1346,15 +1395,16 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dq_kernel(
   const float* Vb = V + (size_t)b * Tk * dk + hd * 32 * DT;
   const int q = qb + 32 * wv + jl;                                       // this lane's query (the S^T / dP^T column)
   const float lse_q = q < Tq ? LSE[((size_t)b * H + hd) * Tq + q] : 0.f;
-  const float dl_q = q < Tq ? delta[((size_t)b * H + hd) * Tq + q] : 0.f;
 
   SK tk(Kb, dk); SV tv(Vb, dk);
   auto request = [&](int k0) { tk.request(k0, Tk); tv.request(k0, Tk); };
   auto stage = [&](int buf) { tk.stage(lds_u + buf * kBuf); tv.stage(lds_u + buf * kBuf + SK::kDwords); };
   request(0);
   u32x4v qh[2 * DT], ql[2 * DT], gh[2 * DT], gl[2 * DT];
-  own_rows<DT>(Q + (size_t)b * Tq * dk + hd * 32 * DT, dk, qb, Tq, lds_u, qh, ql);
-  own_rows<DT>(dO + (size_t)b * Tq * dk + hd * 32 * DT, dk, qb, Tq, lds_u, gh, gl);
+  own_rows<DT>(Q + (size_t)b * Tq * dk + hd * 32 * DT, dk, qb, Tq, qh, ql);
+  // delta[q] = <dO[q], O[q]> is formed here, from the dO rows this wave reads anyway, and written for the dK/dV kernel that follows
+  const float dl_q = xhalf_sum(own_rows_delta<DT>(dO + (size_t)b * Tq * dk + hd * 32 * DT, O + (size_t)b * Tq * dk + hd * 32 * DT, dk, qb, Tq, gh, gl));
+  if (hh == 0 && q < Tq) delta[((size_t)b * H + hd) * Tq + q] = dl_q;
   f32x16 dqt[DT];
 #pragma unroll
   for (int ct = 0; ct < DT; ++ct)
@@ -1446,7 +1496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto stage = [&](int buf) { tk.stage(lds_u + buf * kBuf); tv.stage(lds_u + buf * kBuf + SK::kDwords); };
   request(0);
   u32x4v qh[2 * DT], ql[2 * DT];
-  own_rows<DT>(Q + (size_t)b * Tq * dk + hd * 32 * DT, dk, qb, Tq, lds_u, qh, ql);
+  own_rows<DT>(Q + (size_t)b * Tq * dk + hd * 32 * DT, dk, qb, Tq, qh, ql);
   f32x16 ot[DT];
 #pragma unroll
   for (int ct = 0; ct < DT; ++ct)
@@ -1535,8 +1585,7 @@ int launch_fwd_split(const char* fn, const float* Q, const float* K, const float
   using SK = SplitTile<DT, false>;
   using SV = SplitTile<DT, true, false>;
   size_t lds = sizeof(unsigned) * (size_t)(2 * (SK::kDwords + SV::kDwords));
-  const size_t own = sizeof(unsigned) * (size_t)(4 * SK::kDwords), outb = sizeof(float) * 4 * 32 * (32 * DT + 4);
-  if (own > lds) lds = own;
+  const size_t outb = sizeof(float) * 4 * 32 * (32 * DT + 4);
   if (outb > lds) lds = outb;
   auto kf = mha_fwd_split_kernel<DT, DROP>;
   hipError_t e = allow_lds(kf, lds);
@@ -1545,12 +1594,217 @@ int launch_fwd_split(const char* fn, const float* Q, const float* K, const float
   return check_launch(fn);
 }
 
+// (C) backward for ONE key tile (Tk <= 32: cross attention over the T_word <= 32 words of a query) -- one kernel, every input read
+// once from HBM.  Workgroup = (b, head, 128 queries), wave = 32 queries whose Q / dO rows are register fragments; the K / V tile is
+// staged once.  The wave forms S and dP twice, in both orientations (the matrix work is negligible: 168 MFMAs per wave):
+//   * with the queries on the lanes (S^T = K Q^T): dS^T registers are the B operand of dQ^T = K^T dS^T -> dQ through LDS;
+//   * with the keys on the lanes (S = Q K^T): P / dS registers are the A operand of the wave's PARTIAL dV = P^T dO, dK = dS^T Q over
+//     its 32 queries, whose other operand is gathered from global memory row by row (128-byte segments, no transposed staging).
+// The four waves' partial dK / dV tiles are added through LDS; with more than one query block per head they are added to the
+// (zero-filled) outputs with float atomics, with one block (Tq <= 128) they are stored.  Two workgroups per CU.
 template <int DT, bool DROP>
-int launch_bwd_split(const char* fn, const float* Q, const float* K, const float* V, const float* dO, const float* lse,
-                     const float* delta, float* dQ, float* dK, float* dV, int B, int Tq, int Tk, int dk, int H, float inv_scale,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mha_bwd_split_cross_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
+    const float* __restrict__ LSE, const float* __restrict__ O, float* __restrict__ dQ, float* __restrict__ dK,
+    float* __restrict__ dV, int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, int atomic_out, DropCfg dc) {
+  drop_resolve(dc);
+  using SK = SplitTile<DT, true>;                                        // K tile: row-major + transposed planes
+  using SV = SplitTile<DT, false>;                                       // V tile: row-major planes
+  extern __shared__ __align__(16) unsigned lds_u[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hh = lane >> 5;
+  const int qblocks = (Tq + 127) / 128;
+  const int b = blockIdx.x / (H * qblocks), hd = (blockIdx.x / qblocks) % H, qb = (blockIdx.x % qblocks) * 128;
+  const float* Qb = Q + (size_t)b * Tq * dk + hd * 32 * DT;
+  const float* Gb = dO + (size_t)b * Tq * dk + hd * 32 * DT;
+  const float* lse = LSE + ((size_t)b * H + hd) * Tq;
+  const int qw0 = qb + 32 * wv, q = qw0 + jl;                            // the wave's first query; this lane's query / key
+  const int key = jl;
+  {
+    SK tk(K + (size_t)b * Tk * dk + hd * 32 * DT, dk); SV tv(V + (size_t)b * Tk * dk + hd * 32 * DT, dk);
+    tk.request(0, Tk); tv.request(0, Tk);
+    tk.stage(lds_u); tv.stage(lds_u + SK::kDwords);
+  }
+  u32x4v qh[2 * DT], ql[2 * DT], gh[2 * DT], gl[2 * DT];
+  own_rows<DT>(Qb, dk, qb, Tq, qh, ql);
+  // delta[q] = <dO[q], O[q]> of this lane's query: the two lanes of a query hold disjoint channel pieces
+  const float dl_q = xhalf_sum(own_rows_delta<DT>(Gb, O + (size_t)b * Tq * dk + hd * 32 * DT, dk, qb, Tq, gh, gl));
+  float* dls = reinterpret_cast<float*>(lds_u + SK::kDwords + SV::kDwords);      // [128]: delta of the workgroup's queries
+  if (hh == 0) dls[32 * wv + jl] = dl_q;
+  __syncthreads();
+  const unsigned* Kt = lds_u; const unsigned* Vt = lds_u + SK::kDwords;
+
+  // ---- keys on the lanes: S = Q K^T, dP = dO V^T (rows = the wave's queries rho(r, hh)) -> P, dS packed as A operands
+  u32x4v ph[2], pl[2], sh[2], sl[2];
+  {
+    f32x16 sp, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sp[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 2 * DT; ++ks) {
+      u32x4v bh, bl;
+      SK::row_frag(Kt, ks, jl, hh, bh, bl);
+      sp = mfma3(qh[ks], ql[ks], bh, bl, sp);
+      SV::row_frag(Vt, ks, jl, hh, bh, bl);
+      dp = mfma3(gh[ks], gl[ks], bh, bl, dp);
+    }
+    float lsev[16], dlv[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 dd = *reinterpret_cast<const float4*>(dls + 32 * wv + 8 * i + 4 * hh);      // rho(4 i + j, hh) = 8 i + 4 hh + j
+      dlv[4 * i] = dd.x; dlv[4 * i + 1] = dd.y; dlv[4 * i + 2] = dd.z; dlv[4 * i + 3] = dd.w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int qq = qw0 + 8 * i + 4 * hh + j;
+        lsev[4 * i + j] = qq < Tq ? lse[qq] : 0.f;
+      }
+    }
+    float pm[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = qw0 + rho(r, hh);
+      float sv = sp[r];
+      if (causal && key > qq) sv -= 1e10f;
+      sv *= inv_scale;
+      const float p = (key < Tk && qq < Tq) ? __expf(sv - lsev[r]) : 0.f;
+      const float mk = DROP ? drop_scale(dc, b, H, hd, Tq, qq, Tk, key) : 1.f;
+      pm[r] = p * mk;
+      ds[r] = p * (dp[r] * mk - dlv[r]) * inv_scale;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float pa[8] = {pm[8 * s], pm[8 * s + 1], pm[8 * s + 2], pm[8 * s + 3], pm[8 * s + 4], pm[8 * s + 5], pm[8 * s + 6], pm[8 * s + 7]};
+      const float sa[8] = {ds[8 * s], ds[8 * s + 1], ds[8 * s + 2], ds[8 * s + 3], ds[8 * s + 4], ds[8 * s + 5], ds[8 * s + 6], ds[8 * s + 7]};
+      split8(pa, ph[s], pl[s]);
+      split8(sa, sh[s], sl[s]);
+    }
+  }
+  // ---- queries on the lanes: S^T = K Q^T, dP^T = V dO^T (rows = keys rho(r, hh)) -> dS^T -> dQ^T = K^T dS^T
+  f32x16 dqt[DT];
+  {
+    f32x16 sp, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sp[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 2 * DT; ++ks) {
+      u32x4v ah, al;
+      SK::row_frag(Kt, ks, jl, hh, ah, al);
+      sp = mfma3(ah, al, qh[ks], ql[ks], sp);
+      SV::row_frag(Vt, ks, jl, hh, ah, al);
+      dp = mfma3(ah, al, gh[ks], gl[ks], dp);
+    }
+    const float lse_q = q < Tq ? lse[q] : 0.f;
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = rho(r, hh);
+      float sv = sp[r];
+      if (causal && kk > q) sv -= 1e10f;
+      sv *= inv_scale;
+      const float p = (kk < Tk && q < Tq) ? __expf(sv - lse_q) : 0.f;
+      const float mk = DROP ? drop_scale(dc, b, H, hd, Tq, q, Tk, kk) : 1.f;
+      ds[r] = p * (dp[r] * mk - dl_q) * inv_scale;
+    }
+#pragma unroll
+    for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqt[ct][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4v th, tl;
+      const float sa[8] = {ds[8 * s], ds[8 * s + 1], ds[8 * s + 2], ds[8 * s + 3], ds[8 * s + 4], ds[8 * s + 5], ds[8 * s + 6], ds[8 * s + 7]};
+      split8(sa, th, tl);
+#pragma unroll
+      for (int ct = 0; ct < DT; ++ct) {
+        u32x4v ah, al;
+        SK::col_frag(Kt, ct, s, jl, hh, ah, al);
+        dqt[ct] = mfma3(ah, al, th, tl, dqt[ct]);
+      }
+    }
+  }
+  __syncthreads();                                                       // every wave is done with the K / V planes: the LDS is reused
+  constexpr int OP = 32 * DT + 4;                                        // floats per row of a wave's [32][dh] block
+  float* Ol = reinterpret_cast<float*>(lds_u) + wv * 32 * OP;
+  auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+  // dQ: rows = channels rho(r, hh) + 32 ct, column = this lane's query -> the wave's block -> whole rows out
+#pragma unroll
+  for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ol[jl * OP + 32 * ct + rho(r, hh)] = dqt[ct][r];
+  wave_sync();
+  float* dQb = dQ + (size_t)b * Tq * dk + hd * 32 * DT;
+  for (int idx = lane; idx < 32 * 8 * DT; idx += 64) {
+    const int r = idx / (8 * DT), c = (idx % (8 * DT)) * 4;
+    if (qw0 + r < Tq) *reinterpret_cast<float4*>(dQb + (size_t)(qw0 + r) * dk + c) = *reinterpret_cast<const float4*>(Ol + r * OP + c);
+  }
+  wave_sync();
+  // partial dV / dK of this wave's 32 queries: A = P / dS registers (row = key on the lane), B gathered from the wave's dO / Q rows;
+  // accumulator: rows = keys rho(r, hh), column = channel 32 ct + jl.  Folded over the four waves through LDS.
+  const int valid = Tq - qw0;                                            // rows of this wave that exist (may be <= 0)
+  float* dst[2] = {dV + (size_t)b * Tk * dk + hd * 32 * DT, dK + (size_t)b * Tk * dk + hd * 32 * DT};
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const float* rows = (which == 0 ? Gb : Qb) + (size_t)qw0 * dk;
+    f32x16 acc[DT];
+#pragma unroll
+    for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ct = 0; ct < DT; ++ct) {
+        u32x4v bh, bl;
+        gather_frag(rows, dk, valid, s, hh, 32 * ct + jl, bh, bl);
+        acc[ct] = which == 0 ? mfma3(ph[s], pl[s], bh, bl, acc[ct]) : mfma3(sh[s], sl[s], bh, bl, acc[ct]);
+      }
+#pragma unroll
+    for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ol[rho(r, hh) * OP + 32 * ct + jl] = acc[ct][r];
+    __syncthreads();
+    const float* all = reinterpret_cast<const float*>(lds_u);
+    for (int idx = tid; idx < 32 * 8 * DT; idx += 256) {
+      const int r = idx / (8 * DT), c = (idx % (8 * DT)) * 4;
+      if (r < Tk) {
+        float4 t = *reinterpret_cast<const float4*>(all + r * OP + c);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          const float4 u = *reinterpret_cast<const float4*>(all + (w * 32 + r) * OP + c);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        float* o = dst[which] + (size_t)r * dk + c;
+        if (atomic_out) { atomicAdd(o, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w); }
+        else *reinterpret_cast<float4*>(o) = t;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int DT, bool DROP>
+int launch_bwd_split(const char* fn, const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* lse,
+                     float* delta, float* dQ, float* dK, float* dV, int B, int Tq, int Tk, int dk, int H, float inv_scale,
                      int causal, const DropCfg& dc, hipStream_t st) {
   using ST = SplitTile<DT, true>;
   using SV = SplitTile<DT, false>;
+  if (Tk <= 32) {                                                          // one key tile: the fused kernel
+    size_t lds_c = sizeof(unsigned) * (size_t)(ST::kDwords + SV::kDwords) + sizeof(float) * 128;
+    const size_t out_c = sizeof(float) * 4 * 32 * (32 * DT + 4);
+    if (out_c > lds_c) lds_c = out_c;
+    const int qblocks = cdiv(Tq, 128);
+    auto kc = mha_bwd_split_cross_kernel<DT, DROP>;
+    hipError_t e = allow_lds(kc, lds_c);
+    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+    if (qblocks > 1) {                                                     // several query blocks add into dK / dV
+      const size_t nb = sizeof(float) * (size_t)B * Tk * dk;
+      e = zero_async(dK, nb, st);
+      if (e == hipSuccess) e = zero_async(dV, nb, st);
+      if (e != hipSuccess) return set_error((int)e, "%s: zero fill: %s", fn, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kc, dim3(B * H * qblocks), dim3(256), lds_c, st, Q, K, V, dO, lse, O, dQ, dK, dV, B, Tq, Tk, dk, H, inv_scale,
+                       causal, qblocks > 1 ? 1 : 0, dc);
+    return check_launch(fn);
+  }
   const size_t lds_a = sizeof(unsigned) * (size_t)(2 * 2 * ST::kDwords) + sizeof(float) * 128;
   size_t lds_b = sizeof(unsigned) * (size_t)(2 * (ST::kDwords + SV::kDwords));
   const size_t out_b = sizeof(float) * 4 * 32 * (32 * DT + 4);
@@ -1560,10 +1814,11 @@ int launch_bwd_split(const char* fn, const float* Q, const float* K, const float
   hipError_t e = allow_lds(ka, lds_a);
   if (e == hipSuccess) e = allow_lds(kq, lds_b);
   if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
-  hipLaunchKernelGGL(ka, dim3(B * H * cdiv(Tk, 128)), dim3(256), lds_a, st, Q, K, V, dO, lse, delta, dK, dV, B, Tq, Tk, dk, H, inv_scale, causal, dc);
+  // dQ first: it also writes delta = <dO, O>, which the dK/dV kernel reads
+  hipLaunchKernelGGL(kq, dim3(B * H * cdiv(Tq, 128)), dim3(256), lds_b, st, Q, K, V, dO, lse, O, delta, dQ, B, Tq, Tk, dk, H, inv_scale, causal, dc);
   int rc = check_launch(fn);
   if (rc) return rc;
-  hipLaunchKernelGGL(kq, dim3(B * H * cdiv(Tq, 128)), dim3(256), lds_b, st, Q, K, V, dO, lse, delta, dQ, B, Tq, Tk, dk, H, inv_scale, causal, dc);
+  hipLaunchKernelGGL(ka, dim3(B * H * cdiv(Tk, 128)), dim3(256), lds_a, st, Q, K, V, dO, lse, (const float*)delta, dK, dV, B, Tq, Tk, dk, H, inv_scale, causal, dc);
   return check_launch(fn);
 }
 
@@ -1697,20 +1952,16 @@ static int mha_bwd_impl(const void* Q, const void* K, const void* V, const void*
   const int dh = d_key / n_heads, dvh = d_value / n_heads;
   static int split_on = -1;                                         // TSG_MHA_SPLIT=0: exact-fp32 kernels also for TSG_F32S (A/B)
   if (split_on < 0) { const char* e = getenv("TSG_MHA_SPLIT"); split_on = e ? atoi(e) : 1; }
-  // split-precision path; not for a single short key tile (Tk = 20 cross attention: 89 vs 85 us, three of four waves hold no keys)
-  if (dtype == TSG_F32S && split_on && delta_ws && dh == dvh && dh % 32 == 0 && dh <= 128 && Tk > 32) {
+  // split-precision path (one key tile: the fused kernel, else the dK/dV + dQ pair)
+  if (dtype == TSG_F32S && split_on && delta_ws && dh == dvh && dh % 32 == 0 && dh <= 128) {
     auto st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(mha_bwd_delta_kernel, dim3(cdiv(B * Tq, 4)), dim3(256), 0, st, (const float*)O, (const float*)dO,
-                       (float*)delta_ws, B, Tq, d_value, n_heads);
-    rc = check_launch(fn);
-    if (rc) return rc;
     const float* q = (const float*)Q; const float* k = (const float*)K; const float* v = (const float*)V; const float* g = (const float*)dO;
-    const float* l = (const float*)lse; const float* dl = (const float*)delta_ws;
+    const float* o = (const float*)O; const float* l = (const float*)lse; float* dl = (float*)delta_ws;
     float* dq = (float*)dQ; float* dk_ = (float*)dK; float* dv_ = (float*)dV;
     const float is = 1.f / scale;
 #define TSG_SPLIT_CASE(DT) \
-    return dc.thresh ? launch_bwd_split<DT, true>(fn, q, k, v, g, l, dl, dq, dk_, dv_, B, Tq, Tk, d_key, n_heads, is, causal, dc, st) \
-                     : launch_bwd_split<DT, false>(fn, q, k, v, g, l, dl, dq, dk_, dv_, B, Tq, Tk, d_key, n_heads, is, causal, dc, st)
+    return dc.thresh ? launch_bwd_split<DT, true>(fn, q, k, v, o, g, l, dl, dq, dk_, dv_, B, Tq, Tk, d_key, n_heads, is, causal, dc, st) \
+                     : launch_bwd_split<DT, false>(fn, q, k, v, o, g, l, dl, dq, dk_, dv_, B, Tq, Tk, d_key, n_heads, is, causal, dc, st)
     switch (dh / 32) {
       case 1: TSG_SPLIT_CASE(1);
       case 2: TSG_SPLIT_CASE(2);

@@ -182,7 +182,10 @@ def test_attention_dropout_under_graph_capture():
 
 @pytest.mark.parametrize("B,Tq,Tk,d,h,causal,p", [
     (2, 128, 128, 1024, 8, False, 0.0),   # temporal self-attention at the north-star width: head width 128
-    (2, 128, 20, 1024, 8, False, 0.0),    # cross attention, Tk = 20 (one ragged key tile)
+    (2, 128, 20, 1024, 8, False, 0.0),    # cross attention, Tk = 20: one key tile -> the fused single-tile backward
+    (1, 300, 20, 512, 8, False, 0.0),     # one key tile, three query blocks (dK / dV added with atomics), head width 64
+    (2, 100, 32, 768, 8, False, 0.2),     # full key tile, head width 96, ragged query block, dropout
+    (3, 20, 20, 256, 8, True, 0.0),       # tiny causal self-attention inside one tile, head width 32
     (1, 70, 70, 256, 2, True, 0.0),       # ragged tiles, causal
     (2, 33, 45, 256, 8, False, 0.0),      # head width 32
     (1, 300, 257, 192, 2, False, 0.0),    # head width 96, several 128-row blocks, ragged
