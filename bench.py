@@ -187,11 +187,11 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
             lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d,
                                     heads, sc, 0, 0.0, 0, 0, TSG_F32, st),
             B * (4 * T + 4 * Tk) * d * e)          # read Q,K,V,O,dO ; write dQ,dK,dV
-        # the split-precision kernels (dtype TSG_F32S: what the "f32s" mode launches; the backward only for more than one key tile)
+        # the split-precision kernels (dtype TSG_F32S: what the "f32s" mode launches)
         run(f"tsg_mha_fwd[{tag}, f32s: {B},{T},{Tk},{d},h{heads}]",
             lambda: lib.tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), None, None, ptr(lse), B, T, Tk, d, d, heads, sc, 0, 0.0, 0, 0, 2, st),
             B * (2 * T + 2 * Tk) * d * e)
-        if Tk > 32:
+        if True:
             run(f"tsg_mha_bwd[{tag}, f32s: {B},{T},{Tk},{d},h{heads}]",
                 lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d,
                                         heads, sc, 0, 0.0, 0, 0, 2, st),
