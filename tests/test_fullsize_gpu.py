@@ -23,7 +23,10 @@ def _sub(batch, sl, device=None):
     return out
 
 
-@pytest.mark.parametrize("gemm", ["f32s", None])
+BF16_TOL = dict(atol=1e-2, rtol=2e-2)     # the bf16 GEMM mode has its own tolerance (~1e-2 relative)
+
+
+@pytest.mark.parametrize("gemm", ["f32s", None, "bf16"])
 def test_full_size_gmd_step_vs_oracle(gemm, request):
     """engine.gmd_step at the bench shape; the oracle cannot run 64 pairs in seconds, so:
       * boundary scores / matching logits / discriminator logits of 2 batch items vs the oracle on those items (1e-4);
@@ -35,7 +38,10 @@ def test_full_size_gmd_step_vs_oracle(gemm, request):
     from shufflingvideosfortsg_amd import data, engine, functional as TF
     from shufflingvideosfortsg_amd import loss as L
     from shufflingvideosfortsg_amd.model.networks.attention import masked_softmax
-    engine.precision(gemm)
+    bf16 = gemm == "bf16"                 # library GEMM operands bf16 (autocast), fp32 accumulate; HIP kernels fp32: BASELINE config 2 names it
+    mode = torch.bfloat16 if bf16 else gemm
+    tol = BF16_TOL if bf16 else TOL
+    precision = lambda: engine.precision(mode)
     request.addfinalizer(lambda: engine.precision(None))
     B, T, N = 64, 128, 20
     params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, dropout=0.0, video_len=T, sent_len=N)
@@ -67,19 +73,22 @@ def test_full_size_gmd_step_vs_oracle(gemm, request):
     model = model.cuda().train()
     model.tod.dropout.p = 0.0
     dg, dpg = dev["gt"], dev["pseudo_gt"]
-    span, om, pm, od, pd = model(dev["query"], dev["query_mask"], dev["video"], dev["video_mask"], dev["pseudo_video"], dev["video_mask"],
-                                 dg["temporal_labels"], dg["fore_masks"], dg["back_masks"],
-                                 dpg["temporal_labels"], dpg["fore_masks"], dpg["back_masks"])
+    with precision():
+        span, om, pm, od, pd = model(dev["query"], dev["query_mask"], dev["video"], dev["video_mask"], dev["pseudo_video"], dev["video_mask"],
+                                     dg["temporal_labels"], dg["fore_masks"], dg["back_masks"],
+                                     dpg["temporal_labels"], dpg["fore_masks"], dpg["back_masks"])
+    span = {k: v.float() for k, v in span.items()}
+    om, pm, od, pd = om.float(), pm.float(), od.float(), pd.float()
     torch.cuda.synchronize()
     TF.check_lstm_errors()
     # (1) two items vs the oracle
     for got, want, name in ((span["start"], ref[0]["start"], "start"), (span["end"], ref[0]["end"], "end"), (om, ref[1], "ori_match"),
                             (pm, ref[2], "pseudo_match"), (od, ref[3], "ori_disc"), (pd, ref[4], "pseudo_disc")):
-        torch.testing.assert_close(got[:2].detach().cpu(), want.detach(), **TOL, msg=lambda m, n=name: f"{n}: {m}")
+        torch.testing.assert_close(got[:2].detach().cpu(), want.detach(), **tol, msg=lambda m, n=name: f"{n}: {m}")
     # (3) properties over the whole batch
     for p in (span["start"], span["end"]):
         assert torch.isfinite(p).all()
-        torch.testing.assert_close(p.sum(1), torch.ones(B, device="cuda"), atol=1e-5, rtol=0)
+        torch.testing.assert_close(p.sum(1), torch.ones(B, device="cuda"), atol=1e-3 if bf16 else 1e-5, rtol=0)
     for t in (span["start"], span["end"], om, pm, od, pd):
         assert torch.equal(t[0:2], t[2:4]), "batch items are not independent"
     # (2) the 2-item losses through the full-size backward
@@ -89,17 +98,18 @@ def test_full_size_gmd_step_vs_oracle(gemm, request):
             + L.BCE_loss(om[:2], dg["temporal_labels"][:2], vm) + L.BCE_loss(pm[:2], dpg["temporal_labels"][:2], vm)
             + L.matching_KL_divergence(masked_softmax(om[:2], dg["temporal_labels"][:2]), masked_softmax(pm[:2], dpg["temporal_labels"][:2]), fs, pfs)
             + L.temporal_order_discrimination_loss(od[:2], pd[:2]))
-    torch.testing.assert_close(lsub.detach().cpu(), ref_loss.detach(), **TOL)
+    torch.testing.assert_close(lsub.detach().cpu(), ref_loss.detach(), **tol)
     lsub.backward()
     torch.cuda.synchronize()
     TF.check_lstm_errors()
     for k, p in model.named_parameters():
         want = sd[k].grad
-        atol = 5e-4 * max(1.0, float(want.abs().max()))
-        torch.testing.assert_close(p.grad.cpu(), want, atol=atol, rtol=5e-3, msg=lambda m, k=k: f"grad {k}: {m}")
+        atol = (3e-2 if bf16 else 5e-4) * max(1.0, float(want.abs().max()))
+        torch.testing.assert_close(p.grad.cpu(), want, atol=atol, rtol=1e-1 if bf16 else 5e-3, msg=lambda m, k=k: f"grad {k}: {m}")
     # the fused full-batch step (K4 losses) is finite and its backward too
     model.zero_grad(set_to_none=True)
-    loss, parts, _ = engine.gmd_step(model, dev, params)
+    with precision():
+        loss, parts, _ = engine.gmd_step(model, dev, params)
     loss.backward()
     torch.cuda.synchronize()
     TF.check_lstm_errors()
