@@ -48,6 +48,16 @@ def test_argument_errors_without_gpu(lib):
     assert lib.tsg_mha_fwd(p, p, p, p, None, None, p, 1, 4, 4, 8, 8, 3, 1.0, 0, 0.0, 0, 0, TSG_F32, None) == -2  # 8 % 3
     assert lib.tsg_mha_fwd(p, p, p, p, None, None, p, 1, 4, 4, 8, 8, 2, 1.0, 0, 1.0, 0, 0, TSG_F32, None) == -2  # dropout probability outside [0,1)
     assert lib.tsg_boundary_score_fwd(p, p, p, p, p, None, None, p, p, 1, 4, 3, TSG_F32, None) == -2             # 2*Hm % 4
+    assert lib.tsg_mha_bwd(p, p, p, p, p, p, p, p, p, p, 1, 4, 4, 8, 8, 2, 1.0, 0, 0.0, 0, 0, 7, None) == -4     # dtype (TSG_F32 / TSG_F32S only)
+    # the weight-gradient GEMM: host-side plan and argument checks (no launch)
+    assert lib.tsg_wgrad_f32s_ws_bytes(16384, 1024, 1024, 0, 1) == 8 * 4 * 1024 * 1024      # 32 tiles -> 8 row ranges of partial tiles
+    assert lib.tsg_wgrad_f32s_ws_bytes(16384, 2048, 1024, 512, 2) == 4 * 4 * 2 * 2048 * 1536  # the LSTM shape: 192 tiles -> 4 ranges
+    assert lib.tsg_wgrad_f32s_ws_bytes(32, 256, 128, 0, 1) == 0                               # one chunk: no partials
+    assert lib.tsg_wgrad_f32s_ws_bytes(48, 256, 128, 0, 1) == -1                              # M % 32
+    assert lib.tsg_wgrad_f32s_ws_bytes(64, 128, 128, 0, 1) == -1                              # N % 256
+    assert lib.tsg_wgrad_f32s(p, 256, 0, p, 128, 128, None, 0, 0, 0, 0, 0, p, 128, 0, None, 0, 64, 256, 3, None) == -2   # groups
+    assert lib.tsg_wgrad_f32s(p, 256, 0, p, 100, 128, None, 0, 0, 0, 0, 0, p, 128, 0, None, 0, 64, 256, 1, None) == -2   # ldb0 < K0
+    assert lib.tsg_wgrad_f32s(None, 256, 0, p, 128, 128, None, 0, 0, 0, 0, 0, p, 128, 0, None, 0, 64, 256, 1, None) == -1  # NULL
 
 
 def test_no_cpu_fallback():
