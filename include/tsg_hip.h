@@ -19,7 +19,8 @@
  *     co-residency cache, and the three LSTM switches set by tsg_lstm_error_sink / tsg_lstm_set_l2_exchange /
  *     tsg_lstm_set_persist (initialised from TSG_LSTM_L2X / TSG_LSTM_PERSIST in the environment on first use).
  *   - results are bitwise reproducible run to run except the sums formed with float atomics: dw of K1, dgbias of K1g, dcs / dw2 /
- *     db2 of K5, the K4 loss accumulators and the LSTM's dbias (one atomic add per batch slice and column).
+ *     db2 of K5, the K4 loss accumulators, the LSTM's dbias (one atomic add per batch slice and column), dcs / db1 / dw2 of K3, and
+ *     dK / dV of tsg_mha_bwd with TSG_F32S when Tk <= 32 and Tq > 128 (one atomic add per query block).
  */
 #ifndef TSG_HIP_H
 #define TSG_HIP_H
