@@ -34,8 +34,8 @@ extern "C" {
 #define TSG_VERSION 2   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points */
 #define TSG_F32 0
 #define TSG_BF16 1
-#define TSG_F32S 2   /* fp32 storage; the LSTM recurrence's W_hh products run as split-precision bf16 MFMAs
-                        (hi*hi + hi*lo + lo*hi, fp32 accumulation) -- accepted by tsg_lstm_fwd / tsg_lstm_bwd[_ws] only */
+#define TSG_F32S 2   /* fp32 storage; matrix products as split-precision bf16 MFMAs (x = hi + lo; hi*hi + hi*lo + lo*hi,
+                        fp32 accumulation) -- accepted by the LSTM entry points and by tsg_mha_fwd / tsg_mha_bwd[_rng] */
 
 #define TSG_LSTM_SYNC_BYTES 2048   /* size of tsg_lstm_fwd's sync_ws */
 #define TSG_E_NULL   (-1)   /* a required pointer is NULL                      */
