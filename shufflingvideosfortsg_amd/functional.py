@@ -237,7 +237,8 @@ def _mm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         if a.shape[1] % 4 or a.shape[0] % 4 or b.shape[1] % 4:
             return a @ b
         return torch.mm(_split_operand(a, 1, False), _split_operand(b, 0, True), out_dtype=torch.float32)
-    return (a.to(_GEMM_DTYPE) @ b.to(_GEMM_DTYPE)).float()
+    # bf16 operands, fp32 accumulate AND fp32 output straight from the GEMM (no bf16 round trip of the result, no cast kernel)
+    return torch.mm(a.to(_GEMM_DTYPE), b.to(_GEMM_DTYPE), out_dtype=torch.float32)
 
 
 _fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)     # under autocast: fp32 in, autocast off inside
