@@ -235,3 +235,39 @@ def test_mha_split_precision(B, Tq, Tk, d, h, causal, p):
         for a_, t, name in zip(g_s, (q, k, v), "QKV"):
             scale = float(t.grad.abs().max())
             assert float((a_.double() - t.grad).abs().max()) < 2e-5 * scale + 1e-7, name
+
+
+def test_split_precision_attention_in_a_captured_graph():
+    """The split-precision forward / backward kernels inside a HIP graph (the f32s train step can be graph-replayed with a
+    self-attention head): same results as the eager launches, with dropout drawing a fresh mask per replay."""
+    from shufflingvideosfortsg_amd import functional as F
+    torch.manual_seed(0)
+    B, T, d, h = 2, 96, 256, 2                                   # head width 128
+    q, k, v = (torch.randn(B, T, d, device="cuda", requires_grad=True) for _ in range(3))
+    gO = torch.randn(B, T, d, device="cuda")
+    F.set_gemm_dtype("f32s")
+    try:
+        def run(p):
+            for t in (q, k, v):
+                t.grad = None
+            o = F.mha(q, k, v, h, math.sqrt(d), False, p_drop=p)
+            o.backward(gO)
+            return o.detach().clone(), q.grad.clone()
+        o_e, g_e = run(0.0)
+        F.mha_graph_rng("cuda")
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            run(0.0); run(0.2)                                   # warm-up (kernel attributes, allocator)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                o0, g0 = run(0.0)
+                o1, g1 = run(0.2)
+        torch.cuda.current_stream().wait_stream(s)
+        graph.replay(); torch.cuda.synchronize()
+        assert torch.equal(o0, o_e) and torch.equal(g0, g_e)
+        a = o1.clone()
+        graph.replay(); torch.cuda.synchronize()
+        assert torch.equal(o0, o_e) and not torch.equal(o1, a)   # the captured offset increment gives every replay a new mask
+    finally:
+        F.set_gemm_dtype(None)
