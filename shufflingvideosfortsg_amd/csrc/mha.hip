@@ -1119,47 +1119,56 @@ struct SplitTile {
   static constexpr int kRow = 32 * PR, kCol = 32 * DT * PT;                 // dwords per plane
   static constexpr int kT0 = ROW ? 2 * kRow : 0;                            // first dword of the transposed planes
   static constexpr int kDwords = kT0 + (TR ? 2 * kCol : 0);                 // [R hi][R lo][T hi][T lo]
-  float4 v[4];
+  static constexpr int NR = DT > 4 ? 2 : 1;                                 // 128-channel column blocks per thread (head widths > 128)
+  float4 v[NR][4];
   const float* p0;                                                       // this thread's first row of tile 0
   int mg, c4, ld;
-  bool on;
+  bool on[NR];
   // src: the matrix (row stride ld_ floats) with the head's first channel already applied
   __device__ __forceinline__ SplitTile(const float* __restrict__ src, int ld_) {
     const int tid = threadIdx.x;
-    mg = (tid >> 2) & 7; c4 = (tid & 3) + 4 * (tid >> 5); on = tid < 64 * DT; ld = ld_;
+    mg = (tid >> 2) & 7; c4 = (tid & 3) + 4 * (tid >> 5); ld = ld_;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) on[k] = 4 * (c4 + 32 * k) < 32 * DT;
     p0 = src + (size_t)(4 * mg) * ld + 4 * c4;
   }
   // rows [row0, row0+32), zero fill beyond rows_total
   __device__ __forceinline__ void request(int row0, int rows_total) {
     const float* p = p0 + (size_t)row0 * ld;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      v[i] = (on && row0 + 4 * mg + i < rows_total) ? *reinterpret_cast<const float4*>(p + i * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        v[k][i] = (on[k] && row0 + 4 * mg + i < rows_total) ? *reinterpret_cast<const float4*>(p + i * ld + 128 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __device__ __forceinline__ void stage(unsigned* __restrict__ base) const {
-    if (!on) return;
-    const float e[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
-                           {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
-    if (ROW) {
-      unsigned* Rh = base; unsigned* Rl = Rh + kRow;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        unsigned h0, l0, h1, l1;
-        split_pair(e[i][0], e[i][1], h0, l0);
-        split_pair(e[i][2], e[i][3], h1, l1);
-        *reinterpret_cast<uint2*>(Rh + (4 * mg + i) * PR + 2 * c4) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(Rl + (4 * mg + i) * PR + 2 * c4) = make_uint2(l0, l1);
+    for (int k = 0; k < NR; ++k) {
+      if (!on[k]) continue;
+      const int cq = c4 + 32 * k;
+      const float e[4][4] = {{v[k][0].x, v[k][0].y, v[k][0].z, v[k][0].w}, {v[k][1].x, v[k][1].y, v[k][1].z, v[k][1].w},
+                             {v[k][2].x, v[k][2].y, v[k][2].z, v[k][2].w}, {v[k][3].x, v[k][3].y, v[k][3].z, v[k][3].w}};
+      if (ROW) {
+        unsigned* Rh = base; unsigned* Rl = Rh + kRow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned h0, l0, h1, l1;
+          split_pair(e[i][0], e[i][1], h0, l0);
+          split_pair(e[i][2], e[i][3], h1, l1);
+          *reinterpret_cast<uint2*>(Rh + (4 * mg + i) * PR + 2 * cq) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(Rl + (4 * mg + i) * PR + 2 * cq) = make_uint2(l0, l1);
+        }
       }
-    }
-    if (TR) {
-      unsigned* Th = base + kT0; unsigned* Tl = Th + kCol;
+      if (TR) {
+        unsigned* Th = base + kT0; unsigned* Tl = Th + kCol;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        unsigned h0, l0, h1, l1;
-        split_pair(e[0][j], e[1][j], h0, l0);
-        split_pair(e[2][j], e[3][j], h1, l1);
-        *reinterpret_cast<uint2*>(Th + (4 * c4 + j) * PT + 2 * mg) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(Tl + (4 * c4 + j) * PT + 2 * mg) = make_uint2(l0, l1);
+        for (int j = 0; j < 4; ++j) {
+          unsigned h0, l0, h1, l1;
+          split_pair(e[0][j], e[1][j], h0, l0);
+          split_pair(e[2][j], e[3][j], h1, l1);
+          *reinterpret_cast<uint2*>(Th + (4 * cq + j) * PT + 2 * mg) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(Tl + (4 * cq + j) * PT + 2 * mg) = make_uint2(l0, l1);
+        }
       }
     }
   }
@@ -1479,7 +1488,7 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dq_kernel(
 // + one exchange with lane ^ 32, which holds the other 16 keys of the same query), O^T[c][q] += V^T[c][key] P^T[key][q] with the
 // P^T registers as the B operand and the transposed V planes as A.  O leaves through LDS as whole rows.
 template <int DT, bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mha_fwd_split_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DT <= 4 ? 2 : 1, DT <= 4 ? 2 : 1))) void mha_fwd_split_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, float* __restrict__ O,
     float* __restrict__ LSE, int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
   drop_resolve(dc);
@@ -1876,7 +1885,7 @@ static int mha_fwd_impl(const void* Q, const void* K, const void* V, void* O, vo
   const int dh = d_key / n_heads, dvh = d_value / n_heads;
   static int split_on = -1;                                         // TSG_MHA_SPLIT=0: exact-fp32 kernels also for TSG_F32S (A/B)
   if (split_on < 0) { const char* e = getenv("TSG_MHA_SPLIT"); split_on = e ? atoi(e) : 1; }
-  if (dtype == TSG_F32S && split_on && !A_sum && !S_sum && dh == dvh && dh % 32 == 0 && dh <= 128) {     // split precision
+  if (dtype == TSG_F32S && split_on && !A_sum && !S_sum && dh == dvh && dh % 32 == 0 && dh <= 256) {     // split precision
     const float* q = (const float*)Q; const float* k = (const float*)K; const float* v = (const float*)V;
     const float is = 1.f / scale;
 #define TSG_SPLIT_CASE(DT) \
@@ -1886,7 +1895,11 @@ static int mha_fwd_impl(const void* Q, const void* K, const void* V, void* O, vo
       case 1: TSG_SPLIT_CASE(1);
       case 2: TSG_SPLIT_CASE(2);
       case 3: TSG_SPLIT_CASE(3);
-      default: TSG_SPLIT_CASE(4);
+      case 4: TSG_SPLIT_CASE(4);
+      case 5: TSG_SPLIT_CASE(5);
+      case 6: TSG_SPLIT_CASE(6);
+      case 7: TSG_SPLIT_CASE(7);
+      default: TSG_SPLIT_CASE(8);
     }
 #undef TSG_SPLIT_CASE
   }

@@ -7,7 +7,7 @@ from shufflingvideosfortsg_amd import _lib
 from shufflingvideosfortsg_amd._lib import TSG_F32, TSG_F32S, ptr
 lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
-for (B, T, Tk, d, h) in [(64, 128, 128, 1024, 8), (64, 128, 20, 1024, 8), (64, 128, 128, 512, 8), (16, 512, 512, 1024, 8)]:
+for (B, T, Tk, d, h) in [(64, 128, 128, 1024, 8), (64, 128, 20, 1024, 8), (64, 128, 128, 512, 8), (16, 512, 512, 1024, 8), (64, 128, 128, 2048, 8)]:
     Q = torch.randn(B, T, d, device="cuda"); K = torch.randn(B, Tk, d, device="cuda"); V = torch.randn(B, Tk, d, device="cuda")
     O = torch.empty(B, T, d, device="cuda"); lse = torch.empty(B, h, T, device="cuda"); g = torch.randn(B, T, d, device="cuda")
     dQ, dK, dV, dlt = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V), torch.empty_like(lse)
