@@ -192,6 +192,7 @@ def test_attention_dropout_under_graph_capture():
     (2, 64, 64, 512, 8, False, 0.3),      # head width 64, attention dropout (mask regenerated from the counters)
     (1, 512, 512, 1024, 8, True, 0.1),    # config-4 length, causal + dropout
     (2, 128, 128, 2048, 8, False, 0.0),   # head width 256 (Self_Attention_predictor at d = 1024): split forward, exact wide backward
+    (1, 200, 150, 1280, 8, False, 0.25),  # head width 160, ragged blocks, dropout
     (1, 70, 45, 384, 2, True, 0.1),       # head width 192, ragged, causal needs Tq == Tk -> see below
     (2, 100, 20, 1280, 8, False, 0.0),    # head width 160, one key tile
 ])
