@@ -191,11 +191,10 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
         run(f"tsg_mha_fwd[{tag}, f32s: {B},{T},{Tk},{d},h{heads}]",
             lambda: lib.tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), None, None, ptr(lse), B, T, Tk, d, d, heads, sc, 0, 0.0, 0, 0, 2, st),
             B * (2 * T + 2 * Tk) * d * e)
-        if True:
-            run(f"tsg_mha_bwd[{tag}, f32s: {B},{T},{Tk},{d},h{heads}]",
-                lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d,
-                                        heads, sc, 0, 0.0, 0, 0, 2, st),
-                B * (4 * T + 4 * Tk) * d * e)
+        run(f"tsg_mha_bwd[{tag}, f32s: {B},{T},{Tk},{d},h{heads}]",
+            lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d,
+                                    heads, sc, 0, 0.0, 0, 0, 2, st),
+            B * (4 * T + 4 * Tk) * d * e)
     # the hand-written weight-gradient GEMM (csrc/wgrad_split.hip) at the step's three shapes: MFMA-bound, so its roofline is the
     # dense bf16 MFMA peak; flops = the bf16 matrix work it issues (3 products per fp32 product)
     for (M, Nn, Kk) in ((2 * B * T, d, d), (2 * B * N, d, d), (B * T, 512, d)):
