@@ -125,7 +125,8 @@ int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O, void* A_su
  * delta_ws: caller-owned workspace of B*n_heads*Tq floats (NULL selects the slower non-MFMA kernel).
  * dtype TSG_F32: exact fp32 products.  TSG_F32S (fp32 storage): the five products of the backward as split-precision bf16 MFMA
  * products (x = hi + lo, hi*hi + hi*lo + lo*hi, fp32 accumulate -- fp32-GEMM-level error) in two kernels (dK/dV, dQ), where
- * d_key == d_value, the head width is 32 / 64 / 96 / 128 and Tk > 32; otherwise the exact kernels run.  tsg_mha_fwd with
+ * d_key == d_value and the head width is a multiple of 32 up to 256 (above 128: channel halves per wave pair); otherwise the exact
+ * kernels run.  tsg_mha_fwd with
  * TSG_F32S: one split-precision kernel with an online softmax for head widths 32 .. 256 in steps of 32 (any Tk) when no A_sum /
  * S_sum side outputs are requested; otherwise the exact kernels.                                                                  */
 int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* lse,

@@ -1186,6 +1186,20 @@ struct SplitTile {
     hi = (u32x4v){a.x, a.y, b.x, b.y};
     lo = (u32x4v){c.x, c.y, d.x, d.y};
   }
+  // the same operand read out of the ROW-major planes (no transposed planes staged): eight 2-byte reads per plane, lane = channel ch
+  static __device__ __forceinline__ void col_from_rows(const unsigned* __restrict__ base, int ch, int s, int hh, u32x4v& hi, u32x4v& lo) {
+    const unsigned short* Rh = reinterpret_cast<const unsigned short*>(base) + ch;
+    const unsigned short* Rl = Rh + 2 * kRow;
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r0 = rho(8 * s + 2 * j, hh), r1 = rho(8 * s + 2 * j + 1, hh);
+      h[j] = (unsigned)Rh[r0 * 2 * PR] | ((unsigned)Rh[r1 * 2 * PR] << 16);
+      l[j] = (unsigned)Rl[r0 * 2 * PR] | ((unsigned)Rl[r1 * 2 * PR] << 16);
+    }
+    hi = (u32x4v){h[0], h[1], h[2], h[3]};
+    lo = (u32x4v){l[0], l[1], l[2], l[3]};
+  }
 };
 
 // The workgroup's own 128 rows (wave w: rows row0 + 32 w .. +31) as B-operand fragments over the channels -- lane (jl, hh) holds
@@ -1480,6 +1494,300 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dq_kernel(
     const int qq = qb + 32 * wv + r;
     if (qq < Tq) *reinterpret_cast<float4*>(dQb + (size_t)qq * dk + c) = *reinterpret_cast<const float4*>(Ol + r * OP + c);
   }
+}
+
+// ---- wide heads (160 .. 256 channels) in the backward: at width 256 a 32-row wave's own rows are 128 registers per tensor, and two
+// such tensors plus the accumulators do not fit (the kernels above with the accumulators taken in passes spilled 80-380 registers).
+// Here TWO waves share a 32-row group and split the CHANNELS: wave (g, c) holds channels [128 c, 128 c + 128) of its rows (64
+// registers per tensor), forms the partial S / dP over them, the two partial tiles meet in LDS (one exchange per tile, both waves
+// then hold the full tile and compute P / dS redundantly), and each accumulates its own channel half of dV / dK (dQ).  Workgroup =
+// 64 rows (2 groups x 2 halves).  The operand contracted over the tile's rows is read out of the ROW-major planes with eight 2-byte
+// LDS reads per plane (gathering the fp32 rows from global memory and splitting them again per use measured 511 instead of
+// 360 us), so the tiles are staged as row-major planes only: one LDS buffer (the next tile waits in registers) + the exchange
+// block = 100 KiB.
+template <int NKS>
+__device__ __forceinline__ void own_rows_half(const float* __restrict__ src, int ld, int row, int rows_total, int nks, int hh,
+                                              u32x4v (&hi)[NKS], u32x4v (&lo)[NKS]) {
+  float4 x[NKS], y[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    x[ks] = y[ks] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows_total && ks < nks) {
+      x[ks] = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 16 * ks + 8 * hh);
+      y[ks] = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 16 * ks + 8 * hh + 4);
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const float e[8] = {x[ks].x, x[ks].y, x[ks].z, x[ks].w, y[ks].x, y[ks].y, y[ks].z, y[ks].w};
+    split8(e, hi[ks], lo[ks]);
+  }
+}
+
+// partial S / dP tiles of the two channel halves -> the full tiles in both waves of the pair.  X: [4 waves][2][16][64] floats.
+__device__ __forceinline__ void exchange_halves(float* __restrict__ X, int wv, int lane, f32x16& sp, f32x16& dp) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { X[((wv * 2 + 0) * 16 + r) * 64 + lane] = sp[r]; X[((wv * 2 + 1) * 16 + r) * 64 + lane] = dp[r]; }
+  __syncthreads();
+  const int pw = wv ^ 1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { sp[r] += X[((pw * 2 + 0) * 16 + r) * 64 + lane]; dp[r] += X[((pw * 2 + 1) * 16 + r) * 64 + lane]; }
+}
+
+template <int DT, bool DROP>
+__global__ __launch_bounds__(256) void mha_bwd_split_dq_wide_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
+    const float* __restrict__ LSE, const float* __restrict__ O, float* __restrict__ delta, float* __restrict__ dQ,
+    int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
+  drop_resolve(dc);
+  using SR = SplitTile<DT, false>;
+  extern __shared__ __align__(16) unsigned lds_u[];
+  float* X = reinterpret_cast<float*>(lds_u + 2 * SR::kDwords);          // exchange block behind the K | V tile
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hh = lane >> 5;
+  const int g = wv >> 1, c = wv & 1;                                     // 32-query group, channel half
+  const int nt = c ? DT - 4 : 4, nks = 2 * nt, ks0 = 8 * c;             // channel tiles / contraction steps of this half
+  const int qblocks = (Tq + 63) / 64;
+  const int b = blockIdx.x / (H * qblocks), hd = (blockIdx.x / qblocks) % H, qb = (blockIdx.x % qblocks) * 64;
+  const float* Kb = K + (size_t)b * Tk * dk + hd * 32 * DT;
+  const float* Vb = V + (size_t)b * Tk * dk + hd * 32 * DT;
+  const int q = qb + 32 * g + jl;
+  const float lse_q = q < Tq ? LSE[((size_t)b * H + hd) * Tq + q] : 0.f;
+  SR tk(Kb, dk), tv(Vb, dk);
+  tk.request(0, Tk); tv.request(0, Tk);
+  u32x4v qh[8], ql[8], gh[8], gl[8];
+  const float* Qr = Q + (size_t)b * Tq * dk + hd * 32 * DT + 128 * c;
+  const float* Gr = dO + (size_t)b * Tq * dk + hd * 32 * DT + 128 * c;
+  const float* Or = O + (size_t)b * Tq * dk + hd * 32 * DT + 128 * c;
+  own_rows_half<8>(Qr, dk, q, Tq, nks, hh, qh, ql);
+  own_rows_half<8>(Gr, dk, q, Tq, nks, hh, gh, gl);
+  // delta[q] = <dO[q], O[q]> over ALL channels: this lane's pieces of its half, + lane ^ 32, + the partner wave's half (through X)
+  float dpart = 0.f;
+  if (q < Tq) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      if (ks < nks) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float4 a = *reinterpret_cast<const float4*>(Gr + (size_t)q * dk + 16 * ks + 8 * hh + 4 * u);
+          const float4 o = *reinterpret_cast<const float4*>(Or + (size_t)q * dk + 16 * ks + 8 * hh + 4 * u);
+          dpart = fmaf(a.x, o.x, fmaf(a.y, o.y, fmaf(a.z, o.z, fmaf(a.w, o.w, dpart))));
+        }
+      }
+  }
+  dpart = xhalf_sum(dpart);
+  if (hh == 0) X[wv * 32 + jl] = dpart;
+  tk.stage(lds_u); tv.stage(lds_u + SR::kDwords);
+  __syncthreads();
+  const float dl_q = dpart + X[(wv ^ 1) * 32 + jl];
+  if (c == 0 && hh == 0 && q < Tq) delta[((size_t)b * H + hd) * Tq + q] = dl_q;
+  __syncthreads();                                                       // X is reused by the tile loop
+  f32x16 dqt[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqt[ct][r] = 0.f;
+  const unsigned* Kt = lds_u; const unsigned* Vt = lds_u + SR::kDwords;
+  const int ntiles = (Tk + 31) / 32;
+  for (int t = 0; t < ntiles; ++t) {
+    const int k0 = 32 * t;
+    const int kn = min(k0 + 32, 32 * (ntiles - 1));
+    tk.request(kn, Tk); tv.request(kn, Tk);
+    f32x16 sp, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sp[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      if (ks < nks) {
+        u32x4v ah, al;
+        SR::row_frag(Kt, ks0 + ks, jl, hh, ah, al);
+        sp = mfma3(ah, al, qh[ks], ql[ks], sp);
+        SR::row_frag(Vt, ks0 + ks, jl, hh, ah, al);
+        dp = mfma3(ah, al, gh[ks], gl[ks], dp);
+      }
+    exchange_halves(X, wv, lane, sp, dp);
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + rho(r, hh);
+      float sv = sp[r];
+      if (causal && key > q) sv -= 1e10f;
+      sv *= inv_scale;
+      const float p = (key < Tk && q < Tq) ? __expf(sv - lse_q) : 0.f;
+      const float mk = DROP ? drop_scale(dc, b, H, hd, Tq, q, Tk, key) : 1.f;
+      ds[r] = p * (dp[r] * mk - dl_q) * inv_scale;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4v sh, sl;
+      const float sa[8] = {ds[8 * s], ds[8 * s + 1], ds[8 * s + 2], ds[8 * s + 3], ds[8 * s + 4], ds[8 * s + 5], ds[8 * s + 6], ds[8 * s + 7]};
+      split8(sa, sh, sl);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        if (ct < nt) {
+          u32x4v ah, al;                                                 // K^T[c][key]: the key tile's rows at this lane's channel
+          SR::col_from_rows(Kt, 128 * c + 32 * ct + jl, s, hh, ah, al);
+          dqt[ct] = mfma3(ah, al, sh, sl, dqt[ct]);
+        }
+    }
+    __syncthreads();                                                     // the tile and the exchange block have been read
+    tk.stage(lds_u); tv.stage(lds_u + SR::kDwords);
+    __syncthreads();
+  }
+  constexpr int OP = 132;                                                // floats per query row of a wave's [32][128] block
+  float* Ol = reinterpret_cast<float*>(lds_u) + wv * 32 * OP;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+    if (ct < nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ol[jl * OP + 32 * ct + rho(r, hh)] = dqt[ct][r];
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float* dQb = dQ + (size_t)b * Tq * dk + hd * 32 * DT + 128 * c;
+  for (int idx = lane; idx < 32 * 8 * nt; idx += 64) {
+    const int r = idx / (8 * nt), cc = (idx % (8 * nt)) * 4;
+    const int qq = qb + 32 * g + r;
+    if (qq < Tq) *reinterpret_cast<float4*>(dQb + (size_t)qq * dk + cc) = *reinterpret_cast<const float4*>(Ol + r * OP + cc);
+  }
+}
+
+template <int DT, bool DROP>
+__global__ __launch_bounds__(256) void mha_bwd_split_dkv_wide_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
+    const float* __restrict__ LSE, const float* __restrict__ delta, float* __restrict__ dK, float* __restrict__ dV,
+    int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
+  drop_resolve(dc);
+  using SR = SplitTile<DT, false>;
+  extern __shared__ __align__(16) unsigned lds_u[];
+  float* X = reinterpret_cast<float*>(lds_u + 2 * SR::kDwords);
+  float* rows = X + 4 * 2 * 16 * 64;                                     // [2][32]: lse, delta of the tile's queries
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hh = lane >> 5;
+  const int g = wv >> 1, c = wv & 1;
+  const int nt = c ? DT - 4 : 4, nks = 2 * nt, ks0 = 8 * c;
+  const int kblocks = (Tk + 63) / 64;
+  const int b = blockIdx.x / (H * kblocks), hd = (blockIdx.x / kblocks) % H, kb = (blockIdx.x % kblocks) * 64;
+  const float* Qb = Q + (size_t)b * Tq * dk + hd * 32 * DT;
+  const float* Gb = dO + (size_t)b * Tq * dk + hd * 32 * DT;
+  const float* lse = LSE + ((size_t)b * H + hd) * Tq;
+  const float* dlt = delta + ((size_t)b * H + hd) * Tq;
+  const int key = kb + 32 * g + jl;
+  SR tq(Qb, dk), tg(Gb, dk);
+  float lse_n = 0.f, dl_n = 0.f;
+  auto request = [&](int q0) {
+    tq.request(q0, Tq); tg.request(q0, Tq);
+    if (tid < 32) { lse_n = q0 + tid < Tq ? lse[q0 + tid] : 0.f; dl_n = q0 + tid < Tq ? dlt[q0 + tid] : 0.f; }
+  };
+  auto stage = [&]() {
+    tq.stage(lds_u); tg.stage(lds_u + SR::kDwords);
+    if (tid < 32) { rows[tid] = lse_n; rows[32 + tid] = dl_n; }
+  };
+  request(0);
+  u32x4v kh[8], kl[8], vh[8], vl[8];
+  own_rows_half<8>(K + (size_t)b * Tk * dk + hd * 32 * DT + 128 * c, dk, key, Tk, nks, hh, kh, kl);
+  own_rows_half<8>(V + (size_t)b * Tk * dk + hd * 32 * DT + 128 * c, dk, key, Tk, nks, hh, vh, vl);
+  f32x16 dkt[4], dvt[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[ct][r] = 0.f; dvt[ct][r] = 0.f; }
+  stage();
+  __syncthreads();
+  const unsigned* Qt = lds_u; const unsigned* Gt = lds_u + SR::kDwords;
+  const int ntiles = (Tq + 31) / 32;
+  for (int t = 0; t < ntiles; ++t) {
+    const int q0 = 32 * t;
+    f32x16 sp, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sp[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      if (ks < nks) {
+        u32x4v ah, al;
+        SR::row_frag(Qt, ks0 + ks, jl, hh, ah, al);
+        sp = mfma3(ah, al, kh[ks], kl[ks], sp);
+        SR::row_frag(Gt, ks0 + ks, jl, hh, ah, al);
+        dp = mfma3(ah, al, vh[ks], vl[ks], dp);
+      }
+    exchange_halves(X, wv, lane, sp, dp);
+    float pm[16], ds[16], lsev[16], dlv[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 a = *reinterpret_cast<const float4*>(rows + 8 * i + 4 * hh), d4 = *reinterpret_cast<const float4*>(rows + 32 + 8 * i + 4 * hh);
+      lsev[4 * i] = a.x; lsev[4 * i + 1] = a.y; lsev[4 * i + 2] = a.z; lsev[4 * i + 3] = a.w;
+      dlv[4 * i] = d4.x; dlv[4 * i + 1] = d4.y; dlv[4 * i + 2] = d4.z; dlv[4 * i + 3] = d4.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = q0 + rho(r, hh);
+      float sv = sp[r];
+      if (causal && key > q) sv -= 1e10f;
+      sv *= inv_scale;
+      const float p = (key < Tk && q < Tq) ? __expf(sv - lsev[r]) : 0.f;
+      const float mk = DROP ? drop_scale(dc, b, H, hd, Tq, q, Tk, key) : 1.f;
+      pm[r] = p * mk;
+      ds[r] = p * (dp[r] * mk - dlv[r]) * inv_scale;
+    }
+    u32x4v ph[2], pl[2], sh[2], sl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float pa[8] = {pm[8 * s], pm[8 * s + 1], pm[8 * s + 2], pm[8 * s + 3], pm[8 * s + 4], pm[8 * s + 5], pm[8 * s + 6], pm[8 * s + 7]};
+      const float sa[8] = {ds[8 * s], ds[8 * s + 1], ds[8 * s + 2], ds[8 * s + 3], ds[8 * s + 4], ds[8 * s + 5], ds[8 * s + 6], ds[8 * s + 7]};
+      split8(pa, ph[s], pl[s]);
+      split8(sa, sh[s], sl[s]);
+    }
+    __builtin_amdgcn_sched_barrier(0);                                   // the next tile's rows are requested only now: while S / dP and
+    request(min(q0 + 32, 32 * (ntiles - 1)));                            // the softmax were live every register was taken
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        if (ct < nt) {
+          u32x4v bh, bl;
+          SR::col_from_rows(Gt, 128 * c + 32 * ct + jl, s, hh, bh, bl);
+          dvt[ct] = mfma3(ph[s], pl[s], bh, bl, dvt[ct]);
+          SR::col_from_rows(Qt, 128 * c + 32 * ct + jl, s, hh, bh, bl);
+          dkt[ct] = mfma3(sh[s], sl[s], bh, bl, dkt[ct]);
+        }
+    __syncthreads();
+    stage();
+    __syncthreads();
+  }
+  float* dKb = dK + (size_t)b * Tk * dk + hd * 32 * DT + 128 * c;
+  float* dVb = dV + (size_t)b * Tk * dk + hd * 32 * DT + 128 * c;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+    if (ct < nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = kb + 32 * g + rho(r, hh);
+        if (k < Tk) {
+          dKb[(size_t)k * dk + 32 * ct + jl] = dkt[ct][r];
+          dVb[(size_t)k * dk + 32 * ct + jl] = dvt[ct][r];
+        }
+      }
+    }
+}
+
+template <int DT, bool DROP>
+int launch_bwd_split_wide(const char* fn, const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* lse,
+                          float* delta, float* dQ, float* dK, float* dV, int B, int Tq, int Tk, int dk, int H, float inv_scale,
+                          int causal, const DropCfg& dc, hipStream_t st) {
+  using SR = SplitTile<DT, false>;
+  size_t lds = sizeof(unsigned) * (size_t)(2 * SR::kDwords) + sizeof(float) * (4 * 2 * 16 * 64 + 64);
+  const size_t outb = sizeof(float) * 4 * 32 * 132;
+  if (outb > lds) lds = outb;
+  auto ka = mha_bwd_split_dkv_wide_kernel<DT, DROP>;
+  auto kq = mha_bwd_split_dq_wide_kernel<DT, DROP>;
+  static bool ok = false;
+  hipError_t e = ok ? hipSuccess : allow_lds(ka, lds);
+  if (e == hipSuccess && !ok) e = allow_lds(kq, lds);
+  if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+  ok = true;
+  hipLaunchKernelGGL(kq, dim3(B * H * cdiv(Tq, 64)), dim3(256), lds, st, Q, K, V, dO, lse, O, delta, dQ, B, Tq, Tk, dk, H, inv_scale, causal, dc);
+  int rc = check_launch(fn);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ka, dim3(B * H * cdiv(Tk, 64)), dim3(256), lds, st, Q, K, V, dO, lse, (const float*)delta, dK, dV, B, Tq, Tk, dk, H, inv_scale, causal, dc);
+  return check_launch(fn);
 }
 
 // Forward in split precision (dtype TSG_F32S, no A_forward side outputs; same shapes as the backward): the dQ kernel's structure with
@@ -1986,6 +2294,23 @@ static int mha_bwd_impl(const void* Q, const void* K, const void* V, const void*
       case 2: TSG_SPLIT_CASE(2);
       case 3: TSG_SPLIT_CASE(3);
       default: TSG_SPLIT_CASE(4);
+    }
+#undef TSG_SPLIT_CASE
+  }
+  if (dtype == TSG_F32S && split_on && delta_ws && dh == dvh && dh % 32 == 0 && dh > 128 && dh <= 256) {    // wide heads: channel halves per wave pair
+    auto st = static_cast<hipStream_t>(stream);
+    const float* q = (const float*)Q; const float* k = (const float*)K; const float* v = (const float*)V; const float* g = (const float*)dO;
+    const float* o = (const float*)O; const float* l = (const float*)lse; float* dl = (float*)delta_ws;
+    float* dq = (float*)dQ; float* dk_ = (float*)dK; float* dv_ = (float*)dV;
+    const float is = 1.f / scale;
+#define TSG_SPLIT_CASE(DT) \
+    return dc.thresh ? launch_bwd_split_wide<DT, true>(fn, q, k, v, o, g, l, dl, dq, dk_, dv_, B, Tq, Tk, d_key, n_heads, is, causal, dc, st) \
+                     : launch_bwd_split_wide<DT, false>(fn, q, k, v, o, g, l, dl, dq, dk_, dv_, B, Tq, Tk, d_key, n_heads, is, causal, dc, st)
+    switch (dh / 32) {
+      case 5: TSG_SPLIT_CASE(5);
+      case 6: TSG_SPLIT_CASE(6);
+      case 7: TSG_SPLIT_CASE(7);
+      default: TSG_SPLIT_CASE(8);
     }
 #undef TSG_SPLIT_CASE
   }

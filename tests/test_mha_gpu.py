@@ -191,10 +191,11 @@ def test_attention_dropout_under_graph_capture():
     (1, 300, 257, 192, 2, False, 0.0),    # head width 96, several 128-row blocks, ragged
     (2, 64, 64, 512, 8, False, 0.3),      # head width 64, attention dropout (mask regenerated from the counters)
     (1, 512, 512, 1024, 8, True, 0.1),    # config-4 length, causal + dropout
-    (2, 128, 128, 2048, 8, False, 0.0),   # head width 256 (Self_Attention_predictor at d = 1024): split forward, exact wide backward
-    (1, 200, 150, 1280, 8, False, 0.25),  # head width 160, ragged blocks, dropout
+    (2, 128, 128, 2048, 8, False, 0.0),   # head width 256 (Self_Attention_predictor at d = 1024): split forward, wide split backward (channel halves per wave pair)
+    (1, 200, 150, 1280, 8, False, 0.25),  # head width 160 (second half: one tile), ragged blocks, dropout
+    (1, 70, 70, 448, 2, True, 0.0),       # head width 224, causal, ragged
     (1, 70, 45, 384, 2, True, 0.1),       # head width 192, ragged, causal needs Tq == Tk -> see below
-    (2, 100, 20, 1280, 8, False, 0.0),    # head width 160, one key tile
+    (2, 100, 20, 1280, 8, False, 0.0),    # head width 160, one key tile (wide backward with an idle key group)
 ])
 def test_mha_split_precision(B, Tq, Tk, d, h, causal, p):
     """dtype TSG_F32S (the 'f32s' GEMM mode): the attention products as bf16 hi/lo products on the MFMA -- one forward kernel with an
