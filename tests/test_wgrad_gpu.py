@@ -99,3 +99,21 @@ def test_wgrad_argument_checks():
         F.wgrad_f32s(A[:, :128], B)
     with pytest.raises(RuntimeError):
         F.wgrad_f32s(A.cpu(), B.cpu())
+
+
+def test_wgrad_alternate_tile_variant():
+    """TSG_WGRAD_CFG=1 (128 x 128 tiles, two workgroups per CU) is read once per process: checked in a child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from shufflingvideosfortsg_amd import functional as F\n"
+        "g = torch.Generator().manual_seed(2)\n"
+        "for (M, N, K) in ((2560, 1024, 1024), (4128, 256, 384)):\n"
+        "    A = torch.randn(M, N, generator=g).cuda(); B = torch.randn(M, K, generator=g).cuda()\n"
+        "    C = F.wgrad_f32s(A, B)[0]; ref = A.double().t() @ B.double()\n"
+        "    assert float((C.double() - ref).abs().max() / ref.abs().max()) < 1e-5\n"
+        "    assert torch.equal(C, F.wgrad_f32s(A, B)[0])\n"
+        "print('variant ok')\n") % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TSG_WGRAD_CFG="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout + r.stderr
