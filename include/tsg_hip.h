@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define TSG_VERSION 2   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points */
+#define TSG_VERSION 3   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points
+                           3: tsg_error_word (device-side expiry report); dtype TSG_BF16 (bf16 storage) in K1 / K1g / K2 / K3 / LSTM */
 #define TSG_F32 0
 #define TSG_BF16 1
 #define TSG_F32S 2   /* fp32 storage; matrix products as split-precision bf16 MFMAs (x = hi + lo; hi*hi + hi*lo + lo*hi,
@@ -171,6 +172,12 @@ int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* Whh, void* o
  * checks it on every LSTM call, so a failed launch raises at the next call instead of passing silently.               */
 int tsg_lstm_error_sink(void* flag);
 int tsg_error_sink(void* flag);          /* the same sink under its general name: the K1 backward's bounded exchange wait reports there too */
+/* The same report into DEVICE memory: a 4-byte word (caller-owned, cleared by the caller) every kernel with a bounded wait sets to
+ * 1 on expiry, in addition to the host sink.  It exists for guards that run on the device -- the host code ORs it into the fused
+ * optimizer's found_inf input, so the update of a step whose backward was corrupted by an expired wait is skipped even when the
+ * step is replayed from a HIP graph and no host code runs between its launches.  On expiry the K1 backward also poisons the
+ * affected item's da / ds / dw with NaN instead of summing incomplete partials.  NULL (default) disables it.               */
+int tsg_error_word(void* device_flag);
 /* Allow (default, TSG_LSTM_L2X) or forbid the exchange that stays inside one XCD's L2 (plain stores when a group's one-XCD
  * placement is verified); forbidden = write-through stores always.  The Python host turns it off when its start-up self-test
  * of the persistent kernels reports an expired wait.                                                                       */

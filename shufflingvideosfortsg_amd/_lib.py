@@ -23,6 +23,7 @@ _SIGNATURES = {
     "tsg_scdm_attn_bwd": [_P] * 11 + [c_longlong] + [_I] * 6 + [_P],
     "tsg_scdm_bwd_ws_bytes": [_I] * 6,
     "tsg_error_sink": [_P],
+    "tsg_error_word": [_P],
     "tsg_scdm_gate_fwd": [_P] * 8 + [_I] * 6 + [_P],
     "tsg_scdm_gate_bwd": [_P] * 15 + [c_longlong] + [_I] * 6 + [_P],
     "tsg_wgrad_f32s_ws_bytes": [c_longlong] + [_I] * 4,
@@ -83,8 +84,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)            # AttributeError here = header / library mismatch
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, c_int)
-    if lib.tsg_version() != 2:
-        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 2 expected by the Python host code")
+    if lib.tsg_version() != 3:
+        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 3 expected by the Python host code")
     _lib = lib
     return lib
 

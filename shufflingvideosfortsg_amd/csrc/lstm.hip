@@ -423,13 +423,13 @@ __device__ __forceinline__ unsigned err_word(const unsigned* sync) {
 // A bounded wait expired: raise the launch's error word (what the other workgroups look at) and, when the caller registered
 // one (tsg_lstm_error_sink), the process-wide sink -- host-mapped memory the host can read without synchronising, so a
 // failed launch is reported by the next call instead of silently leaving invalid results.
-__device__ __forceinline__ void raise_error(unsigned* sync, unsigned* esink) {
+__device__ __forceinline__ void raise_error(unsigned* sync, ErrSink esink) {
   __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (esink) __hip_atomic_store(esink, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  report_expiry(esink);
 }
 // start barrier of the persistent kernels: publish this workgroup's XCD in its group's mask, meet the grid once, and
 // report whether the whole group sits on one XCD.  false + error word set when the bounded wait expires.
-__device__ __forceinline__ bool grid_start(unsigned* sync, int group, int l2x, unsigned* esink) {
+__device__ __forceinline__ bool grid_start(unsigned* sync, int group, int l2x, ErrSink esink) {
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_or(sync + kSyncGroupWord + group, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" : : "v"(old) : "memory");       // the mask update has been performed before this workgroup counts as arrived
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
                                                                         // NW = waves = A-tiles per workgroup (8: 32 units, one workgroup
                                                                         // per CU; 4: 16 units, two independent chains per CU)
     const float* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh, float* __restrict__ out,
-    float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int Bs, int T, int h, int HLS, int flags, int bm, unsigned* __restrict__ esink) {
+    float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int Bs, int T, int h, int HLS, int flags, int bm, ErrSink esink) {
   constexpr int NT = 64 * NW, UW = 4 * NW, HTS = UW + 1;  // threads, units per workgroup, h-tile row stride
   constexpr int SV = 16 * (kPersistMaxH / 4) / NT;         // float4 of the 16-row slab per thread (4 / 8 at h = 512)
   extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice (SPLIT: two bf16 planes
@@ -772,7 +772,7 @@ template <int TW, bool SPLIT>                     // TW = 16-unit tiles per wave
 __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPLIT: split-precision bf16 MFMA arithmetic
     const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
     const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG,
-    float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int Bs, int T, int h, int flags, int bm, unsigned* __restrict__ esink) {
+    float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int Bs, int T, int h, int flags, int bm, ErrSink esink) {
   extern __shared__ __align__(16) float smem2[];
   float* Dl = smem2;                              // [16][kDLS]  this workgroup's dG tile, local column g*32 + ul
   unsigned* Dhi = reinterpret_cast<unsigned*>(Dl);          // (SPLIT: the same tile as two bf16 planes [16][kDLB] dwords)
@@ -1047,10 +1047,13 @@ static int persist_capacity(int slot, K kern, int threads, size_t lds, int per_c
   std::call_once(once, [] { for (auto& d : cache) for (auto& c : d) c.store(-1); });
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 0;
+  // the LDS attribute is per (device, INSTANTIATION): a slot serves several instantiations (hidden size x arithmetic), so it is
+  // requested for the one being launched on every call (a table hit after the first), not only when the slot's cache is filled
+  hipError_t e1 = allow_lds(kern, lds);
+  if (e1 != hipSuccess) return 0;
   int cap = cache[dev][slot].load(std::memory_order_relaxed);
   if (cap >= 0) return cap;
   int cus = 0, per = 0;
-  hipError_t e1 = allow_lds(kern, lds);
   if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, threads, lds);
   cap = (e1 == hipSuccess && per >= per_cu) ? cus * per_cu : 0;

@@ -1778,11 +1778,9 @@ int launch_bwd_split_wide(const char* fn, const float* Q, const float* K, const 
   if (outb > lds) lds = outb;
   auto ka = mha_bwd_split_dkv_wide_kernel<DT, DROP>;
   auto kq = mha_bwd_split_dq_wide_kernel<DT, DROP>;
-  static bool ok = false;
-  hipError_t e = ok ? hipSuccess : allow_lds(ka, lds);
-  if (e == hipSuccess && !ok) e = allow_lds(kq, lds);
+  hipError_t e = allow_lds(ka, lds);                       // (device, kernel)-keyed table: cheap when already set
+  if (e == hipSuccess) e = allow_lds(kq, lds);
   if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
-  ok = true;
   hipLaunchKernelGGL(kq, dim3(B * H * cdiv(Tq, 64)), dim3(256), lds, st, Q, K, V, dO, lse, O, delta, dQ, B, Tq, Tk, dk, H, inv_scale, causal, dc);
   int rc = check_launch(fn);
   if (rc) return rc;
@@ -1905,10 +1903,8 @@ int launch_fwd_split(const char* fn, const float* Q, const float* K, const float
   const size_t outb = sizeof(float) * 4 * 32 * (32 * DT + 4);
   if (outb > lds) lds = outb;
   auto kf = mha_fwd_split_kernel<DT, DROP>;
-  static bool lds_f_ok = false;
-  hipError_t e = lds_f_ok ? hipSuccess : allow_lds(kf, lds);
+  hipError_t e = allow_lds(kf, lds);
   if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
-  lds_f_ok = true;
   hipLaunchKernelGGL(kf, dim3(B * H * cdiv(Tq, 128)), dim3(256), lds, st, Q, K, V, O, lse, B, Tq, Tk, dk, H, inv_scale, causal, dc);
   return check_launch(fn);
 }
@@ -2112,10 +2108,8 @@ int launch_bwd_split(const char* fn, const float* Q, const float* K, const float
     if (out_c > lds_c) lds_c = out_c;
     const int qblocks = cdiv(Tq, 128);
     auto kc = mha_bwd_split_cross_kernel<DT, DROP>;
-    static bool lds_c_ok = false;                                          // once per instantiation (and never inside a stream capture
-    hipError_t e = lds_c_ok ? hipSuccess : allow_lds(kc, lds_c);          // after the first, eager, call)
+    hipError_t e = allow_lds(kc, lds_c);          // table hit (no runtime call) after the first, eager, launch on this device
     if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
-    lds_c_ok = true;
     if (qblocks > 1) {                                                     // several query blocks add into dK / dV
       const size_t nb = sizeof(float) * (size_t)B * Tk * dk;
       e = zero_async(dK, nb, st);
@@ -2132,11 +2126,9 @@ int launch_bwd_split(const char* fn, const float* Q, const float* K, const float
   if (out_b > lds_b) lds_b = out_b;
   auto ka = mha_bwd_split_dkv_kernel<DT, DROP>;
   auto kq = mha_bwd_split_dq_kernel<DT, DROP>;
-  static bool lds_ab_ok = false;
-  hipError_t e = lds_ab_ok ? hipSuccess : allow_lds(ka, lds_a);
-  if (e == hipSuccess && !lds_ab_ok) e = allow_lds(kq, lds_b);
+  hipError_t e = allow_lds(ka, lds_a);
+  if (e == hipSuccess) e = allow_lds(kq, lds_b);
   if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
-  lds_ab_ok = true;
   // dQ first: it also writes delta = <dO, O>, which the dK/dV kernel reads
   hipLaunchKernelGGL(kq, dim3(B * H * cdiv(Tq, 128)), dim3(256), lds_b, st, Q, K, V, dO, lse, O, delta, dQ, B, Tq, Tk, dk, H, inv_scale, causal, dc);
   int rc = check_launch(fn);

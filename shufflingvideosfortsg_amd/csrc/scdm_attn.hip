@@ -149,11 +149,13 @@ __device__ __forceinline__ float4 exp2x4(float4 v) {     // exp(2 v), v clamped 
 //   out = r * sigmoid(sent_linear(C)) with sent_linear(P sent) = P (sent W^T) + bias, so V is the
 //   pre-multiplied VW = sent W^T [B,N,Ds], and the epilogue applies bias, sigmoid and the gate:
 //   C itself, the [B*T,d]x[d,d] GEMM on it and three elementwise passes never happen.
-template <int NP, int R, bool GATE>
+// ST = storage type of the activations a, s, V (sent / VW), gr (r) and C (out): float, or bf16_t for dtype TSG_BF16 (half the
+// HBM bytes; the arithmetic, P, w and gbias stay fp32).
+template <int NP, int R, bool GATE, typename ST>
 __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
-    const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w,
-    const float* __restrict__ V, float* __restrict__ C, float* __restrict__ P,
-    const float* __restrict__ gr, const float* __restrict__ gbias,
+    const ST* __restrict__ a, const ST* __restrict__ s, const float* __restrict__ w,
+    const ST* __restrict__ V, ST* __restrict__ C, float* __restrict__ P,
+    const ST* __restrict__ gr, const float* __restrict__ gbias,
     int B, int T, int N, int H, int Ds, int TT, int tiles, int dbg) {
   constexpr int SUB = kFwdWaves * R;
   constexpr int CW = NP <= 20 ? 4 : 2;               // sentence columns per lane in phase 2 (VGPR budget)
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
   const int bid = xcd_remap(blockIdx.x, gridDim.x, tiles);
   const int b = bid / tiles, tile = bid % tiles;
   const int t_tile = tile * TT;
-  const float* ab = a + (size_t)b * T * H;
+  const ST* ab = a + (size_t)b * T * H;
 
   // A wave keeps its current clip row(s) in registers (H <= 1024: 4 float4 per lane and row) and
   // loads the NEXT sub-tile's rows before the current score loop starts.  They are waited for right
@@ -179,11 +181,10 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int t = t_first + wv * R + r;
-      const float* row = ab + (size_t)(t < T ? t : T - 1) * H + lane * 4;
+      const ST* row = ab + (size_t)(t < T ? t : T - 1) * H + lane * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        dst[r][i] = (i * 256 + lane * 4 < H) ? *reinterpret_cast<const float4*>(row + i * 256)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[r][i] = (i * 256 + lane * 4 < H) ? ld4(row + i * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   load_rows(q, t_tile);
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
   // ---- prologue: Es = exp(2 s[b]) and -2w into LDS (zero padding of Es: r = 1, masked below).
   // Up to 12 float4 per thread per round, every load issued before the first exp (the prologue is
   // latency-, not bandwidth-bound: s[b] is 80 KiB).
-  const float* sb = s + (size_t)b * N * H;
+  const ST* sb = s + (size_t)b * N * H;
   const int hp4 = HP / 4, total4 = TSG_SKIP(8) ? 0 : NP * hp4;
   constexpr int PU = 12;
   for (int base = tid; base < total4; base += PU * kFwdThreads) {
@@ -200,8 +201,7 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
     for (int u = 0; u < PU; ++u) {
       const int idx = base + u * kFwdThreads;
       const int n = idx / hp4, k = (idx % hp4) * 4;
-      v[u] = (idx < total4 && n < N && k < H) ? *reinterpret_cast<const float4*>(sb + (size_t)n * H + k)
-                                              : make_float4(-1e30f, 0.f, 0.f, 0.f);
+      v[u] = (idx < total4 && n < N && k < H) ? ld4(sb + (size_t)n * H + k) : make_float4(-1e30f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < PU; ++u) {
@@ -225,17 +225,17 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
   int cgp = 1;
   while (cgp < cgroups && cgp < kFwdWaves) cgp <<= 1;
   const int cg = wv % cgp, rs = wv / cgp, rslots = kFwdWaves / cgp;   // host guarantees cgroups <= 8
-  const float* Vb = V + (size_t)b * N * Ds;
+  const ST* Vb = V + (size_t)b * N * Ds;
   v2f vreg[NP][CW / 2];
   auto load_v = [&](int j) {
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
-      const float* src = Vb + (size_t)(n < N ? n : 0) * Ds + (j < Ds ? j : 0);
+      const ST* src = Vb + (size_t)(n < N ? n : 0) * Ds + (j < Ds ? j : 0);
       if (CW == 4) {
-        const float4 q = *reinterpret_cast<const float4*>(src);
+        const float4 q = ld4(src);
         vreg[n][0] = (v2f){q.x, q.y}; vreg[n][CW / 2 - 1] = (v2f){q.z, q.w};
       } else {
-        const float2 q = *reinterpret_cast<const float2*>(src);
+        const float2 q = ld2(src);
         vreg[n][0] = (v2f){q.x, q.y};
       }
       if (n >= N) {                                    // padded words: P is 0 there, keep V finite
@@ -256,12 +256,12 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
     for (int i = 0; i < SUB; ++i) {
       const int tl = rs + i * rslots, t = t_first + tl;
       if (tl < SUB) {
-        const float* src = gr + ((size_t)b * T + (t < T ? t : T - 1)) * Ds + (jcol < Ds ? jcol : 0);
+        const ST* src = gr + ((size_t)b * T + (t < T ? t : T - 1)) * Ds + (jcol < Ds ? jcol : 0);
         if (CW == 4) {
-          const float4 q4 = *reinterpret_cast<const float4*>(src);
+          const float4 q4 = ld4(src);
           rgv[i][0] = q4.x; rgv[i][1] = q4.y; rgv[i][CW - 2] = q4.z; rgv[i][CW - 1] = q4.w;
         } else {
-          const float2 q2 = *reinterpret_cast<const float2*>(src);
+          const float2 q2 = ld2(src);
           rgv[i][0] = q2.x; rgv[i][1] = q2.y;
         }
       }
@@ -379,9 +379,9 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
             o[cc] = rr[cc] * fast_rcp(1.f + fast_exp2(-(o[cc] + gb[cc]) * kLog2e));      // r * sigmoid(G)
         }
         if (t < T && jok) {
-          float* dst = C + ((size_t)b * T + t) * Ds + jcol;
-          if (CW == 4) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[CW - 2], o[CW - 1]);
-          else *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
+          ST* dst = C + ((size_t)b * T + t) * Ds + jcol;
+          if (CW == 4) st4(dst, make_float4(o[0], o[1], o[CW - 2], o[CW - 1]));
+          else st2(dst, make_float2(o[0], o[1]));
         }
       };
       if (GATE) {
@@ -576,6 +576,14 @@ template <int CPL> __device__ __forceinline__ void ld_cols(const float* __restri
 template <int CPL> __device__ __forceinline__ void st_cols(float* __restrict__ p, const float (&o)[CPL]) {
   if constexpr (CPL == 2) *reinterpret_cast<float2*>(p) = make_float2(o[0], o[1]);
   else *p = o[0];
+}
+template <int CPL> __device__ __forceinline__ void ld_cols(const bf16_t* __restrict__ p, float (&o)[CPL]) {   // bf16 storage
+  if constexpr (CPL == 2) { const float2 t = ld2(p); o[0] = t.x; o[1] = t.y; }
+  else o[0] = ld1(p);
+}
+template <int CPL> __device__ __forceinline__ void st_cols(bf16_t* __restrict__ p, const float (&o)[CPL]) {
+  if constexpr (CPL == 2) st2(p, make_float2(o[0], o[1]));
+  else st1(p, o[0]);
 }
 template <int CPL> __device__ __forceinline__ void exp2_cols(float (&v)[CPL]) {
 #pragma unroll
@@ -854,15 +862,18 @@ FusedPlan fused_plan(int B, int T, int N, int H, int Ds) {
 }
 
 // MROW: the row phase on the matrix pipe (see the block comment inside).
-template <int NP, bool GATE, bool MROW>
+// ST: storage type of the activations and their gradients (a, s, V, dC, gr in; da, ds, dV, dr out): float or bf16_t (TSG_BF16).
+// P, w, gbias, dw, dbias, the exchange workspace and all arithmetic stay fp32.
+template <int NP, bool GATE, bool MROW, typename ST>
 __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
-    const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w, const float* __restrict__ V,
-    const float* __restrict__ P, const float* __restrict__ dC, const float* __restrict__ gr, const float* __restrict__ gbias,
-    float* __restrict__ da, float* __restrict__ ds, float* __restrict__ dw, float* __restrict__ dV, float* __restrict__ dbias,
-    float* __restrict__ drout, float* xch, unsigned* __restrict__ cnt, unsigned* __restrict__ esink,
+    const ST* __restrict__ a, const ST* __restrict__ s, const float* __restrict__ w, const ST* __restrict__ V,
+    const float* __restrict__ P, const ST* __restrict__ dC, const ST* __restrict__ gr, const float* __restrict__ gbias,
+    ST* __restrict__ da, ST* __restrict__ ds, float* __restrict__ dw, ST* __restrict__ dV, float* __restrict__ dbias,
+    ST* __restrict__ drout, float* xch, unsigned* __restrict__ cnt, ErrSink esink,
     int B, int T, int N, int H, int Ds, int parts, int SP, int dbg) {
   constexpr int CPL = MROW ? 1 : fused_cpl<NP>(), SW = kWave * CPL;
   extern __shared__ __align__(16) float lds[];
+  __shared__ unsigned xch_failed;               // set by thread 0 when the bounded wait on the partner workgroups expired
   const int TL = MROW ? ((T + 31) & ~31) : T;   // rows of the P / de tiles in LDS (MROW: padded to whole 32-row MFMA tiles)
   float* Pl = lds;                              // [TL][NP]  P rows, zero beyond N (and beyond T)
   float* De = Pl + (size_t)TL * NP;             // [TL][NP]  partial dP -> de
@@ -905,7 +916,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
     for (int idx = lane; idx < NP * (SW / 4); idx += kWave) {
       const int n = idx / (SW / 4), c4 = (idx % (SW / 4)) * 4;
       float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N && colw + c4 < Ds) v4 = *reinterpret_cast<const float4*>(V + ((size_t)b * N + n) * Ds + colw + c4);
+      if (n < N && colw + c4 < Ds) v4 = ld4(V + ((size_t)b * N + n) * Ds + colw + c4);
       *reinterpret_cast<float4*>(myV + n * VS + c4) = v4;
     }
     f32x16 dvw[CTW];
@@ -944,9 +955,9 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
             const bool cok = col < Ds;
             const float cmask = cok ? 1.f : 0.f;
             const size_t base = ((size_t)b * T + (RAG ? 0 : tfirst)) * Ds + (cok ? col : 0);
-            const float* gp = dC + base;
-            const float* rp = gr + base;
-            float* op = drout + base;
+            const ST* gp = dC + base;
+            const ST* rp = gr + base;
+            ST* op = drout + base;
             auto ro = [&](int v) -> size_t {                        // element offset of row v from the base
               const int dt = (v & 3) + 8 * (v >> 2);
               if (!RAG) return (size_t)dt * Ds;
@@ -956,10 +967,10 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
             auto live = [&](int v) -> bool { return !RAG || tfirst + (v & 3) + 8 * (v >> 2) < T; };
             float g[16], rr[16];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) g[v] = gp[ro(v)];
+            for (int v = 0; v < 16; ++v) g[v] = ld1(gp + ro(v));
             if (GATE) {
 #pragma unroll
-              for (int v = 0; v < 16; ++v) rr[v] = rp[ro(v)];
+              for (int v = 0; v < 16; ++v) rr[v] = ld1(rp + ro(v));
             }
             float vb[NP / 2];
 #pragma unroll
@@ -977,7 +988,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
               for (int v = 0; v < 16; ++v) {
                 const float sg = fast_rcp(1.f + fast_exp2(-(G[v] + gb[ct]) * kLog2e));
                 const float drv = g[v] * sg;
-                if (cok && live(v)) op[ro(v)] = drv;
+                if (cok && live(v)) st1(op + ro(v), drv);
                 g[v] = g[v] * rr[v] * sg * (1.f - sg);             // dG: from here on "dC" (g is 0 outside the matrix)
               }
             }
@@ -1041,7 +1052,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
           float acc = dvw[ct][v];
           for (int q = 1; q < RS; ++q) acc += redm[((((size_t)(q - 1) * SP + sw) * CTW + ct) * 16 + v) * 64 + lane];
           const int n = (v & 3) + 8 * (v >> 2) + 4 * kk;
-          if (n < N && col < Ds) dV[((size_t)b * N + n) * Ds + col] = acc;
+          if (n < N && col < Ds) st1(dV + ((size_t)b * N + n) * Ds + col, acc);
         }
       }
     }
@@ -1206,12 +1217,14 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
       __hip_atomic_store(mine + idx, De[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (tid == 0) {
+      xch_failed = 0u;
       __threadfence();
       __hip_atomic_fetch_add(cnt + b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       unsigned spins = 0;
       while (!TSG_SKIP(64) && __hip_atomic_load(cnt + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)parts) {
         if (++spins > kXchSpinLimit) {
-          if (esink) __hip_atomic_store(esink, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          report_expiry(esink);                  // host sink + device word (the optimizer's guard reads the latter)
+          xch_failed = 1u;
           break;
         }
         __builtin_amdgcn_s_sleep(8);
@@ -1222,8 +1235,11 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
     // every part's partial in part order (deterministic).  Plain loads: thread 0's agent-scope acquire followed by the
     // workgroup barrier orders them after the neighbours' published stores, and they can be issued back to back (atomic
     // loads are kept in program order by the compiler: one memory round trip each, ~40 in a row).
+    // An expired wait poisons dP with NaN: da / ds / dw of this item then carry the failure instead of a finite sum of
+    // incomplete partials (a finite-but-wrong gradient would pass every isfinite guard downstream).
+    const float poison = xch_failed ? __int_as_float(0x7FC00000) : 0.f;
     for (int idx = tid; idx < T * NP; idx += kFusedThreads) {
-      float v = 0.f;
+      float v = poison;
       for (int p = 0; p < parts; ++p) v += xch[((size_t)b * parts + p) * T * NP + idx];
       De[idx] = v;
     }
@@ -1373,9 +1389,9 @@ __global__ void zero3_kernel(unsigned* p0, int n0, unsigned* p1, int n1, unsigne
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
 
-template <int NP, bool GATE>
-int launch_fwd(const float* a, const float* s, const float* w, const float* V, float* C, float* P,
-               const float* gr, const float* gbias, int B, int T, int N, int H, int Ds, hipStream_t st) {
+template <int NP, bool GATE, typename ST>
+int launch_fwd(const ST* a, const ST* s, const float* w, const ST* V, ST* C, float* P,
+               const ST* gr, const float* gbias, int B, int T, int N, int H, int Ds, hipStream_t st) {
   constexpr int R = 1;                       // clip rows per wave and sub-tile (sub-tile = 8R rows)
   constexpr int SUB = kFwdWaves * R;
   // rows per workgroup: as many as still give every CU a workgroup (the Es prologue, the launch ramp and the store
@@ -1391,13 +1407,9 @@ int launch_fwd(const float* a, const float* s, const float* w, const float* V, f
                      H, Ds, NP <= 20 ? 2048 : 1024, N);
   if (lds > (size_t)kLdsBytes)
     return set_error(TSG_E_LDS, "scdm_attn_fwd: N=%d H=%d needs %zu B of LDS (> %d)", N, H, lds, kLdsBytes);
-  auto kern = scdm_fwd_kernel<NP, R, GATE>;
-  static thread_local size_t allowed = 0;     // per instantiation
-  if (lds > allowed) {
-    hipError_t e = allow_lds(kern, lds);
-    if (e != hipSuccess) return set_error((int)e, "scdm_attn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
-    allowed = lds;
-  }
+  auto kern = scdm_fwd_kernel<NP, R, GATE, ST>;
+  hipError_t e = allow_lds(kern, lds);
+  if (e != hipSuccess) return set_error((int)e, "scdm_attn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
   hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kFwdThreads), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
   return check_launch("scdm_attn_fwd");
 }
@@ -1434,10 +1446,10 @@ inline long long split_ws_bytes(int B, int T, int N, int Ds, bool gate) {
   return (long long)sizeof(float) * ((long long)B * T * roundup(N, 4) + (gate ? (long long)B * T * Ds : 0));
 }
 
-template <int NP, bool GATE>
-int launch_bwd(const float* a, const float* s, const float* w, const float* V, const float* P,
-               const float* dC, float* da, float* ds, float* dw, float* dV, const float* gr, const float* gbias,
-               float* dbias, float* dr, void* ws, long long ws_bytes, int B, int T, int N, int H, int Ds, hipStream_t st) {
+template <int NP, bool GATE, typename ST>
+int launch_bwd(const ST* a, const ST* s, const float* w, const ST* V, const float* P,
+               const ST* dC, ST* da, ST* ds, float* dw, ST* dV, const ST* gr, const float* gbias,
+               float* dbias, ST* dr, void* ws, long long ws_bytes, int B, int T, int N, int H, int Ds, hipStream_t st) {
   const char* fn = GATE ? "tsg_scdm_gate_bwd" : "tsg_scdm_attn_bwd";
   if (Ds > (NP <= 20 ? 2048 : 1024))
     return set_error(TSG_E_SHAPE, "%s: Ds=%d (max %d at N=%d) not supported", fn, Ds, NP <= 20 ? 2048 : 1024, N);
@@ -1448,27 +1460,34 @@ int launch_bwd(const float* a, const float* s, const float* w, const float* V, c
   // plain; 256 pairs -- 2 parts instead of 1 -- 355 vs 326 us)
   const bool mrow = pm.ok && !valu_rows && (!pv.ok || pm.parts <= pv.parts);
   const FusedPlan& pl = mrow ? pm : pv;
-  if (pl.ok && !want_split()) {
+  // The parts of an item wait for each other (bounded spin).  They are `parts` block ids inside a window of 8*(parts-1)+1
+  // consecutive ids (xcd_remap keeps an item on one XCD); with in-order dispatch the oldest resident workgroup's partners
+  // are all dispatched as long as that window fits the workgroups the chip holds at once (one per CU).  Half the CUs is the
+  // margin kept for CUs a collective or another stream occupies; beyond it the two-kernel path (no waiting) runs.
+  const bool window_ok = pl.parts == 1 || 8 * (pl.parts - 1) + 1 <= device_cu_count() / 2;
+  if (pl.ok && window_ok && !want_split()) {
     if (ws_bytes < pl.ws_bytes) return set_error(TSG_E_SHAPE, "%s: workspace of %lld B < %lld B (tsg_scdm_bwd_ws_bytes)", fn, ws_bytes, pl.ws_bytes);
     float* xch = static_cast<float*>(ws);
     unsigned* cnt = reinterpret_cast<unsigned*>(xch + (size_t)B * pl.parts * T * NP);
     hipLaunchKernelGGL(zero3_kernel, dim3(4), dim3(256), 0, st, (unsigned*)dw, H, (unsigned*)dbias, GATE ? Ds : 0, cnt, B);
-    auto kern = mrow ? scdm_bwd_fused_kernel<NP, GATE, true> : scdm_bwd_fused_kernel<NP, GATE, false>;
-    static thread_local size_t allowed[2] = {0, 0};     // per instantiation
-    if (pl.lds > allowed[mrow]) {
-      hipError_t e = allow_lds(kern, pl.lds);
-      if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute(%zu): %s", fn, pl.lds, hipGetErrorString(e));
-      allowed[mrow] = pl.lds;
-    }
+    auto kern = mrow ? scdm_bwd_fused_kernel<NP, GATE, true, ST> : scdm_bwd_fused_kernel<NP, GATE, false, ST>;
+    hipError_t e = allow_lds(kern, pl.lds);
+    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute(%zu): %s", fn, pl.lds, hipGetErrorString(e));
     hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kFusedThreads), pl.lds, st, a, s, w, V, P, dC, gr, gbias, da, ds, dw, dV, dbias, dr,
                        xch, cnt, error_sink(), B, T, N, H, Ds, pl.parts, pl.SP, ablate_mask());
     return check_launch(fn);
   }
-  if (ws_bytes < split_ws_bytes(B, T, N, Ds, GATE))
-    return set_error(TSG_E_SHAPE, "%s: workspace of %lld B < %lld B (tsg_scdm_bwd_ws_bytes)", fn, ws_bytes, split_ws_bytes(B, T, N, Ds, GATE));
-  float* de = static_cast<float*>(ws);
-  float* dG = de + (size_t)B * T * roundup(N, 4);
-  return launch_bwd_split<NP, GATE>(a, s, w, V, P, dC, da, ds, dw, dV, de, gr, gbias, dbias, dr, GATE ? dG : nullptr, B, T, N, H, Ds, st);
+  if constexpr (storage_is_bf16<ST>::value) {
+    // the two-kernel path exists for fp32 storage only; the host code runs such a shape through it with fp32 copies
+    return set_error(TSG_E_SHAPE, "%s: this shape (T=%d N=%d H=%d Ds=%d: P / de tiles beyond the fused kernel's LDS, or an exchange "
+                     "window beyond the co-residency margin) is not supported with dtype TSG_BF16", fn, T, N, H, Ds);
+  } else {
+    if (ws_bytes < split_ws_bytes(B, T, N, Ds, GATE))
+      return set_error(TSG_E_SHAPE, "%s: workspace of %lld B < %lld B (tsg_scdm_bwd_ws_bytes)", fn, ws_bytes, split_ws_bytes(B, T, N, Ds, GATE));
+    float* de = static_cast<float*>(ws);
+    float* dG = de + (size_t)B * T * roundup(N, 4);
+    return launch_bwd_split<NP, GATE>(a, s, w, V, P, dC, da, ds, dw, dV, de, gr, gbias, dbias, dr, GATE ? dG : nullptr, B, T, N, H, Ds, st);
+  }
 }
 
 int check_common(const char* fn, std::initializer_list<const void*> ptrs, int B, int T, int N, int H, int Ds, int dtype) {
@@ -1476,7 +1495,8 @@ int check_common(const char* fn, std::initializer_list<const void*> ptrs, int B,
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
     if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
   }
-  if (dtype != TSG_F32) return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (fp32 only)", fn, dtype);
+  if (dtype != TSG_F32 && dtype != TSG_BF16)
+    return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32, or TSG_BF16 = bf16 storage of the activations)", fn, dtype);
   if (B <= 0 || T <= 0 || N <= 0 || H <= 0 || Ds <= 0)
     return set_error(TSG_E_SHAPE, "%s: non-positive dimension B=%d T=%d N=%d H=%d Ds=%d", fn, B, T, N, H, Ds);
   if (N > 32) return set_error(TSG_E_SHAPE, "%s: N=%d > 32 words not supported", fn, N);
@@ -1507,8 +1527,13 @@ extern "C" int tsg_scdm_attn_fwd(const void* a, const void* s, const void* w, co
   if (rc) return rc;
   const int np = roundup(N, 4);
   auto st = static_cast<hipStream_t>(stream);
-  TSG_DISPATCH_NP(np, (launch_fwd<NP, false>((const float*)a, (const float*)s, (const float*)w, (const float*)sent,
-                                             (float*)C, (float*)P, nullptr, nullptr, B, T, N, H, Ds, st)));
+  if (dtype == TSG_BF16) {
+    using S = bf16_t;
+    TSG_DISPATCH_NP(np, (launch_fwd<NP, false, S>((const S*)a, (const S*)s, (const float*)w, (const S*)sent,
+                                                  (S*)C, (float*)P, nullptr, nullptr, B, T, N, H, Ds, st)));
+  }
+  TSG_DISPATCH_NP(np, (launch_fwd<NP, false, float>((const float*)a, (const float*)s, (const float*)w, (const float*)sent,
+                                                    (float*)C, (float*)P, nullptr, nullptr, B, T, N, H, Ds, st)));
 }
 
 extern "C" long long tsg_scdm_bwd_ws_bytes(int B, int T, int N, int H, int Ds, int gate) {
@@ -1536,10 +1561,17 @@ extern "C" int tsg_scdm_attn_bwd(const void* a, const void* s, const void* w, co
   if (rc) return rc;
   const int np = roundup(N, 4);
   auto st = static_cast<hipStream_t>(stream);
-  TSG_DISPATCH_NP(np, (launch_bwd<NP, false>((const float*)a, (const float*)s, (const float*)w, (const float*)sent,
-                                             (const float*)P, (const float*)dC, (float*)da, (float*)ds, (float*)dw,
-                                             (float*)dsent, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
-                                             B, T, N, H, Ds, st)));
+  if (dtype == TSG_BF16) {
+    using S = bf16_t;
+    TSG_DISPATCH_NP(np, (launch_bwd<NP, false, S>((const S*)a, (const S*)s, (const float*)w, (const S*)sent,
+                                                  (const float*)P, (const S*)dC, (S*)da, (S*)ds, (float*)dw,
+                                                  (S*)dsent, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
+                                                  B, T, N, H, Ds, st)));
+  }
+  TSG_DISPATCH_NP(np, (launch_bwd<NP, false, float>((const float*)a, (const float*)s, (const float*)w, (const float*)sent,
+                                                    (const float*)P, (const float*)dC, (float*)da, (float*)ds, (float*)dw,
+                                                    (float*)dsent, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
+                                                    B, T, N, H, Ds, st)));
 }
 
 extern "C" int tsg_scdm_gate_fwd(const void* a, const void* s, const void* w, const void* VW, const void* gbias,
@@ -1549,8 +1581,13 @@ extern "C" int tsg_scdm_gate_fwd(const void* a, const void* s, const void* w, co
   if (rc) return rc;
   const int np = roundup(N, 4);
   auto st = static_cast<hipStream_t>(stream);
-  TSG_DISPATCH_NP(np, (launch_fwd<NP, true>((const float*)a, (const float*)s, (const float*)w, (const float*)VW,
-                                            (float*)out, (float*)P, (const float*)r, (const float*)gbias, B, T, N, H, Ds, st)));
+  if (dtype == TSG_BF16) {
+    using S = bf16_t;
+    TSG_DISPATCH_NP(np, (launch_fwd<NP, true, S>((const S*)a, (const S*)s, (const float*)w, (const S*)VW,
+                                                 (S*)out, (float*)P, (const S*)r, (const float*)gbias, B, T, N, H, Ds, st)));
+  }
+  TSG_DISPATCH_NP(np, (launch_fwd<NP, true, float>((const float*)a, (const float*)s, (const float*)w, (const float*)VW,
+                                                   (float*)out, (float*)P, (const float*)r, (const float*)gbias, B, T, N, H, Ds, st)));
 }
 
 extern "C" int tsg_scdm_gate_bwd(const void* a, const void* s, const void* w, const void* VW, const void* gbias,
@@ -1562,8 +1599,15 @@ extern "C" int tsg_scdm_gate_bwd(const void* a, const void* s, const void* w, co
   if (rc) return rc;
   const int np = roundup(N, 4);
   auto st = static_cast<hipStream_t>(stream);
-  TSG_DISPATCH_NP(np, (launch_bwd<NP, true>((const float*)a, (const float*)s, (const float*)w, (const float*)VW,
-                                            (const float*)P, (const float*)dout, (float*)da, (float*)ds, (float*)dw,
-                                            (float*)dVW, (const float*)r, (const float*)gbias,
-                                            (float*)dgbias, (float*)dr, ws, ws_bytes, B, T, N, H, Ds, st)));
+  if (dtype == TSG_BF16) {
+    using S = bf16_t;
+    TSG_DISPATCH_NP(np, (launch_bwd<NP, true, S>((const S*)a, (const S*)s, (const float*)w, (const S*)VW,
+                                                 (const float*)P, (const S*)dout, (S*)da, (S*)ds, (float*)dw,
+                                                 (S*)dVW, (const S*)r, (const float*)gbias,
+                                                 (float*)dgbias, (S*)dr, ws, ws_bytes, B, T, N, H, Ds, st)));
+  }
+  TSG_DISPATCH_NP(np, (launch_bwd<NP, true, float>((const float*)a, (const float*)s, (const float*)w, (const float*)VW,
+                                                   (const float*)P, (const float*)dout, (float*)da, (float*)ds, (float*)dw,
+                                                   (float*)dVW, (const float*)r, (const float*)gbias,
+                                                   (float*)dgbias, (float*)dr, ws, ws_bytes, B, T, N, H, Ds, st)));
 }

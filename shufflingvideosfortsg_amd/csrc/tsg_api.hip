@@ -2,14 +2,44 @@
 #include "tsg_common.h"
 
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace tsg {
 namespace {
 thread_local char g_err[512] = "";
 std::atomic<unsigned*> g_error_sink{nullptr};
+std::atomic<unsigned*> g_error_word{nullptr};
 }
 
-unsigned* error_sink() { return g_error_sink.load(std::memory_order_relaxed); }
+ErrSink error_sink() { return ErrSink{g_error_sink.load(std::memory_order_relaxed), g_error_word.load(std::memory_order_relaxed)}; }
+
+hipError_t ensure_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> told;      // (device, kernel) -> largest size set so far
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = told[{dev, kernel}];
+  if (bytes <= have) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
+
+int device_cu_count() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cus[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 
 int set_error(int code, const char* fmt, ...) {
   va_list ap;
@@ -30,5 +60,8 @@ int check_launch(const char* what) {
 // cross-workgroup exchange): a host-readable word set to 1 when a wait expired.  tsg_lstm_error_sink is the original name.
 extern "C" int tsg_error_sink(void* p) { tsg::g_error_sink.store(static_cast<unsigned*>(p), std::memory_order_relaxed); return 0; }
 extern "C" int tsg_lstm_error_sink(void* p) { return tsg_error_sink(p); }
+// The same report into DEVICE memory (a 4-byte word the caller owns and clears): what a device-side guard -- the optimizer's
+// found_inf input -- can read without the host, e.g. between the two graphs of a replayed train step.
+extern "C" int tsg_error_word(void* p) { tsg::g_error_word.store(static_cast<unsigned*>(p), std::memory_order_relaxed); return 0; }
 extern "C" int tsg_version(void) { return TSG_VERSION; }
 extern "C" const char* tsg_last_error(void) { return tsg::g_err; }

@@ -17,18 +17,25 @@ constexpr float kLog2e = 1.4426950408889634f;
 // ---- host side ---------------------------------------------------------------------------
 int set_error(int code, const char* fmt, ...);   // stores a thread-local message, returns code
 int check_launch(const char* what);              // hipGetLastError() -> 0 or positive hipError_t
-unsigned* error_sink();                          // the registered error sink (tsg_error_sink), or nullptr
+// Where a kernel with a bounded wait reports an expiry: `host` = the registered sink (tsg_error_sink: host-mapped memory the
+// host polls without synchronising), `dev` = the registered device word (tsg_error_word: device memory the optimizer's
+// skip-the-update guard reads on the device, so a corrupted backward never reaches the parameters -- also under graph replay,
+// where no host code runs between the launches).  Either may be nullptr.
+struct ErrSink { unsigned* host; unsigned* dev; };
+ErrSink error_sink();
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int roundup(int a, int b) { return cdiv(a, b) * b; }
 
-// Allow a kernel to use more than the default 64 KiB of dynamic LDS.
+// Allow a kernel to use more than the default 64 KiB of dynamic LDS.  The attribute is per (device, kernel): ensure_lds keeps a
+// process-wide table keyed by both (a mutex-protected map in tsg_api.hip) and calls hipFuncSetAttribute only when the requested
+// size exceeds what that device has been told for that kernel -- so call it on EVERY launch path (a table hit costs ~50 ns); the
+// call sites keep no one-shot flags of their own (such flags were not keyed per device).
+hipError_t ensure_lds(const void* kernel, size_t bytes);
 template <typename K>
-inline hipError_t allow_lds(K kernel, size_t bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-}
+inline hipError_t allow_lds(K kernel, size_t bytes) { return ensure_lds(reinterpret_cast<const void*>(kernel), bytes); }
+int device_cu_count();                           // CUs of the current device (cached per device)
 
 // ---- device side -------------------------------------------------------------------------
 #if defined(__HIPCC__)
@@ -36,6 +43,46 @@ inline hipError_t allow_lds(K kernel, size_t bytes) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
+// ---- storage types.  Kernels compute in fp32; `ST` is what the activations are stored as in HBM: float (TSG_F32 / TSG_F32S) or
+// bf16_t (TSG_BF16: 2 bytes per element, converted on load, rounded to nearest-even on store with v_cvt_pk_bf16_f32, which keeps
+// a NaN a NaN).  ldN / stN move N consecutive elements (N*sizeof(ST)-byte aligned).
+struct bf16_t { unsigned short bits; };
+template <typename ST> struct storage_is_bf16 { static constexpr bool value = false; };
+template <> struct storage_is_bf16<bf16_t> { static constexpr bool value = true; };
+typedef __bf16 tsg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float tsg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {      // (rne(lo), rne(hi)), lo in the low half
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((tsg_f32x2){lo, hi}, tsg_bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((unsigned)p->bits << 16); }
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 ld2(const bf16_t* p) {
+  const unsigned u = *reinterpret_cast<const unsigned*>(p);
+  return make_float2(bf16_lo(u), bf16_hi(u));
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+}
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { p->bits = (unsigned short)(pack_bf16x2(v, 0.f) & 0xffffu); }
+__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ void st2(bf16_t* p, float2 v) { *reinterpret_cast<unsigned*>(p) = pack_bf16x2(v.x, v.y); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+}
+
+__device__ __forceinline__ void report_expiry(ErrSink es) {
+  if (es.host) __hip_atomic_store(es.host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (es.dev) __hip_atomic_store(es.dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // DPP cross-lane move (bit pattern preserved).
 template <int CTRL>

@@ -357,12 +357,8 @@ Plan make_plan(long long M, int N, int K, int groups) {
 template <int WN, int WK>
 int launch(const char* fn, const WgradArgs& a, int grid, hipStream_t st) {
   using G = Geo<WN, WK>;
-  static bool lds_ok = false;
-  if (!lds_ok) {
-    hipError_t e = allow_lds(wgrad_split_kernel<WN, WK>, G::kLds);
-    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
-    lds_ok = true;
-  }
+  hipError_t e = allow_lds(wgrad_split_kernel<WN, WK>, G::kLds);
+  if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
   hipLaunchKernelGGL((wgrad_split_kernel<WN, WK>), dim3(grid), dim3(G::NT), G::kLds, st, a);
   return check_launch(fn);
 }

@@ -82,14 +82,22 @@ def make_optimizer(model, params, capturable=False):
 
 
 def optimizer_step(opt, loss):
-    """``opt.step()`` guarded on the DEVICE: a non-finite loss (a persistent LSTM launch whose bounded wait expired leaves
-    NaN sentinels in its output; an overflow) makes the fused Adam kernel skip the update -- its ``found_inf`` input, the
-    GradScaler mechanism -- so the parameters and the Adam moments are not corrupted by a step the host has already
-    enqueued.  No synchronisation; the host-side report follows at the next LSTM call / ``functional.check_lstm_errors()``.
-    With a non-fused optimizer (CPU tests) it is a plain ``opt.step()``."""
+    """``opt.step()`` guarded on the DEVICE: the fused Adam kernel skips the update -- its ``found_inf`` input, the GradScaler
+    mechanism -- when the loss is not finite (a persistent LSTM forward whose bounded wait expired leaves NaN sentinels in its
+    output; an overflow) OR when any kernel of the step reported an expired bounded wait into the device error word
+    (``functional.error_word``: the persistent LSTM backward and the K1 backward's partner exchange run AFTER the loss is
+    known to be finite -- ADVICE r2: the loss alone did not cover them; the K1 backward additionally poisons the affected
+    gradients with NaN).  So the parameters and the Adam moments are not corrupted by a step the host has already enqueued, also
+    when the step is replayed from HIP graphs.  No synchronisation; the host-side report follows at the next
+    ``functional.check_kernel_errors()`` (every LSTM call, every graph replay).  With a non-fused optimizer (CPU tests) it is a
+    plain ``opt.step()``."""
     fused = any(g.get("fused") for g in opt.param_groups)
     if fused:
-        opt.found_inf = (~torch.isfinite(loss.detach())).to(torch.float32).reshape(())
+        from . import functional as TF
+        bad = ~torch.isfinite(loss.detach()).reshape(())
+        if loss.is_cuda:
+            bad = bad | (TF.error_word(loss.device)[0] != 0)
+        opt.found_inf = bad.to(torch.float32).reshape(())
     try:
         opt.step()
     finally:
@@ -117,6 +125,7 @@ class GraphedTrainStep:
             raise ValueError("GraphedTrainStep: the gradient exchange must run after the backward (FlatGradAllReduce(overlap=False))")
         self.params = [p for p in model.parameters() if p.requires_grad]
         TF.mha_graph_rng(next(model.parameters()).device)   # K2 dropout state, created outside the capture
+        TF.error_word(next(model.parameters()).device)      # the device error word exists (and is registered) before the capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # eager warm-up on the capture stream: lazy initialisation happens here
@@ -151,7 +160,11 @@ class GraphedTrainStep:
             self.dp.zero_grad()
 
     def __call__(self):
-        """Replay one step on the current batch tensors -> the (static) loss tensor of this step."""
+        """Replay one step on the current batch tensors -> the (static) loss tensor of this step.  The pinned error sink is
+        polled on every call (a host read, no synchronisation): no Python LSTM call runs during a replay, so this is where an
+        expired wait of an EARLIER replay surfaces (its update was already skipped on the device)."""
+        from . import functional as TF
+        TF.check_kernel_errors()
         self.graph_a.replay()
         if self.dp is not None and self.dp.active:
             self.dp.exchange_static(self.grads)

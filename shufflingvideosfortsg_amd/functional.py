@@ -44,26 +44,63 @@ class _KernelTimer:
 kernel_timer = _KernelTimer()
 
 
-class LstmWaitExpired(RuntimeError):
-    pass
+class KernelWaitExpired(RuntimeError):
+    """A bounded wait inside a kernel expired (persistent LSTM hand-off, K1 backward partner exchange): the outputs of that
+    launch are invalid."""
 
 
-_lstm_sink = None          # pinned host word the persistent LSTM kernels set when a bounded wait expires (tsg_lstm_error_sink)
+LstmWaitExpired = KernelWaitExpired     # the name of rounds 1-2 (the LSTM was the only kernel with a bounded wait then)
+
+_err_sink = None           # pinned host word every kernel with a bounded wait sets on expiry (tsg_error_sink)
+_err_words = {}            # device index -> int32 [1] device tensor set on expiry as well (tsg_error_word): the optimizer guard reads it
+_selftest_done = False
+
+
+def _register_error_channels(device) -> None:
+    """Register the process-wide expiry channels with the library: the pinned host word (polled by ``check_kernel_errors``) and
+    the current device's error word (read on the device by ``engine.optimizer_step``).  Called from ``_call`` on the first launch
+    of ANY entry point (the K1 backward's exchange reported into an unregistered sink when no LSTM call had run)."""
+    global _err_sink
+    lib = load()
+    if _err_sink is None:
+        _err_sink = torch.zeros(1, dtype=torch.int32).pin_memory()
+        check(lib.tsg_error_sink(_err_sink.data_ptr()), "tsg_error_sink")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _err_words:
+        _err_words[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+        # one process drives one GPU (one rank per device): the library keeps ONE device word, that of the last device used
+        check(lib.tsg_error_word(_err_words[idx].data_ptr()), "tsg_error_word")
+
+
+def error_word(device=None) -> torch.Tensor:
+    """The device-resident expiry word (int32 [1]; non-zero after a launch whose bounded wait expired)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    _register_error_channels(device)
+    return _err_words[device.index if device.index is not None else torch.cuda.current_device()]
+
+
+def check_kernel_errors() -> None:
+    """Raise if a launch reported an expired bounded wait since the last check (its outputs are invalid).  Reads a pinned host
+    word -- no synchronisation; called on every LSTM launch, by GraphedTrainStep on every replay, and by bench.py / the tests at
+    the end of a region."""
+    if _err_sink is not None and int(_err_sink[0]) != 0:
+        _err_sink[0] = 0
+        for wd in _err_words.values():
+            wd.zero_()
+        raise KernelWaitExpired("a kernel's bounded wait on other workgroups expired (persistent LSTM hand-off or the K1 backward's "
+                                "partner exchange: workgroups not co-resident, e.g. the GPU is shared with another process?): the "
+                                "outputs of that launch are invalid and the optimizer update of that step was skipped.  "
+                                "TSG_LSTM_PERSIST=0 selects the launch-per-step LSTM kernels, TSG_K1_BWD=split the two-kernel K1 backward.")
 
 
 def check_lstm_errors() -> None:
-    """Raise if a persistent LSTM launch reported an expired bounded wait since the last check (its outputs are invalid).
-    Reads a pinned host word -- no synchronisation; called on every LSTM launch, and by bench.py / the tests at the end."""
-    global _lstm_sink
-    if _lstm_sink is None:
-        _lstm_sink = torch.zeros(1, dtype=torch.int32).pin_memory()
-        check(load().tsg_error_sink(_lstm_sink.data_ptr()), "tsg_error_sink")
+    """``check_kernel_errors`` preceded, once per process, by the persistent-LSTM self-test (before the first LSTM launch)."""
+    global _selftest_done
+    if not _selftest_done:
+        _selftest_done = True
+        _register_error_channels(torch.device("cuda", torch.cuda.current_device()))
         _lstm_selftest()
-    elif int(_lstm_sink[0]) != 0:
-        _lstm_sink[0] = 0
-        raise LstmWaitExpired("a persistent LSTM kernel's bounded wait expired (workgroups not co-resident, e.g. the GPU is shared "
-                              "with another process?): the recurrence outputs of that launch are invalid.  TSG_LSTM_PERSIST=0 "
-                              "selects the launch-per-step kernels.")
+    check_kernel_errors()
 
 
 def _lstm_selftest() -> None:
@@ -88,9 +125,11 @@ def _lstm_selftest() -> None:
         check(lib.tsg_lstm_bwd_ws_layout(ptr(W), ptr(R), ptr(Cs), ptr(out), None, ptr(dG), ptr(dC), ptr(ws), nb, None, B, T, h,
                                          TSG_F32S, 0, st), "tsg_lstm_bwd_ws_layout")
         torch.cuda.synchronize(dev)
-        if int(_lstm_sink[0]) == 0:
+        if int(_err_sink[0]) == 0:
             return
-        _lstm_sink[0] = 0
+        _err_sink[0] = 0
+        for wd in _err_words.values():
+            wd.zero_()
         if attempt == 0:
             warnings.warn("persistent LSTM self-test: a bounded wait expired with the L2-local exchange; falling back to "
                           "write-through exchange stores for this process (TSG_LSTM_L2X=0)")
@@ -104,6 +143,8 @@ def _call(name: str, like: torch.Tensor, *args) -> None:
     """Invoke one C-ABI entry point on ``like``'s current stream and raise on a non-zero return."""
     fn = getattr(load(), name)
     st = stream_of(like)
+    if like.is_cuda and like.device.index not in _err_words:
+        _register_error_channels(like.device)
     if kernel_timer.on and (kernel_timer.only is None or name.startswith(kernel_timer.only)):
         stream = torch.cuda.current_stream(like.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -464,7 +505,7 @@ def mha(Q, K, V, n_heads, scale, causal=False, return_maps=False, p_drop=0.0):
     if p_drop > 0.0:
         seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         if Q.is_cuda and torch.cuda.is_current_stream_capturing():
-            st = _mha_rng_state.get(Q.device)
+            st = _mha_rng_state.get(_cuda_device(Q.device))
             if st is None:
                 raise RuntimeError("mha: attention dropout under graph capture needs functional.mha_graph_rng(device) called before the "
                                    "capture (engine.GraphedTrainStep does)")
@@ -476,10 +517,18 @@ def mha(Q, K, V, n_heads, scale, causal=False, return_maps=False, p_drop=0.0):
     return (O, A, S) if return_maps else O
 
 
+def _cuda_device(device) -> torch.device:
+    """``device`` with its index resolved: torch.device('cuda') and torch.device('cuda', current) are different dict keys."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 def mha_graph_rng(device):
     """Create (outside any capture) the device-resident (seed, offset) state the in-kernel attention dropout uses while a HIP
     graph is being captured / replayed on ``device``."""
-    device = torch.device(device)
+    device = _cuda_device(device)
     if device not in _mha_rng_state:
         seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
         _mha_rng_state[device] = torch.tensor([seed, int(torch.randint(0, 2 ** 40, (1,)).item())], dtype=torch.int64, device=device)

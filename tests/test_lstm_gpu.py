@@ -253,12 +253,19 @@ def test_persistent_lstm_timeout_is_reported():
         "out,_=TF.bilstm_layer(x,W_ih,b,W_hh); torch.cuda.synchronize(); TF.check_lstm_errors(); assert torch.isfinite(out).all()\n"
         "os.environ['TSG_LSTM_INJECT_TIMEOUT']='1'\n"
         "out,_=TF.bilstm_layer(x,W_ih,b,W_hh); torch.cuda.synchronize()\n"
+        "assert int(TF.error_word()[0]) == 1, 'device error word not set'\n"
+        "from shufflingvideosfortsg_amd import engine\n"
+        "p=torch.nn.Parameter(torch.ones(4,device='cuda')); p.grad=torch.ones(4,device='cuda')\n"
+        "opt=torch.optim.Adam([p],lr=0.1,fused=True); engine.optimizer_step(opt, torch.zeros((),device='cuda'))\n"
+        "assert torch.equal(p.detach().cpu(), torch.ones(4)), 'update not skipped on the device after an expired wait'\n"
         "os.environ['TSG_LSTM_INJECT_TIMEOUT']='0'\n"
         "try:\n"
         "    TF.bilstm_layer(x,W_ih,b,W_hh); print('NOT RAISED')\n"
         "except TF.LstmWaitExpired as e:\n"
         "    print('raised ok')\n"
-        "out,_=TF.bilstm_layer(x,W_ih,b,W_hh); torch.cuda.synchronize(); TF.check_lstm_errors(); assert torch.isfinite(out).all(); print('recovered ok')\n"
+        "out,_=TF.bilstm_layer(x,W_ih,b,W_hh); torch.cuda.synchronize(); TF.check_lstm_errors(); assert torch.isfinite(out).all()\n"
+        "assert int(TF.error_word()[0]) == 0\n"
+        "engine.optimizer_step(opt, torch.zeros((),device='cuda')); assert not torch.equal(p.detach().cpu(), torch.ones(4)); print('recovered ok')\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "raised ok" in r.stdout and "recovered ok" in r.stdout, r.stdout + r.stderr
