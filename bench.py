@@ -42,18 +42,28 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="gmd", choices=["gmd", "qave"])
-    ap.add_argument("--B", type=int, default=64, help="clip-query pairs per GPU")
+    ap.add_argument("--B", type=int, default=64, help="clip-query pairs per GPU (--scaling weak, default) or in the GLOBAL batch (--scaling strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: B pairs per GPU, the job grows with N (default; `value` = N*B*steps / time).  strong: B is the GLOBAL batch, "
+                         "every rank takes its contiguous B/N shard (dp.shard_batch: what the reference's DataParallel does with one batch, "
+                         "train.py:343) -- BASELINE configs 3 / 4 are global batches of 64 / 128 over 4 / 8 GPUs = 16 pairs per GPU")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the train step from two HIP graphs (engine.GraphedTrainStep) in THIS process and report it next to the "
+                         "eager step; auto = on when N > 1 (eight ranks share one host: 0.15 instead of 12 ms of host time per step), and "
+                         "then the faster of the two is `value` (`value_mode` says which)")
     ap.add_argument("--T", type=int, default=128)
     ap.add_argument("--N", type=int, default=20)
     ap.add_argument("--d", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=32, help="pairs in the CPU-baseline sample (0 = skip); bounded to ~30 s")
     ap.add_argument("--no-micro", action="store_true", help="skip the stand-alone K1 / K2 launches")
-    ap.add_argument("--dtype", default="f32s", choices=["f32", "bf16", "f32s"],
-                    help="precision mode of the GEMM-shaped glue (LSTM GEMMs and recurrence products, large projections); the hot-path "
-                         "HIP kernels are f32 in all of them.  "
-                         "f32s (default): split-precision bf16 MFMA products, hi*hi+hi*lo+lo*hi with fp32 accumulate -- error at the "
-                         "fp32 GEMM's level, the parity suite passes at the fp32 tolerances, and it is above the bf16 that BASELINE "
-                         "config 2 names; f32: rocBLAS fp32 GEMMs; bf16: bf16 operands, fp32 accumulate (~1e-3 from the reference)")
+    ap.add_argument("--dtype", default="f32s", choices=["f32", "bf16", "f32s", "bf16g"],
+                    help="f32s (default, the fp32-parity headline): fp32 storage, matrix products as split-precision bf16 MFMA products, "
+                         "hi*hi+hi*lo+lo*hi with fp32 accumulate -- error at the fp32 GEMM's level, the parity suite passes at the fp32 "
+                         "tolerances; f32: strict fp32 (rocBLAS fp32 GEMMs, fp32 MFMA recurrence); bf16: the bf16 STORAGE path that BASELINE "
+                         "configs 2 / 4 name -- activations and their gradients live in HBM as bf16 through every hand-written kernel "
+                         "(dtype TSG_BF16), plain bf16 GEMMs, fp32 arithmetic / master weights / optimizer (~1e-2 relative to the fp32 "
+                         "reference, tests/test_bf16_storage_gpu.py); bf16g: the older operands-only mode (fp32 storage, library GEMM "
+                         "operands cast to bf16)")
     ap.add_argument("--predictor", default="mlp", choices=["mlp", "self_attn"],
                     help="boundary head: mlp (reference default, K3) or self_attn (temporal self-attention, K2 in the step)")
     ap.add_argument("--fwd-only", action="store_true",
@@ -108,6 +118,7 @@ from shufflingvideosfortsg_amd.dp import FlatGradAllReduce      # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; no sparsity)
+MFMA_F32_PEAK_TFLOPS = 157.3    # fp32-input MFMA peak = the fp32 vector rate (MI355X_MICROARCH.md)
 _T0 = time.time()
 
 
@@ -123,20 +134,30 @@ def log(msg):
         print(f"[bench {time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+ALG_FORMULA = {     # per pair; e = bytes per stored activation element (4, or 2 with dtype TSG_BF16); P and the [B,T] vectors are fp32
+    "scdm_fwd": "(2T+2N)*d*e + T*N*4   [SURVEY 8d: read a, s, sent; write C, P]",
+    "scdm_bwd": "(3T+4N)*d*e + T*N*4   [SURVEY 8d: read a, s, sent, dC, P; write da, ds, dsent]",
+    "scdm_gate_fwd": "(3T+2N)*d*e + T*N*4   [gate-fused K1g, NOT SURVEY 8d's plain-K1 figure: read a, r (2T), s, VW (2N); write out (T), P]",
+    "scdm_gate_bwd": "(5T+4N)*d*e + T*N*4   [gate-fused: read a, r, dout (3T), s, VW (2N), P; write da, dr (2T), ds, dVW (2N)]",
+    "boundary_fwd": "T*2Hm*e + 2T*4   [read y; write p_start, p_end]",
+    "boundary_bwd": "2*T*2Hm*e + 4T*4   [read y; write dy]",
+}
+
+
 def alg_bytes(kind, B, T, N, d, Hm=256, e=4):
-    """Algorithmic HBM bytes per launch (SURVEY.md 8d / DESIGN.md)."""
+    """Algorithmic HBM bytes per launch (SURVEY.md 8d / DESIGN.md; formulas in ALG_FORMULA)."""
     if kind == "scdm_fwd":
-        return B * ((2 * T + 2 * N) * d * e + T * N * e)
+        return B * ((2 * T + 2 * N) * d * e + T * N * 4)
     if kind == "scdm_bwd":
-        return B * ((3 * T + 4 * N) * d * e + T * N * e)
+        return B * ((3 * T + 4 * N) * d * e + T * N * 4)
     if kind == "scdm_gate_fwd":          # reads a, r (2T), s, VW (2N); writes out (T), P
-        return B * ((3 * T + 2 * N) * d * e + T * N * e)
+        return B * ((3 * T + 2 * N) * d * e + T * N * 4)
     if kind == "scdm_gate_bwd":          # reads a, r, dout (3T), s, VW (2N), P; writes da, dr (2T), ds, dVW (2N)
-        return B * ((5 * T + 4 * N) * d * e + T * N * e)
+        return B * ((5 * T + 4 * N) * d * e + T * N * 4)
     if kind == "boundary_fwd":
-        return B * (T * 2 * Hm * e + 2 * T * e)
+        return B * (T * 2 * Hm * e + 2 * T * 4)
     if kind == "boundary_bwd":
-        return B * (2 * T * 2 * Hm * e + 4 * T * e)
+        return B * (2 * T * 2 * Hm * e + 4 * T * 4)
     raise KeyError(kind)
 
 
@@ -180,21 +201,33 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
         Q = torch.randn(B, T, d, device=dev); K = torch.randn(B, Tk, d, device=dev); V = torch.randn(B, Tk, d, device=dev)
         O = torch.empty(B, T, d, device=dev); lse = torch.empty(B, heads, T, device=dev); g = torch.randn(B, T, d, device=dev)
         dQ, dK, dV, dlt = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V), torch.empty_like(lse)
-        run(f"tsg_mha_fwd[{tag}: {B},{T},{Tk},{d},h{heads}]",
-            lambda: lib.tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), None, None, ptr(lse), B, T, Tk, d, d, heads, sc, 0, 0.0, 0, 0, TSG_F32, st),
+        # matrix work: forward = QK^T + PV = 4 B Tq Tk d flops, backward = five such products = 10 B Tq Tk d.  The exact kernels
+        # issue it on the fp32 MFMA (157 TFLOP/s: at ~40 flop/B they sit above that pipe's ridge, so their bound is the fp32 MFMA peak,
+        # reported next to the HBM fraction); the split-precision kernels issue 3 bf16 products per fp32 product
+        ffl, bfl = 4.0 * B * T * Tk * d, 10.0 * B * T * Tk * d
+
+        def mfma(name, flops, peak, label):
+            out[name].update({"mfma_flops": flops, "achieved_TFLOPs": round(flops / out[name]["mean_us"] / 1e6, 1),
+                              "mfma_frac": round(flops / out[name]["mean_us"] / 1e6 / peak, 4), "mfma_peak": label})
+        n = f"tsg_mha_fwd[{tag}: {B},{T},{Tk},{d},h{heads}]"
+        run(n, lambda: lib.tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), None, None, ptr(lse), B, T, Tk, d, d, heads, sc, 0, 0.0, 0, 0, TSG_F32, st),
             B * (2 * T + 2 * Tk) * d * e)
-        run(f"tsg_mha_bwd[{tag}: {B},{T},{Tk},{d},h{heads}]",
-            lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d,
-                                    heads, sc, 0, 0.0, 0, 0, TSG_F32, st),
+        mfma(n, ffl, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA 157.3 TFLOP/s")
+        n = f"tsg_mha_bwd[{tag}: {B},{T},{Tk},{d},h{heads}]"
+        run(n, lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d,
+                                       heads, sc, 0, 0.0, 0, 0, TSG_F32, st),
             B * (4 * T + 4 * Tk) * d * e)          # read Q,K,V,O,dO ; write dQ,dK,dV
+        mfma(n, bfl, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA 157.3 TFLOP/s")
         # the split-precision kernels (dtype TSG_F32S: what the "f32s" mode launches)
-        run(f"tsg_mha_fwd[{tag}, f32s: {B},{T},{Tk},{d},h{heads}]",
-            lambda: lib.tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), None, None, ptr(lse), B, T, Tk, d, d, heads, sc, 0, 0.0, 0, 0, 2, st),
+        n = f"tsg_mha_fwd[{tag}, f32s: {B},{T},{Tk},{d},h{heads}]"
+        run(n, lambda: lib.tsg_mha_fwd(ptr(Q), ptr(K), ptr(V), ptr(O), None, None, ptr(lse), B, T, Tk, d, d, heads, sc, 0, 0.0, 0, 0, 2, st),
             B * (2 * T + 2 * Tk) * d * e)
-        run(f"tsg_mha_bwd[{tag}, f32s: {B},{T},{Tk},{d},h{heads}]",
-            lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d,
-                                    heads, sc, 0, 0.0, 0, 0, 2, st),
+        mfma(n, 3 * ffl, MFMA_BF16_PEAK_TFLOPS, "bf16 MFMA 2500 TFLOP/s, 3 products per fp32 product")
+        n = f"tsg_mha_bwd[{tag}, f32s: {B},{T},{Tk},{d},h{heads}]"
+        run(n, lambda: lib.tsg_mha_bwd(ptr(Q), ptr(K), ptr(V), ptr(O), ptr(g), ptr(lse), ptr(dQ), ptr(dK), ptr(dV), ptr(dlt), B, T, Tk, d, d,
+                                       heads, sc, 0, 0.0, 0, 0, 2, st),
             B * (4 * T + 4 * Tk) * d * e)
+        mfma(n, 3 * bfl, MFMA_BF16_PEAK_TFLOPS, "bf16 MFMA 2500 TFLOP/s, 3 products per fp32 product")
     # the hand-written weight-gradient GEMM (csrc/wgrad_split.hip) at the step's three shapes: MFMA-bound, so its roofline is the
     # dense bf16 MFMA peak; flops = the bf16 matrix work it issues (3 products per fp32 product)
     for (M, Nn, Kk) in ((2 * B * T, d, d), (2 * B * N, d, d), (B * T, 512, d)):
@@ -211,24 +244,26 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
     return out
 
 
-def pmc_traffic(kernel, B, T, N, d, launch_B=None):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes, see
-    profiles/r2/k1_pmc_traffic.json; profiles/r1 for the shapes only measured there); None when no pass exists for this shape."""
+def pmc_traffic(kernel, B, T, N, d, launch_B=None, dtype="f32"):
+    """(HBM bytes per launch, source file) from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes;
+    profiles/r3 first, then r2, r1) -- a citation of a profile of the same kernel and shape, not something this run observed:
+    the JSON says so in `traffic_source`.  (None, None) when no pass exists for this shape and storage dtype."""
     launch_B = launch_B or B
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
+        rel = os.path.join("profiles", rnd, "k1_pmc_traffic.json")
         try:
-            with open(os.path.join(ROOT, "profiles", rnd, "k1_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, rel)) as f:
                 j = json.load(f)
-            if j["shape"] != {"B": B, "T": T, "N": N, "d": d, "dtype": "f32"}:
+            if j["shape"] != {"B": B, "T": T, "N": N, "d": d, "dtype": dtype}:
                 continue
             exact = j["kernels"].get(f"{kernel}@B{launch_B}")          # a pass at the launch's own pair count, if committed
             if exact:
-                return exact["hbm_bytes_per_launch"]
+                return exact["hbm_bytes_per_launch"], rel
             if kernel in j["kernels"]:
-                return int(j["kernels"][kernel]["hbm_bytes_per_launch"] * launch_B / B)
+                return int(j["kernels"][kernel]["hbm_bytes_per_launch"] * launch_B / B), rel + f" (scaled from B={B})"
         except (OSError, KeyError, ValueError):
             pass
-    return None
+    return None, None
 
 
 def cpu_baseline(kind, params, T, N, sample_B):
@@ -298,15 +333,33 @@ def main():
     # exchange groups may lose the one-XCD placement) for at most ~1 ms of hidden communication (186 MB per step)
     dp = FlatGradAllReduce(model, overlap=os.environ.get("TSG_DP_OVERLAP", "0") == "1")
     opt = engine.make_optimizer(model, params)
-    batch = data.synthetic_batch(a.B, a.T, a.N, seed=1234 + rank, pair=(a.model == "gmd"), device=dev)
-
-    gdt = {"f32": None, "bf16": torch.bfloat16, "f32s": "f32s"}[a.dtype]
+    # weak scaling: B pairs per rank.  strong scaling: B is the GLOBAL batch; every rank builds the same global batch (same seed)
+    # and keeps its contiguous shard, as the reference's DataParallel scatters one batch over the GPUs (train.py:343)
+    if a.scaling == "strong":
+        if a.B % world:
+            raise SystemExit(f"--scaling strong: the global batch {a.B} must be divisible by --gpus {world}")
+        from shufflingvideosfortsg_amd.dp import shard_batch
+        Bl, Bglobal = a.B // world, a.B
+        batch = shard_batch(data.synthetic_batch(a.B, a.T, a.N, seed=1234, pair=(a.model == "gmd")), rank, world)
+        batch = data.to_device(batch, dev)
+    else:
+        Bl, Bglobal = a.B, a.B * world
+        batch = data.synthetic_batch(a.B, a.T, a.N, seed=1234 + rank, pair=(a.model == "gmd"), device=dev)
+    # the bf16 storage mode keeps the clip features resident in its storage dtype (inputs are resident in HBM before the timed region
+    # in every mode; which dtype they are resident in is part of the mode)
+    batch_bf16 = dict(batch)
+    for k in ("video", "pseudo_video"):
+        if k in batch:
+            batch_bf16[k] = batch[k].to(torch.bfloat16)
+    MODES = {"f32": None, "bf16": "bf16", "f32s": "f32s", "bf16g": torch.bfloat16}
+    gdt = MODES[a.dtype]
 
     def forward():
+        bt = batch_bf16 if (isinstance(gdt, str) and gdt == "bf16") else batch
         with engine.precision(gdt):
             if a.model == "gmd":
-                return engine.gmd_step(model, batch, params)[0]
-            return engine.baseline_step(model, batch)[0]
+                return engine.gmd_step(model, bt, params)[0]
+            return engine.baseline_step(model, bt)[0]
 
     def train_step():
         dp.zero_grad()
@@ -352,7 +405,7 @@ def main():
             gstep()
         dt4, enq4, loss4 = timed(gstep, a.steps)
         functional.check_lstm_errors()
-        out = {"graph_replay": {"value": round(a.B * world * a.steps / dt4, 2), "unit": "pairs/s", "ms_per_step": round(dt4 / a.steps * 1e3, 3),
+        out = {"graph_replay": {"value": round(Bglobal * a.steps / dt4, 2), "unit": "pairs/s", "ms_per_step": round(dt4 / a.steps * 1e3, 3),
                                 "host_enqueue_ms_per_step": round(enq4 / a.steps * 1e3, 3), "finite": bool(torch.isfinite(loss4)),
                                 "note": "same step and mode replayed from two HIP graphs (forward+losses+backward | guarded Adam), gradient "
                                         "exchange eager between them (engine.GraphedTrainStep); measured in a child process"}}
@@ -378,10 +431,12 @@ def main():
 
     # side measurements, outside the timed region above and never `value`: the same K steps in the other library-GEMM
     # modes (strict fp32 library GEMMs, and the bf16 operands that BASELINE config 2 names)
-    MODES = {"f32": None, "bf16": torch.bfloat16, "f32s": "f32s"}
     NOTES = {"f32": "all-f32 (rocBLAS fp32 MFMA GEMMs)",
-             "bf16": "library GEMM operands bf16, fp32 accumulate; HIP kernels, recurrent state, softmax, losses, optimizer "
-                     "f32; deviates ~1e-3 from the fp32 reference",
+             "bf16": "bf16 STORAGE (BASELINE configs 2 / 4): activations and their gradients in HBM as bf16 through every hand-written "
+                     "kernel of the step (dtype TSG_BF16: K1g, K3, K5, persistent LSTM), plain bf16 MFMA GEMMs, fp32 arithmetic inside "
+                     "the kernels, fp32 cell state / softmax / losses / master weights / optimizer; ~1e-2 relative to the fp32 reference",
+             "bf16g": "library GEMM operands bf16, fp32 accumulate, fp32 storage; HIP kernels, recurrent state, softmax, losses, "
+                      "optimizer f32; deviates ~1e-3 from the fp32 reference",
              "f32s": "LSTM GEMMs, LSTM recurrence products and the large projections as split-precision bf16 MFMA products "
                      "(hi*hi+hi*lo+lo*hi, fp32 accumulate: fp32-GEMM-level error, passes the fp32 parity suite); everything else f32"}
     alt = []
@@ -391,7 +446,7 @@ def main():
         for _ in range(2):
             step()
         dt2, _, loss2 = timed(step, a.steps)
-        alt.append({"dtype": mode, "value": round(a.B * world * a.steps / dt2, 2), "unit": "pairs/s",
+        alt.append({"dtype": mode, "value": round(Bglobal * a.steps / dt2, 2), "unit": "pairs/s",
                     "ms_per_step": round(dt2 / a.steps * 1e3, 3), "finite": bool(torch.isfinite(loss2)), "note": NOTES[mode]})
         log(f"alternate GEMM mode {mode}: {alt[-1]['ms_per_step']} ms/step")
     gdt = gdt_main
@@ -405,7 +460,7 @@ def main():
         ms_ = torch.cuda.memory_stats()
         log(f"forward-only: host enqueue {enq3 / a.steps * 1e3:.3f} ms/step; device allocs {ms_.get('num_device_alloc')} frees {ms_.get('num_device_free')} "
             f"reserved {ms_.get('reserved_bytes.all.current', 0) / 2**30:.1f} GiB retries {ms_.get('num_alloc_retries')}")
-        fwd_only = {"value": round(a.B * world * a.steps / dt3, 2), "unit": "pairs/s", "ms_per_step": round(dt3 / a.steps * 1e3, 3),
+        fwd_only = {"value": round(Bglobal * a.steps / dt3, 2), "unit": "pairs/s", "ms_per_step": round(dt3 / a.steps * 1e3, 3),
                     "finite": bool(torch.isfinite(loss3)), "note": "forward + losses under no_grad, same batch and mode as `value`"}
         log(f"forward-only: {fwd_only['ms_per_step']} ms/step")
     functional.check_lstm_errors()
@@ -416,7 +471,7 @@ def main():
         import subprocess
 
         def graph_child(dtype):
-            cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(a.steps), "--model", a.model, "--B", str(a.B),
+            cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(a.steps), "--model", a.model, "--B", str(Bl),
                    "--T", str(a.T), "--N", str(a.N), "--d", str(a.d), "--dtype", dtype, "--predictor", a.predictor]
             try:
                 r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
@@ -428,6 +483,47 @@ def main():
         graph_replay = graph_child(a.dtype)
         log(f"graph replay: {graph_replay}")
 
+    # the same train step replayed from two HIP graphs IN THIS PROCESS (every rank), gradient exchange eager between them:
+    # what --gpus N > 1 runs by default.  A rank that cannot capture reports it and ALL ranks skip the leg (agreed by an
+    # all-reduce) -- a half-captured world would deadlock in the exchange.
+    graph_inproc = None
+    enq_ranks = [round(t_enq / a.steps * 1e3, 3)]
+    if use_dist:
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = t_enq / a.steps * 1e3
+        dist.all_reduce(t)
+        enq_ranks = [round(float(v), 3) for v in t.tolist()]
+    want_graph = (not a.fwd_only) and (a.graph == "on" or (a.graph == "auto" and world > 1))
+    if want_graph:
+        gstep, err = None, ""
+        try:
+            opt_g = engine.make_optimizer(model, params, capturable=True)
+            gstep = engine.GraphedTrainStep(model, opt_g, lambda m, b: forward(), batch, dp=dp)
+        except Exception as e:                                    # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"[:300]
+        ok = torch.tensor([1.0 if gstep is not None else 0.0], device=dev)
+        if use_dist:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0:
+            for _ in range(3):
+                gstep()
+            dtg, enqg, lossg = timed(gstep, a.steps)
+            functional.check_lstm_errors()
+            genq = [round(enqg / a.steps * 1e3, 3)]
+            if use_dist:
+                t = torch.zeros(world, device=dev, dtype=torch.float64)
+                t[rank] = enqg / a.steps * 1e3
+                dist.all_reduce(t)
+                genq = [round(float(v), 3) for v in t.tolist()]
+            graph_inproc = {"value": round(Bglobal * a.steps / dtg, 2), "unit": "pairs/s", "ms_per_step": round(dtg / a.steps * 1e3, 3),
+                            "host_enqueue_ms_per_step_by_rank": genq, "finite": bool(torch.isfinite(lossg)),
+                            "note": "same step, mode and batch replayed from two HIP graphs in this process on every rank "
+                                    "(forward+losses+backward | guarded Adam), RCCL gradient exchange eager between them"}
+            log(f"graph replay (in process): {graph_inproc['ms_per_step']} ms/step")
+        else:
+            graph_inproc = {"error": err or "another rank could not capture the step"}
+            log(f"graph replay (in process) skipped: {graph_inproc['error']}")
+
     if rank == 0:
         kt = functional.kernel_timer.summary()          # (name, dims) -> (mean us, launches, median us)
         kern = {}
@@ -436,45 +532,59 @@ def main():
             key = {"tsg_scdm_attn_fwd": "scdm_fwd", "tsg_scdm_attn_bwd": "scdm_bwd",
                    "tsg_scdm_gate_fwd": "scdm_gate_fwd", "tsg_scdm_gate_bwd": "scdm_gate_bwd",
                    "tsg_boundary_score_fwd": "boundary_fwd", "tsg_boundary_score_bwd": "boundary_bwd"}.get(name)
+            esz = 2 if (dims and dims[-1] == 1) else 4    # last integer argument = dtype: TSG_BF16 (1) stores activations in 2 bytes
             if key and key.startswith("scdm"):            # dims = (B, T, N, H, Ds, dtype)
-                by = alg_bytes(key, dims[0], dims[1], dims[2], dims[3])
+                by = alg_bytes(key, dims[0], dims[1], dims[2], dims[3], e=esz)
             elif key:                                     # dims = (B, T, Hm, dtype)
-                by = alg_bytes(key, dims[0], dims[1], 0, 0, Hm=dims[2])
+                by = alg_bytes(key, dims[0], dims[1], 0, 0, Hm=dims[2], e=esz)
             else:
                 by = None
             if by:
-                entry.update(alg_bytes=by, achieved_GBs=round(by / us / 1e3, 1), frac=round(by / us / 1e3 / HBM_PEAK_GBS, 4))
+                entry.update(alg_bytes=by, alg_bytes_formula=ALG_FORMULA[key] + f", e={esz}", achieved_GBs=round(by / us / 1e3, 1),
+                             frac=round(by / us / 1e3 / HBM_PEAK_GBS, 4))
             kern[f"{name}{list(dims[:-1])}"] = entry
         if not a.no_micro:
             log("stand-alone K1 / K2 launches")
-            kern.update(micro_kernels(a.B, a.T, a.N, a.d))
+            kern.update(micro_kernels(Bl, a.T, a.N, a.d))
         # the cross-attention kernel as the train step launches it: scdm_fwd_kernel with the gate epilogue
         # (tsg_scdm_gate_fwd) when the recalibration layer is fused, else the plain tsg_scdm_attn_fwd
         cands = [(k, v) for k, v in kern.items() if k.startswith(("tsg_scdm_gate_fwd[", "tsg_scdm_attn_fwd[")) and "dims" in v]
         k1name, k1 = max(cands, key=lambda kv: kv[1]["launches"], default=("", {}))
         gate = k1name.startswith("tsg_scdm_gate_fwd")
-        k1B = (k1.get("dims") or [a.B])[0]
-        tr = pmc_traffic("scdm_fwd_kernel[gate]" if gate else "scdm_fwd_kernel", 64, a.T, a.N, a.d, launch_B=k1B)   # PMC passes at B=64 (+ exact ones)
+        k1B = (k1.get("dims") or [Bl])[0]
+        k1bf = bool(k1.get("dims")) and k1["dims"][-1] == 1
+        tr, tr_src = pmc_traffic("scdm_fwd_kernel[gate]" if gate else "scdm_fwd_kernel", 64, a.T, a.N, a.d, launch_B=k1B,
+                                 dtype="bf16" if k1bf else "f32")                               # PMC passes at B=64 (+ exact ones)
         roof = {"kernel": "scdm_fwd_kernel<GATE=%s> (%s)" % ("true" if gate else "false", k1name.split("[")[0]), "bound": "hbm",
                 "achieved": k1.get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": k1.get("frac"), "traffic": tr,
+                "traffic_source": (tr_src + ": committed rocprofv3 PMC pass (FETCH_SIZE x2 + WRITE_SIZE) of the same kernel and shape -- a "
+                                   "profile citation, not observed by this run") if tr_src else None,
                 "pairs_per_launch": k1B,
-                "alg_bytes_per_launch": k1.get("alg_bytes"), "mean_launch_us": k1.get("mean_us"),
-                "launches_timed": k1.get("launches")}
+                "alg_bytes_per_launch": k1.get("alg_bytes"), "alg_bytes_formula": k1.get("alg_bytes_formula"),
+                "mean_launch_us": k1.get("mean_us"), "launches_timed": k1.get("launches")}
         what = "fwd-only" if a.fwd_only else "fwd+bwd"
         wl = (f"{a.model}_forward: fwd+losses under no_grad, " if a.fwd_only else
               f"{a.model}_train_step: fwd+losses+bwd+grad-allreduce+Adam, ")
-        out = {"metric": f"clip-query pairs/sec {what} at B={a.B},T={a.T},d={a.d}", "value": round(a.B * world * a.steps / dt, 2),
+        eager = {"value": round(Bglobal * a.steps / dt, 2), "ms_per_step": round(dt / a.steps * 1e3, 3)}
+        value, ms_step, value_mode = eager["value"], eager["ms_per_step"], "eager"
+        if graph_inproc and "value" in graph_inproc and graph_inproc["finite"] and graph_inproc["value"] > value:
+            value, ms_step, value_mode = graph_inproc["value"], graph_inproc["ms_per_step"], "graph_replay"
+        bdesc = (f"global B={a.B} sharded over {world} GPU(s) = {Bl}/GPU (strong scaling)" if a.scaling == "strong" else f"B={a.B}/GPU")
+        out = {"metric": f"clip-query pairs/sec {what} at B={a.B},T={a.T},d={a.d}", "value": value,
                "unit": "pairs/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 1,
                "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": ms_step, "higher_is_better": True, "scaling": a.scaling,
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": wl + f"B={a.B}/GPU,T_clip={a.T},T_word={a.N},d={a.d}, i3d width 1024, GloVe 300"
+               "value_mode": value_mode + (": the same full step replayed from two HIP graphs per rank (engine.GraphedTrainStep)"
+                                           if value_mode == "graph_replay" else ": one Python-enqueued step per iteration"),
+               "eager": eager, "graph_replay_in_process": graph_inproc,
+               "config": {"workload": wl + f"{bdesc},T_clip={a.T},T_word={a.N},d={a.d}, i3d width 1024, GloVe 300"
                                       + ("" if a.predictor == "mlp" else f", boundary head {a.predictor}")
                                       + ("" if a.dtype == "f32" else "; " + NOTES[a.dtype]),
-                          "global_batch": a.B * world, "parallelism": f"dp{world}", "grad_bytes": dp.grad_bytes},
+                          "global_batch": Bglobal, "pairs_per_gpu": Bl, "parallelism": f"dp{world}", "grad_bytes": dp.grad_bytes},
                "roofline": roof, "alt_gemm_modes": alt, "fwd_only": fwd_only, "graph_replay": graph_replay, "kernels": kern,
-               "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
+               "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3), "host_enqueue_ms_per_step_by_rank": enq_ranks,
                "cpu_baseline": cpu_baseline(a.model, params, a.T, a.N, a.cpu_sample) if (a.cpu_sample > 0 and world == 1) else None}
         os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
     if use_dist:

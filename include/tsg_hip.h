@@ -231,11 +231,12 @@ int tsg_gmd_losses_bwd(const void* ps, const void* pe, const void* om, const voi
 /* ---- K5: matching head (VideoTextSemanticMatch = VideoTextConcat + TwoLayerdMLP, components/DistributionAlign.py:51-98)
  * after the video-half GEMM, as K3 does for the boundary head: y [B,T,H] = video @ W1v^T (no bias), cs [B,H] = query @ W1s^T
  * + b1, w2 [H], b2 [1]:   logits[b,t] = w2 . act(y[b,t,:] + cs[b,:]) + b2,   activation 0 = relu, 1 = tanh, 2 = sigmoid.
- * The backward writes dy [B,T,H] and accumulates dcs [B,H], dw2 [H], db2 [1] (zeroed by the call).  H % 4 == 0, H <= 1024. */
+ * The backward writes dy [B,T,H] and accumulates dcs [B,H], dw2 [H], db2 [1] (zeroed by the call).  H % 4 == 0, H <= 1024.
+ * dtype (ABI revision 3): TSG_F32, or TSG_BF16 = y and dy stored as bf16 (cs, w2, b2, logits and the sums stay fp32).    */
 int tsg_match_head_fwd(const void* y, const void* cs, const void* w2, const void* b2, void* logits,
-                       int B, int T, int H, int activation, void* stream);
+                       int B, int T, int H, int activation, int dtype, void* stream);
 int tsg_match_head_bwd(const void* y, const void* cs, const void* w2, const void* dlogits, void* dy, void* dcs,
-                       void* dw2, void* db2, int B, int T, int H, int activation, void* stream);
+                       void* dw2, void* db2, int B, int T, int H, int activation, int dtype, void* stream);
 
 /* ---- dense projection GEMM on the fp32 matrix cores ("tsg_gemm_*" of SURVEY section 8b) ------------------------------
  * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL): torch.nn.Linear's layout, i.e. the d x d projections of the path

@@ -38,8 +38,8 @@ _SIGNATURES = {
     "tsg_lstm_error_sink": [_P],
     "tsg_lstm_set_l2_exchange": [_I],
     "tsg_lstm_set_persist": [_I],
-    "tsg_match_head_fwd": [_P] * 5 + [_I] * 4 + [_P],
-    "tsg_match_head_bwd": [_P] * 8 + [_I] * 4 + [_P],
+    "tsg_match_head_fwd": [_P] * 5 + [_I] * 5 + [_P],
+    "tsg_match_head_bwd": [_P] * 8 + [_I] * 5 + [_P],
     "tsg_gmd_losses_fwd": [_P] * 13 + [_I, _I, c_float, c_float, c_float, _P],
     "tsg_gmd_losses_bwd": [_P] * 20 + [_I, _I, c_float, c_float, c_float, _P],
     "tsg_lstm_fwd_bias": [_P] * 7 + [_I] * 5 + [_P],

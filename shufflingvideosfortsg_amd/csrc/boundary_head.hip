@@ -67,8 +67,11 @@ __device__ void block_softmax(float* v, int T, float* scratch) {
 constexpr int TR = 32;                 // rows per workgroup
 constexpr int RW = TR / kWaves;        // rows per wave
 
+// ST: storage type of y (and dy in the backward): float or bf16_t (dtype TSG_BF16).  cs, the parameters, gate, the
+// probabilities and every accumulator stay fp32 (they are [B,T] / [B,J]-sized).
+template <typename ST>
 __global__ __launch_bounds__(kThreads) void boundary_logits_kernel(
-    const float* __restrict__ y, const float* __restrict__ cs, const float* __restrict__ b1,
+    const ST* __restrict__ y, const float* __restrict__ cs, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ gate,
     const int* __restrict__ mask, float* __restrict__ ls, float* __restrict__ le, int B, int T, int Hm, int tiles) {
   const int lane = threadIdx.x & 63, wv = wave_id();
@@ -80,8 +83,7 @@ __global__ __launch_bounds__(kThreads) void boundary_logits_kernel(
 #pragma unroll
     for (int i = 0; i < kMaxJ4; ++i) {
       const int j = i * 256 + lane * 4;
-      yv[r][i] = (t0 + r < T && j < J) ? *reinterpret_cast<const float4*>(y + ((size_t)b * T + t0 + r) * J + j)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      yv[r][i] = (t0 + r < T && j < J) ? ld4(y + ((size_t)b * T + t0 + r) * J + j) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   float c[kMaxJ4][4], bb[kMaxJ4][4], ww[kMaxJ4][4];
 #pragma unroll
@@ -175,10 +177,11 @@ __global__ __launch_bounds__(kThreads) void boundary_dl_kernel(
 // ---- backward, kernel 2 (grid = B * ceil(T/TR)):  dz = dl*w2*(1-u^2);  dy = g*dz;
 // dcs[b,:] += sum_t g*dz;  db1p[b,:] += sum_t dz;  dw2p[b,:] += sum_t dl*u  (atomics: ceil(T/32) adders
 // per address, buffers zeroed by kernel 1);  dgate[b,t] = sum_j dz*(y+cs). ----
+template <typename ST>
 __global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
-    const float* __restrict__ y, const float* __restrict__ cs, const float* __restrict__ b1,
+    const ST* __restrict__ y, const float* __restrict__ cs, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ gate, const float* __restrict__ dl,
-    float* __restrict__ dy, float* __restrict__ dcs, float* __restrict__ db1p,
+    ST* __restrict__ dy, float* __restrict__ dcs, float* __restrict__ db1p,
     float* __restrict__ dw2p, float* __restrict__ dgate, int B, int T, int Hm, int tiles) {
   extern __shared__ float red[];                 // [kWaves][3][J]
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
@@ -190,8 +193,7 @@ __global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < kMaxJ4; ++i) {
       const int j = i * 256 + lane * 4;
-      yv[r][i] = (t0 + r < T && j < J) ? *reinterpret_cast<const float4*>(y + ((size_t)b * T + t0 + r) * J + j)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      yv[r][i] = (t0 + r < T && j < J) ? ld4(y + ((size_t)b * T + t0 + r) * J + j) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   float c[kMaxJ4][4], bb[kMaxJ4][4], ww[kMaxJ4][4];
   float acs[kMaxJ4][4], ab1[kMaxJ4][4], aw2[kMaxJ4][4];
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
     if (t >= T) break;
     const float g = gate ? gate[(size_t)b * T + t] : 1.f;
     const float dl0 = dl[((size_t)b * T + t) * 2], dl1 = dl[((size_t)b * T + t) * 2 + 1];
-    float* dyr = dy + ((size_t)b * T + t) * J;
+    ST* dyr = dy + ((size_t)b * T + t) * J;
     float dg = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxJ4; ++i) {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
           aw2[i][q] = fmaf(dlv, u, aw2[i][q]);
           dg = fmaf(dz, pre, dg);
         }
-        *reinterpret_cast<float4*>(dyr + j) = make_float4(o[0], o[1], o[2], o[3]);
+        st4(dyr + j, make_float4(o[0], o[1], o[2], o[3]));
       }
     }
     if (dgate) {
@@ -266,7 +268,8 @@ __global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
 }
 
 int check(const char* fn, int B, int T, int Hm, int dtype) {
-  if (dtype != TSG_F32) return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (fp32 only)", fn, dtype);
+  if (dtype != TSG_F32 && dtype != TSG_BF16)
+    return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32, or TSG_BF16 = y / dy stored as bf16)", fn, dtype);
   if (B <= 0 || T <= 0 || Hm <= 0) return set_error(TSG_E_SHAPE, "%s: non-positive dimension B=%d T=%d Hm=%d", fn, B, T, Hm);
   if ((2 * Hm) % 4 || 2 * Hm > 256 * kMaxJ4)
     return set_error(TSG_E_SHAPE, "%s: 2*Hm=%d must be a multiple of 4 and <= %d", fn, 2 * Hm, 256 * kMaxJ4);
@@ -290,9 +293,14 @@ extern "C" int tsg_boundary_score_fwd(const void* y, const void* cs, const void*
   if (rc) return rc;
   auto st = static_cast<hipStream_t>(stream);
   const int tiles = cdiv(T, TR);
-  hipLaunchKernelGGL(boundary_logits_kernel, dim3(B * tiles), dim3(kThreads), 0, st,
-                     (const float*)y, (const float*)cs, (const float*)b1, (const float*)w2, (const float*)b2,
-                     (const float*)gate, mask, (float*)p_start, (float*)p_end, B, T, Hm, tiles);
+  if (dtype == TSG_BF16)
+    hipLaunchKernelGGL(boundary_logits_kernel<bf16_t>, dim3(B * tiles), dim3(kThreads), 0, st,
+                       (const bf16_t*)y, (const float*)cs, (const float*)b1, (const float*)w2, (const float*)b2,
+                       (const float*)gate, mask, (float*)p_start, (float*)p_end, B, T, Hm, tiles);
+  else
+    hipLaunchKernelGGL(boundary_logits_kernel<float>, dim3(B * tiles), dim3(kThreads), 0, st,
+                       (const float*)y, (const float*)cs, (const float*)b1, (const float*)w2, (const float*)b2,
+                       (const float*)gate, mask, (float*)p_start, (float*)p_end, B, T, Hm, tiles);
   rc = check_launch(fn);
   if (rc) return rc;
   const size_t lds = sizeof(float) * (2 * (size_t)T + 2 * kWaves);
@@ -321,14 +329,21 @@ extern "C" int tsg_boundary_score_bwd(const void* y, const void* cs, const void*
   if (rc) return rc;
   const size_t lds = sizeof(float) * (size_t)kWaves * 3 * J;
   if (lds > (size_t)kLdsBytes) return set_error(TSG_E_LDS, "%s: needs %zu B of LDS", fn, lds);
-  auto kern = boundary_bwd_kernel;
-  if (lds > 64 * 1024) {
+  const int tiles = cdiv(T, TR);
+  if (dtype == TSG_BF16) {
+    auto kern = boundary_bwd_kernel<bf16_t>;
     hipError_t e = allow_lds(kern, lds);
     if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kThreads), lds, st, (const bf16_t*)y, (const float*)cs, (const float*)b1,
+                       (const float*)w2, (const float*)gate, (const float*)dl_ws, (bf16_t*)dy, (float*)dcs, (float*)db1_part,
+                       (float*)dw2_part, (float*)dgate, B, T, Hm, tiles);
+  } else {
+    auto kern = boundary_bwd_kernel<float>;
+    hipError_t e = allow_lds(kern, lds);
+    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kThreads), lds, st, (const float*)y, (const float*)cs, (const float*)b1,
+                       (const float*)w2, (const float*)gate, (const float*)dl_ws, (float*)dy, (float*)dcs, (float*)db1_part,
+                       (float*)dw2_part, (float*)dgate, B, T, Hm, tiles);
   }
-  const int tiles = cdiv(T, TR);
-  hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kThreads), lds, st, (const float*)y, (const float*)cs, (const float*)b1,
-                     (const float*)w2, (const float*)gate, (const float*)dl_ws, (float*)dy, (float*)dcs, (float*)db1_part,
-                     (float*)dw2_part, (float*)dgate, B, T, Hm, tiles);
   return check_launch(fn);
 }

@@ -478,14 +478,26 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 constexpr int kHLB = kPersistMaxH / 2 + 8;       // bf16 slab plane row stride in dwords (= 8 mod 64)
 constexpr int kSlabFloats = 2 * 16 * kHLB;       // LDS dwords of the slab region: two bf16 planes (>= the fp32 slab's 16 x 520)
 
-template <int HJ, bool SPLIT, int NW>             // HJ = h / 16 when known at compile time (no branch between MFMAs), else 0;
-__global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT: split-precision bf16 MFMA arithmetic (needs HJ > 0, even);
-                                                                        // NW = waves = A-tiles per workgroup (8: 32 units, one workgroup
+// MODE 0: fp32 storage, fp32 MFMA.  MODE 1 (TSG_F32S): fp32 storage, split-precision bf16 MFMA arithmetic (needs HJ > 0, even).
+// MODE 2 (TSG_BF16): bf16 STORAGE of Gx, out and R -- the sequence tensors; Cs, bias, W_hh and the cell state stay fp32 -- and ONE
+// bf16 MFMA per k block (W_hh rounded to bf16 once in the prologue; h_t is exchanged, and fed back, as the bf16 value written to
+// `out`).  The hand-off is the same data-is-the-flag protocol on 16-bit elements: the sentinel is a bf16 NaN pattern per
+// element (0x7FA5: never the rounding of h = o tanh(c)), the slab a workgroup polls per step is 16 KiB instead of 32.
+constexpr unsigned kSentinel16 = 0x7fa5u;
+typedef bf16_t lstm_bf16;
+template <int MODE> struct SeqT { typedef float type; };
+template <> struct SeqT<2> { typedef lstm_bf16 type; };
+
+template <int HJ, int MODE, int NW>               // HJ = h / 16 when known at compile time (no branch between MFMAs), else 0;
+__global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // NW = waves = A-tiles per workgroup (8: 32 units, one workgroup
                                                                         // per CU; 4: 16 units, two independent chains per CU)
-    const float* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh, float* __restrict__ out,
-    float* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int Bs, int T, int h, int HLS, int flags, int bm, ErrSink esink) {
+    const typename SeqT<MODE>::type* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh,
+    typename SeqT<MODE>::type* __restrict__ out, typename SeqT<MODE>::type* __restrict__ R, float* __restrict__ Cs,
+    unsigned* __restrict__ sync, int B, int Bs, int T, int h, int HLS, int flags, int bm, ErrSink esink) {
+  constexpr bool SPLIT = MODE >= 1, BF = MODE == 2;
+  typedef typename SeqT<MODE>::type GT;
   constexpr int NT = 64 * NW, UW = 4 * NW, HTS = UW + 1;  // threads, units per workgroup, h-tile row stride
-  constexpr int SV = 16 * (kPersistMaxH / 4) / NT;         // float4 of the 16-row slab per thread (4 / 8 at h = 512)
+  constexpr int SV = (BF ? 8 : 16) * (kPersistMaxH / 4) / NT;   // 16-byte pieces of the 16-row slab per thread (fp32: 4 / 8 at h = 512; bf16: half)
   extern __shared__ __align__(16) float Hl[];            // [16][HLS]  h_{t-1} rows of this batch slice (SPLIT: two bf16 planes
   float* Ht = Hl + kSlabFloats;                          // [16][kHLB] dwords), then Ht [16][33] = this step's h tile (16 rows x
   unsigned* Hhi = reinterpret_cast<unsigned*>(Hl);       // 32 units), gathered for whole-line stores
@@ -540,8 +552,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
     // (arrival counter sync[1]) so that no consumer can poll an element before its sentinel is in memory.
     {
       const int row = tid / UW, col = tid % UW;              // the same whole-line pattern as the h stores of the step loop
-      if (b0 + row < B)
-        for (int t = 0; t < T; ++t) store_sc1_u(out + seq_row(t, b0 + row, Bs, T, bm) * 2 * h + d * h + us * UW + col, kSentinel);
+      if (b0 + row < B && (!BF || (col & 1) == 0))           // bf16: the even columns mark (and later store) two elements per dword
+        for (int t = 0; t < T; ++t)
+          store_sc1_u(reinterpret_cast<float*>(out + seq_row(t, b0 + row, Bs, T, bm) * 2 * h + d * h + us * UW + col),
+                      BF ? (kSentinel16 | (kSentinel16 << 16)) : kSentinel);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -558,8 +572,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
 #endif
   float gxn[4] = {0.f, 0.f, 0.f, 0.f};                     // input gates of the NEXT step (see the loop head)
   if (live) {
-    const float* g = Gx + (seq_row(d == 0 ? 0 : T - 1, b, Bs, T, bm) * 2 + d) * 4 * h + u;
-    gxn[0] = g[0]; gxn[1] = g[h]; gxn[2] = g[2 * h]; gxn[3] = g[3 * h];
+    const GT* g = Gx + (seq_row(d == 0 ? 0 : T - 1, b, Bs, T, bm) * 2 + d) * 4 * h + u;
+    gxn[0] = ld1(g); gxn[1] = ld1(g + h); gxn[2] = ld1(g + 2 * h); gxn[3] = ld1(g + 3 * h);
   }
   for (int step = 0; step < T; ++step) {
 #ifdef TSG_LSTM_TIMING
@@ -578,42 +592,52 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
       for (int k = 0; k < 4; ++k) gx[k] = gxn[k] + bi[k];
       if (live && step + 1 < T) {
         const int tn = d == 0 ? step + 1 : T - 2 - step;
-        const float* g = Gx + (seq_row(tn, b, Bs, T, bm) * 2 + d) * 4 * h + u;
-        gxn[0] = g[0]; gxn[1] = g[h]; gxn[2] = g[2 * h]; gxn[3] = g[3 * h];
+        const GT* g = Gx + (seq_row(tn, b, Bs, T, bm) * 2 + d) * 4 * h + u;
+        gxn[0] = ld1(g); gxn[1] = ld1(g + h); gxn[2] = ld1(g + 2 * h); gxn[3] = ld1(g + 3 * h);
       }
     };
     if (step == 0) prefetch_gx();
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (step > 0) {
       f32x4 v[SV];
+      u32x4 q[SV];
+      const int nrowp = BF ? h / 8 : nrow4;                  // 16-byte pieces per h row (bf16: 8 elements each)
       {
-        // poll the slab until no element of this thread's 8 float4 is the sentinel (loads unconditional, see above)
+        // poll the slab until no element of this thread's 16-byte pieces is the sentinel (loads unconditional, see above)
         unsigned pending = 0u;
         const float* src[SV];
 #pragma unroll
         for (int i = 0; i < SV; ++i) {
-          const int idx = tid + i * NT, r = idx / nrow4, c4 = idx % nrow4;
+          const int idx = tid + i * NT, r = idx / nrowp, c4 = idx % nrowp;
           const bool ok = r < 16 && b0 + r < B;
           if (ok) pending |= 1u << i;
-          src[i] = out + seq_row(tp, ok ? b0 + r : b0, Bs, T, bm) * 2 * h + d * h + (ok ? c4 * 4 : 0);
+          src[i] = reinterpret_cast<const float*>(out + seq_row(tp, ok ? b0 + r : b0, Bs, T, bm) * 2 * h + d * h + (ok ? c4 * (BF ? 8 : 4) : 0));
         }
         // (measured and dropped: two or three staggered copies of the poll in flight -- the extra slab traffic costs more
         // than the shorter retry saves, 13.7 vs 11.5 us per step)
-        static_assert(SV == 4 || SV == 8, "the wait below lists 4 or 8 loads");
+        static_assert(SV == 2 || SV == 4 || SV == 8, "the wait below lists 2, 4 or 8 loads");
         int spins = 0;
-        u32x4 q[SV];
         while (true) {
 #pragma unroll
           for (int i = 0; i < SV; ++i) q[i] = load_sc1_u4(src[i]);
-          if constexpr (SV == 4)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : : "memory");
+          if constexpr (SV == 2)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]) : : "memory");
+          else if constexpr (SV == 4)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2 % SV]), "+v"(q[3 % SV]) : : "memory");
           else
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4 % SV]), "+v"(q[5 % SV]),
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2 % SV]), "+v"(q[3 % SV]), "+v"(q[4 % SV]), "+v"(q[5 % SV]),
                          "+v"(q[6 % SV]), "+v"(q[7 % SV]) : : "memory");
           unsigned raw = 0u;
 #pragma unroll
-          for (int i = 0; i < SV; ++i)
-            if (q[i][0] == kSentinel || q[i][1] == kSentinel || q[i][2] == kSentinel || q[i][3] == kSentinel) raw |= 1u << i;
+          for (int i = 0; i < SV; ++i) {
+            bool pend = false;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              if constexpr (BF) pend = pend || (q[i][m] & 0xffffu) == kSentinel16 || (q[i][m] >> 16) == kSentinel16;
+              else pend = pend || q[i][m] == kSentinel;
+            }
+            if (pend) raw |= 1u << i;
+          }
           raw &= pending;
 #ifdef TSG_DEBUG_SENTINEL
           if (raw) __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -638,8 +662,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
       prefetch_gx();
 #pragma unroll
       for (int i = 0; i < SV; ++i) {
-        const int idx = tid + i * NT, r = idx / nrow4, c4 = idx % nrow4;
-        if constexpr (SPLIT) {
+        const int idx = tid + i * NT, r = idx / nrowp, c4 = idx % nrowp;
+        if constexpr (BF) {
+          if (r < 16) *reinterpret_cast<u32x4*>(Hhi + r * kHLB + c4 * 4) = q[i];      // the bf16 row as it is: the one operand plane
+        } else if constexpr (SPLIT) {
           uint2 hi2, lo2;
           split_pair(v[i][0], v[i][1], hi2.x, lo2.x);
           split_pair(v[i][2], v[i][3], hi2.y, lo2.y);
@@ -664,18 +690,22 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
 #pragma unroll
         for (int j = 0; j < PFB; ++j) {
           bh[j] = *reinterpret_cast<const u32x4*>(hr + 16 * j);
-          bl[j] = *reinterpret_cast<const u32x4*>(hr + 16 * kHLB + 16 * j);
+          if constexpr (!BF) bl[j] = *reinterpret_cast<const u32x4*>(hr + 16 * kHLB + 16 * j); else bl[j] = bh[j];
         }
 #pragma unroll
         for (int j = 0; j < NJB; ++j) {
           const u32x4 vh = bh[j % PFB], vl = bl[j % PFB];
           if (j + PFB < NJB) {
             bh[j % PFB] = *reinterpret_cast<const u32x4*>(hr + 16 * (j + PFB));
-            bl[j % PFB] = *reinterpret_cast<const u32x4*>(hr + 16 * kHLB + 16 * (j + PFB));
+            if constexpr (!BF) bl[j % PFB] = *reinterpret_cast<const u32x4*>(hr + 16 * kHLB + 16 * (j + PFB));
           }
-          acc = mfma_bf16(ahi[j], vh, acc);
-          acc2 = mfma_bf16(ahi[j], vl, acc2);
-          acc3 = mfma_bf16(alo[j], vh, acc3);
+          if constexpr (BF) {                              // one product per k block, two accumulator chains
+            if (j & 1) acc2 = mfma_bf16(ahi[j], vh, acc2); else acc = mfma_bf16(ahi[j], vh, acc);
+          } else {
+            acc = mfma_bf16(ahi[j], vh, acc);
+            acc2 = mfma_bf16(ahi[j], vl, acc2);
+            acc3 = mfma_bf16(alo[j], vh, acc3);
+          }
         }
         acc += acc2 + acc3;
       } else {
@@ -720,12 +750,18 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
     lds_barrier();                                        // tile complete; the slab in LDS is free again
     {
       const int row = tid / UW, col = tid % UW;
-      if (b0 + row < B) store_x(out + seq_row(tt, b0 + row, Bs, T, bm) * 2 * h + d * h + us * UW + col, Ht[row * HTS + col], local);
+      if constexpr (BF) {
+        if (b0 + row < B && (col & 1) == 0)
+          store_x(reinterpret_cast<float*>(out + seq_row(tt, b0 + row, Bs, T, bm) * 2 * h + d * h + us * UW + col),
+                  __uint_as_float(pack_bf16x2(Ht[row * HTS + col], Ht[row * HTS + col + 1])), local);
+      } else {
+        if (b0 + row < B) store_x(out + seq_row(tt, b0 + row, Bs, T, bm) * 2 * h + d * h + us * UW + col, Ht[row * HTS + col], local);
+      }
     }
     if (live) {
       const size_t s = (((size_t)tt * 2 + d) * Bs + b) * h + u;
       Cs[s] = c;
-      *reinterpret_cast<float4*>(R + s * 4) = make_float4(gi, gf, gg, go);
+      st4(R + s * 4, make_float4(gi, gf, gg, go));
     }
 #ifdef TSG_LSTM_TIMING
     if (step > 0) TSG_TICK(3)                                // gates, stores issued, workgroup met
@@ -739,8 +775,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // SPLIT:
 
 
 static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
-  if (dtype != TSG_F32 && dtype != TSG_F32S)
-    return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32 or TSG_F32S)", fn, dtype);
+  if (dtype != TSG_F32 && dtype != TSG_F32S && dtype != TSG_BF16)
+    return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32, TSG_F32S or TSG_BF16)", fn, dtype);
   if (B <= 0 || T <= 0 || h <= 0) return set_error(TSG_E_SHAPE, "%s: non-positive dimension B=%d T=%d h=%d", fn, B, T, h);
   if (h % 4) return set_error(TSG_E_ALIGN, "%s: hidden size %d must be a multiple of 4", fn, h);
   return 0;
@@ -768,11 +804,15 @@ constexpr int kDlFloats = 2 * 16 * kDLB;         // LDS dwords of the dG tile re
 constexpr int kPLS = kPersistMaxH + 8;           // partial-dh gather row stride
 constexpr int kQLS = 36;                         // polled partial sums row stride
 
-template <int TW, bool SPLIT>                     // TW = 16-unit tiles per wave = h / 128 (compile time: no branch between MFMAs);
-__global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPLIT: split-precision bf16 MFMA arithmetic
-    const float* __restrict__ WhhT, const float* __restrict__ R, const float* __restrict__ Cs,
-    const float* __restrict__ dOut, const float* __restrict__ dHn, float* __restrict__ dG,
+// MODE as in the forward kernel: 0 fp32, 1 split precision (TSG_F32S), 2 = bf16 storage of R, dOut and dG with one bf16 MFMA per
+// k block (TSG_BF16; the partial-dh ring, Cs, dHn, dbias stay fp32).
+template <int TW, int MODE>                       // TW = 16-unit tiles per wave = h / 128 (compile time: no branch between MFMAs)
+__global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
+    const float* __restrict__ WhhT, const typename SeqT<MODE>::type* __restrict__ R, const float* __restrict__ Cs,
+    const typename SeqT<MODE>::type* __restrict__ dOut, const float* __restrict__ dHn, typename SeqT<MODE>::type* __restrict__ dG,
     float* __restrict__ ring, unsigned* __restrict__ sync, float* __restrict__ dbias, int B, int Bs, int T, int h, int flags, int bm, ErrSink esink) {
+  constexpr bool SPLIT = MODE >= 1, BF = MODE == 2;
+  typedef typename SeqT<MODE>::type GT;
   extern __shared__ __align__(16) float smem2[];
   float* Dl = smem2;                              // [16][kDLS]  this workgroup's dG tile, local column g*32 + ul
   unsigned* Dhi = reinterpret_cast<unsigned*>(Dl);          // (SPLIT: the same tile as two bf16 planes [16][kDLB] dwords)
@@ -849,10 +889,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
       // requesting them one step ahead, after the previous poll -- what the forward kernel does with its input gates --
       // measured 4.8-5.6 us in every variant tried)
       const size_t sidx = (((size_t)tt * 2 + d) * Bs + b) * h + u;
-      g4 = *reinterpret_cast<const float4*>(R + sidx * 4);
+      g4 = ld4(R + sidx * 4);
       cc = Cs[sidx];
       if (has_prev) cpv = Cs[(((size_t)tp * 2 + d) * Bs + b) * h + u];
-      dov = dOut[seq_row(tt, b, Bs, T, bm) * 2 * h + d * h + u];
+      dov = ld1(dOut + seq_row(tt, b, Bs, T, bm) * 2 * h + d * h + u);
       if (step == 0 && dHn) dov += dHn[((size_t)d * Bs + b) * h + u];
     }
     float rec = 0.f;
@@ -903,9 +943,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
       dc_carry = dc * gf;
       const float dg[4] = {dc * gg * gi * (1.f - gi), dc * cpv * gf * (1.f - gf), dc * gi * (1.f - gg * gg), dh * tc * go * (1.f - go)};
       if (live) {
-        float* g = dG + (seq_row(tt, b, Bs, T, bm) * 2 + d) * K + u;
+        GT* g = dG + (seq_row(tt, b, Bs, T, bm) * 2 + d) * K + u;
 #pragma unroll
-        for (int gate = 0; gate < 4; ++gate) g[gate * h] = dg[gate];
+        for (int gate = 0; gate < 4; ++gate) st1(g + gate * h, dg[gate]);
       }
 #pragma unroll
       for (int gate = 0; gate < 4; ++gate) {
@@ -913,8 +953,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
         if constexpr (SPLIT) {
           unsigned hi, lo;
           split_pair(dgv, 0.f, hi, lo);
-          reinterpret_cast<unsigned short*>(Dhi)[row * 2 * kDLB + gate * 32 + ul] = (unsigned short)hi;
-          reinterpret_cast<unsigned short*>(Dlo)[row * 2 * kDLB + gate * 32 + ul] = (unsigned short)lo;
+          reinterpret_cast<unsigned short*>(Dhi)[row * 2 * kDLB + gate * 32 + ul] = (unsigned short)hi;   // = the bf16 written to dG (BF)
+          if constexpr (!BF) reinterpret_cast<unsigned short*>(Dlo)[row * 2 * kDLB + gate * 32 + ul] = (unsigned short)lo;
         } else {
           Dl[row * kDLS + gate * 32 + ul] = dgv;
         }
@@ -941,17 +981,19 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(     // SPL
           for (int t = 0; t < TW; ++t) accc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         const unsigned* dr = Dhi + jb * kDLB + 4 * ku;
-        u32x4 nh = *reinterpret_cast<const u32x4*>(dr), nl = *reinterpret_cast<const u32x4*>(dr + 16 * kDLB);
+        u32x4 nh = *reinterpret_cast<const u32x4*>(dr), nl = BF ? nh : *reinterpret_cast<const u32x4*>(dr + 16 * kDLB);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
           const u32x4 vh = nh, vl = nl;
           if (kb + 1 < 4) {
             nh = *reinterpret_cast<const u32x4*>(dr + 16 * (kb + 1));
-            nl = *reinterpret_cast<const u32x4*>(dr + 16 * kDLB + 16 * (kb + 1));
+            if constexpr (!BF) nl = *reinterpret_cast<const u32x4*>(dr + 16 * kDLB + 16 * (kb + 1));
           }
 #pragma unroll
           for (int t = 0; t < TW; ++t) acc[t] = mfma_bf16(ahi[t][kb], vh, acc[t]);
-          if constexpr (ONE) {
+          if constexpr (BF) {
+            // bf16 storage: the one product per k block is the whole arithmetic
+          } else if constexpr (ONE) {
 #pragma unroll
             for (int t = 0; t < TW; ++t) acc[t] = mfma_bf16(ahi[t][kb], vl, acc[t]);
 #pragma unroll
@@ -1093,20 +1135,44 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
   if (rc) return rc;
   auto st = static_cast<hipStream_t>(stream);
   // persistent path: weights stationary, one launch for all T steps -- needs every workgroup resident
-  if (sync_ws && persist_wanted(T) && h % 32 == 0 && h <= kPersistMaxH && T > 1) {
+  const bool bf = dtype == TSG_BF16;
+  // bf16 storage exists in the persistent kernels only (hidden sizes 128 / 256 / 384 / 512): other shapes are reported as
+  // unsupported and the caller runs them through the fp32-storage entry points
+  if (bf && !(sync_ws && persist_mode() != 0 && h % 128 == 0 && h <= kPersistMaxH && T > 1))
+    return set_error(TSG_E_SHAPE, "%s: dtype TSG_BF16 needs the persistent kernel (sync_ws given, TSG_LSTM_PERSIST != 0, T > 1, h in "
+                     "{128,256,384,512}); got T=%d h=%d", fn, T, h);
+  if (sync_ws && (bf || persist_wanted(T)) && h % 32 == 0 && h <= kPersistMaxH && T > 1) {
     static int nw_env = -1;                                 // TSG_LSTM_NW=4: 16-unit workgroups of 4 waves, two per CU (experiment)
     if (nw_env < 0) { const char* e = getenv("TSG_LSTM_NW"); nw_env = (e && atoi(e) == 4) ? 4 : 8; }
     const bool split = dtype == TSG_F32S;                  // other hidden sizes: the fp32 arithmetic (more accurate, slower)
-    const int NW = (nw_env == 4 && h == 512 && split) ? 4 : 8;
+    const int NW = (nw_env == 4 && h == 512 && split && !bf) ? 4 : 8;
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
     const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 33 + 4);
     static_assert(kSlabFloats >= 16 * (kPersistMaxH + 8), "slab region holds the fp32 slab too");
-    auto pk = NW == 4 ? lstm_fwd_persist_kernel<32, true, 4>
-            : h == 512 ? (split ? lstm_fwd_persist_kernel<32, true, 8> : lstm_fwd_persist_kernel<32, false, 8>)
-            : h == 256 ? (split ? lstm_fwd_persist_kernel<16, true, 8> : lstm_fwd_persist_kernel<16, false, 8>)
-            : h == 384 ? (split ? lstm_fwd_persist_kernel<24, true, 8> : lstm_fwd_persist_kernel<24, false, 8>)
-            : h == 128 ? (split ? lstm_fwd_persist_kernel<8, true, 8> : lstm_fwd_persist_kernel<8, false, 8>)
-            : lstm_fwd_persist_kernel<0, false, 8>;
+    if (bf) {
+      auto pb = h == 512 ? lstm_fwd_persist_kernel<32, 2, 8> : h == 384 ? lstm_fwd_persist_kernel<24, 2, 8>
+              : h == 256 ? lstm_fwd_persist_kernel<16, 2, 8> : lstm_fwd_persist_kernel<8, 2, 8>;
+      const int capb = persist_capacity(3, pb, 64 * 8, plds, 1);
+      const int rowsb = persist_chunk_rows(B, h / 32, capb);
+      if (rowsb <= 0) return set_error(TSG_E_SHAPE, "%s: the persistent kernel cannot be co-resident on this device (TSG_BF16)", fn);
+      const size_t K8 = (size_t)8 * h, H2 = (size_t)2 * h;
+      for (int c0 = 0; c0 < B; c0 += rowsb) {
+        const int Bc = B - c0 < rowsb ? B - c0 : rowsb;
+        const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;
+        hipError_t e = zero_async(sync_ws, kSyncBytes, st);
+        if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+        hipLaunchKernelGGL(pb, dim3(2 * (h / 32) * cdiv(Bc, 16)), dim3(512), plds, st, (const lstm_bf16*)Gx + seq * K8, (const float*)bias,
+                           (const float*)Whh, (lstm_bf16*)out + seq * H2, (lstm_bf16*)R + (size_t)c0 * h * 4, (float*)Cs + (size_t)c0 * h,
+                           (unsigned*)sync_ws, Bc, B, T, h, HLS, launch_flags(), bm, error_sink());
+      }
+      return check_launch(fn);
+    }
+    auto pk = NW == 4 ? lstm_fwd_persist_kernel<32, 1, 4>
+            : h == 512 ? (split ? lstm_fwd_persist_kernel<32, 1, 8> : lstm_fwd_persist_kernel<32, 0, 8>)
+            : h == 256 ? (split ? lstm_fwd_persist_kernel<16, 1, 8> : lstm_fwd_persist_kernel<16, 0, 8>)
+            : h == 384 ? (split ? lstm_fwd_persist_kernel<24, 1, 8> : lstm_fwd_persist_kernel<24, 0, 8>)
+            : h == 128 ? (split ? lstm_fwd_persist_kernel<8, 1, 8> : lstm_fwd_persist_kernel<8, 0, 8>)
+            : lstm_fwd_persist_kernel<0, 0, 8>;
     const int cap = persist_capacity(NW == 4 ? 1 : 0, pk, 64 * NW, plds, NW == 4 ? 2 : 1);
     // more rows than co-resident workgroups allow (B = 256 at h = 512: grid 512 on 256 CUs): the rows are independent, so the
     // layer runs as consecutive launches over balanced row chunks (pointer offsets; Bs = B keeps the tensors' strides)
@@ -1173,7 +1239,7 @@ extern "C" long long tsg_lstm_bwd_ws_bytes(int B, int T, int h) {
 
 static constexpr size_t kBwd2Lds = sizeof(float) * ((size_t)kDlFloats + 16 * kPLS + 4 * 16 * kQLS + 4);
 static_assert(kDlFloats >= 16 * kDLS, "dG tile region holds the fp32 tile too");
-static int bwd_persist_capacity() { return persist_capacity(2, lstm_bwd_persist2_kernel<4, false>, kThreads, kBwd2Lds, 1); }
+static int bwd_persist_capacity() { return persist_capacity(2, lstm_bwd_persist2_kernel<4, 0>, kThreads, kBwd2Lds, 1); }
 
 extern "C" int tsg_lstm_bwd_ws_persistent(int B, int T, int h, long long ws_bytes) {
   const long long need = tsg_lstm_bwd_ws_bytes(B, T, h);
@@ -1192,7 +1258,13 @@ extern "C" int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const voi
   const char* fn = "tsg_lstm_bwd_ws";
   const int bm = batch_major != 0;
   const long long need = tsg_lstm_bwd_ws_bytes(B, T, h);
-  if (ws && aligned16(ws) && tsg_lstm_bwd_ws_persistent(B, T, h, ws_bytes)) {
+  const bool bf = dtype == TSG_BF16;
+  const bool bf_ok = bf && ws && aligned16(ws) && need > 0 && ws_bytes >= need && T > 1 && persist_mode() != 0 &&
+                     persist_chunk_rows(B, h / 32, bwd_persist_capacity()) > 0;
+  if (bf && !bf_ok)
+    return set_error(TSG_E_SHAPE, "%s: dtype TSG_BF16 needs the persistent kernel (ring workspace of tsg_lstm_bwd_ws_bytes, T > 1, h in "
+                     "{128,256,384,512}, TSG_LSTM_PERSIST != 0); got T=%d h=%d ws=%lld", fn, T, h, ws_bytes);
+  if (bf_ok || (ws && aligned16(ws) && tsg_lstm_bwd_ws_persistent(B, T, h, ws_bytes))) {
     for (const void* p : {WhhT, R, Cs, dOut, (const void*)dG}) {
       if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
       if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
@@ -1203,12 +1275,31 @@ extern "C" int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const voi
     hipError_t e = dbias ? zero_async(dbias, sizeof(float) * 8 * h, st) : hipSuccess;
     if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
     const bool split = dtype == TSG_F32S;
-    auto pk = h == 512 ? (split ? lstm_bwd_persist2_kernel<4, true> : lstm_bwd_persist2_kernel<4, false>)
-            : h == 384 ? (split ? lstm_bwd_persist2_kernel<3, true> : lstm_bwd_persist2_kernel<3, false>)
-            : h == 256 ? (split ? lstm_bwd_persist2_kernel<2, true> : lstm_bwd_persist2_kernel<2, false>)
-            : (split ? lstm_bwd_persist2_kernel<1, true> : lstm_bwd_persist2_kernel<1, false>);
     const int rows = persist_chunk_rows(B, h / 32, bwd_persist_capacity());      // > 0 (tsg_lstm_bwd_ws_persistent)
     const size_t K8 = (size_t)8 * h, H2 = (size_t)2 * h;
+    if (bf) {
+      auto pb = h == 512 ? lstm_bwd_persist2_kernel<4, 2> : h == 384 ? lstm_bwd_persist2_kernel<3, 2>
+              : h == 256 ? lstm_bwd_persist2_kernel<2, 2> : lstm_bwd_persist2_kernel<1, 2>;
+      e = allow_lds(pb, kBwd2Lds);
+      if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+      for (int c0 = 0; c0 < B; c0 += rows) {
+        const int Bc = B - c0 < rows ? B - c0 : rows;
+        const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;
+        e = zero_async(ws, kSyncBytes, st);
+        if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+        hipLaunchKernelGGL(pb, dim3(2 * (h / 32) * cdiv(Bc, 16)), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT,
+                           (const lstm_bf16*)R + (size_t)c0 * h * 4, (const float*)Cs + (size_t)c0 * h, (const lstm_bf16*)dOut + seq * H2,
+                           dHn ? (const float*)dHn + (size_t)c0 * h : nullptr, (lstm_bf16*)dG + seq * K8, (float*)((char*)ws + kSyncBytes),
+                           (unsigned*)ws, (float*)dbias, Bc, B, T, h, launch_flags(), bm, error_sink());
+      }
+      return check_launch(fn);
+    }
+    auto pk = h == 512 ? (split ? lstm_bwd_persist2_kernel<4, 1> : lstm_bwd_persist2_kernel<4, 0>)
+            : h == 384 ? (split ? lstm_bwd_persist2_kernel<3, 1> : lstm_bwd_persist2_kernel<3, 0>)
+            : h == 256 ? (split ? lstm_bwd_persist2_kernel<2, 1> : lstm_bwd_persist2_kernel<2, 0>)
+            : (split ? lstm_bwd_persist2_kernel<1, 1> : lstm_bwd_persist2_kernel<1, 0>);
+    e = allow_lds(pk, kBwd2Lds);
+    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
     for (int c0 = 0; c0 < B; c0 += rows) {                   // row chunks as in the forward; the ring is reused, dbias accumulates
       const int Bc = B - c0 < rows ? B - c0 : rows;
       const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;

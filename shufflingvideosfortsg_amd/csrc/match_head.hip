@@ -31,8 +31,9 @@ template <int ACT> __device__ __forceinline__ float act_d(float z, float a) {  /
   return a * (1.f - a);
 }
 
-template <int ACT>
-__global__ __launch_bounds__(kMhThreads) void match_head_fwd_kernel(const float* __restrict__ y, const float* __restrict__ cs,
+// ST: storage type of y (and dy): float or bf16_t (dtype TSG_BF16); cs, w2, b2, the logits and all sums stay fp32.
+template <int ACT, typename ST>
+__global__ __launch_bounds__(kMhThreads) void match_head_fwd_kernel(const ST* __restrict__ y, const float* __restrict__ cs,
                                                                     const float* __restrict__ w2, const float* __restrict__ b2,
                                                                     float* __restrict__ logit, int B, int T, int H) {
   const int lane = threadIdx.x & 63, wv = mh_wave_id();
@@ -52,11 +53,11 @@ __global__ __launch_bounds__(kMhThreads) void match_head_fwd_kernel(const float*
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int t = t0 + wv + kMhWaves * i;
-    const float4* row = reinterpret_cast<const float4*>(y + ((size_t)b * T + (t < T ? t : 0)) * H);
+    const ST* row = y + ((size_t)b * T + (t < T ? t : 0)) * H;
 #pragma unroll
     for (int q = 0; q < kMhMaxH4; ++q) {
       const int j = lane + 64 * q;
-      v[i][q] = (t < T && j < H4) ? row[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[i][q] = (t < T && j < H4) ? ld4(row + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 #pragma unroll
@@ -75,10 +76,10 @@ __global__ __launch_bounds__(kMhThreads) void match_head_fwd_kernel(const float*
   }
 }
 
-template <int ACT>
-__global__ __launch_bounds__(kMhThreads) void match_head_bwd_kernel(const float* __restrict__ y, const float* __restrict__ cs,
+template <int ACT, typename ST>
+__global__ __launch_bounds__(kMhThreads) void match_head_bwd_kernel(const ST* __restrict__ y, const float* __restrict__ cs,
                                                                     const float* __restrict__ w2, const float* __restrict__ dl,
-                                                                    float* __restrict__ dy, float* __restrict__ dcs,
+                                                                    ST* __restrict__ dy, float* __restrict__ dcs,
                                                                     float* __restrict__ dw2, float* __restrict__ db2,
                                                                     int B, int T, int H) {
   __shared__ float fold[kMhWaves][256 * kMhMaxH4];                 // per wave: H partial sums (<= 1024 floats)
@@ -108,11 +109,11 @@ __global__ __launch_bounds__(kMhThreads) void match_head_bwd_kernel(const float*
       const bool ok = t < T;                                       // wave-uniform
       const size_t r = (size_t)b * T + (ok ? t : 0);
       g[i] = ok ? dl[r] : 0.f;
-      const float4* row = reinterpret_cast<const float4*>(y + r * H);
+      const ST* row = y + r * H;
 #pragma unroll
       for (int q = 0; q < kMhMaxH4; ++q) {
         const int j = lane + 64 * q;
-        v[i][q] = (ok && j < H4) ? row[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i][q] = (ok && j < H4) ? ld4(row + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(kMhThreads) void match_head_bwd_kernel(const float*
       if (t >= T) break;
       const size_t r = (size_t)b * T + t;
       sb += g[i];
-      float4* drow = reinterpret_cast<float4*>(dy + r * H);
+      ST* drow = dy + r * H;
 #pragma unroll
       for (int q = 0; q < kMhMaxH4; ++q) {
         const int j = lane + 64 * q;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(kMhThreads) void match_head_bwd_kernel(const float*
           float d[4], a[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) { a[k] = act_f<ACT>(z[k]); d[k] = g[i] * ww[k] * act_d<ACT>(z[k], a[k]); }
-          drow[j] = make_float4(d[0], d[1], d[2], d[3]);
+          st4(drow + 4 * j, make_float4(d[0], d[1], d[2], d[3]));
           sc[q].x += d[0]; sc[q].y += d[1]; sc[q].z += d[2]; sc[q].w += d[3];
           sw[q].x += g[i] * a[0]; sw[q].y += g[i] * a[1]; sw[q].z += g[i] * a[2]; sw[q].w += g[i] * a[3];
         }
@@ -160,7 +161,9 @@ __global__ __launch_bounds__(kMhThreads) void match_head_bwd_kernel(const float*
   if (lane == 0) atomicAdd(db2, sb);
 }
 
-int mh_check(const char* fn, int B, int T, int H, int act) {
+int mh_check(const char* fn, int B, int T, int H, int act, int dtype) {
+  if (dtype != TSG_F32 && dtype != TSG_BF16)
+    return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32, or TSG_BF16 = y / dy stored as bf16)", fn, dtype);
   if (B <= 0 || T <= 0 || H <= 0) return set_error(TSG_E_SHAPE, "%s: non-positive dimension B=%d T=%d H=%d", fn, B, T, H);
   if (H % 4 || H > 256 * kMhMaxH4) return set_error(TSG_E_SHAPE, "%s: H=%d must be a multiple of 4 and <= %d", fn, H, 256 * kMhMaxH4);
   if (act < 0 || act > 2) return set_error(TSG_E_SHAPE, "%s: activation %d (0 relu, 1 tanh, 2 sigmoid)", fn, act);
@@ -173,30 +176,37 @@ int mh_check(const char* fn, int B, int T, int H, int act) {
 using namespace tsg;
 
 extern "C" int tsg_match_head_fwd(const void* y, const void* cs, const void* w2, const void* b2, void* logits,
-                                  int B, int T, int H, int activation, void* stream) {
+                                  int B, int T, int H, int activation, int dtype, void* stream) {
   const char* fn = "tsg_match_head_fwd";
   for (const void* p : {y, cs, w2, b2, (const void*)logits}) {
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
     if (p != b2 && !aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
   }
-  int rc = mh_check(fn, B, T, H, activation);
+  int rc = mh_check(fn, B, T, H, activation, dtype);
   if (rc) return rc;
   const int grid = B * cdiv(T, kMhRows);
   auto st = static_cast<hipStream_t>(stream);
-  auto k = activation == 0 ? match_head_fwd_kernel<0> : activation == 1 ? match_head_fwd_kernel<1> : match_head_fwd_kernel<2>;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(kMhThreads), 0, st, (const float*)y, (const float*)cs, (const float*)w2, (const float*)b2,
-                     (float*)logits, B, T, H);
+  if (dtype == TSG_BF16) {
+    using S = bf16_t;
+    auto k = activation == 0 ? match_head_fwd_kernel<0, S> : activation == 1 ? match_head_fwd_kernel<1, S> : match_head_fwd_kernel<2, S>;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kMhThreads), 0, st, (const S*)y, (const float*)cs, (const float*)w2, (const float*)b2,
+                       (float*)logits, B, T, H);
+  } else {
+    auto k = activation == 0 ? match_head_fwd_kernel<0, float> : activation == 1 ? match_head_fwd_kernel<1, float> : match_head_fwd_kernel<2, float>;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kMhThreads), 0, st, (const float*)y, (const float*)cs, (const float*)w2, (const float*)b2,
+                       (float*)logits, B, T, H);
+  }
   return check_launch(fn);
 }
 
 extern "C" int tsg_match_head_bwd(const void* y, const void* cs, const void* w2, const void* dlogits, void* dy, void* dcs,
-                                  void* dw2, void* db2, int B, int T, int H, int activation, void* stream) {
+                                  void* dw2, void* db2, int B, int T, int H, int activation, int dtype, void* stream) {
   const char* fn = "tsg_match_head_bwd";
   for (const void* p : {y, cs, w2, dlogits, (const void*)dy, (const void*)dcs, (const void*)dw2, (const void*)db2}) {
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
     if (p != db2 && !aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
   }
-  int rc = mh_check(fn, B, T, H, activation);
+  int rc = mh_check(fn, B, T, H, activation, dtype);
   if (rc) return rc;
   auto st = static_cast<hipStream_t>(stream);
   hipError_t e = zero_async(dcs, sizeof(float) * (size_t)B * H, st);
@@ -204,8 +214,15 @@ extern "C" int tsg_match_head_bwd(const void* y, const void* cs, const void* w2,
   if (e == hipSuccess) e = zero_async(db2, sizeof(float), st);
   if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
   const int grid = B * cdiv(T, kMhRows);
-  auto k = activation == 0 ? match_head_bwd_kernel<0> : activation == 1 ? match_head_bwd_kernel<1> : match_head_bwd_kernel<2>;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(kMhThreads), 0, st, (const float*)y, (const float*)cs, (const float*)w2,
-                     (const float*)dlogits, (float*)dy, (float*)dcs, (float*)dw2, (float*)db2, B, T, H);
+  if (dtype == TSG_BF16) {
+    using S = bf16_t;
+    auto k = activation == 0 ? match_head_bwd_kernel<0, S> : activation == 1 ? match_head_bwd_kernel<1, S> : match_head_bwd_kernel<2, S>;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kMhThreads), 0, st, (const S*)y, (const float*)cs, (const float*)w2,
+                       (const float*)dlogits, (S*)dy, (float*)dcs, (float*)dw2, (float*)db2, B, T, H);
+  } else {
+    auto k = activation == 0 ? match_head_bwd_kernel<0, float> : activation == 1 ? match_head_bwd_kernel<1, float> : match_head_bwd_kernel<2, float>;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kMhThreads), 0, st, (const float*)y, (const float*)cs, (const float*)w2,
+                       (const float*)dlogits, (float*)dy, (float*)dcs, (float*)dw2, (float*)db2, B, T, H);
+  }
   return check_launch(fn);
 }

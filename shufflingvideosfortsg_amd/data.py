@@ -72,18 +72,25 @@ def synthetic_batch(B, T, N, video_dim=1024, word_dim=300, seed=1234, pair=False
             pv.append(torch.from_numpy(np.ascontiguousarray(nv[0])).float()); pfs.append([int(nf[0]), int(nf[1])])
         out["pseudo_video"] = torch.stack(pv)
         out["pseudo_gt"] = labels(pfs)
-    if device != "cpu":
-        for k, v in list(out.items()):
-            if isinstance(v, torch.Tensor):
-                out[k] = v.to(device)
-        for gt in ("gt", "pseudo_gt"):
-            if gt in out:
-                for k, v in list(out[gt].items()):
-                    if isinstance(v, torch.Tensor):
-                        out[gt][k] = v.to(device)
-                # the collate's list of [start, end] pairs becomes ONE resident index tensor: the losses gather with it
-                # three times per step, and a list would be a blocking host-to-device copy each time
-                out[gt]["framestps"] = torch.tensor(out[gt]["framestps"], dtype=torch.long).to(device)
+    return out if device == "cpu" else to_device(out, device)
+
+
+def to_device(batch, device):
+    """Move a (possibly sharded) host batch dict to ``device``; the collate's lists of [start, end] pairs become ONE resident
+    index tensor per label group: the losses gather with it three times per step, and a list would be a blocking host-to-device
+    copy each time."""
+    out = dict(batch)
+    for k, v in list(out.items()):
+        if isinstance(v, torch.Tensor):
+            out[k] = v.to(device)
+    for gt in ("gt", "pseudo_gt"):
+        if gt in out:
+            out[gt] = dict(out[gt])
+            for k, v in list(out[gt].items()):
+                if isinstance(v, torch.Tensor):
+                    out[gt][k] = v.to(device)
+            fs = out[gt]["framestps"]
+            out[gt]["framestps"] = (fs if isinstance(fs, torch.Tensor) else torch.tensor(fs, dtype=torch.long)).to(device)
     return out
 
 

@@ -60,13 +60,16 @@ def build_model(kind: str, params: Dict, logger=LOG) -> torch.nn.Module:
 
 
 def precision(gemm_dtype=None):
-    """Context for one forward: ``None`` / fp32 = parity mode; ``torch.bfloat16`` = every library GEMM
-    (nn.Linear projections via autocast, the LSTM GEMMs via functional.set_gemm_dtype) takes bf16 operands
-    with fp32 accumulation while the HIP kernels, softmaxes and losses stay fp32."""
+    """Context for one forward.  ``None`` / fp32 = strict fp32 (parity mode); ``"f32s"`` = split-precision bf16 MFMA products,
+    fp32 storage (the headline mode: fp32-level error); ``"bf16"`` = bf16 STORAGE mode (BASELINE configs 2 / 4): activations and
+    their gradients live in HBM as bf16, the hand-written kernels run with dtype TSG_BF16 (fp32 arithmetic inside), the GEMMs are
+    plain bf16 MFMA GEMMs, parameters / weight gradients / optimizer state stay fp32 -- no autocast involved;
+    ``torch.bfloat16`` = the older operands-only mode: every library GEMM (nn.Linear projections via autocast, the LSTM GEMMs via
+    functional.set_gemm_dtype) takes bf16 operands with fp32 accumulation while the HIP kernels and all storage stay fp32."""
     import contextlib
     from . import functional as TF
     TF.set_gemm_dtype(gemm_dtype)
-    if gemm_dtype in (None, torch.float32, "f32s"):        # "f32s": split-precision LSTM GEMMs, everything else fp32
+    if gemm_dtype in (None, torch.float32, "f32s", "bf16"):
         return contextlib.nullcontext()
     return torch.autocast("cuda", dtype=gemm_dtype)
 

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import TSG_F32, TSG_F32S, check, load, ptr, require_device, stream_of
+from ._lib import TSG_BF16, TSG_F32, TSG_F32S, check, load, ptr, require_device, stream_of
 
 
 class _KernelTimer:
@@ -162,15 +162,24 @@ def _call(name: str, like: torch.Tensor, *args) -> None:
 # (parity mode, default); torch.bfloat16 = bf16 operands with fp32 accumulation (BASELINE configs 2-4);
 # "f32s" = split precision: both operands as bf16 (hi, lo) planes (tsg_split_bf16x3), ONE bf16 MFMA GEMM over the
 # 3x longer contraction with fp32 accumulate = hi·hi + hi·lo + lo·hi, fp32-GEMM-level error at 2-3x its speed.
+# "bf16" (the string) = bf16 STORAGE mode (BASELINE configs 2 / 4): every activation and activation
+# gradient of the path lives in HBM as bf16 -- the hand-written kernels take dtype TSG_BF16 (half the bytes; fp32
+# arithmetic, softmax, cell state and accumulation inside), the GEMMs are plain bf16 MFMA GEMMs with fp32 accumulation
+# (no 3x contraction, no operand passes), parameters, weight gradients and the optimizer stay fp32.
 # The hand-written kernels always compute in fp32.
 _GEMM_DTYPE = None
 
 
 def set_gemm_dtype(dtype=None):
     global _GEMM_DTYPE
-    if dtype not in (None, torch.float32, torch.bfloat16, "f32s"):
-        raise ValueError("gemm dtype must be None/float32, bfloat16 or 'f32s'")
+    if dtype not in (None, torch.float32, torch.bfloat16, "f32s", "bf16"):
+        raise ValueError("gemm dtype must be None/float32, bfloat16 (library-GEMM operands only), 'f32s' or 'bf16' (bf16 storage)")
     _GEMM_DTYPE = None if dtype in (None, torch.float32) else dtype
+
+
+def bf16_storage() -> bool:
+    """True in the bf16 storage mode (``engine.precision("bf16")``)."""
+    return isinstance(_GEMM_DTYPE, str) and _GEMM_DTYPE == "bf16"
 
 
 def split_bf16x3(x: torch.Tensor, k_dim: int, right: bool) -> torch.Tensor:
@@ -279,7 +288,7 @@ def _mm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
             return a @ b
         return torch.mm(_split_operand(a, 1, False), _split_operand(b, 0, True), out_dtype=torch.float32)
     # bf16 operands, fp32 accumulate AND fp32 output straight from the GEMM (no bf16 round trip of the result, no cast kernel)
-    return torch.mm(a.to(_GEMM_DTYPE), b.to(_GEMM_DTYPE), out_dtype=torch.float32)
+    return torch.mm(a.to(_BF), b.to(_BF), out_dtype=torch.float32)
 
 
 _fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)     # under autocast: fp32 in, autocast off inside
@@ -292,6 +301,23 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+_BF = torch.bfloat16
+
+
+def _bfc(t: torch.Tensor) -> torch.Tensor:
+    """bf16 contiguous (activations of the bf16 storage mode; an fp32 tensor -- a model input -- is rounded once here)."""
+    return t.to(_BF).contiguous()
+
+
+def _f32p(t: torch.Tensor) -> torch.Tensor:
+    """fp32 contiguous: parameters and the small [B,T] / [B,J] side inputs the kernels keep in fp32 in every mode."""
+    return t.float().contiguous()
+
+
+def _act(t: torch.Tensor, bf: bool) -> torch.Tensor:
+    return _bfc(t) if bf else _f32c(t)
+
+
 class _ScdmAttn(torch.autograd.Function):
     """K1: (a=[B,T,H], s=[B,N,H], w=[H], sent=[B,N,Ds]) -> (C=[B,T,Ds], P=[B,T,N])."""
 
@@ -299,15 +325,17 @@ class _ScdmAttn(torch.autograd.Function):
     @_fwd
     def forward(ctx, a, s, w, sent):
         require_device(a, s, w, sent)
-        a, s, w, sent = _f32c(a), _f32c(s), _f32c(w), _f32c(sent)
+        bf = a.dtype == _BF                                    # bf16 storage: a, s, sent, C (and their gradients) as bf16
+        a, s, w, sent = _act(a, bf), _act(s, bf), _f32p(w), _act(sent, bf)
         B, T, H = a.shape
         _, N, Ds = sent.shape
         if s.shape != (B, N, H) or w.numel() != H:
             raise ValueError(f"scdm_attn: shape mismatch a{tuple(a.shape)} s{tuple(s.shape)} w{tuple(w.shape)} sent{tuple(sent.shape)}")
-        C = torch.empty(B, T, Ds, device=a.device, dtype=torch.float32)
+        C = torch.empty(B, T, Ds, device=a.device, dtype=a.dtype)
         P = torch.empty(B, T, N, device=a.device, dtype=torch.float32)
+        ctx.dt = TSG_BF16 if bf else TSG_F32
         _call("tsg_scdm_attn_fwd", a, ptr(a), ptr(s), ptr(w), ptr(sent), ptr(C), ptr(P),
-                                       B, T, N, H, Ds, TSG_F32)
+                                       B, T, N, H, Ds, ctx.dt)
         ctx.save_for_backward(a, s, w, sent, P)
         ctx.mark_non_differentiable(P)
         return C, P
@@ -316,15 +344,25 @@ class _ScdmAttn(torch.autograd.Function):
     @_bwd
     def backward(ctx, dC, _dP):
         a, s, w, sent, P = ctx.saved_tensors
-        dC = _f32c(dC)
+        dC = _act(dC, ctx.dt == TSG_BF16)
         B, T, H = a.shape
         _, N, Ds = sent.shape
         da = torch.empty_like(a); ds = torch.empty_like(s)
         dw = torch.empty_like(w); dsent = torch.empty_like(sent)
         nb = int(load().tsg_scdm_bwd_ws_bytes(B, T, N, H, Ds, 0))
         ws = torch.empty(nb // 4 + 4, device=a.device, dtype=torch.float32)
-        _call("tsg_scdm_attn_bwd", a, ptr(a), ptr(s), ptr(w), ptr(sent), ptr(P), ptr(dC), ptr(da), ptr(ds),
-                                       ptr(dw), ptr(dsent), ptr(ws), nb, B, T, N, H, Ds, TSG_F32)
+        try:
+            _call("tsg_scdm_attn_bwd", a, ptr(a), ptr(s), ptr(w), ptr(sent), ptr(P), ptr(dC), ptr(da), ptr(ds),
+                                           ptr(dw), ptr(dsent), ptr(ws), nb, B, T, N, H, Ds, ctx.dt)
+        except RuntimeError:
+            if ctx.dt != TSG_BF16:
+                raise
+            # a shape only the two-kernel (fp32-storage) backward takes: fp32 copies through it, results rounded to bf16
+            af, sf, vf, gf = a.float(), s.float(), sent.float(), dC.float()
+            daf, dsf, dvf = torch.empty_like(af), torch.empty_like(sf), torch.empty_like(vf)
+            _call("tsg_scdm_attn_bwd", af, ptr(af), ptr(sf), ptr(w), ptr(vf), ptr(P), ptr(gf), ptr(daf), ptr(dsf),
+                                           ptr(dw), ptr(dvf), ptr(ws), nb, B, T, N, H, Ds, TSG_F32)
+            da, ds, dsent = daf.to(_BF), dsf.to(_BF), dvf.to(_BF)
         return da, ds, dw, dsent
 
 
@@ -341,15 +379,17 @@ class _ScdmGate(torch.autograd.Function):
     @_fwd
     def forward(ctx, a, s, w, VW, gbias, r):
         require_device(a, s, w, VW, gbias, r)
-        a, s, w, VW, gbias, r = _f32c(a), _f32c(s), _f32c(w), _f32c(VW), _f32c(gbias), _f32c(r)
+        bf = r.dtype == _BF                                    # bf16 storage: a, s, VW, r, out (and their gradients) as bf16
+        a, s, w, VW, gbias, r = _act(a, bf), _act(s, bf), _f32p(w), _act(VW, bf), _f32p(gbias), _act(r, bf)
         B, T, H = a.shape
         _, N, Ds = VW.shape
         if s.shape != (B, N, H) or w.numel() != H or r.shape != (B, T, Ds) or gbias.numel() != Ds:
             raise ValueError(f"scdm_gate: shape mismatch a{tuple(a.shape)} s{tuple(s.shape)} VW{tuple(VW.shape)} r{tuple(r.shape)}")
-        out = torch.empty(B, T, Ds, device=a.device, dtype=torch.float32)
+        out = torch.empty(B, T, Ds, device=a.device, dtype=a.dtype)
         P = torch.empty(B, T, N, device=a.device, dtype=torch.float32)
+        ctx.dt = TSG_BF16 if bf else TSG_F32
         _call("tsg_scdm_gate_fwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(r), ptr(out), ptr(P),
-              B, T, N, H, Ds, TSG_F32)
+              B, T, N, H, Ds, ctx.dt)
         ctx.save_for_backward(a, s, w, VW, gbias, r, P)
         return out
 
@@ -357,15 +397,24 @@ class _ScdmGate(torch.autograd.Function):
     @_bwd
     def backward(ctx, dout):
         a, s, w, VW, gbias, r, P = ctx.saved_tensors
-        dout = _f32c(dout)
+        dout = _act(dout, ctx.dt == TSG_BF16)
         B, T, H = a.shape
         _, N, Ds = VW.shape
         da = torch.empty_like(a); ds = torch.empty_like(s); dw = torch.empty_like(w)
         dVW = torch.empty_like(VW); dgb = torch.empty_like(gbias); dr = torch.empty_like(r)
         nb = int(load().tsg_scdm_bwd_ws_bytes(B, T, N, H, Ds, 1))
         ws = torch.empty(nb // 4 + 4, device=a.device, dtype=torch.float32)
-        _call("tsg_scdm_gate_bwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(r), ptr(P), ptr(dout),
-              ptr(da), ptr(ds), ptr(dw), ptr(dVW), ptr(dgb), ptr(dr), ptr(ws), nb, B, T, N, H, Ds, TSG_F32)
+        try:
+            _call("tsg_scdm_gate_bwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(r), ptr(P), ptr(dout),
+                  ptr(da), ptr(ds), ptr(dw), ptr(dVW), ptr(dgb), ptr(dr), ptr(ws), nb, B, T, N, H, Ds, ctx.dt)
+        except RuntimeError:
+            if ctx.dt != TSG_BF16:
+                raise
+            af, sf, vf, rf, gf = a.float(), s.float(), VW.float(), r.float(), dout.float()
+            daf, dsf, dvf, drf = torch.empty_like(af), torch.empty_like(sf), torch.empty_like(vf), torch.empty_like(rf)
+            _call("tsg_scdm_gate_bwd", af, ptr(af), ptr(sf), ptr(w), ptr(vf), ptr(gbias), ptr(rf), ptr(P), ptr(gf),
+                  ptr(daf), ptr(dsf), ptr(dw), ptr(dvf), ptr(dgb), ptr(drf), ptr(ws), nb, B, T, N, H, Ds, TSG_F32)
+            da, ds, dVW, dr = daf.to(_BF), dsf.to(_BF), dvf.to(_BF), drf.to(_BF)
         return da, ds, dw, dVW, dgb, dr
 
 
@@ -382,18 +431,20 @@ class _BoundaryScore(torch.autograd.Function):
     @_fwd
     def forward(ctx, y, cs, b1, w2, b2, gate, mask):
         require_device(y, cs, b1, w2, b2, gate, mask)
-        y, cs, b1, w2, b2 = _f32c(y), _f32c(cs), _f32c(b1), _f32c(w2), _f32c(b2)
+        bf = y.dtype == _BF                                    # bf16 storage: y / dy as bf16, everything [B,T]- or [B,J]-sized fp32
+        y, cs, b1, w2, b2 = _act(y, bf), _f32p(cs), _f32p(b1), _f32p(w2), _f32p(b2)
+        ctx.dt = TSG_BF16 if bf else TSG_F32
         B, T, J = y.shape
         if J % 2 or cs.shape != (B, J) or b1.numel() != J or w2.numel() != J or b2.numel() != 2:
             raise ValueError(f"boundary_score: shape mismatch y{tuple(y.shape)} cs{tuple(cs.shape)}")
-        gate_c = _f32c(gate) if gate is not None else None
+        gate_c = _f32p(gate) if gate is not None else None
         mask_c = mask.to(torch.int32).contiguous() if mask is not None else None
         ps = torch.empty(B, T, device=y.device, dtype=torch.float32)
         pe = torch.empty_like(ps)
         _call("tsg_boundary_score_fwd", y, ptr(y), ptr(cs), ptr(b1), ptr(w2), ptr(b2),
                                             ptr(gate_c) if gate_c is not None else None,
                                             ptr(mask_c) if mask_c is not None else None,
-                                            ptr(ps), ptr(pe), B, T, J // 2, TSG_F32)
+                                            ptr(ps), ptr(pe), B, T, J // 2, ctx.dt)
         ctx.save_for_backward(y, cs, b1, w2, ps, pe, *( [gate_c] if gate_c is not None else []), *([mask_c] if mask_c is not None else []))
         ctx.has_gate, ctx.has_mask = gate_c is not None, mask_c is not None
         return ps, pe
@@ -407,8 +458,8 @@ class _BoundaryScore(torch.autograd.Function):
         gate = rest.pop(0) if ctx.has_gate else None
         mask = rest.pop(0) if ctx.has_mask else None
         B, T, J = y.shape
-        dps = _f32c(dps) if dps is not None else torch.zeros_like(ps)
-        dpe = _f32c(dpe) if dpe is not None else torch.zeros_like(pe)
+        dps = _f32p(dps) if dps is not None else torch.zeros_like(ps)
+        dpe = _f32p(dpe) if dpe is not None else torch.zeros_like(pe)
         dy = torch.empty_like(y); dcs = torch.empty_like(cs)
         db1p = torch.empty(B, J, device=y.device, dtype=torch.float32)
         dw2p = torch.empty_like(db1p)
@@ -420,7 +471,7 @@ class _BoundaryScore(torch.autograd.Function):
                                             ptr(mask) if mask is not None else None,
                                             ptr(ps), ptr(pe), ptr(dps), ptr(dpe), ptr(dy), ptr(dcs), ptr(db1p),
                                             ptr(dw2p), ptr(db2p), ptr(dgate) if dgate is not None else None, ptr(dl),
-                                            B, T, J // 2, TSG_F32)
+                                            B, T, J // 2, ctx.dt)
         return dy, dcs, db1p.sum(0), dw2p.sum(0), db2p.sum(0), dgate, None
 
 
@@ -452,7 +503,7 @@ class _MHA(torch.autograd.Function):
                 int(n_heads), float(scale), int(bool(causal)), float(p_drop))
         # in the split-precision GEMM mode the attention products run on the bf16 MFMA as hi/lo products as well (TSG_F32S:
         # include/tsg_hip.h, K2; shapes the split kernels do not cover, and the A_forward maps, run the exact kernels)
-        dt = TSG_F32S if _GEMM_DTYPE == "f32s" else TSG_F32
+        dt = TSG_F32S if _GEMM_DTYPE in ("f32s", "bf16") else TSG_F32
         if rng is not None:                                         # (seed, offset) in device memory: graph-capture safe
             _call("tsg_mha_fwd_rng", Q, *head, ptr(rng), dt)
         else:
@@ -513,6 +564,11 @@ def mha(Q, K, V, n_heads, scale, causal=False, return_maps=False, p_drop=0.0):
             rng = st.clone()                                        # this call's (seed, offset), shared by forward and backward
         else:
             offset = int(torch.randint(0, 2 ** 62, (1,)).item())
+    if Q.dtype == _BF:
+        # bf16 storage mode: K2 has no bf16-storage kernels yet -- the split-precision kernels run on fp32 copies (their LDS
+        # operand planes are bf16 already; the hi plane of a bf16-valued input is the input itself) and O is rounded back
+        O, A, S = _MHA.apply(Q.float(), K.float(), V.float(), n_heads, scale, causal, return_maps, float(p_drop), seed, offset, rng)
+        return (O.to(_BF), A, S) if return_maps else O.to(_BF)
     O, A, S = _MHA.apply(Q, K, V, n_heads, scale, causal, return_maps, float(p_drop), seed, offset, rng)
     return (O, A, S) if return_maps else O
 
@@ -582,12 +638,14 @@ class _MatchHead(torch.autograd.Function):
     @_fwd
     def forward(ctx, y, cs, w2, b2, act):
         require_device(y, cs, w2, b2)
-        y, cs, w2, b2 = _f32c(y), _f32c(cs), _f32c(w2).view(-1), _f32c(b2).view(-1)
+        bf = y.dtype == _BF                                    # bf16 storage: y / dy as bf16
+        y, cs, w2, b2 = _act(y, bf), _f32p(cs), _f32p(w2).view(-1), _f32p(b2).view(-1)
+        ctx.dt = TSG_BF16 if bf else TSG_F32
         B, T, H = y.shape
         if cs.shape != (B, H) or w2.numel() != H or b2.numel() != 1:
             raise ValueError(f"match_head: shape mismatch y{tuple(y.shape)} cs{tuple(cs.shape)} w2{tuple(w2.shape)} b2{tuple(b2.shape)}")
         out = torch.empty(B, T, device=y.device, dtype=torch.float32)
-        _call("tsg_match_head_fwd", y, ptr(y), ptr(cs), ptr(w2), ptr(b2), ptr(out), B, T, H, int(act))
+        _call("tsg_match_head_fwd", y, ptr(y), ptr(cs), ptr(w2), ptr(b2), ptr(out), B, T, H, int(act), ctx.dt)
         ctx.save_for_backward(y, cs, w2)
         ctx.act = int(act)
         return out
@@ -597,10 +655,10 @@ class _MatchHead(torch.autograd.Function):
     def backward(ctx, dl):
         y, cs, w2 = ctx.saved_tensors
         B, T, H = y.shape
-        dl = _f32c(dl)
+        dl = _f32p(dl)
         dy = torch.empty_like(y)
         dcs = torch.empty_like(cs); dw2 = torch.empty_like(w2); db2 = torch.empty(1, device=y.device, dtype=torch.float32)
-        _call("tsg_match_head_bwd", y, ptr(y), ptr(cs), ptr(w2), ptr(dl), ptr(dy), ptr(dcs), ptr(dw2), ptr(db2), B, T, H, ctx.act)
+        _call("tsg_match_head_bwd", y, ptr(y), ptr(cs), ptr(w2), ptr(dl), ptr(dy), ptr(dcs), ptr(dw2), ptr(db2), B, T, H, ctx.act, ctx.dt)
         return dy, dcs, dw2, db2, None
 
 
@@ -712,9 +770,38 @@ class _LinearSplit(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LinearBf16(torch.autograd.Function):
+    """y = x w^T (+ b) in the bf16 storage mode: bf16 activations in and out, the fp32 parameter rounded to bf16 once per use
+    (kept for the backward), plain bf16 MFMA GEMMs with fp32 accumulation; the weight / bias gradients come out of their GEMM /
+    reduction in fp32 (the master gradient is never rounded to bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = _bfc(x).view(-1, x.shape[-1])
+        wb = w.detach().to(_BF)
+        y = torch.mm(x2, wb.t()) if b is None else torch.addmm(b.detach().to(_BF), x2, wb.t())
+        ctx.save_for_backward(x2, wb)
+        ctx.has_bias, ctx.xshape = b is not None, x.shape
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wb = ctx.saved_tensors
+        dy2 = _bfc(dy).view(-1, wb.shape[0])
+        dx = torch.mm(dy2, wb).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = torch.mm(dy2.t(), x2, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        db = torch.sum(dy2, 0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
 def linear(x, w, b=None):
     """torch.nn.functional.linear; in the "f32s" GEMM mode the large projections of the path (>= 2048 rows: SCDM W_a
-    attention.py:104-106, the matching head's and the boundary head's first Linear) run as split-precision GEMMs."""
+    attention.py:104-106, the matching head's and the boundary head's first Linear) run as split-precision GEMMs; in the bf16
+    storage mode every projection of the path is a bf16 GEMM with bf16 output (``_LinearBf16``)."""
+    if bf16_storage() and x.is_cuda:
+        return _LinearBf16.apply(x, w, b)
+    if x.dtype == _BF and w.dtype != _BF:                    # a bf16 activation met outside the storage mode's context
+        return torch.nn.functional.linear(x.float(), w, b)
     rows = x.numel() // max(x.shape[-1], 1)
     if _GEMM_DTYPE == "f32s" and x.is_cuda and rows >= 2048 and rows % 4 == 0 and x.shape[-1] % 4 == 0 and w.shape[0] % 4 == 0:
         return _LinearSplit.apply(x, w, b)
@@ -833,6 +920,81 @@ class _BiLSTMLayer(torch.autograd.Function):
         return dx, dW_ih, dbias, dW_hh, None
 
 
+def lstm_bf16_ok(T: int, h: int) -> bool:
+    """Shapes the persistent kernels take with dtype TSG_BF16 (include/tsg_hip.h)."""
+    return T > 1 and h in (128, 256, 384, 512)
+
+
+class _BiLSTMLayerBf16(torch.autograd.Function):
+    """``_BiLSTMLayer`` in the bf16 storage mode: x, Gx = x W_ih^T, out, the saved gates R and the gradients dOut / dG / dX are
+    bf16 tensors; the recurrence kernels run with dtype TSG_BF16 (one bf16 MFMA per k block, W_hh rounded once in the kernel's
+    prologue, fp32 cell state, fp32 Cs); W_ih / W_hh / bias gradients leave their GEMMs / the kernel in fp32.  Batch-major."""
+
+    @staticmethod
+    def forward(ctx, x, W_ih, bias, W_hh):
+        require_device(x, W_ih, bias, W_hh)
+        x, bias, W_hh = _bfc(x), _f32p(bias), _f32p(W_hh)
+        B, T, I = x.shape
+        h = W_hh.shape[2]
+        if W_ih.shape != (8 * h, I) or W_hh.shape != (2, 4 * h, h) or bias.numel() != 8 * h:
+            raise ValueError(f"bilstm: shape mismatch x{tuple(x.shape)} W_ih{tuple(W_ih.shape)} W_hh{tuple(W_hh.shape)}")
+        Wb = W_ih.detach().to(_BF)                                        # [8h, I]
+        Gx = torch.mm(x.view(B * T, I), Wb.t())                           # bf16 [B*T, 8h]; the bias is added inside the kernel
+        out = torch.empty(B, T, 2 * h, device=x.device, dtype=_BF)
+        R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=_BF)
+        Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
+        sync = torch.empty(512, device=x.device, dtype=torch.int32)
+        check_lstm_errors()
+        _call("tsg_lstm_fwd_bias", x, ptr(Gx), ptr(bias), ptr(W_hh), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, TSG_BF16, 1)
+        ctx.lstm_sync = sync
+        ctx.save_for_backward(x, Wb, W_hh, out, R, Cs)
+        ctx.mark_non_differentiable(Cs)
+        ctx.set_materialize_grads(False)
+        return out, Cs
+
+    @staticmethod
+    def backward(ctx, dOut, _dCs):
+        x, Wb, W_hh, out, R, Cs = ctx.saved_tensors
+        B, T, I = x.shape
+        h = W_hh.shape[2]
+        TB = T * B
+        dOut = _bfc(dOut) if dOut is not None else torch.zeros_like(out)
+        WhhT = W_hh.transpose(1, 2).contiguous()
+        dG = torch.empty(B, T, 2, 4 * h, device=x.device, dtype=_BF)
+        dC = torch.empty(2, B, h, device=x.device, dtype=torch.float32)
+        nb = int(load().tsg_lstm_bwd_ws_bytes(B, T, h))
+        ws = torch.empty(nb // 4 + 4, device=x.device, dtype=torch.float32)
+        dbias = torch.empty(8 * h, device=x.device, dtype=torch.float32)
+        check_lstm_errors()
+        _call("tsg_lstm_bwd_ws_layout", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC), ptr(ws), nb, ptr(dbias),
+              B, T, h, TSG_BF16, 1)
+        dGf = dG.view(TB, 8 * h)
+        dx = torch.mm(dGf, Wb).view(x.shape) if ctx.needs_input_grad[0] else None
+        dW_ih = torch.mm(dGf.t(), x.view(TB, I), out_dtype=torch.float32)           # [8h, I], both directions
+        # dW_hh[d] = sum_t dG_t[d]^T h_{t-1}[d] (h_{t+1} for the reverse direction): the partner rows as ONE shifted bf16 copy of
+        # `out` (zero at the sequence ends), then a GEMM per direction on strided column views (no cat, no fp32 operands)
+        hp = torch.empty_like(out)
+        hp[:, 1:, :h] = out[:, :-1, :h]; hp[:, 0, :h] = 0
+        hp[:, :-1, h:] = out[:, 1:, h:]; hp[:, -1, h:] = 0
+        g2, hp2 = dG.view(TB, 2, 4 * h), hp.view(TB, 2 * h)
+        dW_hh = torch.stack([torch.mm(g2[:, 0].t(), hp2[:, :h], out_dtype=torch.float32),
+                             torch.mm(g2[:, 1].t(), hp2[:, h:], out_dtype=torch.float32)])
+        return dx, dW_ih, dbias, dW_hh
+
+
 def bilstm_layer(x, W_ih, bias, W_hh, batch_major=False):
-    """x [T,B,I] (or [B,T,I] with batch_major) -> (out in the same layout, Cs [T,2,B,h] cell states, not differentiable)."""
+    """x [T,B,I] (or [B,T,I] with batch_major) -> (out in the same layout, Cs [T,2,B,h] cell states, not differentiable).
+    bf16 storage mode: bf16 in and out through the TSG_BF16 recurrence kernels where they exist (T > 1, h in 128..512 step 128,
+    batch-major); other shapes run the fp32-storage path on an fp32 copy and return bf16."""
+    if bf16_storage() and x.is_cuda:
+        T, h = (x.shape[1] if batch_major else x.shape[0]), W_hh.shape[2]
+        if batch_major and lstm_bf16_ok(T, h):
+            return _BiLSTMLayerBf16.apply(x, W_ih, bias, W_hh)
+        global _GEMM_DTYPE
+        _GEMM_DTYPE = "f32s"                                   # forward of the fallback; its backward reads ctx, not the global
+        try:
+            out, Cs = _BiLSTMLayer.apply(x.float(), W_ih, bias, W_hh, batch_major)
+        finally:
+            _GEMM_DTYPE = "bf16"
+        return out.to(_BF), Cs
     return _BiLSTMLayer.apply(x, W_ih, bias, W_hh, batch_major)

@@ -97,7 +97,7 @@ class VideoTextSemanticMatch(nn.Module):
         if video_feat.is_cuda and act_name is not None and H % 4 == 0 and H <= 1024 and lin2.weight.size(0) == 1:
             # K5: add + activation + the 1-output Linear in one pass over the video half's GEMM output (and one pass back)
             y = TF.linear(video_feat, lin1.weight[:, :Dv])
-            cs = F.linear(query_feat, lin1.weight[:, Dv:], lin1.bias)
+            cs = TF.linear(query_feat, lin1.weight[:, Dv:], lin1.bias)
             return TF.match_head(y, cs, lin2.weight, lin2.bias, act_name), None
         hid = TF.linear(video_feat, lin1.weight[:, :Dv]) + F.linear(query_feat, lin1.weight[:, Dv:], lin1.bias).unsqueeze(1)
         # (measured and dropped: the 1-output Linear as torch.matmul(hid, w) -- its mv / ger backward is slower than the two

@@ -74,7 +74,7 @@ class MLP_predictor(nn.Module):
         Dv = video_feat.size(-1)
         W1, b1, w2, b2 = self._stacked()
         y = TF.linear(video_feat, W1[:, :Dv])
-        cs = F.linear(sent_feat, W1[:, Dv:])
+        cs = TF.linear(sent_feat, W1[:, Dv:])
         return TF.boundary_score(y, cs, b1, w2, b2, gate, v_mask)
 
 

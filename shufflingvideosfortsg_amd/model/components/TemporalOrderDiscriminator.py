@@ -33,7 +33,7 @@ class MomentPooling(nn.Module):
 
     def forward(self, feat, target_mask, fore_mask, back_mask):
         if feat.dim() == 3 and target_mask.dim() == 2:
-            pooled = self.average_masks(feat, (target_mask, fore_mask, back_mask))
+            pooled = self.average_masks(feat, (target_mask, fore_mask, back_mask)).float()      # [B,3,D]: the small MLPs stay fp32
             tgt, fore_avg, back_avg = pooled[:, 0], pooled[:, 1], pooled[:, 2]
         else:
             tgt, fore_avg, back_avg = (self.average_mask(feat, m) for m in (target_mask, fore_mask, back_mask))

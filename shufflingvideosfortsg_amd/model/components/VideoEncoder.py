@@ -35,7 +35,10 @@ class RNNEncoder(nn.Module):
 
     def forward(self, input, *args):
         video_encoding, _, _ = self.rnn_cell(input)
-        return self.video_layernorm(video_encoding)
+        ln = self.video_layernorm
+        if video_encoding.dtype != ln.weight.dtype:
+            return F.layer_norm(video_encoding, ln.normalized_shape, ln.weight.to(video_encoding.dtype), ln.bias.to(video_encoding.dtype), ln.eps)
+        return ln(video_encoding)
 
 
 class rnn_recalibration_layer(nn.Module):
@@ -87,4 +90,6 @@ class QueryAwareEncoder(nn.Module):
         x = video_feat
         for blk, q in zip(self.blocks, queries):
             x = blk(x, q)
+        if x.dtype != self.norm.weight.dtype:                # bf16 storage mode: bf16 in and out, fp32 statistics inside the kernel
+            return F.layer_norm(x, self.norm.normalized_shape, self.norm.weight.to(x.dtype), self.norm.bias.to(x.dtype), self.norm.eps)
         return self.norm(x)

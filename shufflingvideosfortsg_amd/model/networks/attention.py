@@ -128,5 +128,5 @@ class SCDM_Attention(nn.Module):
         a = TF.linear(video_feat, self.W_a.weight, None)
         s = TF.linear(sent_feat, self.W_s.weight, None)
         if self.W_a.bias is not None:
-            s = s + self.W_a.bias
+            s = s + self.W_a.bias.to(s.dtype)               # (bf16 storage mode: stays bf16)
         return a, s

@@ -1,0 +1,215 @@
+"""bf16 STORAGE path (dtype TSG_BF16; BASELINE configs 2 / 4 name bf16; SURVEY 7 step 8 "bf16 storage, fp32 accumulate"): every
+hand-written kernel of the path with its activations stored as bf16 in HBM, against the fp32 CPU oracle.
+
+Tolerance story.  The kernels compute in fp32; what bf16 storage changes is (i) the inputs are bf16 values and (ii) every stored
+output is rounded once to bf16 (relative 2^-9 = 2e-3).  So each kernel test feeds the ORACLE the same bf16-rounded inputs (as
+fp32) and allows one output rounding plus fp32-level arithmetic differences: rtol 1e-2 / atol 1e-2 x the tensor's scale -- the
+"~1e-2 relative" of SURVEY 7 step 8 -- while quantities that stay fp32 (P, boundary probabilities, matching logits, parameter
+gradients summed in fp32) are held tighter.  The recurrence feeds its own rounded h back for T steps, and the model-level tests
+compose ~10 such stages: their tolerance is stated at each test."""
+import pytest
+import torch
+
+from oracle import tsg_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _r(t):
+    """round to bf16 and back: the value a bf16 tensor stores, as fp32 (what the oracle is given)"""
+    return t.to(BF).float()
+
+
+def _close(got, want, name, rel=1e-2, tight=None):
+    """|got - want| <= rel * max(1, max|want|) elementwise (+ rel * |want|); `tight` overrides rel for fp32-kept tensors"""
+    rel = tight if tight is not None else rel
+    scale = max(1.0, float(want.abs().max()))
+    torch.testing.assert_close(got.float().cpu(), want, atol=rel * scale, rtol=rel, msg=lambda m: f"{name}: {m}")
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 5, 24, 24), (3, 17, 20, 40, 24), (2, 64, 20, 512, 512), (2, 128, 20, 1024, 1024),
+                                   (2, 40, 25, 1024, 1024), (1, 33, 32, 260, 516), (130, 100, 20, 256, 256)])
+def test_scdm_bf16_storage(shape):
+    """K1 (tsg_scdm_attn_fwd / _bwd, dtype TSG_BF16) vs the oracle on the same bf16-valued inputs."""
+    from shufflingvideosfortsg_amd import functional as F
+    B, T, N, H, Ds = shape
+    g = torch.Generator().manual_seed(7)
+    a, s, sent = (_r(torch.randn(*sh, generator=g)).requires_grad_(True) for sh in ((B, T, H), (B, N, H), (B, N, Ds)))
+    w = (torch.randn(H, generator=g) / H ** 0.5).requires_grad_(True)
+    gC = _r(torch.randn(B, T, Ds, generator=g))
+    C0, P0 = O.scdm_core(a, s, w, sent)
+    C0.backward(gC)
+    ad, sd, vd = (x.detach().to(BF).cuda().requires_grad_(True) for x in (a, s, sent))
+    wd = w.detach().cuda().requires_grad_(True)
+    C1, P1 = F.scdm_attn(ad, sd, wd, vd, return_p=True)
+    assert C1.dtype == BF and P1.dtype == torch.float32
+    C1.backward(gC.to(BF).cuda())
+    torch.cuda.synchronize()
+    _close(P1, P0.detach(), "P", tight=1e-4)                 # fp32 in, fp32 arithmetic, fp32 out
+    _close(C1, C0.detach(), "C")
+    for got, want, name in ((ad.grad, a.grad, "da"), (sd.grad, s.grad, "ds"), (vd.grad, sent.grad, "dsent")):
+        assert got.dtype == BF
+        _close(got, want, name)
+    _close(wd.grad, w.grad, "dw", tight=2e-3)                # summed in fp32 from fp32 arithmetic
+    # bitwise run-to-run reproducibility of the stored outputs
+    C2 = F.scdm_attn(ad.detach(), sd.detach(), wd.detach(), vd.detach())
+    assert torch.equal(C2, C1.detach())
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 5, 24), (3, 17, 20, 40), (32, 64, 20, 512), (2, 128, 20, 1024), (2, 40, 25, 1024), (130, 100, 20, 256)])
+def test_scdm_gate_bf16_storage(shape):
+    """K1g (tsg_scdm_gate_fwd / _bwd, dtype TSG_BF16): attention + reassociated sent_linear + sigmoid gate, vs the oracle's
+    un-fused tail given the same bf16-valued projected operands."""
+    from shufflingvideosfortsg_amd import functional as F
+    B, T, N, d = shape
+    g = torch.Generator().manual_seed(8)
+    a, r = (_r(torch.randn(B, T, d, generator=g)).requires_grad_(True) for _ in range(2))
+    s, VW = (_r(torch.randn(B, N, d, generator=g)).requires_grad_(True) for _ in range(2))
+    w = (torch.randn(d, generator=g) / d ** 0.5).requires_grad_(True)
+    gb = (torch.randn(d, generator=g) * 0.1).requires_grad_(True)
+    go = _r(torch.randn(B, T, d, generator=g))
+    e = (torch.tanh(a.unsqueeze(2) + s.unsqueeze(1)) * w).sum(-1)            # attention.py:112-118 on the projected operands
+    P0 = torch.softmax(e, -1)
+    out0 = r * torch.sigmoid(torch.bmm(P0, VW) + gb)                          # VideoEncoder.py:70-72 with sent_linear reassociated
+    out0.backward(go)
+    dev = [x.detach().to(BF).cuda().requires_grad_(True) for x in (a, s, VW, r)]
+    wd, gbd = w.detach().cuda().requires_grad_(True), gb.detach().cuda().requires_grad_(True)
+    out1 = F.scdm_gate(dev[0], dev[1], wd, dev[2], gbd, dev[3])
+    assert out1.dtype == BF
+    out1.backward(go.to(BF).cuda())
+    torch.cuda.synchronize()
+    _close(out1, out0.detach(), "out")
+    for got, want, name in zip(dev, (a, s, VW, r), ("da", "ds", "dVW", "dr")):
+        assert got.grad.dtype == BF
+        _close(got.grad, want.grad, name)
+    _close(wd.grad, w.grad, "dw", tight=2e-3)
+    _close(gbd.grad, gb.grad, "dgbias", tight=2e-3)
+
+
+@pytest.mark.parametrize("B,T,Dv,Ds,Hm,use_mask,use_gate", [(3, 11, 24, 16, 16, True, False), (32, 64, 512, 512, 256, False, True),
+                                                             (2, 128, 1024, 1024, 256, True, True), (2, 300, 64, 32, 130, True, True)])
+def test_boundary_bf16_storage(B, T, Dv, Ds, Hm, use_mask, use_gate):
+    """K3 (tsg_boundary_score_fwd / _bwd, dtype TSG_BF16: y and dy as bf16) vs the oracle's MLP_predictor tail on the same
+    bf16-valued y.  The probabilities stay fp32: they are held to 1e-4."""
+    from shufflingvideosfortsg_amd import functional as F
+    J = 2 * Hm
+    g = torch.Generator().manual_seed(9)
+    y = _r(torch.randn(B, T, J, generator=g)).requires_grad_(True)
+    cs = torch.randn(B, J, generator=g).requires_grad_(True)
+    b1 = (torch.randn(J, generator=g) * 0.1).requires_grad_(True)
+    w2 = (torch.randn(J, generator=g) / Hm ** 0.5).requires_grad_(True)
+    b2 = (torch.randn(2, generator=g) * 0.1).requires_grad_(True)
+    gate = torch.randn(B, T, generator=g).requires_grad_(True) if use_gate else None
+    mask = None
+    if use_mask:
+        n = torch.randint(max(1, T // 2), T + 1, (B,), generator=g)
+        mask = (torch.arange(T)[None, :] < n[:, None]).int()
+    gs, ge = torch.randn(B, T, generator=g), torch.randn(B, T, generator=g)
+    z = (gate.unsqueeze(2) if use_gate else 1.0) * (y + cs.unsqueeze(1)) + b1           # SpanGroundMatchDisc.py:86, SpanPredictor.py:75-78
+    u = torch.tanh(z)
+    ls, le = u[..., :Hm] @ w2[:Hm] + b2[0], u[..., Hm:] @ w2[Hm:] + b2[1]
+    if use_mask:
+        ls, le = O.mask_logits(ls, mask), O.mask_logits(le, mask)
+    s0, e0 = torch.softmax(ls, 1), torch.softmax(le, 1)
+    (s0 * gs + e0 * ge).sum().backward()
+    leaves = [y, cs, b1, w2, b2] + ([gate] if use_gate else [])
+    dev = [x.detach().cuda().requires_grad_(True) for x in leaves]
+    dev[0] = y.detach().to(BF).cuda().requires_grad_(True)
+    s1, e1 = F.boundary_score(dev[0], dev[1], dev[2], dev[3], dev[4], dev[5] if use_gate else None, mask.cuda() if use_mask else None)
+    assert s1.dtype == torch.float32
+    (s1 * gs.cuda() + e1 * ge.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    _close(s1, s0.detach(), "start", tight=1e-4)
+    _close(e1, e0.detach(), "end", tight=1e-4)
+    assert dev[0].grad.dtype == BF
+    _close(dev[0].grad, y.grad, "dy")
+    for got, want, name in zip(dev[1:], leaves[1:], ["dcs", "db1", "dw2", "db2", "dgate"]):
+        _close(got.grad, want.grad, name, tight=2e-3)
+
+
+@pytest.mark.parametrize("B,T,H,act", [(3, 40, 128, "relu"), (2, 128, 1024, "relu"), (2, 33, 260, "tanh"), (2, 16, 64, "sigmoid")])
+def test_match_head_bf16_storage(B, T, H, act):
+    """K5 (tsg_match_head_fwd / _bwd, dtype TSG_BF16: y and dy as bf16) vs the torch formulation on the same bf16-valued y."""
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(10)
+    y = _r(torch.randn(B, T, H, generator=g)).requires_grad_(True)
+    cs = torch.randn(B, H, generator=g).requires_grad_(True)
+    w2 = (torch.randn(H, generator=g) / H ** 0.5).requires_grad_(True)
+    b2 = torch.randn(1, generator=g).requires_grad_(True)
+    gl = torch.randn(B, T, generator=g)
+    fn = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act]
+    l0 = fn(y + cs.unsqueeze(1)) @ w2 + b2                                   # DistributionAlign.py:88-96 after the split first Linear
+    l0.backward(gl)
+    yd = y.detach().to(BF).cuda().requires_grad_(True)
+    csd, w2d, b2d = (x.detach().cuda().requires_grad_(True) for x in (cs, w2, b2))
+    l1 = F.match_head(yd, csd, w2d, b2d, act)
+    l1.backward(gl.cuda())
+    torch.cuda.synchronize()
+    _close(l1, l0.detach(), "logits", tight=1e-4)
+    assert yd.grad.dtype == BF
+    _close(yd.grad, y.grad, "dy")
+    for got, want, name in ((csd, cs, "dcs"), (w2d, w2, "dw2"), (b2d, b2, "db2")):
+        _close(got.grad, want.grad, name, tight=2e-3)
+
+
+@pytest.mark.parametrize("B,T,I,h", [(5, 20, 300, 256), (32, 64, 1024, 256), (4, 128, 1024, 512), (40, 12, 64, 128), (3, 9, 40, 384)])
+def test_bilstm_bf16_storage(B, T, I, h, request):
+    """The 2-layer BiLSTM in the bf16 storage mode (TSG_BF16 persistent recurrence kernels: bf16 Gx / out / R / dOut / dG, one bf16
+    MFMA per k block, h_t fed back as the bf16 value it is stored as) vs the oracle's fp32 recurrence with the same weights and the
+    same bf16-valued input.  bf16 recurrences accumulate rounding over T steps: outputs within 3e-2 abs (|h| <= 1), gradients
+    within 5e-2 of their scale."""
+    from shufflingvideosfortsg_amd import engine, functional as TF
+    from shufflingvideosfortsg_amd.model.networks.RNN import BiLSTM
+    from test_lstm_gpu import _params
+    engine.precision("bf16")
+    request.addfinalizer(lambda: engine.precision(None))
+    g = torch.Generator().manual_seed(11)
+    p = {k: v.requires_grad_(True) for k, v in _params(I, h, 2, g).items()}
+    x = _r(torch.randn(B, T, I, generator=g)).requires_grad_(True)
+    go = _r(torch.randn(B, T, 2 * h, generator=g))
+    out0, hn0, cn0 = O.bilstm(x, p, 2)
+    (out0 * go).sum().backward()
+    m = BiLSTM(I, h, 2, 0.0)
+    m.load_state_dict({k: v.detach() for k, v in p.items()})
+    m.cuda().train()
+    xd = x.detach().to(BF).cuda().requires_grad_(True)
+    out1, hn1, cn1 = m(xd)
+    assert out1.dtype == BF and cn1.dtype == torch.float32
+    (out1.float() * go.cuda()).sum().backward()
+    torch.cuda.synchronize(); TF.check_lstm_errors()
+    torch.testing.assert_close(out1.float().cpu(), out0.detach(), atol=3e-2, rtol=3e-2)
+    torch.testing.assert_close(hn1.float().cpu(), hn0.detach(), atol=3e-2, rtol=3e-2)
+    torch.testing.assert_close(cn1.cpu(), cn0.detach(), atol=5e-2, rtol=5e-2)
+    _close(xd.grad, x.grad, "dx", rel=5e-2)
+    for k, v in m.named_parameters():
+        assert v.grad.dtype == torch.float32
+        _close(v.grad, p[k].grad, k, rel=5e-2)
+    # run-to-run bitwise reproducible (the exchange protocol does not change the arithmetic)
+    out2, _, _ = m(xd.detach())
+    torch.cuda.synchronize(); TF.check_lstm_errors()
+    assert torch.equal(out2, out1.detach())
+
+
+def test_linear_bf16_storage(request):
+    """functional.linear in the storage mode: bf16 in / out, fp32 weight and bias gradients."""
+    from shufflingvideosfortsg_amd import engine, functional as TF
+    engine.precision("bf16")
+    request.addfinalizer(lambda: engine.precision(None))
+    g = torch.Generator().manual_seed(12)
+    x = _r(torch.randn(6, 50, 96, generator=g)).requires_grad_(True)
+    w = _r(torch.randn(64, 96, generator=g) / 10).requires_grad_(True)
+    b = torch.randn(64, generator=g).requires_grad_(True)
+    gy = _r(torch.randn(6, 50, 64, generator=g))
+    y0 = torch.nn.functional.linear(x, w, b)
+    y0.backward(gy)
+    xd = x.detach().to(BF).cuda().requires_grad_(True)
+    wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    y1 = TF.linear(xd, wd, bd)
+    assert y1.dtype == BF
+    y1.backward(gy.to(BF).cuda())
+    _close(y1, y0.detach(), "y")
+    _close(xd.grad, x.grad, "dx")
+    assert wd.grad.dtype == torch.float32 and bd.grad.dtype == torch.float32
+    _close(wd.grad, w.grad, "dw", tight=2e-3)
+    _close(bd.grad, b.grad, "db", tight=2e-3)

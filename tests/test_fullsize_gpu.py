@@ -26,7 +26,7 @@ def _sub(batch, sl, device=None):
 BF16_TOL = dict(atol=1e-2, rtol=2e-2)     # the bf16 GEMM mode has its own tolerance (~1e-2 relative)
 
 
-@pytest.mark.parametrize("gemm", ["f32s", None, "bf16"])
+@pytest.mark.parametrize("gemm", ["f32s", None, "bf16", "bf16-storage"])
 def test_full_size_gmd_step_vs_oracle(gemm, request):
     """engine.gmd_step at the bench shape; the oracle cannot run 64 pairs in seconds, so:
       * boundary scores / matching logits / discriminator logits of 2 batch items vs the oracle on those items (1e-4);
@@ -38,8 +38,11 @@ def test_full_size_gmd_step_vs_oracle(gemm, request):
     from shufflingvideosfortsg_amd import data, engine, functional as TF
     from shufflingvideosfortsg_amd import loss as L
     from shufflingvideosfortsg_amd.model.networks.attention import masked_softmax
-    bf16 = gemm == "bf16"                 # library GEMM operands bf16 (autocast), fp32 accumulate; HIP kernels fp32: BASELINE config 2 names it
-    mode = torch.bfloat16 if bf16 else gemm
+    # "bf16": library GEMM operands bf16 (autocast), fp32 accumulate, fp32 storage; "bf16-storage": the TSG_BF16 path -- bf16
+    # activations in HBM through every hand-written kernel (BASELINE configs 2 / 4), fp32 arithmetic inside, fp32 master weights
+    storage = gemm == "bf16-storage"
+    bf16 = gemm == "bf16" or storage
+    mode = "bf16" if storage else (torch.bfloat16 if bf16 else gemm)
     tol = BF16_TOL if bf16 else TOL
     precision = lambda: engine.precision(mode)
     request.addfinalizer(lambda: engine.precision(None))
@@ -59,6 +62,8 @@ def test_full_size_gmd_step_vs_oracle(gemm, request):
             else:
                 v[2:4] = [list(x) for x in v[0:2]]
     dev = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in cpu.items() if not isinstance(v, dict)}
+    if storage:                           # the clip features are resident in the storage dtype (as bench.py --dtype bf16 holds them)
+        dev["video"], dev["pseudo_video"] = dev["video"].to(torch.bfloat16), dev["pseudo_video"].to(torch.bfloat16)
     for gt in ("gt", "pseudo_gt"):
         dev[gt] = {k: (v.cuda() if isinstance(v, torch.Tensor) else torch.tensor(v, dtype=torch.long).cuda()) for k, v in cpu[gt].items()}
 
