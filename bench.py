@@ -449,6 +449,7 @@ def main():
         alt.append({"dtype": mode, "value": round(Bglobal * a.steps / dt2, 2), "unit": "pairs/s",
                     "ms_per_step": round(dt2 / a.steps * 1e3, 3), "finite": bool(torch.isfinite(loss2)), "note": NOTES[mode]})
         log(f"alternate GEMM mode {mode}: {alt[-1]['ms_per_step']} ms/step")
+        del loss2
     gdt = gdt_main
     functional.set_gemm_dtype(gdt_main)
     fwd_only = None
@@ -463,6 +464,7 @@ def main():
         fwd_only = {"value": round(Bglobal * a.steps / dt3, 2), "unit": "pairs/s", "ms_per_step": round(dt3 / a.steps * 1e3, 3),
                     "finite": bool(torch.isfinite(loss3)), "note": "forward + losses under no_grad, same batch and mode as `value`"}
         log(f"forward-only: {fwd_only['ms_per_step']} ms/step")
+        del loss3
     functional.check_lstm_errors()
     graph_replay = None
     if not a.fwd_only and not a.no_alt and world == 1:
@@ -496,6 +498,15 @@ def main():
     want_graph = (not a.fwd_only) and (a.graph == "on" or (a.graph == "auto" and world > 1))
     if want_graph:
         gstep, err = None, ""
+        # nothing of the eager steps may stay alive: their autograd graph owns AccumulateGrad nodes bound to the eager stream, and the
+        # capture runs on GraphedTrainStep's own stream (a stale node there breaks the capture)
+        loss = float(loss)
+        dp.zero_grad()
+        for p_ in model.parameters():
+            p_.grad = None
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
         try:
             opt_g = engine.make_optimizer(model, params, capturable=True)
             gstep = engine.GraphedTrainStep(model, opt_g, lambda m, b: forward(), batch, dp=dp)

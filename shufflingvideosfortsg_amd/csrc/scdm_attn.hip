@@ -73,10 +73,9 @@ __device__ __forceinline__ int wave_id() {    // wave-uniform (SGPR) wave index 
 // 160+ VGPRs and spills).  (Calibration, tools/ubench: v_rcp_f32 ~10 cyc, v_fma_f32 ~2.8 cyc per
 // wave-instruction; v_pk_fma_f32 costs two v_fma_f32, and sharing one rcp between two elements
 // (1/x0 = x1/(x0 x1)) buys nothing, so the plain fma-rcp-fma triple is the floor: ~15.6 cyc.)
-template <int NP, int R>
+template <int NP, int R, int G = (R == 1) ? 4 : 2>     // G = words per scheduling group (~16 triples of VALU work at G R = 4)
 __device__ __forceinline__ void scdm_chunk_step(const float (&Ea)[R][4], const float* __restrict__ esp, int HP,
                                                 const float (&w2)[4], float (&acc)[R][NP]) {
-  constexpr int G = (R == 1) ? 4 : 2;          // words per scheduling group (~16 triples of VALU work)
   static_assert(NP % G == 0, "word groups");
   float4 cur[G], nxt[G];
 #pragma unroll
@@ -176,15 +175,17 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
   // after that loop -- before this sub-tile's P / C stores are issued -- so that no wait in the
   // steady state sits behind a store (vmcnt counts loads and stores together, in order; a wait
   // that follows the C stores would drain them and serialise the store tail with the next loop).
-  float4 q[R][4], qn[R][4];
-  auto load_rows = [&](float4 (&dst)[R][4], int t_first) {
+  // (raw pieces: with bf16 storage the conversion happens where the row is consumed, not where it is requested)
+  typedef typename Raw4T<ST>::type Raw4;
+  Raw4 q[R][4], qn[R][4];
+  auto load_rows = [&](Raw4 (&dst)[R][4], int t_first) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int t = t_first + wv * R + r;
       const ST* row = ab + (size_t)(t < T ? t : T - 1) * H + lane * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        dst[r][i] = (i * 256 + lane * 4 < H) ? ld4(row + i * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[r][i] = (i * 256 + lane * 4 < H) ? ldraw4(row + i * 256) : zero_raw4(row);
     }
   };
   load_rows(q, t_tile);
@@ -248,7 +249,9 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
   if (!TSG_SKIP(4)) load_v(jcol);
   // GATE: bias of this lane's columns, and the r rows of the current sub-tile's phase-2 rows (requested
   // before the score loop, landed with the next a rows -- i.e. ahead of this sub-tile's stores)
-  float gb[CW], rgv[SUB][CW];
+  typedef typename std::conditional<CW == 4, typename Raw4T<ST>::type, typename Raw2T<ST>::type>::type RawR;
+  float gb[CW];
+  RawR rgv[SUB];                                          // raw r pieces of the phase-2 rows (converted in the epilogue)
 #pragma unroll
   for (int c = 0; c < CW; ++c) gb[c] = (GATE && jcol + c < Ds) ? gbias[jcol + c] : 0.f;
   auto load_r = [&](int t_first) {
@@ -257,13 +260,7 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
       const int tl = rs + i * rslots, t = t_first + tl;
       if (tl < SUB) {
         const ST* src = gr + ((size_t)b * T + (t < T ? t : T - 1)) * Ds + (jcol < Ds ? jcol : 0);
-        if (CW == 4) {
-          const float4 q4 = ld4(src);
-          rgv[i][0] = q4.x; rgv[i][1] = q4.y; rgv[i][CW - 2] = q4.z; rgv[i][CW - 1] = q4.w;
-        } else {
-          const float2 q2 = ld2(src);
-          rgv[i][0] = q2.x; rgv[i][1] = q2.y;
-        }
+        if constexpr (CW == 4) rgv[i] = ldraw4(src); else rgv[i] = ldraw2(src);
       }
     }
   };
@@ -291,7 +288,7 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
       float Ea[R][4];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float4 e = exp2x4(q[r][0]);
+        const float4 e = exp2x4(cvt4(q[r][0]));
         Ea[r][0] = e.x; Ea[r][1] = e.y; Ea[r][2] = e.z; Ea[r][3] = e.w;
         q[r][0] = q[r][1]; q[r][1] = q[r][2]; q[r][2] = q[r][3];   // H <= 1024: the whole row is here
       }
@@ -302,14 +299,20 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        asm volatile("" : "+v"(qn[r][i].x), "+v"(qn[r][i].y), "+v"(qn[r][i].z), "+v"(qn[r][i].w));
+        if constexpr (storage_is_bf16<ST>::value) asm volatile("" : "+v"(qn[r][i].x), "+v"(qn[r][i].y));
+        else asm volatile("" : "+v"(qn[r][i].x), "+v"(qn[r][i].y), "+v"(qn[r][i].z), "+v"(qn[r][i].w));
         q[r][i] = qn[r][i];
       }
     if (GATE) {
 #pragma unroll
-      for (int i = 0; i < SUB; ++i)
-#pragma unroll
-        for (int c = 0; c < CW; ++c) asm volatile("" : "+v"(rgv[i][c]));
+      for (int i = 0; i < SUB; ++i) {
+        if constexpr (storage_is_bf16<ST>::value) {
+          if constexpr (CW == 4) asm volatile("" : "+v"(rgv[i].x), "+v"(rgv[i].y)); else asm volatile("" : "+v"(rgv[i]));
+        } else {
+          if constexpr (CW == 4) asm volatile("" : "+v"(rgv[i].x), "+v"(rgv[i].y), "+v"(rgv[i].z), "+v"(rgv[i].w));
+          else asm volatile("" : "+v"(rgv[i].x), "+v"(rgv[i].y));
+        }
+      }
     }
 
     // k-reduction + softmax over the N words, one clip row at a time
@@ -355,8 +358,11 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
     // ---- phase 2: C[t, cols] = sum_n P[t,n] * sent[b,n,cols] for rows rs, rs+rslots, ... ---------
     if (!TSG_SKIP(4)) {
       const bool jok = jcol < Ds;
-      auto row = [&](int tl, const float (&rr)[CW]) {
+      auto row = [&](int tl, const RawR& rraw) {
         const int t = t0 + tl;
+        float rr[CW];
+        if constexpr (CW == 4) { const float4 f = cvt4(rraw); rr[0] = f.x; rr[1] = f.y; rr[2] = f.z; rr[3] = f.w; }
+        else { const float2 f = cvt2(rraw); rr[0] = f.x; rr[1] = f.y; }
         v2f c[CW / 2];
 #pragma unroll
         for (int h = 0; h < CW / 2; ++h) c[h] = (v2f){0.f, 0.f};
@@ -389,9 +395,264 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_kernel(
         for (int i = 0; i < SUB; ++i)
           if (rs + i * rslots < SUB) row(rs + i * rslots, rgv[i]);
       } else {
-        const float none[CW] = {};
+        const RawR none = {};
 #pragma unroll 2
         for (int tl = rs; tl < SUB; tl += rslots) row(tl, none);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, split-precision variant (dtype TSG_F32S): phase 2 on the bf16 matrix pipe.
+//
+// The forward above is bound by VALU issue (PMC: the SIMDs' vector pipes are busy ~70 % of the launch, HBM traffic is 1.00x the
+// algorithmic bytes): per 64-row workgroup tile a wave spends ~46 k cycles of issue in the score loop (fma, rcp, fma per (t,n,k))
+// and ~16 k in phase 2 (C = P VW: T N Ds multiply-adds as v_pk_fma_f32, which costs two v_fma_f32 here) + the gate epilogue.
+// Phase 2 is a [32 rows x N words] x [N words x Ds] product per 32-row group: on v_mfma_f32_32x32x16_bf16 it is 6 MFMAs per
+// 32 x 32 output tile (2 k steps of 16 words x the three split-precision products hi*hi + hi*lo + lo*hi; P in [0,1] and VW are
+// written as hi + lo with hi = rne_bf16(x), lo = rne_bf16(x - hi): error 2^-16 relative, the arithmetic of the "f32s" mode's
+// GEMMs) = 24 MFMAs per wave and group against ~8 k cycles of VALU issue, and the matrix pipe runs beside the other wave's
+// score loop.  What it costs is the accumulator layout: a lane holds ONE output column and 16 rows, so the r loads and the out
+// stores are one dword per lane (two 128-byte row segments per wave instruction) instead of 16 bytes per lane: 4x the vector
+// memory instructions for the same bytes.  (Round 2 tried this with the exact fp32 MFMA -- 10 x 64 cycles per tile -- and an LDS
+// transpose to keep 16-byte rows, restructured around 32-row sub-tiles: slower.  Here the 8-row score pipeline is untouched,
+// the P rows of four sub-tiles collect in LDS, and the MFMA phase runs once per 32 rows with the VW fragments resident.)
+// Used for fp32 storage when H = Ds = 256 * CT, CT in {1, 2, 4} (SCDM_Attention's default hidden_dim = video_dim at d = 256, 512,
+// 1024); everything else runs the kernel above.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 k1_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned k1_u32x4 __attribute__((ext_vector_type(4)));
+typedef float k1_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void k1_split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16x2(a, b);
+  lo = pack_bf16x2(a - bf16_lo(hi), b - bf16_hi(hi));
+}
+__device__ __forceinline__ void k1_split8(const float (&v)[8], k1_u32x4& hi, k1_u32x4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) k1_split_pair(v[2 * i], v[2 * i + 1], h[i], l[i]);
+  hi = (k1_u32x4){h[0], h[1], h[2], h[3]};
+  lo = (k1_u32x4){l[0], l[1], l[2], l[3]};
+}
+__device__ __forceinline__ k1_f32x16 k1_mfma(k1_u32x4 a, k1_u32x4 b, k1_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k1_bf16x8, a), __builtin_bit_cast(k1_bf16x8, b), c, 0, 0, 0);
+}
+
+template <int NP, bool GATE, int CT>
+__global__ __launch_bounds__(kFwdThreads) void scdm_fwd_mm_kernel(
+    const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w,
+    const float* __restrict__ V, float* __restrict__ C, float* __restrict__ P,
+    const float* __restrict__ gr, const float* __restrict__ gbias,
+    int B, int T, int N, int H, int Ds, int TT, int tiles, int dbg) {
+  constexpr int SUB = kFwdWaves;                     // 8 rows per sub-tile, one per wave
+  constexpr int PP = 36;                             // P tile row pitch (32 word slots + 4: 16-byte aligned rows)
+  constexpr int KS = NP > 16 ? 2 : 1;                // MFMA k steps of 16 words
+  const int HP = roundup256(H);
+  extern __shared__ __align__(16) float lds[];
+  float* Es = lds;                       // [NP][HP]
+  float* Wl = lds + NP * HP;             // [HP]   -2*w
+  float* Pl = Wl + HP;                   // [2][SUB][PP]  softmax rows of a sub-tile (double-buffered), zero beyond NP
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+  const int jl = lane & 31, hh = lane >> 5;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x, tiles);
+  const int b = bid / tiles, tile = bid % tiles;
+  const int t_tile = tile * TT;
+  const float* ab = a + (size_t)b * T * H;
+
+  // The wave's current clip row lives in 4 float4 (H <= 1024); chunk c of the NEXT sub-tile's row is requested into slot c as soon
+  // as the score loop has consumed it (three chunks = ~4 k cycles of cover): 16 registers instead of a second row buffer.
+  float4 q[4];
+  auto row_ptr = [&](int t_first) {
+    const int t = t_first + wv;
+    return ab + (size_t)(t < T ? t : T - 1) * H + lane * 4;
+  };
+  {
+    const float* row = row_ptr(t_tile);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      q[i] = (i * 256 + lane * 4 < H) ? *reinterpret_cast<const float4*>(row + i * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- prologue: Es = exp(2 s[b]), -2w, zeroed P tiles (as the kernel above)
+  const float* sb = s + (size_t)b * N * H;
+  const int hp4 = HP / 4, total4 = NP * hp4;
+  constexpr int PU = 12;
+  for (int base = tid; base < total4; base += PU * kFwdThreads) {
+    float4 v[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int idx = base + u * kFwdThreads;
+      const int n = idx / hp4, k = (idx % hp4) * 4;
+      v[u] = (idx < total4 && n < N && k < H) ? *reinterpret_cast<const float4*>(sb + (size_t)n * H + k) : make_float4(-1e30f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int idx = base + u * kFwdThreads;
+      if (idx < total4) {
+        const int n = idx / hp4, k = (idx % hp4) * 4;
+        float4 e = exp2x4(v[u]);
+        if (v[u].x == -1e30f) e = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Es + n * HP + k) = e;
+      }
+    }
+  }
+  for (int k = tid * 4; k < HP; k += 4 * kFwdThreads) {
+    float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < H) wq = *reinterpret_cast<const float4*>(w + k);
+    *reinterpret_cast<float4*>(Wl + k) = make_float4(-2.f * wq.x, -2.f * wq.y, -2.f * wq.z, -2.f * wq.w);
+  }
+  for (int i = tid; i < 2 * SUB * PP; i += kFwdThreads) Pl[i] = 0.f;
+
+  // ---- this wave's strip of VW (32*CT columns) as resident B-operand fragments of v_mfma_f32_32x32x16_bf16: lane (jl, hh) holds
+  // words 16 ks + 8 hh .. +7 of column col0 + 32 ct + jl, as hi and lo bf16 planes (hi = rne_bf16(x), lo = rne_bf16(x - hi))
+  const int col0 = wv * 32 * CT;
+  const float* Vb = V + (size_t)b * N * Ds + col0 + jl;      // Ds = 256 CT: every column exists
+  k1_u32x4 vh[CT][KS], vl[CT][KS];
+  float gb[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    gb[ct] = GATE ? -kLog2e * gbias[col0 + 32 * ct + jl] : 0.f;      // folded into the sigmoid's exponent
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = 16 * ks + 8 * hh + j;
+        e[j] = Vb[(size_t)(n < N ? n : 0) * Ds + 32 * ct];
+        if (n >= N) e[j] = 0.f;
+      }
+      k1_split8(e, vh[ct][ks], vl[ct][ks]);
+    }
+  }
+  // The MFMA tile is 32 rows; a sub-tile has 8: rows 8 .. 31 of the A operand are zero, and of the 16 accumulator registers of a
+  // lane only i = 0 .. 3 (rows i + 4 hh) are real -- every lane of the wave has live outputs, 4 per column tile.  (The matrix pipe is
+  // otherwise idle: 6 CT MFMAs per wave and sub-tile run beside the partner wave's score loop.)
+  // r / out addresses: wave-uniform row base (scalar registers) + ONE 32-bit lane offset (4 hh rows + the lane's column).  Rows beyond
+  // T (ragged last tile) read an in-bounds row instead (the uniform row clamped to T - 1; the upper half wave drops its 4-row offset
+  // when that would leave the sequence -- a wave-uniform choice between two lane offsets) and are never stored.
+  const unsigned lane_off = (unsigned)(4 * hh) * (unsigned)Ds + (unsigned)(col0 + jl);
+  const unsigned lane_col = (unsigned)(col0 + jl);
+  float rr[CT][4];
+  auto load_rr = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = min(t0 + i, T - 1);                    // wave-uniform
+      const float* base = gr + ((size_t)b * T + u) * Ds;
+      const unsigned off = u + 4 < T ? lane_off : lane_col;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) rr[ct][i] = (base + 32 * ct)[off];
+    }
+  };
+  // nothing may be pending at the loop head (see the landing point inside the loop): the first row is consumed right away anyway
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(q[i].x), "+v"(q[i].y), "+v"(q[i].z), "+v"(q[i].w));
+  lds_barrier();
+
+  const int nsub = TT / SUB;
+#pragma unroll 1
+  for (int st = 0; st < nsub; ++st) {
+    const int t0 = t_tile + st * SUB;
+    float* Pcur = Pl + (st & 1) * SUB * PP;
+
+    // ---- phase 1: scores + softmax of this wave's row (as above) ---------------------------------
+    float acc[1][NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) acc[0][n] = 0.f;
+    if (GATE) load_rr(t0);                                 // lands under the score loop below: phase 2 never waits for HBM
+    // next sub-tile's row (beyond the tile / the sequence: a clamped, valid row that is never used).  The loads below are
+    // UNCONDITIONAL on clamped addresses: a load under a condition becomes a copy of its destination behind a vmcnt(0) wait right
+    // after the chunk (the value must be merged with the old register contents) -- a stall on its own latency, four times per row.
+    const float* nrow = row_ptr(t0 + SUB) - lane * 4;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {                         // H = Ds = 256 CT (host-checked): the chunk count is a compile-time constant,
+      const int k0 = 256 * c;                              // so no chunk (and no load inside it) sits under a condition
+      if (!TSG_SKIP(1)) {
+        const int k = k0 + lane * 4;
+        const float4 wq = *reinterpret_cast<const float4*>(Wl + k);
+        const float w2[4] = {wq.x, wq.y, wq.z, wq.w};
+        float Ea[1][4];
+        const float4 e = exp2x4(q[c]);
+        Ea[0][0] = e.x; Ea[0][1] = e.y; Ea[0][2] = e.z; Ea[0][3] = e.w;
+        q[c] = *reinterpret_cast<const float4*>(nrow + k);
+        scdm_chunk_step<NP, 1, 2>(Ea, Es + k, HP, w2, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // Land the next row (and this sub-tile's r values) HERE, ahead of this sub-tile's P / out stores: vmcnt counts loads and stores
+    // together, in order, and a wait that the compiler places at the loop head for a load still pending across the back edge is
+    // `vmcnt(0)` -- it would drain the out stores of every sub-tile (an HBM write round trip, ~2 us, eight times per tile: what made
+    // the first version of this kernel no faster than the VALU one).  After this point only stores are in flight.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(q[i].x), "+v"(q[i].y), "+v"(q[i].z), "+v"(q[i].w));
+    if (GATE) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(rr[ct][i]));
+    }
+    {
+      float z[NP / 4];
+      wave_transpose_sum<NP>(acc[0], z);
+      const int qd = lane >> 4;
+      const int nq = ((qd & 1) << 1) | (qd >> 1);
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < NP / 4; ++j) {
+        if (4 * j + nq >= N) z[j] = -INFINITY;
+        m = fmaxf(m, z[j]);
+      }
+      m = xrow_max(m);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < NP / 4; ++j) {
+        z[j] = fast_exp2((z[j] - m) * kLog2e);
+        sum += z[j];
+      }
+      const float inv = 1.f / xrow_sum(sum);
+      const int t = t0 + wv;
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < NP / 4; ++j) {
+          const int n = 4 * j + nq;
+          const float pv = z[j] * inv;
+          Pcur[wv * PP + n] = pv;
+          if (n < N && t < T) P[((size_t)b * T + t) * N + n] = pv;
+        }
+      }
+    }
+    lds_barrier();                                        // the sub-tile's 8 P rows are in LDS (the other buffer is free again)
+    if (TSG_SKIP(4)) continue;
+
+    // ---- phase 2: out[8 rows, this wave's 32*CT columns] on the matrix pipe --------------------------
+    k1_u32x4 ph[KS], pl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float* pr = Pcur + (jl & 7) * PP + 16 * ks + 8 * hh;
+      float4 x = *reinterpret_cast<const float4*>(pr), y = *reinterpret_cast<const float4*>(pr + 4);
+      if (jl >= 8) { x = make_float4(0.f, 0.f, 0.f, 0.f); y = x; }         // rows 8 .. 31 of the MFMA tile do not exist
+      const float e[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+      k1_split8(e, ph[ks], pl[ks]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      k1_f32x16 o;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        o = k1_mfma(ph[ks], vh[ct][ks], o);
+        o = k1_mfma(ph[ks], vl[ct][ks], o);
+        o = k1_mfma(pl[ks], vh[ct][ks], o);
+      }
+      float* dst = C + ((size_t)b * T + t0) * Ds + 32 * ct;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                          // accumulator register i <-> row i + 4 hh
+        float v = o[i];
+        if (GATE) v = rr[ct][i] * fast_rcp(1.f + fast_exp2(fmaf(v, -kLog2e, gb[ct])));      // r * sigmoid(G + bias)
+        if (t0 + i + 4 * hh < T) (dst + (size_t)i * Ds)[lane_off] = v;
       }
     }
   }
@@ -1414,6 +1675,27 @@ int launch_fwd(const ST* a, const ST* s, const float* w, const ST* V, ST* C, flo
   return check_launch("scdm_attn_fwd");
 }
 
+// dtype TSG_F32S, fp32 storage: the forward with phase 2 on the bf16 matrix pipe where its tiling applies (Ds = 256, 512, 1024);
+// TSG_K1_FWD=valu in the environment keeps the VALU kernel (A/B timing).  Returns -1000 when the shape is not covered.
+template <int NP, bool GATE>
+int launch_fwd_mm(const float* a, const float* s, const float* w, const float* V, float* C, float* P,
+                  const float* gr, const float* gbias, int B, int T, int N, int H, int Ds, hipStream_t st) {
+  static const bool valu_only = [] { const char* e = getenv("TSG_K1_FWD"); return e && e[0] == 'v'; }();
+  if (valu_only || H != Ds || (Ds != 256 && Ds != 512 && Ds != 1024)) return -1000;
+  int TT = 64;                               // rows per workgroup: as many as still give every CU a workgroup (as launch_fwd)
+  while (TT > 8 && (long)B * cdiv(T, TT) < 256) TT >>= 1;
+  static const int tt_env = [] { const char* e = getenv("TSG_K1_TT"); return e ? atoi(e) : 0; }();
+  if (tt_env >= 8 && tt_env % 8 == 0) TT = tt_env;
+  const int tiles = cdiv(T, TT);
+  const size_t lds = sizeof(float) * ((size_t)(NP + 1) * roundup256(H) + (size_t)2 * 8 * 36);
+  if (lds > (size_t)kLdsBytes) return -1000;
+  auto kern = Ds == 1024 ? scdm_fwd_mm_kernel<NP, GATE, 4> : Ds == 512 ? scdm_fwd_mm_kernel<NP, GATE, 2> : scdm_fwd_mm_kernel<NP, GATE, 1>;
+  hipError_t e = allow_lds(kern, lds);
+  if (e != hipSuccess) return set_error((int)e, "scdm_attn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+  hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kFwdThreads), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
+  return check_launch("scdm_attn_fwd");
+}
+
 // Two-kernel path (kept for shapes whose P / de tiles do not fit the fused kernel's LDS, and for A/B timing with
 // TSG_K1_BWD=split).  GATE: V = VW, dC = dout; extra outputs dbias [Ds], dr [B,T,Ds]; dG_ws [B,T,Ds] workspace.
 template <int NP, bool GATE>
@@ -1495,8 +1777,8 @@ int check_common(const char* fn, std::initializer_list<const void*> ptrs, int B,
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
     if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
   }
-  if (dtype != TSG_F32 && dtype != TSG_BF16)
-    return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32, or TSG_BF16 = bf16 storage of the activations)", fn, dtype);
+  if (dtype != TSG_F32 && dtype != TSG_BF16 && dtype != TSG_F32S)
+    return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32, TSG_F32S, or TSG_BF16 = bf16 storage of the activations)", fn, dtype);
   if (B <= 0 || T <= 0 || N <= 0 || H <= 0 || Ds <= 0)
     return set_error(TSG_E_SHAPE, "%s: non-positive dimension B=%d T=%d N=%d H=%d Ds=%d", fn, B, T, N, H, Ds);
   if (N > 32) return set_error(TSG_E_SHAPE, "%s: N=%d > 32 words not supported", fn, N);
@@ -1531,6 +1813,14 @@ extern "C" int tsg_scdm_attn_fwd(const void* a, const void* s, const void* w, co
     using S = bf16_t;
     TSG_DISPATCH_NP(np, (launch_fwd<NP, false, S>((const S*)a, (const S*)s, (const float*)w, (const S*)sent,
                                                   (S*)C, (float*)P, nullptr, nullptr, B, T, N, H, Ds, st)));
+  }
+  if (dtype == TSG_F32S) {
+    auto mm = [&]() -> int {
+      TSG_DISPATCH_NP(np, (launch_fwd_mm<NP, false>((const float*)a, (const float*)s, (const float*)w, (const float*)sent,
+                                                    (float*)C, (float*)P, nullptr, nullptr, B, T, N, H, Ds, st)));
+    };
+    rc = mm();
+    if (rc != -1000) return rc;
   }
   TSG_DISPATCH_NP(np, (launch_fwd<NP, false, float>((const float*)a, (const float*)s, (const float*)w, (const float*)sent,
                                                     (float*)C, (float*)P, nullptr, nullptr, B, T, N, H, Ds, st)));
@@ -1585,6 +1875,14 @@ extern "C" int tsg_scdm_gate_fwd(const void* a, const void* s, const void* w, co
     using S = bf16_t;
     TSG_DISPATCH_NP(np, (launch_fwd<NP, true, S>((const S*)a, (const S*)s, (const float*)w, (const S*)VW,
                                                  (S*)out, (float*)P, (const S*)r, (const float*)gbias, B, T, N, H, Ds, st)));
+  }
+  if (dtype == TSG_F32S) {
+    auto mm = [&]() -> int {
+      TSG_DISPATCH_NP(np, (launch_fwd_mm<NP, true>((const float*)a, (const float*)s, (const float*)w, (const float*)VW,
+                                                   (float*)out, (float*)P, (const float*)r, (const float*)gbias, B, T, N, H, Ds, st)));
+    };
+    rc = mm();
+    if (rc != -1000) return rc;
   }
   TSG_DISPATCH_NP(np, (launch_fwd<NP, true, float>((const float*)a, (const float*)s, (const float*)w, (const float*)VW,
                                                    (float*)out, (float*)P, (const float*)r, (const float*)gbias, B, T, N, H, Ds, st)));

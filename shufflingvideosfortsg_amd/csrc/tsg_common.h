@@ -70,6 +70,23 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
   const uint2 u = *reinterpret_cast<const uint2*>(p);
   return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
 }
+// Raw (unconverted) 4-element pieces: a prefetch must keep what the load instruction returned -- converting right away puts the
+// s_waitcnt for the load next to the load and the prefetch hides nothing.  cvt4() at the point of use.
+template <typename ST> struct Raw4T { typedef float4 type; };
+template <> struct Raw4T<bf16_t> { typedef uint2 type; };
+__device__ __forceinline__ float4 ldraw4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uint2 ldraw4(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ float4 cvt4(float4 v) { return v; }
+__device__ __forceinline__ float4 cvt4(uint2 u) { return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y)); }
+__device__ __forceinline__ float4 zero_raw4(const float*) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ uint2 zero_raw4(const bf16_t*) { return make_uint2(0u, 0u); }
+template <typename ST> struct Raw2T { typedef float2 type; };
+template <> struct Raw2T<bf16_t> { typedef unsigned type; };
+__device__ __forceinline__ float2 ldraw2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ unsigned ldraw2(const bf16_t* p) { return *reinterpret_cast<const unsigned*>(p); }
+__device__ __forceinline__ float2 cvt2(float2 v) { return v; }
+__device__ __forceinline__ float2 cvt2(unsigned u) { return make_float2(bf16_lo(u), bf16_hi(u)); }
+
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(bf16_t* p, float v) { p->bits = (unsigned short)(pack_bf16x2(v, 0.f) & 0xffffu); }
 __device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }

@@ -333,7 +333,8 @@ class _ScdmAttn(torch.autograd.Function):
             raise ValueError(f"scdm_attn: shape mismatch a{tuple(a.shape)} s{tuple(s.shape)} w{tuple(w.shape)} sent{tuple(sent.shape)}")
         C = torch.empty(B, T, Ds, device=a.device, dtype=a.dtype)
         P = torch.empty(B, T, N, device=a.device, dtype=torch.float32)
-        ctx.dt = TSG_BF16 if bf else TSG_F32
+        # "f32s" mode: TSG_F32S selects the forward whose P @ sent product runs as split-precision bf16 MFMAs (csrc/scdm_attn.hip)
+        ctx.dt = TSG_BF16 if bf else (TSG_F32S if _GEMM_DTYPE == "f32s" else TSG_F32)
         _call("tsg_scdm_attn_fwd", a, ptr(a), ptr(s), ptr(w), ptr(sent), ptr(C), ptr(P),
                                        B, T, N, H, Ds, ctx.dt)
         ctx.save_for_backward(a, s, w, sent, P)
@@ -387,7 +388,7 @@ class _ScdmGate(torch.autograd.Function):
             raise ValueError(f"scdm_gate: shape mismatch a{tuple(a.shape)} s{tuple(s.shape)} VW{tuple(VW.shape)} r{tuple(r.shape)}")
         out = torch.empty(B, T, Ds, device=a.device, dtype=a.dtype)
         P = torch.empty(B, T, N, device=a.device, dtype=torch.float32)
-        ctx.dt = TSG_BF16 if bf else TSG_F32
+        ctx.dt = TSG_BF16 if bf else (TSG_F32S if _GEMM_DTYPE == "f32s" else TSG_F32)
         _call("tsg_scdm_gate_fwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(r), ptr(out), ptr(P),
               B, T, N, H, Ds, ctx.dt)
         ctx.save_for_backward(a, s, w, VW, gbias, r, P)

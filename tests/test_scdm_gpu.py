@@ -107,3 +107,43 @@ def test_scdm_gate_parity(shape):
     for got, want, name in zip([rd, wd] + list(pd.values()), ref, ["r", "word"] + list(p.keys())):
         atol = 3e-4 * max(1.0, float(want.abs().max()))        # on the gradient's own scale (parameter gradients sum B*T terms)
         torch.testing.assert_close(got.grad.cpu(), want, atol=atol, rtol=2e-3, msg=lambda m, n=name: f"d{n}: {m}")
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 15, 512), (32, 64, 20, 512), (64, 128, 20, 1024), (3, 200, 25, 1024), (5, 100, 32, 256),
+                                   (130, 100, 20, 256), (2, 70, 9, 1024), (1, 3, 4, 256)])
+def test_scdm_split_precision_forward(shape, request):
+    """The "f32s" mode's forward (dtype TSG_F32S: scdm_fwd_mm_kernel, phase 2 = P @ VW on the bf16 matrix pipe as hi*hi + hi*lo +
+    lo*hi with fp32 accumulation, output columns 256 / 512 / 1024; ragged last tiles, 8- to 64-row workgroups, N <= 16 (one k step)
+    and N > 16 (two)) vs the oracle at the UNCHANGED fp32 tolerance, gate-fused and plain; the backward is the fp32 kernel."""
+    from shufflingvideosfortsg_amd import engine, functional as F
+    engine.precision("f32s")
+    request.addfinalizer(lambda: engine.precision(None))
+    lin = torch.nn.functional.linear
+    B, T, N, d = shape
+    g = torch.Generator().manual_seed(14)
+    r = torch.randn(B, T, d, generator=g, requires_grad=True)
+    word = torch.randn(B, N, d, generator=g, requires_grad=True)
+    p = {k: (torch.randn(*sh, generator=g) / d ** 0.5).requires_grad_(True) for k, sh in
+         dict(Ws=(d, d), Wa=(d, d), ba=(d,), w=(1, d), Wl=(d, d), bl=(d,)).items()}
+    gout = torch.randn(B, T, d, generator=g)
+    C0 = O.scdm_attention(r, word, p["Ws"], p["Wa"], p["ba"], p["w"])
+    out0 = r * torch.sigmoid(lin(C0, p["Wl"], p["bl"]))
+    out0.backward(gout)
+    leaves = [r, word] + list(p.values())
+    ref = [t.grad.clone() for t in leaves]
+    rd, wd = r.detach().cuda().requires_grad_(True), word.detach().cuda().requires_grad_(True)
+    pd = {k: v.detach().cuda().requires_grad_(True) for k, v in p.items()}
+    a, s = torch.nn.functional.linear(rd, pd["Wa"], pd["ba"]), torch.nn.functional.linear(wd, pd["Ws"])      # exact fp32 projections
+    out1 = F.scdm_gate(a, s, pd["w"], lin(wd, pd["Wl"]), pd["bl"], rd)
+    C1 = F.scdm_attn(a.detach(), s.detach(), pd["w"].detach(), wd.detach())
+    out1.backward(gout.cuda())
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out1.detach().cpu(), out0.detach(), **TOL)
+    torch.testing.assert_close(C1.cpu(), C0.detach(), **TOL)
+    for got, want, name in zip([rd, wd] + list(pd.values()), ref, ["r", "word"] + list(p.keys())):
+        atol = 3e-4 * max(1.0, float(want.abs().max()))
+        torch.testing.assert_close(got.grad.cpu(), want, atol=atol, rtol=2e-3, msg=lambda m, n=name: f"d{n}: {m}")
+    # the matrix-pipe forward against the VALU forward on the same operands: the split-precision product is at fp32-GEMM level
+    engine.precision(None)
+    out2 = F.scdm_gate(a.detach(), s.detach(), pd["w"].detach(), lin(wd, pd["Wl"]).detach(), pd["bl"].detach(), rd.detach())
+    torch.testing.assert_close(out1.detach(), out2, atol=2e-5, rtol=2e-5)
