@@ -9,9 +9,15 @@
  *   - all pointers are DEVICE pointers on the current HIP device, 16-byte aligned, row-major
  *     contiguous, batch-first; the caller owns every buffer (outputs and workspaces included);
  *     the library never allocates, frees or synchronises.
- *   - `dtype`: TSG_F32 (0) everywhere; TSG_F32S (2) additionally in the LSTM entry points and in tsg_mha_bwd (fp32 storage,
- *     split-precision bf16 MFMA products; LSTM hidden sizes other than 128/256/384/512 and attention shapes outside the ones
- *     named at tsg_mha_bwd compute in plain fp32); TSG_BF16 (1) is reserved.
+ *   - `dtype`: TSG_F32 (0) everywhere; TSG_F32S (2) additionally in the K1 forwards, the LSTM entry points and tsg_mha_* (fp32
+ *     storage, split-precision bf16 MFMA products; LSTM hidden sizes other than 128/256/384/512 and attention shapes outside
+ *     the ones named at tsg_mha_bwd compute in plain fp32); TSG_BF16 (1) = bf16 STORAGE (ABI revision 3): the activation tensors
+ *     of the entry point -- named at each -- are 2-byte bf16 elements in HBM (rows 8-byte aligned: widths % 4 == 0), converted on
+ *     load and rounded to nearest-even on store; arithmetic, softmax, cell state and every accumulation stay fp32, as do the
+ *     parameters, the small [B,T] / [B,J]-sized side tensors and all parameter gradients.  Taken by tsg_scdm_attn_*,
+ *     tsg_scdm_gate_*, tsg_boundary_score_*, tsg_match_head_*, tsg_mha_* (head widths as stated there) and the persistent
+ *     tsg_lstm_* paths; shapes an entry point does not take in this dtype return TSG_E_SHAPE (the host code then runs the fp32
+ *     storage kernels on fp32 copies).
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); work is only enqueued.
  *   - return 0 on success; <0 = argument error (TSG_E_*); >0 = hipError_t from the launch.
  *     tsg_last_error() returns a thread-local message for the last non-zero return.
@@ -34,7 +40,7 @@ extern "C" {
 #define TSG_VERSION 3   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points
                            3: tsg_error_word (device-side expiry report); dtype TSG_BF16 (bf16 storage) in K1 / K1g / K2 / K3 / LSTM */
 #define TSG_F32 0
-#define TSG_BF16 1
+#define TSG_BF16 1   /* bf16 storage of the activations, fp32 arithmetic (see Conventions)                               */
 #define TSG_F32S 2   /* fp32 storage; matrix products as split-precision bf16 MFMAs (x = hi + lo; hi*hi + hi*lo + lo*hi,
                         fp32 accumulation) -- accepted by the LSTM entry points and by tsg_mha_fwd / tsg_mha_bwd[_rng] */
 
@@ -53,7 +59,9 @@ const char* tsg_last_error(void);
  * [1,H] weight of self.w), sent [B,N,Ds].  Computes, without ever materialising [B,T,N,H]:
  *   e[b,t,n] = sum_k w[k]*tanh(a[b,t,k]+s[b,n,k]);  P = softmax_n(e);  C = P @ sent.
  * Outputs C [B,T,Ds] and P [B,T,N] (kept for the backward).  Limits: N <= 32, H%4==0, Ds%4==0,
- * roundup(N,4)*roundup(H,256)*4 B must fit LDS (TSG_E_LDS otherwise).                           */
+ * roundup(N,4)*roundup(H,256)*4 B must fit LDS (TSG_E_LDS otherwise).
+ * dtype TSG_F32S: C = P @ sent as split-precision bf16 MFMA products where H == Ds in {256, 512, 1024} (else as TSG_F32).
+ * dtype TSG_BF16: a, s, sent, C (and dC, da, ds, dsent in the backward) are bf16; w, P, dw stay fp32.                  */
 int tsg_scdm_attn_fwd(const void* a, const void* s, const void* w, const void* sent,
                       void* C, void* P, int B, int T, int N, int H, int Ds, int dtype, void* stream);
 
@@ -73,7 +81,8 @@ int tsg_scdm_attn_bwd(const void* a, const void* s, const void* w, const void* s
  * Because sent_linear(P sent) = P (sent W_l^T) + b_l, the caller passes VW = sent @ W_l^T [B,N,Ds] (a
  * [B*N,d]x[d,d] GEMM instead of the reference's [B*T,d]x[d,d] one) and the kernel's epilogue applies
  * bias, sigmoid and the gate: C is never materialised.  r [B,T,Ds] is the BiLSTM output being gated
- * (video_dim == Ds here), gbias [Ds].  Same limits as tsg_scdm_attn_fwd.                        */
+ * (video_dim == Ds here), gbias [Ds].  Same limits and dtypes as tsg_scdm_attn_fwd (TSG_BF16: a, s, VW, r, out and
+ * dout, da, ds, dVW, dr are bf16; w, gbias, P, dw, dgbias fp32).                                  */
 int tsg_scdm_gate_fwd(const void* a, const void* s, const void* w, const void* VW, const void* gbias,
                       const void* r, void* out, void* P, int B, int T, int N, int H, int Ds, int dtype,
                       void* stream);
@@ -93,7 +102,8 @@ int tsg_scdm_gate_bwd(const void* a, const void* s, const void* w, const void* V
  *         gate [B,T] or NULL (GMD: raw matching logits multiply the concatenated feature),
  *         mask int32 [B,T] or NULL (mask_logits with -1e30, networks/attention.py:129-133).
  *   z = gate*(y + cs) + b1;  l = w2 . tanh(z) + b2 (per branch);  p = softmax over T.
- * outputs p_start, p_end [B,T].   Limits: J % 4 == 0, J <= 1024, T <= 8192.                   */
+ * outputs p_start, p_end [B,T].   Limits: J % 4 == 0, J <= 1024, T <= 8192.
+ * dtype TSG_BF16: y (and dy in the backward) are bf16; cs, b1, w2, b2, gate, the probabilities and every other gradient fp32. */
 int tsg_boundary_score_fwd(const void* y, const void* cs, const void* b1, const void* w2, const void* b2,
                            const void* gate, const int32_t* mask, void* p_start, void* p_end,
                            int B, int T, int Hm, int dtype, void* stream);
@@ -129,7 +139,10 @@ int tsg_mha_fwd(const void* Q, const void* K, const void* V, void* O, void* A_su
  * d_key == d_value and the head width is a multiple of 32 up to 256 (above 128: channel halves per wave pair); otherwise the exact
  * kernels run.  tsg_mha_fwd with
  * TSG_F32S: one split-precision kernel with an online softmax for head widths 32 .. 256 in steps of 32 (any Tk) when no A_sum /
- * S_sum side outputs are requested; otherwise the exact kernels.                                                                  */
+ * S_sum side outputs are requested; otherwise the exact kernels.
+ * dtype TSG_BF16: Q, K, V, O (and dO, dQ, dK, dV) are bf16, lse / delta_ws fp32 -- the split-precision kernels with 2-byte
+ * elements (half the HBM bytes; the lo operand planes are zero).  Needs d_key == d_value, no A_sum / S_sum, head widths 32 .. 256
+ * in steps of 32 in tsg_mha_fwd and 32 .. 128 in tsg_mha_bwd (TSG_E_SHAPE otherwise).                                           */
 int tsg_mha_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* lse,
                 void* dQ, void* dK, void* dV, void* delta_ws, int B, int Tq, int Tk, int d_key, int d_value,
                 int n_heads, float scale, int causal, float p_drop, uint64_t seed, uint64_t offset, int dtype,
@@ -157,7 +170,11 @@ int tsg_mha_bwd_rng(const void* Q, const void* K, const void* V, const void* O, 
  *   registers; workgroups hand h_t over by polling the sentinel-marked `out` slab itself); when the B rows need more workgroups
  *   than can be co-resident (one per CU: B > 128 at h = 512 on 256 CUs) the rows -- independent sequences -- are processed as
  *   consecutive persistent launches over balanced chunks of whole 16-row slices (B = 256 -> 2 x 128), never as step launches;
- *   word 0 of sync_ws is non-zero afterwards if a bounded wait expired (results then invalid).  Otherwise one launch per time step.   */
+ *   word 0 of sync_ws is non-zero afterwards if a bounded wait expired (results then invalid).  Otherwise one launch per time step.
+ * dtype TSG_BF16 (persistent path only: sync_ws given, T > 1, h in {128, 256, 384, 512}; TSG_E_SHAPE otherwise): Gx, out and R are
+ *   bf16 (R: four bf16 per unit), Cs / bias / Whh stay fp32; W_hh is rounded to bf16 once in the kernel's prologue, each step is
+ *   ONE bf16 MFMA per k block, and h_t is exchanged -- and fed back -- as the bf16 value stored to `out` (16-bit sentinels).
+ *   tsg_lstm_bwd_ws[_layout] with TSG_BF16: R, dOut and dG bf16; Cs, dHn, dbias and the ring workspace fp32.               */
 int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                  int B, int T, int h, int dtype, void* stream);
 /* Same, with the bias b_ih + b_hh [2,4h] added inside the kernel (bias may be NULL): for callers whose input GEMM has

@@ -1113,19 +1113,21 @@ __device__ __forceinline__ f32x16 mfma3(u32x4v ah, u32x4v al, u32x4v bh, u32x4v 
 // b128 fragment reads of 16 lanes hit 16 distinct bank quads for DT = 1..4) and, when TR, transposed planes T (pitch 20 dwords
 // per channel: 32 rows + 4).  256 threads: lane bits [1:0] = channel quad inside a 64-byte segment, [4:2] = group of 4 rows,
 // the rest = further segments -- 64-byte global reads per lane quad and conflict-free transposing writes (csrc/wgrad_split.hip).
-template <int DT, bool TR, bool ROW = true>
+// ET = element type in HBM: float, or bf16_t (dtype TSG_BF16: the pieces stay raw in registers until they are staged, so the request
+// still flies under the MFMAs; the lo planes are then all zero -- the arithmetic is exact for bf16-valued operands).
+template <int DT, bool TR, bool ROW = true, typename ET = float>
 struct SplitTile {
   static constexpr int PR = 16 * DT + 4, PT = 20;
   static constexpr int kRow = 32 * PR, kCol = 32 * DT * PT;                 // dwords per plane
   static constexpr int kT0 = ROW ? 2 * kRow : 0;                            // first dword of the transposed planes
   static constexpr int kDwords = kT0 + (TR ? 2 * kCol : 0);                 // [R hi][R lo][T hi][T lo]
   static constexpr int NR = DT > 4 ? 2 : 1;                                 // 128-channel column blocks per thread (head widths > 128)
-  float4 v[NR][4];
-  const float* p0;                                                       // this thread's first row of tile 0
+  typename Raw4T<ET>::type v[NR][4];
+  const ET* p0;                                                          // this thread's first row of tile 0
   int mg, c4, ld;
   bool on[NR];
-  // src: the matrix (row stride ld_ floats) with the head's first channel already applied
-  __device__ __forceinline__ SplitTile(const float* __restrict__ src, int ld_) {
+  // src: the matrix (row stride ld_ elements) with the head's first channel already applied
+  __device__ __forceinline__ SplitTile(const ET* __restrict__ src, int ld_) {
     const int tid = threadIdx.x;
     mg = (tid >> 2) & 7; c4 = (tid & 3) + 4 * (tid >> 5); ld = ld_;
 #pragma unroll
@@ -1134,20 +1136,20 @@ struct SplitTile {
   }
   // rows [row0, row0+32), zero fill beyond rows_total
   __device__ __forceinline__ void request(int row0, int rows_total) {
-    const float* p = p0 + (size_t)row0 * ld;
+    const ET* p = p0 + (size_t)row0 * ld;
 #pragma unroll
     for (int k = 0; k < NR; ++k)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        v[k][i] = (on[k] && row0 + 4 * mg + i < rows_total) ? *reinterpret_cast<const float4*>(p + i * ld + 128 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[k][i] = (on[k] && row0 + 4 * mg + i < rows_total) ? ldraw4(p + i * ld + 128 * k) : zero_raw4(p);
   }
   __device__ __forceinline__ void stage(unsigned* __restrict__ base) const {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       if (!on[k]) continue;
       const int cq = c4 + 32 * k;
-      const float e[4][4] = {{v[k][0].x, v[k][0].y, v[k][0].z, v[k][0].w}, {v[k][1].x, v[k][1].y, v[k][1].z, v[k][1].w},
-                             {v[k][2].x, v[k][2].y, v[k][2].z, v[k][2].w}, {v[k][3].x, v[k][3].y, v[k][3].z, v[k][3].w}};
+      const float4 f0 = cvt4(v[k][0]), f1 = cvt4(v[k][1]), f2 = cvt4(v[k][2]), f3 = cvt4(v[k][3]);
+      const float e[4][4] = {{f0.x, f0.y, f0.z, f0.w}, {f1.x, f1.y, f1.z, f1.w}, {f2.x, f2.y, f2.z, f2.w}, {f3.x, f3.y, f3.z, f3.w}};
       if (ROW) {
         unsigned* Rh = base; unsigned* Rl = Rh + kRow;
 #pragma unroll
@@ -1206,8 +1208,8 @@ struct SplitTile {
 // channels 16 ks + 8 hh .. +7 of row 32 w + jl for every step ks.  Every lane reads its 32-byte pieces itself; staging the rows
 // through LDS as lane-quad segments instead (one L1 lookup per lane quad rather than per lane) measured the same (31.3 vs 31.1 us
 // forward, 121.7 vs 123.3 us backward): this phase waits for HBM, not for the L1 pipe.
-template <int DT>
-__device__ __forceinline__ void own_rows(const float* __restrict__ src, int ld, int row0, int rows_total,
+template <int DT, typename ET>
+__device__ __forceinline__ void own_rows(const ET* __restrict__ src, int ld, int row0, int rows_total,
                                          u32x4v (&hi)[2 * DT], u32x4v (&lo)[2 * DT]) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, jl = lane & 31, hh = lane >> 5;
   const int row = row0 + 32 * wv + jl;
@@ -1216,8 +1218,8 @@ __device__ __forceinline__ void own_rows(const float* __restrict__ src, int ld, 
   for (int ks = 0; ks < 2 * DT; ++ks) {
     x[ks] = y[ks] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < rows_total) {
-      x[ks] = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 16 * ks + 8 * hh);
-      y[ks] = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 16 * ks + 8 * hh + 4);
+      x[ks] = ld4(src + (size_t)row * ld + 16 * ks + 8 * hh);
+      y[ks] = ld4(src + (size_t)row * ld + 16 * ks + 8 * hh + 4);
     }
   }
 #pragma unroll
@@ -1229,8 +1231,8 @@ __device__ __forceinline__ void own_rows(const float* __restrict__ src, int ld, 
 
 // own_rows of dO that also returns this lane's part of delta[row] = <dO[row], O[row]> over the head's channels (the lane's 8-channel
 // pieces; lane ^ 32 holds the others): the delta pre-pass folded into the kernel that reads dO anyway.
-template <int DT>
-__device__ __forceinline__ float own_rows_delta(const float* __restrict__ src, const float* __restrict__ osrc, int ld, int row0, int rows_total,
+template <int DT, typename ET>
+__device__ __forceinline__ float own_rows_delta(const ET* __restrict__ src, const ET* __restrict__ osrc, int ld, int row0, int rows_total,
                                                 u32x4v (&hi)[2 * DT], u32x4v (&lo)[2 * DT]) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, jl = lane & 31, hh = lane >> 5;
   const int row = row0 + 32 * wv + jl;
@@ -1240,10 +1242,10 @@ __device__ __forceinline__ float own_rows_delta(const float* __restrict__ src, c
   for (int ks = 0; ks < 2 * DT; ++ks) {
     x[ks] = y[ks] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < rows_total) {
-      x[ks] = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 16 * ks + 8 * hh);
-      y[ks] = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 16 * ks + 8 * hh + 4);
-      const float4 ox = *reinterpret_cast<const float4*>(osrc + (size_t)row * ld + 16 * ks + 8 * hh);
-      const float4 oy = *reinterpret_cast<const float4*>(osrc + (size_t)row * ld + 16 * ks + 8 * hh + 4);
+      x[ks] = ld4(src + (size_t)row * ld + 16 * ks + 8 * hh);
+      y[ks] = ld4(src + (size_t)row * ld + 16 * ks + 8 * hh + 4);
+      const float4 ox = ld4(osrc + (size_t)row * ld + 16 * ks + 8 * hh);
+      const float4 oy = ld4(osrc + (size_t)row * ld + 16 * ks + 8 * hh + 4);
       acc = fmaf(x[ks].x, ox.x, fmaf(x[ks].y, ox.y, fmaf(x[ks].z, ox.z, fmaf(x[ks].w, ox.w, acc))));
       acc = fmaf(y[ks].x, oy.x, fmaf(y[ks].y, oy.y, fmaf(y[ks].z, oy.z, fmaf(y[ks].w, oy.w, acc))));
     }
@@ -1258,21 +1260,22 @@ __device__ __forceinline__ float own_rows_delta(const float* __restrict__ src, c
 
 // Operand whose contraction runs over the wave's own 32 rows in accumulator order (slot (hh, j) of step s <-> row rho(8 s + j, hh)),
 // gathered from global memory: lane = channel c.  For a fixed j the 32 lanes of a half read 128 contiguous bytes of one row.
-__device__ __forceinline__ void gather_frag(const float* __restrict__ rows, int ld, int valid, int s, int hh, int c, u32x4v& hi, u32x4v& lo) {
+template <typename ET>
+__device__ __forceinline__ void gather_frag(const ET* __restrict__ rows, int ld, int valid, int s, int hh, int c, u32x4v& hi, u32x4v& lo) {
   float e[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int r = rho(8 * s + j, hh);
-    e[j] = r < valid ? rows[(size_t)r * ld + c] : 0.f;
+    e[j] = r < valid ? ld1(rows + (size_t)r * ld + c) : 0.f;
   }
   split8(e, hi, lo);
 }
 
 // (A) dK, dV.  grid = B * H * ceil(Tk / 128); wave w owns keys kb + 32 w .. +31.
-template <int DT, bool DROP>
+template <int DT, bool DROP, typename ET>
 __global__ __launch_bounds__(256) void mha_bwd_split_dkv_kernel(
-    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
-    const float* __restrict__ LSE, const float* __restrict__ delta, float* __restrict__ dK, float* __restrict__ dV,
+    const ET* __restrict__ Q, const ET* __restrict__ K, const ET* __restrict__ V, const ET* __restrict__ dO,
+    const float* __restrict__ LSE, const float* __restrict__ delta, ET* __restrict__ dK, ET* __restrict__ dV,
     int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
   drop_resolve(dc);
 #ifdef TSG_K2_TIMING
@@ -1281,15 +1284,15 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dkv_kernel(
 #else
 #define K2_TICK(i) {}
 #endif
-  using ST = SplitTile<DT, true>;
+  using ST = SplitTile<DT, true, true, ET>;
   extern __shared__ __align__(16) unsigned lds_u[];                      // [2 buffers][Q tile | dO tile] + lse / delta rows
   constexpr int kBuf = 2 * ST::kDwords;
   float* rows = reinterpret_cast<float*>(lds_u + 2 * kBuf);              // [2][2][32]: lse, delta of the tile's queries
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hh = lane >> 5;
   const int kblocks = (Tk + 127) / 128;
   const int b = blockIdx.x / (H * kblocks), hd = (blockIdx.x / kblocks) % H, kb = (blockIdx.x % kblocks) * 128;
-  const float* Qb = Q + (size_t)b * Tq * dk + hd * 32 * DT;
-  const float* Gb = dO + (size_t)b * Tq * dk + hd * 32 * DT;
+  const ET* Qb = Q + (size_t)b * Tq * dk + hd * 32 * DT;
+  const ET* Gb = dO + (size_t)b * Tq * dk + hd * 32 * DT;
   const float* lse = LSE + ((size_t)b * H + hd) * Tq;
   const float* dlt = delta + ((size_t)b * H + hd) * Tq;
   const int key = kb + 32 * wv + jl;                                     // this lane's key (the S / dP column)
@@ -1380,16 +1383,16 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dkv_kernel(
     K2_TICK(6)
   }
   // accumulators: rows = keys rho(r, hh) of this wave, column = channel 32 ct + jl: 128-byte row segments
-  float* dKb = dK + (size_t)b * Tk * dk + hd * 32 * DT;
-  float* dVb = dV + (size_t)b * Tk * dk + hd * 32 * DT;
+  ET* dKb = dK + (size_t)b * Tk * dk + hd * 32 * DT;
+  ET* dVb = dV + (size_t)b * Tk * dk + hd * 32 * DT;
 #pragma unroll
   for (int ct = 0; ct < DT; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = kb + 32 * wv + rho(r, hh);
       if (k < Tk) {
-        dKb[(size_t)k * dk + 32 * ct + jl] = dkt[ct][r];
-        dVb[(size_t)k * dk + 32 * ct + jl] = dvt[ct][r];
+        st1(dKb + (size_t)k * dk + 32 * ct + jl, dkt[ct][r]);
+        st1(dVb + (size_t)k * dk + 32 * ct + jl, dvt[ct][r]);
       }
     }
 #ifdef TSG_K2_TIMING
@@ -1401,21 +1404,21 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dkv_kernel(
 }
 
 // (B) dQ.  grid = B * H * ceil(Tq / 128); wave w owns queries qb + 32 w .. +31.
-template <int DT, bool DROP>
+template <int DT, bool DROP, typename ET>
 __global__ __launch_bounds__(256) void mha_bwd_split_dq_kernel(
-    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
-    const float* __restrict__ LSE, const float* __restrict__ O, float* __restrict__ delta, float* __restrict__ dQ,
+    const ET* __restrict__ Q, const ET* __restrict__ K, const ET* __restrict__ V, const ET* __restrict__ dO,
+    const float* __restrict__ LSE, const ET* __restrict__ O, float* __restrict__ delta, ET* __restrict__ dQ,
     int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
   drop_resolve(dc);
-  using SK = SplitTile<DT, true>;                                        // K tile: row-major + transposed planes
-  using SV = SplitTile<DT, false>;                                       // V tile: row-major planes only
+  using SK = SplitTile<DT, true, true, ET>;                              // K tile: row-major + transposed planes
+  using SV = SplitTile<DT, false, true, ET>;                             // V tile: row-major planes only
   extern __shared__ __align__(16) unsigned lds_u[];
   constexpr int kBuf = SK::kDwords + SV::kDwords;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hh = lane >> 5;
   const int qblocks = (Tq + 127) / 128;
   const int b = blockIdx.x / (H * qblocks), hd = (blockIdx.x / qblocks) % H, qb = (blockIdx.x % qblocks) * 128;
-  const float* Kb = K + (size_t)b * Tk * dk + hd * 32 * DT;
-  const float* Vb = V + (size_t)b * Tk * dk + hd * 32 * DT;
+  const ET* Kb = K + (size_t)b * Tk * dk + hd * 32 * DT;
+  const ET* Vb = V + (size_t)b * Tk * dk + hd * 32 * DT;
   const int q = qb + 32 * wv + jl;                                       // this lane's query (the S^T / dP^T column)
   const float lse_q = q < Tq ? LSE[((size_t)b * H + hd) * Tq + q] : 0.f;
 
@@ -1488,11 +1491,11 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dq_kernel(
     for (int r = 0; r < 16; ++r) Ol[jl * OP + 32 * ct + rho(r, hh)] = dqt[ct][r];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                 // the block is private to this wave
   __builtin_amdgcn_wave_barrier();
-  float* dQb = dQ + (size_t)b * Tq * dk + hd * 32 * DT;
+  ET* dQb = dQ + (size_t)b * Tq * dk + hd * 32 * DT;
   for (int idx = lane; idx < 32 * 8 * DT; idx += 64) {
     const int r = idx / (8 * DT), c = (idx % (8 * DT)) * 4;
     const int qq = qb + 32 * wv + r;
-    if (qq < Tq) *reinterpret_cast<float4*>(dQb + (size_t)qq * dk + c) = *reinterpret_cast<const float4*>(Ol + r * OP + c);
+    if (qq < Tq) st4(dQb + (size_t)qq * dk + c, *reinterpret_cast<const float4*>(Ol + r * OP + c));
   }
 }
 
@@ -1539,6 +1542,7 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dq_wide_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
     const float* __restrict__ LSE, const float* __restrict__ O, float* __restrict__ delta, float* __restrict__ dQ,
     int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
+  using ET = float;                                                      // the wide-head backward is fp32 storage only
   drop_resolve(dc);
   using SR = SplitTile<DT, false>;
   extern __shared__ __align__(16) unsigned lds_u[];
@@ -1548,8 +1552,8 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dq_wide_kernel(
   const int nt = c ? DT - 4 : 4, nks = 2 * nt, ks0 = 8 * c;             // channel tiles / contraction steps of this half
   const int qblocks = (Tq + 63) / 64;
   const int b = blockIdx.x / (H * qblocks), hd = (blockIdx.x / qblocks) % H, qb = (blockIdx.x % qblocks) * 64;
-  const float* Kb = K + (size_t)b * Tk * dk + hd * 32 * DT;
-  const float* Vb = V + (size_t)b * Tk * dk + hd * 32 * DT;
+  const ET* Kb = K + (size_t)b * Tk * dk + hd * 32 * DT;
+  const ET* Vb = V + (size_t)b * Tk * dk + hd * 32 * DT;
   const int q = qb + 32 * g + jl;
   const float lse_q = q < Tq ? LSE[((size_t)b * H + hd) * Tq + q] : 0.f;
   SR tk(Kb, dk), tv(Vb, dk);
@@ -1656,6 +1660,7 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dkv_wide_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
     const float* __restrict__ LSE, const float* __restrict__ delta, float* __restrict__ dK, float* __restrict__ dV,
     int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
+  using ET = float;
   drop_resolve(dc);
   using SR = SplitTile<DT, false>;
   extern __shared__ __align__(16) unsigned lds_u[];
@@ -1666,8 +1671,8 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dkv_wide_kernel(
   const int nt = c ? DT - 4 : 4, nks = 2 * nt, ks0 = 8 * c;
   const int kblocks = (Tk + 63) / 64;
   const int b = blockIdx.x / (H * kblocks), hd = (blockIdx.x / kblocks) % H, kb = (blockIdx.x % kblocks) * 64;
-  const float* Qb = Q + (size_t)b * Tq * dk + hd * 32 * DT;
-  const float* Gb = dO + (size_t)b * Tq * dk + hd * 32 * DT;
+  const ET* Qb = Q + (size_t)b * Tq * dk + hd * 32 * DT;
+  const ET* Gb = dO + (size_t)b * Tq * dk + hd * 32 * DT;
   const float* lse = LSE + ((size_t)b * H + hd) * Tq;
   const float* dlt = delta + ((size_t)b * H + hd) * Tq;
   const int key = kb + 32 * g + jl;
@@ -1793,13 +1798,13 @@ int launch_bwd_split_wide(const char* fn, const float* Q, const float* K, const 
 // S^T = K Q^T (rows = keys in the accumulator registers, column = the lane's query), running max / sum per query (16 registers
 // + one exchange with lane ^ 32, which holds the other 16 keys of the same query), O^T[c][q] += V^T[c][key] P^T[key][q] with the
 // P^T registers as the B operand and the transposed V planes as A.  O leaves through LDS as whole rows.
-template <int DT, bool DROP>
+template <int DT, bool DROP, typename ET>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DT <= 4 ? 2 : 1, DT <= 4 ? 2 : 1))) void mha_fwd_split_kernel(
-    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, float* __restrict__ O,
+    const ET* __restrict__ Q, const ET* __restrict__ K, const ET* __restrict__ V, ET* __restrict__ O,
     float* __restrict__ LSE, int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
   drop_resolve(dc);
-  using SK = SplitTile<DT, false>;                                       // K tile: row-major planes
-  using SV = SplitTile<DT, true, false>;                                 // V tile: transposed planes only
+  using SK = SplitTile<DT, false, true, ET>;                             // K tile: row-major planes
+  using SV = SplitTile<DT, true, false, ET>;                             // V tile: transposed planes only
   extern __shared__ __align__(16) unsigned lds_u[];
   constexpr int kBuf = SK::kDwords + SV::kDwords;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hh = lane >> 5;
@@ -1886,23 +1891,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DT <= 4 ? 2
     for (int r = 0; r < 16; ++r) Ol[jl * OP + 32 * ct + rho(r, hh)] = ot[ct][r] * inv_l;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  float* Ob = O + (size_t)b * Tq * dk + hd * 32 * DT;
+  ET* Ob = O + (size_t)b * Tq * dk + hd * 32 * DT;
   for (int idx = lane; idx < 32 * 8 * DT; idx += 64) {
     const int r = idx / (8 * DT), c = (idx % (8 * DT)) * 4;
     const int qq = qb + 32 * wv + r;
-    if (qq < Tq) *reinterpret_cast<float4*>(Ob + (size_t)qq * dk + c) = *reinterpret_cast<const float4*>(Ol + r * OP + c);
+    if (qq < Tq) st4(Ob + (size_t)qq * dk + c, *reinterpret_cast<const float4*>(Ol + r * OP + c));
   }
 }
 
-template <int DT, bool DROP>
-int launch_fwd_split(const char* fn, const float* Q, const float* K, const float* V, float* O, float* lse, int B, int Tq, int Tk, int dk,
+template <int DT, bool DROP, typename ET = float>
+int launch_fwd_split(const char* fn, const ET* Q, const ET* K, const ET* V, ET* O, float* lse, int B, int Tq, int Tk, int dk,
                      int H, float inv_scale, int causal, const DropCfg& dc, hipStream_t st) {
   using SK = SplitTile<DT, false>;
   using SV = SplitTile<DT, true, false>;
   size_t lds = sizeof(unsigned) * (size_t)(2 * (SK::kDwords + SV::kDwords));
   const size_t outb = sizeof(float) * 4 * 32 * (32 * DT + 4);
   if (outb > lds) lds = outb;
-  auto kf = mha_fwd_split_kernel<DT, DROP>;
+  auto kf = mha_fwd_split_kernel<DT, DROP, ET>;
   hipError_t e = allow_lds(kf, lds);
   if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
   hipLaunchKernelGGL(kf, dim3(B * H * cdiv(Tq, 128)), dim3(256), lds, st, Q, K, V, O, lse, B, Tq, Tk, dk, H, inv_scale, causal, dc);
@@ -1917,20 +1922,20 @@ int launch_fwd_split(const char* fn, const float* Q, const float* K, const float
 //     its 32 queries, whose other operand is gathered from global memory row by row (128-byte segments, no transposed staging).
 // The four waves' partial dK / dV tiles are added through LDS; with more than one query block per head they are added to the
 // (zero-filled) outputs with float atomics, with one block (Tq <= 128) they are stored.  Two workgroups per CU.
-template <int DT, bool DROP>
+template <int DT, bool DROP, typename ET>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mha_bwd_split_cross_kernel(
-    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
-    const float* __restrict__ LSE, const float* __restrict__ O, float* __restrict__ dQ, float* __restrict__ dK,
-    float* __restrict__ dV, int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, int atomic_out, DropCfg dc) {
+    const ET* __restrict__ Q, const ET* __restrict__ K, const ET* __restrict__ V, const ET* __restrict__ dO,
+    const float* __restrict__ LSE, const ET* __restrict__ O, ET* __restrict__ dQ, ET* __restrict__ dK,
+    ET* __restrict__ dV, int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, int atomic_out, DropCfg dc) {
   drop_resolve(dc);
-  using SK = SplitTile<DT, true>;                                        // K tile: row-major + transposed planes
-  using SV = SplitTile<DT, false>;                                       // V tile: row-major planes
+  using SK = SplitTile<DT, true, true, ET>;                              // K tile: row-major + transposed planes
+  using SV = SplitTile<DT, false, true, ET>;                             // V tile: row-major planes
   extern __shared__ __align__(16) unsigned lds_u[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hh = lane >> 5;
   const int qblocks = (Tq + 127) / 128;
   const int b = blockIdx.x / (H * qblocks), hd = (blockIdx.x / qblocks) % H, qb = (blockIdx.x % qblocks) * 128;
-  const float* Qb = Q + (size_t)b * Tq * dk + hd * 32 * DT;
-  const float* Gb = dO + (size_t)b * Tq * dk + hd * 32 * DT;
+  const ET* Qb = Q + (size_t)b * Tq * dk + hd * 32 * DT;
+  const ET* Gb = dO + (size_t)b * Tq * dk + hd * 32 * DT;
   const float* lse = LSE + ((size_t)b * H + hd) * Tq;
   const int qw0 = qb + 32 * wv, q = qw0 + jl;                            // the wave's first query; this lane's query / key
   const int key = jl;
@@ -2046,19 +2051,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) Ol[jl * OP + 32 * ct + rho(r, hh)] = dqt[ct][r];
   wave_sync();
-  float* dQb = dQ + (size_t)b * Tq * dk + hd * 32 * DT;
+  ET* dQb = dQ + (size_t)b * Tq * dk + hd * 32 * DT;
   for (int idx = lane; idx < 32 * 8 * DT; idx += 64) {
     const int r = idx / (8 * DT), c = (idx % (8 * DT)) * 4;
-    if (qw0 + r < Tq) *reinterpret_cast<float4*>(dQb + (size_t)(qw0 + r) * dk + c) = *reinterpret_cast<const float4*>(Ol + r * OP + c);
+    if (qw0 + r < Tq) st4(dQb + (size_t)(qw0 + r) * dk + c, *reinterpret_cast<const float4*>(Ol + r * OP + c));
   }
   wave_sync();
   // partial dV / dK of this wave's 32 queries: A = P / dS registers (row = key on the lane), B gathered from the wave's dO / Q rows;
   // accumulator: rows = keys rho(r, hh), column = channel 32 ct + jl.  Folded over the four waves through LDS.
   const int valid = Tq - qw0;                                            // rows of this wave that exist (may be <= 0)
-  float* dst[2] = {dV + (size_t)b * Tk * dk + hd * 32 * DT, dK + (size_t)b * Tk * dk + hd * 32 * DT};
+  ET* dst[2] = {dV + (size_t)b * Tk * dk + hd * 32 * DT, dK + (size_t)b * Tk * dk + hd * 32 * DT};
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
-    const float* rows = (which == 0 ? Gb : Qb) + (size_t)qw0 * dk;
+    const ET* rows = (which == 0 ? Gb : Qb) + (size_t)qw0 * dk;
     f32x16 acc[DT];
 #pragma unroll
     for (int ct = 0; ct < DT; ++ct)
@@ -2087,27 +2092,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const float4 u = *reinterpret_cast<const float4*>(all + (w * 32 + r) * OP + c);
           t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
-        float* o = dst[which] + (size_t)r * dk + c;
-        if (atomic_out) { atomicAdd(o, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w); }
-        else *reinterpret_cast<float4*>(o) = t;
+        ET* o = dst[which] + (size_t)r * dk + c;
+        if constexpr (storage_is_bf16<ET>::value) {
+          st4(o, t);                                       // bf16 outputs: one query block per head only (host-checked): no atomics
+        } else {
+          if (atomic_out) { atomicAdd(o, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w); }
+          else *reinterpret_cast<float4*>(o) = t;
+        }
       }
     }
     __syncthreads();
   }
 }
 
-template <int DT, bool DROP>
-int launch_bwd_split(const char* fn, const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* lse,
-                     float* delta, float* dQ, float* dK, float* dV, int B, int Tq, int Tk, int dk, int H, float inv_scale,
+template <int DT, bool DROP, typename ET = float>
+int launch_bwd_split(const char* fn, const ET* Q, const ET* K, const ET* V, const ET* O, const ET* dO, const float* lse,
+                     float* delta, ET* dQ, ET* dK, ET* dV, int B, int Tq, int Tk, int dk, int H, float inv_scale,
                      int causal, const DropCfg& dc, hipStream_t st) {
   using ST = SplitTile<DT, true>;
   using SV = SplitTile<DT, false>;
-  if (Tk <= 32) {                                                          // one key tile: the fused kernel
+  // one key tile: the fused kernel (bf16 outputs cannot take the float atomics several query blocks add with: those run the pair)
+  if (Tk <= 32 && (!storage_is_bf16<ET>::value || Tq <= 128)) {
     size_t lds_c = sizeof(unsigned) * (size_t)(ST::kDwords + SV::kDwords) + sizeof(float) * 128;
     const size_t out_c = sizeof(float) * 4 * 32 * (32 * DT + 4);
     if (out_c > lds_c) lds_c = out_c;
     const int qblocks = cdiv(Tq, 128);
-    auto kc = mha_bwd_split_cross_kernel<DT, DROP>;
+    auto kc = mha_bwd_split_cross_kernel<DT, DROP, ET>;
     hipError_t e = allow_lds(kc, lds_c);          // table hit (no runtime call) after the first, eager, launch on this device
     if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
     if (qblocks > 1) {                                                     // several query blocks add into dK / dV
@@ -2124,8 +2134,8 @@ int launch_bwd_split(const char* fn, const float* Q, const float* K, const float
   size_t lds_b = sizeof(unsigned) * (size_t)(2 * (ST::kDwords + SV::kDwords));
   const size_t out_b = sizeof(float) * 4 * 32 * (32 * DT + 4);
   if (out_b > lds_b) lds_b = out_b;
-  auto ka = mha_bwd_split_dkv_kernel<DT, DROP>;
-  auto kq = mha_bwd_split_dq_kernel<DT, DROP>;
+  auto ka = mha_bwd_split_dkv_kernel<DT, DROP, ET>;
+  auto kq = mha_bwd_split_dq_kernel<DT, DROP, ET>;
   hipError_t e = allow_lds(ka, lds_a);
   if (e == hipSuccess) e = allow_lds(kq, lds_b);
   if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
@@ -2138,7 +2148,8 @@ int launch_bwd_split(const char* fn, const float* Q, const float* K, const float
 }
 
 int check(const char* fn, int B, int Tq, int Tk, int dk, int dv, int H, int dtype) {
-  if (dtype != TSG_F32 && dtype != TSG_F32S) return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32 or TSG_F32S)", fn, dtype);
+  if (dtype != TSG_F32 && dtype != TSG_F32S && dtype != TSG_BF16)
+    return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32, TSG_F32S or TSG_BF16)", fn, dtype);
   if (B <= 0 || Tq <= 0 || Tk <= 0 || dk <= 0 || dv <= 0 || H <= 0)
     return set_error(TSG_E_SHAPE, "%s: non-positive dimension B=%d Tq=%d Tk=%d dk=%d dv=%d heads=%d", fn, B, Tq, Tk, dk, dv, H);
   if (dk % H || dv % H) return set_error(TSG_E_SHAPE, "%s: d_key=%d / d_value=%d not divisible by n_heads=%d", fn, dk, dv, H);
@@ -2185,6 +2196,27 @@ static int mha_fwd_impl(const void* Q, const void* K, const void* V, void* O, vo
   const int dh = d_key / n_heads, dvh = d_value / n_heads;
   static int split_on = -1;                                         // TSG_MHA_SPLIT=0: exact-fp32 kernels also for TSG_F32S (A/B)
   if (split_on < 0) { const char* e = getenv("TSG_MHA_SPLIT"); split_on = e ? atoi(e) : 1; }
+  if (dtype == TSG_BF16) {                       // bf16 storage of Q, K, V, O: the split kernels with 2-byte elements (lo planes zero)
+    if (A_sum || S_sum || dh != dvh || dh % 32 || dh > 256)
+      return set_error(TSG_E_SHAPE, "%s: dtype TSG_BF16 needs d_key == d_value, head widths 32 .. 256 in steps of 32 and no A_sum / S_sum "
+                       "outputs (head width %d / %d)", fn, dh, dvh);
+    const bf16_t* q = (const bf16_t*)Q; const bf16_t* k = (const bf16_t*)K; const bf16_t* v = (const bf16_t*)V;
+    const float is = 1.f / scale;
+#define TSG_SPLIT_CASE(DT) \
+    return dc.thresh ? launch_fwd_split<DT, true, bf16_t>(fn, q, k, v, (bf16_t*)O, (float*)lse, B, Tq, Tk, d_key, n_heads, is, causal, dc, st) \
+                     : launch_fwd_split<DT, false, bf16_t>(fn, q, k, v, (bf16_t*)O, (float*)lse, B, Tq, Tk, d_key, n_heads, is, causal, dc, st)
+    switch (dh / 32) {
+      case 1: TSG_SPLIT_CASE(1);
+      case 2: TSG_SPLIT_CASE(2);
+      case 3: TSG_SPLIT_CASE(3);
+      case 4: TSG_SPLIT_CASE(4);
+      case 5: TSG_SPLIT_CASE(5);
+      case 6: TSG_SPLIT_CASE(6);
+      case 7: TSG_SPLIT_CASE(7);
+      default: TSG_SPLIT_CASE(8);
+    }
+#undef TSG_SPLIT_CASE
+  }
   if (dtype == TSG_F32S && split_on && !A_sum && !S_sum && dh == dvh && dh % 32 == 0 && dh <= 256) {     // split precision
     const float* q = (const float*)Q; const float* k = (const float*)K; const float* v = (const float*)V;
     const float is = 1.f / scale;
@@ -2271,6 +2303,26 @@ static int mha_bwd_impl(const void* Q, const void* K, const void* V, const void*
   const int dh = d_key / n_heads, dvh = d_value / n_heads;
   static int split_on = -1;                                         // TSG_MHA_SPLIT=0: exact-fp32 kernels also for TSG_F32S (A/B)
   if (split_on < 0) { const char* e = getenv("TSG_MHA_SPLIT"); split_on = e ? atoi(e) : 1; }
+  if (dtype == TSG_BF16) {                       // bf16 storage of Q, K, V, O, dO, dQ, dK, dV (head widths up to 128)
+    if (!delta_ws || dh != dvh || dh % 32 || dh > 128)
+      return set_error(TSG_E_SHAPE, "%s: dtype TSG_BF16 needs delta_ws, d_key == d_value and head widths 32 .. 128 in steps of 32 "
+                       "(head width %d / %d)", fn, dh, dvh);
+    auto st = static_cast<hipStream_t>(stream);
+    typedef bf16_t E;
+    const float is = 1.f / scale;
+#define TSG_SPLIT_CASE(DT) \
+    return dc.thresh ? launch_bwd_split<DT, true, E>(fn, (const E*)Q, (const E*)K, (const E*)V, (const E*)O, (const E*)dO, (const float*)lse, (float*)delta_ws, \
+                                                     (E*)dQ, (E*)dK, (E*)dV, B, Tq, Tk, d_key, n_heads, is, causal, dc, st) \
+                     : launch_bwd_split<DT, false, E>(fn, (const E*)Q, (const E*)K, (const E*)V, (const E*)O, (const E*)dO, (const float*)lse, (float*)delta_ws, \
+                                                      (E*)dQ, (E*)dK, (E*)dV, B, Tq, Tk, d_key, n_heads, is, causal, dc, st)
+    switch (dh / 32) {
+      case 1: TSG_SPLIT_CASE(1);
+      case 2: TSG_SPLIT_CASE(2);
+      case 3: TSG_SPLIT_CASE(3);
+      default: TSG_SPLIT_CASE(4);
+    }
+#undef TSG_SPLIT_CASE
+  }
   // split-precision path (one key tile: the fused kernel, else the dK/dV + dQ pair)
   if (dtype == TSG_F32S && split_on && delta_ws && dh == dvh && dh % 32 == 0 && dh <= 128) {
     auto st = static_cast<hipStream_t>(stream);

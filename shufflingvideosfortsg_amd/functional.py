@@ -489,14 +489,15 @@ class _MHA(torch.autograd.Function):
     @_fwd
     def forward(ctx, Q, K, V, n_heads, scale, causal, want_maps, p_drop=0.0, seed=0, offset=0, rng=None):
         require_device(Q, K, V)
-        Q, K, V = _f32c(Q), _f32c(K), _f32c(V)
+        bf = Q.dtype == _BF                                    # bf16 storage: Q, K, V, O and their gradients as bf16 (TSG_BF16)
+        Q, K, V = _act(Q, bf), _act(K, bf), _act(V, bf)
         B, Tq, dk = Q.shape
         _, Tk, dv = V.shape
         if K.shape != (B, Tk, dk):
             raise ValueError(f"mha: shape mismatch Q{tuple(Q.shape)} K{tuple(K.shape)} V{tuple(V.shape)}")
         if causal and Tq != Tk:
             raise ValueError("mha: causal attention needs Tq == Tk (the reference subtracts a [Tk,Tk] triangle)")
-        O = torch.empty(B, Tq, dv, device=Q.device, dtype=torch.float32)
+        O = torch.empty(B, Tq, dv, device=Q.device, dtype=Q.dtype)
         lse = torch.empty(B, n_heads, Tq, device=Q.device, dtype=torch.float32)
         A = torch.empty(B, Tq, Tk, device=Q.device, dtype=torch.float32) if want_maps else None
         S = torch.empty(B, Tq, Tk, device=Q.device, dtype=torch.float32) if want_maps else None
@@ -504,7 +505,7 @@ class _MHA(torch.autograd.Function):
                 int(n_heads), float(scale), int(bool(causal)), float(p_drop))
         # in the split-precision GEMM mode the attention products run on the bf16 MFMA as hi/lo products as well (TSG_F32S:
         # include/tsg_hip.h, K2; shapes the split kernels do not cover, and the A_forward maps, run the exact kernels)
-        dt = TSG_F32S if _GEMM_DTYPE in ("f32s", "bf16") else TSG_F32
+        dt = TSG_BF16 if bf else (TSG_F32S if _GEMM_DTYPE in ("f32s", "bf16") else TSG_F32)
         if rng is not None:                                         # (seed, offset) in device memory: graph-capture safe
             _call("tsg_mha_fwd_rng", Q, *head, ptr(rng), dt)
         else:
@@ -527,7 +528,7 @@ class _MHA(torch.autograd.Function):
         rng = ctx.saved_tensors[5] if ctx.has_rng else None
         n_heads, scale, causal = ctx.cfg
         p_drop, seed, offset = ctx.drop
-        dO = _f32c(dO) if dO is not None else torch.zeros_like(O)
+        dO = _act(dO, ctx.bwd_dtype == TSG_BF16) if dO is not None else torch.zeros_like(O)
         B, Tq, dk = Q.shape
         _, Tk, dv = V.shape
         dQ = torch.empty_like(Q); dK = torch.empty_like(K); dV = torch.empty_like(V)
@@ -539,6 +540,13 @@ class _MHA(torch.autograd.Function):
         else:
             _call("tsg_mha_bwd", Q, *head, seed, offset, ctx.bwd_dtype)
         return dQ, dK, dV, None, None, None, None, None, None, None, None
+
+
+def mha_bf16_ok(d_key: int, d_value: int, n_heads: int, want_maps: bool = False) -> bool:
+    """Shapes tsg_mha_fwd AND tsg_mha_bwd take with dtype TSG_BF16 (include/tsg_hip.h): equal key / value widths, head widths
+    32 .. 128 in steps of 32, no A_forward maps."""
+    dh = d_key // max(n_heads, 1)
+    return (not want_maps) and d_key == d_value and d_key % max(n_heads, 1) == 0 and dh % 32 == 0 and 32 <= dh <= 128
 
 
 _mha_rng_state = {}        # device -> int64 [2] tensor (seed, offset): the dropout counter of captured launches
@@ -565,9 +573,9 @@ def mha(Q, K, V, n_heads, scale, causal=False, return_maps=False, p_drop=0.0):
             rng = st.clone()                                        # this call's (seed, offset), shared by forward and backward
         else:
             offset = int(torch.randint(0, 2 ** 62, (1,)).item())
-    if Q.dtype == _BF:
-        # bf16 storage mode: K2 has no bf16-storage kernels yet -- the split-precision kernels run on fp32 copies (their LDS
-        # operand planes are bf16 already; the hi plane of a bf16-valued input is the input itself) and O is rounded back
+    if Q.dtype == _BF and not mha_bf16_ok(Q.shape[-1], V.shape[-1], n_heads, return_maps):
+        # bf16 storage mode, a shape the TSG_BF16 kernels do not take (A_forward maps, head widths that are not multiples of 32 or
+        # above 128, d_key != d_value): the fp32-storage kernels on fp32 copies, O rounded back
         O, A, S = _MHA.apply(Q.float(), K.float(), V.float(), n_heads, scale, causal, return_maps, float(p_drop), seed, offset, rng)
         return (O.to(_BF), A, S) if return_maps else O.to(_BF)
     O, A, S = _MHA.apply(Q, K, V, n_heads, scale, causal, return_maps, float(p_drop), seed, offset, rng)

@@ -213,3 +213,64 @@ def test_linear_bf16_storage(request):
     assert wd.grad.dtype == torch.float32 and bd.grad.dtype == torch.float32
     _close(wd.grad, w.grad, "dw", tight=2e-3)
     _close(bd.grad, b.grad, "db", tight=2e-3)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,d,heads,causal,p_drop", [
+    (2, 128, 128, 1024, 8, False, 0.0),     # temporal self-attention at the north-star width (head width 128)
+    (2, 128, 20, 1024, 8, False, 0.0),      # cross attention over T_word = 20 words: one key tile, the fused backward kernel
+    (3, 200, 25, 512, 8, False, 0.0),       # one key tile, TWO query blocks: bf16 outputs take the dK/dV + dQ pair (no float atomics)
+    (2, 70, 70, 256, 8, True, 0.0),         # causal, ragged tiles, head width 32
+    (2, 100, 50, 384, 4, False, 0.0),       # head width 96
+    (2, 64, 64, 512, 8, False, 0.3),        # attention dropout: the same counter-based mask in forward and backward
+])
+def test_mha_bf16_storage(B, Tq, Tk, d, heads, causal, p_drop):
+    """K2 (tsg_mha_fwd / _bwd, dtype TSG_BF16: Q, K, V, O, dO, dQ, dK, dV as bf16; the split-precision kernels with 2-byte elements)
+    vs float64 attention on the same bf16-valued inputs (the dropout case: vs the fp32-storage kernels on the same inputs, whose
+    mask is the same function of (seed, offset, index))."""
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(21)
+    Q = _r(torch.randn(B, Tq, d, generator=g)); K = _r(torch.randn(B, Tk, d, generator=g)); V = _r(torch.randn(B, Tk, d, generator=g))
+    gO = _r(torch.randn(B, Tq, d, generator=g))
+    scale = float(d) ** 0.5
+    if p_drop == 0.0:
+        q, k, v = (x.double().requires_grad_(True) for x in (Q, K, V))
+        dh = d // heads
+        A = torch.einsum("bqhc,bkhc->bhqk", q.view(B, Tq, heads, dh), k.view(B, Tk, heads, dh))
+        if causal:
+            A = A - 1e10 * torch.triu(torch.ones(Tk, Tk, dtype=torch.float64), 1)
+        S = torch.softmax(A / scale, -1)                                          # attention.py:45-52: scale = sqrt(d_key) of the FULL width
+        O0 = torch.einsum("bhqk,bkhc->bqhc", S, v.view(B, Tk, heads, dh)).reshape(B, Tq, d)
+        O0.backward(gO.double())
+        ref = (O0.detach().float(), q.grad.float(), k.grad.float(), v.grad.float())
+    else:
+        torch.manual_seed(5)
+        q, k, v = (x.cuda().requires_grad_(True) for x in (Q, K, V))
+        O0 = F.mha(q, k, v, heads, scale, causal, p_drop=p_drop)
+        O0.backward(gO.cuda())
+        ref = (O0.detach().cpu(), q.grad.cpu(), k.grad.cpu(), v.grad.cpu())
+        torch.manual_seed(5)                                                       # the same (seed, offset) pair
+    qd, kd, vd = (x.to(BF).cuda().requires_grad_(True) for x in (Q, K, V))
+    assert F.mha_bf16_ok(d, d, heads)
+    O1 = F.mha(qd, kd, vd, heads, scale, causal, p_drop=p_drop)
+    assert O1.dtype == BF
+    O1.backward(gO.to(BF).cuda())
+    torch.cuda.synchronize()
+    for got, want, name in zip((O1.detach(), qd.grad, kd.grad, vd.grad), ref, ("O", "dQ", "dK", "dV")):
+        assert got.dtype == BF
+        _close(got, want, name)
+
+
+def test_mha_bf16_fallback_shapes():
+    """Shapes the TSG_BF16 kernels do not take (A_forward maps; head width 256 in the backward) run the fp32-storage kernels on
+    fp32 copies and still return bf16."""
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 40, 2048, generator=g).to(BF).cuda().requires_grad_(True)          # 8 heads of 256
+    assert not F.mha_bf16_ok(2048, 2048, 8)
+    O = F.mha(x, x, x, 8, 2048 ** 0.5)
+    assert O.dtype == BF
+    O.float().sum().backward()
+    assert x.grad is not None and x.grad.dtype == BF and torch.isfinite(x.grad.float()).all()
+    y = torch.randn(2, 16, 64, generator=g).to(BF).cuda()
+    O2, A, S = F.mha(y, y, y, 2, 8.0, return_maps=True)
+    assert O2.dtype == BF and A.dtype == torch.float32 and S.shape == (2, 16, 16)
