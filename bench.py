@@ -249,8 +249,9 @@ def pmc_traffic(kernel, B, T, N, d, launch_B=None, dtype="f32"):
     profiles/r3 first, then r2, r1) -- a citation of a profile of the same kernel and shape, not something this run observed:
     the JSON says so in `traffic_source`.  (None, None) when no pass exists for this shape and storage dtype."""
     launch_B = launch_B or B
-    for rnd in ("r3", "r2", "r1"):
-        rel = os.path.join("profiles", rnd, "k1_pmc_traffic.json")
+    for rnd, fname in (("r3", "k1_pmc_traffic_bf16.json" if dtype == "bf16" else "k1_pmc_traffic.json"), ("r2", "k1_pmc_traffic.json"),
+                       ("r1", "k1_pmc_traffic.json")):
+        rel = os.path.join("profiles", rnd, fname)
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 j = json.load(f)
