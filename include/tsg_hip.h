@@ -304,6 +304,15 @@ int tsg_wgrad_f32s(const void* A, long long lda, long long a_group_stride, const
                    void* C, long long ldc, long long c_group_stride, void* ws, long long ws_bytes,
                    long long M, int N, int groups, void* stream);
 
+/* The same product with bf16 OPERANDS (the bf16 storage mode, ABI revision 3): A, B0, B1 are bf16 matrices (strides in elements,
+ * multiples of 4; 16-byte aligned bases), C and ws fp32 as above (workspace size: tsg_wgrad_f32s_ws_bytes).  One bf16 MFMA per
+ * product with fp32 accumulation; the operands are transposed through LDS with 16-bit shuffles, nothing is converted.  The library's
+ * bf16 GEMM runs this shape (1024 x 1024 output over a 16384-long contraction of two row-major operands) on 64 output tiles.    */
+int tsg_wgrad_bf16(const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
+                   const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift, long long period,
+                   void* C, long long ldc, long long c_group_stride, void* ws, long long ws_bytes,
+                   long long M, int N, int groups, void* stream);
+
 /* ---- Device-side input pipeline and span decoding (csrc/input_pipeline.hip) ---------------------------
  * The reference does this per sample in numpy inside DataLoader workers; these entry points do it per batch on the GPU.
  * Integer outputs are bit-exact with the reference.  int32 index tensors, fp32 features (dtype TSG_F32).

@@ -29,6 +29,8 @@ _SIGNATURES = {
     "tsg_wgrad_f32s_ws_bytes": [c_longlong] + [_I] * 4,
     "tsg_wgrad_f32s": [_P, c_longlong, c_longlong, _P, c_longlong, _I, _P, c_longlong, c_longlong, _I, c_longlong, c_longlong,
                        _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _I, _I, _P],
+    "tsg_wgrad_bf16": [_P, c_longlong, c_longlong, _P, c_longlong, _I, _P, c_longlong, c_longlong, _I, c_longlong, c_longlong,
+                       _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _I, _I, _P],
     "tsg_boundary_score_fwd": [_P] * 9 + [_I] * 4 + [_P],
     "tsg_boundary_score_bwd": [_P] * 17 + [_I] * 4 + [_P],
     "tsg_mha_fwd": [_P] * 7 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],

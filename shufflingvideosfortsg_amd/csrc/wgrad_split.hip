@@ -45,10 +45,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 32;                                  // rows of the contraction per chunk
 constexpr int P = 20;                                   // LDS pitch of one column in dwords: 16 (32 bf16 rows) + 4
 
-struct WgradArgs {
-  const float* A; long lda; long a_gs;
-  const float* B0; long ldb0; int K0;
-  const float* B1; long ldb1; long b1_gs; int K1; long shift; long period;
+struct WgradArgs {                                      // A / B0 / B1: fp32 (tsg_wgrad_f32s) or bf16 (tsg_wgrad_bf16) elements; strides in elements
+  const void* A; long lda; long a_gs;
+  const void* B0; long ldb0; int K0;
+  const void* B1; long ldb1; long b1_gs; int K1; long shift; long period;
   float* C; long ldc; long c_gs;                        // output (splits == 1) ...
   float* ws;                                            // ... or partials [splits][groups][N][K0+K1]
   long M; int N; int groups; int splits; int cps;       // cps = chunks (of 32 rows) per split
@@ -98,6 +98,22 @@ struct Role {
       : mg((tid >> 2) & 7), c4((tid & 3) + 4 * ((tid >> 5) % (W / 16))), sub((tid >> 5) / (W / 16)) {}
   __device__ __forceinline__ int row0() const { return 4 * mg + R * sub; }
   // split the R x 4 block and write it m-contiguous: column 4*c4 + j, dwords (4*mg + R*sub) / 2 ..
+  // bf16 operands (tsg_wgrad_bf16): the R x 4 block arrives as R uint2 of four bf16; the transposition is a 16-bit shuffle, there is
+  // one plane and nothing to convert
+  __device__ __forceinline__ void write(const uint2 (&v)[R], unsigned* hi, unsigned*) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned e[R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const unsigned d = j < 2 ? v[i].x : v[i].y;
+        e[i] = (j & 1) ? (d >> 16) : (d & 0xffffu);
+      }
+      const int o = (4 * c4 + j) * P + 2 * mg + (R == 2 ? sub : 0);
+      if constexpr (R == 4) *reinterpret_cast<uint2*>(hi + o) = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+      else hi[o] = e[0] | (e[1] << 16);
+    }
+  }
   __device__ __forceinline__ void write(const float4 (&v)[R], unsigned* hi, unsigned* lo) const {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -120,10 +136,12 @@ struct Role {
   }
 };
 
-template <int WN, int WK, bool SHIFTED>
+template <int WN, int WK, bool SHIFTED, typename ET>
 __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, int split, int g, int n0, int k0) {
   using G = Geo<WN, WK>;
-  struct Staged { float4 a[G::RA]; float4 b[G::RB]; };    // one chunk's operand rows of a thread, in flight / waiting for the split
+  constexpr bool BF = storage_is_bf16<ET>::value;          // bf16 operands: one plane per operand, one MFMA per product
+  typedef typename Raw4T<ET>::type Raw;
+  struct Staged { Raw a[G::RA]; Raw b[G::RB]; };          // one chunk's operand rows of a thread, in flight / waiting for the split
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int K = a.K0 + a.K1;
   const long chunks = a.M / BM;
@@ -137,22 +155,22 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
   const long ldb = seg1 ? a.ldb1 : a.ldb0;
   const int shift = SHIFTED ? (int)(g ? -a.shift : a.shift) : 0;
   const unsigned brow0 = (unsigned)(c_begin * BM) + rb.row0();
-  const float* pa = a.A + g * a.a_gs + n0 + 4 * ra.c4 + (c_begin * BM + ra.row0()) * a.lda;
-  const float* pb = (seg1 ? a.B1 + g * a.b1_gs + (k0 - a.K0) : a.B0 + k0) + 4 * rb.c4 + ((long)brow0 - shift) * ldb;
+  const ET* pa = static_cast<const ET*>(a.A) + g * a.a_gs + n0 + 4 * ra.c4 + (c_begin * BM + ra.row0()) * a.lda;
+  const ET* pb = (seg1 ? static_cast<const ET*>(a.B1) + g * a.b1_gs + (k0 - a.K0) : static_cast<const ET*>(a.B0) + k0) + 4 * rb.c4 +
+                 ((long)brow0 - shift) * ldb;
 
   auto request = [&](Staged& r, int c) {                   // chunk c of the range (clamped: the tail re-requests the last chunk)
     c = min(c, nc - 1);
-    const float* qa = pa + (long)c * BM * a.lda;
-    const float* qb = pb + (long)c * BM * ldb;
+    const ET* qa = pa + (long)c * BM * a.lda;
+    const ET* qb = pb + (long)c * BM * ldb;
 #pragma unroll
-    for (int i = 0; i < G::RA; ++i) r.a[i] = *reinterpret_cast<const float4*>(qa + i * a.lda);
+    for (int i = 0; i < G::RA; ++i) r.a[i] = ldraw4(qa + i * a.lda);
 #pragma unroll
     for (int i = 0; i < G::RB; ++i) {
       if (SHIFTED) {
-        r.b[i] = row_ok(brow0 + (unsigned)c * BM + i, shift, (unsigned)a.M, (unsigned)a.period)
-                     ? *reinterpret_cast<const float4*>(qb + i * ldb) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r.b[i] = row_ok(brow0 + (unsigned)c * BM + i, shift, (unsigned)a.M, (unsigned)a.period) ? ldraw4(qb + i * ldb) : zero_raw4(qb);
       } else {
-        r.b[i] = *reinterpret_cast<const float4*>(qb + i * ldb);
+        r.b[i] = ldraw4(qb + i * ldb);
       }
     }
   };
@@ -182,17 +200,21 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         fa_h[t] = *reinterpret_cast<const u32x4*>(Ahi + ao + 32 * t * P + 8 * ms);
-        fa_l[t] = *reinterpret_cast<const u32x4*>(Alo + ao + 32 * t * P + 8 * ms);
         fb_h[t] = *reinterpret_cast<const u32x4*>(Bhi + bo + 32 * t * P + 8 * ms);
-        fb_l[t] = *reinterpret_cast<const u32x4*>(Blo + bo + 32 * t * P + 8 * ms);
+        if constexpr (!BF) {
+          fa_l[t] = *reinterpret_cast<const u32x4*>(Alo + ao + 32 * t * P + 8 * ms);
+          fb_l[t] = *reinterpret_cast<const u32x4*>(Blo + bo + 32 * t * P + 8 * ms);
+        }
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           acc[i][j] = mfma(fa_h[i], fb_h[j], acc[i][j]);
-          acc[i][j] = mfma(fa_h[i], fb_l[j], acc[i][j]);
-          acc[i][j] = mfma(fa_l[i], fb_h[j], acc[i][j]);
+          if constexpr (!BF) {
+            acc[i][j] = mfma(fa_h[i], fb_l[j], acc[i][j]);
+            acc[i][j] = mfma(fa_l[i], fb_h[j], acc[i][j]);
+          }
         }
     }
   };
@@ -204,6 +226,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
 #define TSG_TICK(i) {}
 #endif
   auto interleave = [&]() {
+    if constexpr (BF) return;                              // (the recipe below is counted for the 24-MFMA fp32 chunk)
 #ifndef TSG_WGRAD_NO_SGB
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                    // fragments of the first m-step
 #pragma unroll
@@ -283,7 +306,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
 #endif
 }
 
-template <int WN, int WK>
+template <int WN, int WK, typename ET>
 __global__ __launch_bounds__(64 * WN * WK) void wgrad_split_kernel(const WgradArgs a) {
   extern __shared__ __align__(16) unsigned lds[];
   using G = Geo<WN, WK>;
@@ -291,8 +314,8 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_split_kernel(const WgradAr
   const int v = xcd_major(blockIdx.x, gridDim.x);
   const int split = v / tps, rem = v % tps, g = rem / tpg, tile = rem % tpg;
   const int n0 = (tile / tiles_k) * G::TN, k0 = (tile % tiles_k) * G::TK;
-  if (k0 >= a.K0 && a.shift != 0) wgrad_tile<WN, WK, true>(a, lds, split, g, n0, k0);      // workgroup-uniform
-  else wgrad_tile<WN, WK, false>(a, lds, split, g, n0, k0);
+  if (k0 >= a.K0 && a.shift != 0) wgrad_tile<WN, WK, true, ET>(a, lds, split, g, n0, k0);      // workgroup-uniform
+  else wgrad_tile<WN, WK, false, ET>(a, lds, split, g, n0, k0);
 }
 
 // C[g][n][k] = sum_s ws[s][g][n][k], float4 per thread
@@ -354,12 +377,12 @@ Plan make_plan(long long M, int N, int K, int groups) {
   return p;
 }
 
-template <int WN, int WK>
+template <int WN, int WK, typename ET>
 int launch(const char* fn, const WgradArgs& a, int grid, hipStream_t st) {
   using G = Geo<WN, WK>;
-  hipError_t e = allow_lds(wgrad_split_kernel<WN, WK>, G::kLds);
+  hipError_t e = allow_lds(wgrad_split_kernel<WN, WK, ET>, G::kLds);
   if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
-  hipLaunchKernelGGL((wgrad_split_kernel<WN, WK>), dim3(grid), dim3(G::NT), G::kLds, st, a);
+  hipLaunchKernelGGL((wgrad_split_kernel<WN, WK, ET>), dim3(grid), dim3(G::NT), G::kLds, st, a);
   return check_launch(fn);
 }
 
@@ -373,11 +396,10 @@ extern "C" long long tsg_wgrad_f32s_ws_bytes(long long M, int N, int K0, int K1,
   return make_plan(M, N, K0 + K1, groups).ws;
 }
 
-extern "C" int tsg_wgrad_f32s(const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
-                              const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift,
-                              long long period, void* C, long long ldc, long long c_group_stride, void* ws, long long ws_bytes,
-                              long long M, int N, int groups, void* stream) {
-  const char* fn = "tsg_wgrad_f32s";
+static int wgrad_impl(const char* fn, bool bf, const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
+                      const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift,
+                      long long period, void* C, long long ldc, long long c_group_stride, void* ws, long long ws_bytes,
+                      long long M, int N, int groups, void* stream) {
   int rc = check_args(fn, M, N, K0, K1, groups);
   if (rc) return rc;
   if (!A || !C || (K0 > 0 && !B0) || (K1 > 0 && !B1)) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
@@ -397,12 +419,13 @@ extern "C" int tsg_wgrad_f32s(const void* A, long long lda, long long a_group_st
   auto st = static_cast<hipStream_t>(stream);
   const long chunks = M / BM;
   WgradArgs a;
-  a.A = (const float*)A; a.lda = lda; a.a_gs = a_group_stride;
-  a.B0 = (const float*)B0; a.ldb0 = ldb0; a.K0 = K0;
-  a.B1 = (const float*)B1; a.ldb1 = ldb1; a.b1_gs = b1_group_stride; a.K1 = K1; a.shift = shift; a.period = period;
+  a.A = A; a.lda = lda; a.a_gs = a_group_stride;
+  a.B0 = B0; a.ldb0 = ldb0; a.K0 = K0;
+  a.B1 = B1; a.ldb1 = ldb1; a.b1_gs = b1_group_stride; a.K1 = K1; a.shift = shift; a.period = period;
   a.C = (float*)C; a.ldc = ldc; a.c_gs = c_group_stride; a.ws = (float*)ws;
   a.M = M; a.N = N; a.groups = groups; a.splits = p.splits; a.cps = (int)((chunks + p.splits - 1) / p.splits);
-  rc = p.tn == 256 ? launch<4, 2>(fn, a, p.tiles * p.splits, st) : launch<2, 2>(fn, a, p.tiles * p.splits, st);
+  if (bf) rc = p.tn == 256 ? launch<4, 2, bf16_t>(fn, a, p.tiles * p.splits, st) : launch<2, 2, bf16_t>(fn, a, p.tiles * p.splits, st);
+  else rc = p.tn == 256 ? launch<4, 2, float>(fn, a, p.tiles * p.splits, st) : launch<2, 2, float>(fn, a, p.tiles * p.splits, st);
 #ifdef TSG_WGRAD_TIMING
   return rc;
 #endif
@@ -412,4 +435,22 @@ extern "C" int tsg_wgrad_f32s(const void* A, long long lda, long long a_group_st
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)ws, (float*)C, (long)ldc, (long)c_group_stride,
                      N, K, groups, p.splits);
   return check_launch(fn);
+}
+
+extern "C" int tsg_wgrad_f32s(const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
+                              const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift,
+                              long long period, void* C, long long ldc, long long c_group_stride, void* ws, long long ws_bytes,
+                              long long M, int N, int groups, void* stream) {
+  return wgrad_impl("tsg_wgrad_f32s", false, A, lda, a_group_stride, B0, ldb0, K0, B1, ldb1, b1_group_stride, K1, shift, period, C, ldc,
+                    c_group_stride, ws, ws_bytes, M, N, groups, stream);
+}
+
+// The same product for the bf16 storage mode: A, B0, B1 are bf16 matrices (strides in elements; rows 8-byte aligned), C and the
+// workspace fp32 -- one bf16 MFMA per product, operands transposed through LDS with 16-bit shuffles, nothing converted.
+extern "C" int tsg_wgrad_bf16(const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
+                              const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift,
+                              long long period, void* C, long long ldc, long long c_group_stride, void* ws, long long ws_bytes,
+                              long long M, int N, int groups, void* stream) {
+  return wgrad_impl("tsg_wgrad_bf16", true, A, lda, a_group_stride, B0, ldb0, K0, B1, ldb1, b1_group_stride, K1, shift, period, C, ldc,
+                    c_group_stride, ws, ws_bytes, M, N, groups, stream);
 }

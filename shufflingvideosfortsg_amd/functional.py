@@ -270,6 +270,37 @@ def wgrad_f32s(A: torch.Tensor, B0: torch.Tensor, N: int = None, groups: int = 1
     return C
 
 
+def _rows2d_bf(t: torch.Tensor) -> torch.Tensor:
+    """bf16 2-D operand whose rows are contiguous (a column slice of a row-major matrix is taken as it is)."""
+    if t.dtype != torch.bfloat16 or t.dim() != 2:
+        raise TypeError(f"bf16 matrix expected, got {t.dtype} {tuple(t.shape)}")
+    return t if t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 else t.contiguous()
+
+
+def wgrad_bf16(A: torch.Tensor, B0: torch.Tensor, N: int = None, groups: int = 1, a_group_stride: int = 0,
+               B1: torch.Tensor = None, K1: int = 0, b1_group_stride: int = 0, shift: int = 0, period: int = 0) -> torch.Tensor:
+    """``wgrad_f32s`` for bf16 operands (tsg_wgrad_bf16): C[g] = A[:, g*a_group_stride : +N]^T @ [B0 | B1 shifted] in fp32, one bf16
+    MFMA per product.  The weight gradients of the bf16 storage mode (the library's bf16 GEMM runs this contraction-major shape
+    with a small output on 64 tiles: 187 us at [1024 x 16384] x [16384 x 1024])."""
+    require_device(A, B0, B1)
+    A, B0 = _rows2d_bf(A), _rows2d_bf(B0)
+    B1 = _rows2d_bf(B1) if B1 is not None else None
+    M, K0 = B0.shape
+    N = A.shape[1] if N is None else N
+    if A.shape[0] != M or (B1 is not None and B1.shape[0] != M) or (B1 is None) != (K1 == 0):
+        raise ValueError("wgrad_bf16: operand rows differ")
+    K = K0 + K1
+    C = torch.empty(groups, N, K, device=A.device, dtype=torch.float32)
+    nb = int(load().tsg_wgrad_f32s_ws_bytes(M, N, K0, K1, groups))
+    if nb < 0:
+        raise ValueError(f"wgrad_bf16: unsupported shape M={M} N={N} K0={K0} K1={K1} groups={groups}")
+    ws = torch.empty(nb, device=A.device, dtype=torch.uint8) if nb else None
+    _call("tsg_wgrad_bf16", A, ptr(A), A.stride(0), a_group_stride, ptr(B0), B0.stride(0), K0,
+          ptr(B1) if B1 is not None else None, B1.stride(0) if B1 is not None else 0, b1_group_stride, K1, shift, period,
+          ptr(C), K, N * K, ptr(ws) if ws is not None else None, nb, M, N, groups)
+    return C
+
+
 def _split_operand(m: torch.Tensor, k_dim: int, right: bool) -> torch.Tensor:
     """Split a (possibly transposed-view) fp32 matrix without materialising the transpose."""
     if m.is_contiguous():
@@ -798,7 +829,13 @@ class _LinearBf16(torch.autograd.Function):
         x2, wb = ctx.saved_tensors
         dy2 = _bfc(dy).view(-1, wb.shape[0])
         dx = torch.mm(dy2, wb).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = torch.mm(dy2.t(), x2, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            M, (N, K) = x2.shape[0], wb.shape
+            if _WGRAD_KERNEL and wgrad_f32s_ok(M, N, K):
+                dw = wgrad_bf16(dy2, x2)[0]                    # tsg_wgrad_bf16 (csrc/wgrad_split.hip): dY^T X on the hand-written kernel
+            else:
+                dw = torch.mm(dy2.t(), x2, out_dtype=torch.float32)
         db = torch.sum(dy2, 0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
@@ -979,6 +1016,12 @@ class _BiLSTMLayerBf16(torch.autograd.Function):
               B, T, h, TSG_BF16, 1)
         dGf = dG.view(TB, 8 * h)
         dx = torch.mm(dGf, Wb).view(x.shape) if ctx.needs_input_grad[0] else None
+        if _WGRAD_KERNEL and wgrad_f32s_ok(TB, 4 * h, I, h):
+            # ONE launch per layer: D[d] = dG[d]^T [x | h_{t-+1}[d]] for both directions holds dW_ih[d] and dW_hh[d]; the shifted
+            # h rows are read straight from `out` (row r -+ 1 of the same sequence, zero at its ends) -- no shifted copy, no fp32
+            D = wgrad_bf16(dGf, x.view(TB, I), N=4 * h, groups=2, a_group_stride=4 * h, B1=out.view(TB, 2 * h), K1=h, b1_group_stride=h,
+                           shift=1, period=T)
+            return dx, D[:, :, :I].contiguous().view(8 * h, I), dbias, D[:, :, I:].contiguous()
         dW_ih = torch.mm(dGf.t(), x.view(TB, I), out_dtype=torch.float32)           # [8h, I], both directions
         # dW_hh[d] = sum_t dG_t[d]^T h_{t-1}[d] (h_{t+1} for the reverse direction): the partner rows as ONE shifted bf16 copy of
         # `out` (zero at the sequence ends), then a GEMM per direction on strided column views (no cat, no fp32 operands)

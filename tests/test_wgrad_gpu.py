@@ -117,3 +117,40 @@ def test_wgrad_alternate_tile_variant():
         "print('variant ok')\n") % root
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TSG_WGRAD_CFG="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 256, 128), (2560, 1024, 1024), (16384, 1024, 1024), (8192, 512, 1024), (4128, 256, 384)])
+def test_wgrad_bf16_operands(M, N, K):
+    """tsg_wgrad_bf16: the same product on bf16 operands (the bf16 storage mode's weight gradients): fp32 result equal to the
+    float64 product of the bf16 VALUES to fp32-accumulation level, deterministic."""
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(M + N + 1)
+    A = torch.randn(M, N, generator=g).bfloat16().cuda()
+    B = torch.randn(M, K, generator=g).bfloat16().cuda()
+    C = F.wgrad_bf16(A, B)
+    assert C.shape == (1, N, K) and C.dtype == torch.float32
+    ref = A.double().t() @ B.double()
+    assert _rel(C[0], ref) < 2e-6
+    assert torch.equal(C, F.wgrad_bf16(A, B))
+
+
+def test_wgrad_bf16_lstm_operands():
+    """Two groups, shifted second segment read from a bf16 `out` (batch-major: shift 1, period T), strided column-slice operands:
+    the one-launch LSTM weight gradient of the bf16 storage mode vs the explicitly shifted construction."""
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(6)
+    Bn, T, I, h = 8, 16, 128, 128
+    TB = Bn * T
+    dG = torch.randn(TB, 8 * h, generator=g).bfloat16().cuda()
+    x = torch.randn(TB, I, generator=g).bfloat16().cuda()
+    out = torch.randn(Bn, T, 2 * h, generator=g).bfloat16().cuda()
+    D = F.wgrad_bf16(dG, x, N=4 * h, groups=2, a_group_stride=4 * h, B1=out.view(TB, 2 * h), K1=h, b1_group_stride=h, shift=1, period=T)
+    assert D.shape == (2, 4 * h, I + h)
+    hp = torch.zeros_like(out)
+    hp[:, 1:, :h] = out[:, :-1, :h]
+    hp[:, :-1, h:] = out[:, 1:, h:]
+    hp = hp.view(TB, 2 * h).double()
+    for d in range(2):
+        gd = dG[:, d * 4 * h:(d + 1) * 4 * h].double()
+        ref = torch.cat([gd.t() @ x.double(), gd.t() @ hp[:, d * h:(d + 1) * h]], 1)
+        assert _rel(D[d], ref) < 2e-6, d
