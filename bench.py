@@ -49,8 +49,9 @@ def parse_args(argv=None):
                          "train.py:343) -- BASELINE configs 3 / 4 are global batches of 64 / 128 over 4 / 8 GPUs = 16 pairs per GPU")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the train step from two HIP graphs (engine.GraphedTrainStep) in THIS process and report it next to the "
-                         "eager step; auto = on when N > 1 (eight ranks share one host: 0.15 instead of 12 ms of host time per step), and "
-                         "then the faster of the two is `value` (`value_mode` says which)")
+                         "eager step; auto = on (off with --no-alt at N = 1).  The faster of the two is `value` and `value_mode` says which: "
+                         "it is the same full step either way (with eight ranks on one host the replay's 0.15 instead of 12 ms of host time "
+                         "per step is what keeps the ranks from queueing behind their Python threads)")
     ap.add_argument("--T", type=int, default=128)
     ap.add_argument("--N", type=int, default=20)
     ap.add_argument("--d", type=int, default=1024)
@@ -467,25 +468,6 @@ def main():
         log(f"forward-only: {fwd_only['ms_per_step']} ms/step")
         del loss3
     functional.check_lstm_errors()
-    graph_replay = None
-    if not a.fwd_only and not a.no_alt and world == 1:
-        # the same train step replayed from two HIP graphs (engine.GraphedTrainStep), measured in a CHILD process started from
-        # this one (a fresh capture state; a failure there cannot take this result down).  One GPU only: the child shares it.
-        import subprocess
-
-        def graph_child(dtype):
-            cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(a.steps), "--model", a.model, "--B", str(Bl),
-                   "--T", str(a.T), "--N", str(a.N), "--d", str(a.d), "--dtype", dtype, "--predictor", a.predictor]
-            try:
-                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
-                                   env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
-                lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"graph_replay"')]
-                return json.loads(lines[-1])["graph_replay"] if lines else {"error": f"child exit code {r.returncode}: {r.stderr[-300:]}"}
-            except Exception as e:                                # noqa: BLE001
-                return {"error": f"{type(e).__name__}: {e}"[:300]}
-        graph_replay = graph_child(a.dtype)
-        log(f"graph replay: {graph_replay}")
-
     # the same train step replayed from two HIP graphs IN THIS PROCESS (every rank), gradient exchange eager between them:
     # what --gpus N > 1 runs by default.  A rank that cannot capture reports it and ALL ranks skip the leg (agreed by an
     # all-reduce) -- a half-captured world would deadlock in the exchange.
@@ -496,7 +478,7 @@ def main():
         t[rank] = t_enq / a.steps * 1e3
         dist.all_reduce(t)
         enq_ranks = [round(float(v), 3) for v in t.tolist()]
-    want_graph = (not a.fwd_only) and (a.graph == "on" or (a.graph == "auto" and world > 1))
+    want_graph = (not a.fwd_only) and (a.graph == "on" or (a.graph == "auto" and (world > 1 or not a.no_alt)))
     if want_graph:
         gstep, err = None, ""
         # nothing of the eager steps may stay alive: their autograd graph owns AccumulateGrad nodes bound to the eager stream, and the
@@ -535,6 +517,25 @@ def main():
         else:
             graph_inproc = {"error": err or "another rank could not capture the step"}
             log(f"graph replay (in process) skipped: {graph_inproc['error']}")
+
+    graph_replay = None
+    if not a.fwd_only and not a.no_alt and world == 1 and not (graph_inproc and "value" in graph_inproc):
+        # fallback when the in-process graph leg above did not produce a number: the same measurement in a CHILD process started
+        # from this one (a fresh capture state; a failure there cannot take this result down).  One GPU only: the child shares it.
+        import subprocess
+
+        def graph_child(dtype):
+            cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(a.steps), "--model", a.model, "--B", str(Bl),
+                   "--T", str(a.T), "--N", str(a.N), "--d", str(a.d), "--dtype", dtype, "--predictor", a.predictor]
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                                   env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"graph_replay"')]
+                return json.loads(lines[-1])["graph_replay"] if lines else {"error": f"child exit code {r.returncode}: {r.stderr[-300:]}"}
+            except Exception as e:                                # noqa: BLE001
+                return {"error": f"{type(e).__name__}: {e}"[:300]}
+        graph_replay = graph_child(a.dtype)
+        log(f"graph replay: {graph_replay}")
 
     if rank == 0:
         kt = functional.kernel_timer.summary()          # (name, dims) -> (mean us, launches, median us)

@@ -14,7 +14,7 @@ s, e = groups[k][-1] + 1, groups[k + 1][-1]
 t0 = ev[s][0]
 def cat(n):
     if 'lstm_' in n: return 'lstm recurrence'
-    if n.startswith('Cijk'): return 'gemm bf16' if '_BSS_BH' in n else 'gemm f32'
+    if n.startswith(('Cijk', 'Custom_Cijk')): return 'gemm bf16' if ('_BSS_BH' in n or '_BBS_BH' in n) else 'gemm f32'    # BSS: bf16 in, fp32 out; BBS: bf16 out
     if 'split_bf16' in n: return 'operand split'
     if 'tsg::' in n: return 'hot-path kernels'
     if 'multi_tensor' in n: return 'adam'
