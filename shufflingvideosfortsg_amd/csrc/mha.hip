@@ -2189,6 +2189,9 @@ static int mha_fwd_impl(const void* Q, const void* K, const void* V, void* O, vo
   rc = make_drop(fn, p_drop, seed, offset, rng_dev, &dc);
   if (rc) return rc;
   if (!(scale > 0.f)) return set_error(TSG_E_SHAPE, "%s: scale must be positive", fn);
+  if (dtype == TSG_BF16 && (A_sum || S_sum || d_key != d_value || (d_key / n_heads) % 32 || d_key / n_heads > 256))     // before any launch
+    return set_error(TSG_E_SHAPE, "%s: dtype TSG_BF16 needs d_key == d_value, head widths 32 .. 256 in steps of 32 and no A_sum / S_sum "
+                     "outputs (head width %d / %d)", fn, d_key / n_heads, d_value / n_heads);
   auto st = static_cast<hipStream_t>(stream);
   const size_t map_bytes = sizeof(float) * (size_t)B * Tq * Tk;
   if (A_sum) { hipError_t e = zero_async(A_sum, map_bytes, st); if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e)); }

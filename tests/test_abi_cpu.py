@@ -49,6 +49,18 @@ def test_argument_errors_without_gpu(lib):
     assert lib.tsg_mha_fwd(p, p, p, p, None, None, p, 1, 4, 4, 8, 8, 2, 1.0, 0, 1.0, 0, 0, TSG_F32, None) == -2  # dropout probability outside [0,1)
     assert lib.tsg_boundary_score_fwd(p, p, p, p, p, None, None, p, p, 1, 4, 3, TSG_F32, None) == -2             # 2*Hm % 4
     assert lib.tsg_mha_bwd(p, p, p, p, p, p, p, p, p, p, 1, 4, 4, 8, 8, 2, 1.0, 0, 0.0, 0, 0, 7, None) == -4     # dtype (TSG_F32 / TSG_F32S only)
+    # dtype TSG_BF16 (bf16 storage, ABI revision 3): accepted where the header says so, shapes it does not take are TSG_E_SHAPE (-2)
+    from shufflingvideosfortsg_amd._lib import TSG_BF16
+    assert lib.tsg_mha_fwd(p, p, p, p, p, None, p, 1, 4, 4, 64, 64, 2, 1.0, 0, 0.0, 0, 0, TSG_BF16, None) == -2      # A_sum asked for
+    assert lib.tsg_mha_fwd(p, p, p, p, None, None, p, 1, 4, 4, 40, 40, 2, 1.0, 0, 0.0, 0, 0, TSG_BF16, None) == -2   # head width 20
+    assert lib.tsg_mha_bwd(p, p, p, p, p, p, p, p, p, p, 1, 4, 4, 512, 512, 2, 1.0, 0, 0.0, 0, 0, TSG_BF16, None) == -2   # head width 256
+    assert lib.tsg_lstm_fwd_bias(p, None, p, p, p, p, p, 4, 16, 100, TSG_BF16, 1, None) == -2                      # h = 100: no persistent kernel
+    assert lib.tsg_lstm_fwd_bias(p, None, p, p, p, p, None, 4, 16, 128, TSG_BF16, 1, None) == -2                   # no sync workspace
+    assert lib.tsg_lstm_bwd_ws_layout(p, p, p, p, None, p, p, None, 0, None, 4, 16, 128, TSG_BF16, 1, None) == -2  # no ring workspace
+    assert lib.tsg_match_head_fwd(p, p, p, p, p, 1, 4, 8, 0, 7, None) == -4                                        # dtype (new argument)
+    assert lib.tsg_boundary_score_fwd(p, p, p, p, p, None, None, p, p, 1, 4, 4, 7, None) == -4
+    assert lib.tsg_error_word(None) == 0 and lib.tsg_error_sink(None) == 0                                         # un-registering is allowed
+    assert lib.tsg_wgrad_bf16(p, 256, 0, p, 100, 128, None, 0, 0, 0, 0, 0, p, 128, 0, None, 0, 64, 256, 1, None) == -2    # ldb0 < K0
     # the weight-gradient GEMM: host-side plan and argument checks (no launch)
     assert lib.tsg_wgrad_f32s_ws_bytes(16384, 1024, 1024, 0, 1) == 8 * 4 * 1024 * 1024      # 32 tiles -> 8 row ranges of partial tiles
     assert lib.tsg_wgrad_f32s_ws_bytes(16384, 2048, 1024, 512, 2) == 4 * 4 * 2 * 2048 * 1536  # the LSTM shape: 192 tiles -> 4 ranges

@@ -103,3 +103,21 @@ def test_unsupported_predictor_is_loud():
     p = engine.default_params(predictor="tied_lstm")
     with pytest.raises(NotImplementedError):
         engine.build_model("qave", p, logging.getLogger("t"))
+
+
+def test_strong_scaling_shards_and_device_move():
+    """bench.py --scaling strong: every rank builds the same global batch and keeps its contiguous shard (dp.shard_batch, the
+    reference's DataParallel scatter, train.py:343); data.to_device turns the per-sample [start, end] lists into one index tensor."""
+    import torch
+    from shufflingvideosfortsg_amd import data
+    from shufflingvideosfortsg_amd.dp import shard_batch
+    full = data.synthetic_batch(8, 16, 5, seed=3, pair=True)
+    parts = [shard_batch(full, r, 4) for r in range(4)]
+    for k in ("video", "query", "video_mask", "pseudo_video"):
+        assert torch.equal(torch.cat([p[k] for p in parts]), full[k])
+    for gt in ("gt", "pseudo_gt"):
+        assert sum((p[gt]["framestps"] for p in parts), []) == full[gt]["framestps"]
+        assert torch.equal(torch.cat([p[gt]["temporal_labels"] for p in parts]), full[gt]["temporal_labels"])
+    d = data.to_device(parts[1], "cpu")
+    assert d["gt"]["framestps"].dtype == torch.long and d["gt"]["framestps"].tolist() == full["gt"]["framestps"][2:4]
+    assert isinstance(parts[1]["gt"]["framestps"], list)                      # the host batch is not modified
