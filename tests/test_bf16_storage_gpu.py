@@ -274,3 +274,45 @@ def test_mha_bf16_fallback_shapes():
     y = torch.randn(2, 16, 64, generator=g).to(BF).cuda()
     O2, A, S = F.mha(y, y, y, 2, 8.0, return_maps=True)
     assert O2.dtype == BF and A.dtype == torch.float32 and S.shape == (2, 16, 16)
+
+
+@pytest.mark.parametrize("losses", ["torch", "k4"])
+def test_gmd_golden_in_bf16_storage_mode(golden, losses, request):
+    """The reference's golden GMD step (tiny widths: rnn hidden 8, d = 16) in the bf16 storage mode: every shape here is one the
+    TSG_BF16 kernels do NOT take natively or take at odd sizes (LSTM hidden size 8 -> the fp32-storage recurrence on fp32 copies;
+    K1 / K3 / K5 at widths of 16..24), i.e. the fallback plumbing of the mode end to end -- outputs within bf16 noise of the
+    reference's fp32 result, finite gradients of the right dtype for every parameter, eval_forward too."""
+    import logging
+    from shufflingvideosfortsg_amd import engine
+    from shufflingvideosfortsg_amd.model import GMD
+    from test_models_gpu import _sets
+    engine.precision("bf16")
+    request.addfinalizer(lambda: engine.precision(None))
+    g = golden("gmd")
+    m = GMD(*_sets(24, 8, 12, 16), logging.getLogger("t"), 0.0)
+    m.load_state_dict(g.weights)
+    m.cuda().train()
+    m.tod.dropout.p = 0.0
+    c = lambda k: g.t(k).cuda()
+    batch = {"video": c("video").to(BF), "pseudo_video": c("pvideo").to(BF), "query": c("query"), "video_mask": c("vmask"),
+             "query_mask": None,
+             "gt": {"framestps": g.a["framestps"].tolist(), "temporal_labels": c("ot"), "fore_masks": c("of"), "back_masks": c("ob")},
+             "pseudo_gt": {"framestps": g.a["pframestps"].tolist(), "temporal_labels": c("pt"), "fore_masks": c("pf"), "back_masks": c("pb")}}
+    if losses == "k4":
+        for k in ("gt", "pseudo_gt"):
+            batch[k]["framestps"] = torch.tensor(batch[k]["framestps"], dtype=torch.long).cuda()
+    loss, _, span = engine.gmd_step(m, batch, engine.default_params())
+    assert span["start"].dtype == torch.float32
+    torch.testing.assert_close(span["start"].detach().cpu(), g.t("start"), atol=2e-2, rtol=5e-2)
+    torch.testing.assert_close(span["end"].detach().cpu(), g.t("end"), atol=2e-2, rtol=5e-2)
+    torch.testing.assert_close(loss.detach().cpu(), g.t("loss"), atol=5e-2, rtol=5e-2)
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
+        want = g.wgrads[k]
+        scale = max(1.0, float(want.abs().max()))
+        torch.testing.assert_close(p.grad.cpu(), want, atol=5e-2 * scale, rtol=2e-1, msg=lambda s_, k=k: f"grad {k}: {s_}")
+    m.eval()
+    with torch.no_grad():
+        ev = m.eval_forward(c("video").to(BF), c("query"), c("vmask"), None)
+    torch.testing.assert_close(ev["start"].cpu(), g.t("eval_start"), atol=2e-2, rtol=5e-2)
