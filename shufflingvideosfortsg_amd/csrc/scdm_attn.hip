@@ -659,6 +659,264 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_mm_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// forward, split-precision variant with ROLE-SPECIALISED waves (dtype TSG_F32S, the default for H = Ds = 256 CT).
+//
+// In the kernel above every wave alternates between the score loop (VALU issue) and phase 2 (r loads, MFMAs, out stores), and the
+// barrier between them keeps the 8 waves of the CU in the same phase: the ablation shows the two phases
+// adding up (34 us + 15 us) instead of overlapping.  Here the roles are split across waves instead of across time:
+//   waves 0..PW-1     producers: scores + softmax of 8/PW rows each (one after the other) per 8-row sub-tile, nothing else;
+//   waves PW..2PW-1   consumers: phase 2 of the PREVIOUS sub-tile -- all 8 rows x Ds/PW columns each on the matrix pipe, the r loads,
+//                     the sigmoid gate and the out stores.
+// PW = 8 (1024 threads: two producers and two consumers per SIMD, 128 VGPRs each) when the consumer's resident VW strip fits, i.e.
+// N <= 24 (words 16..23 then ride a 32x32x8 k step with 2-register operands); PW = 4 (512 threads, one of each per SIMD) otherwise.
+// One barrier per sub-tile hands the P rows over (double-buffered in LDS), so phase 2 of sub-tile i runs beside the score loop of
+// sub-tile i + 1 by construction, on the SIMD's other wave.  A consumer's r rows are requested a whole score loop (~5 us) before they
+// are used and its stores have as long to drain; a producer issues no stores but the 80-byte P rows.  Cost: the score loop runs on one
+// wave per SIMD (tools/ubench: 18.2 instead of 16.1 cycles per fma-rcp-fma triple when nothing else fills the gaps).
+// ------------------------------------------------------------------------------------------
+typedef short k1_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned k1_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ k1_f32x16 k1_mfma8(k1_u32x2 a, k1_u32x2 b, k1_f32x16 c) {      // 32x32x8: k = 4 (lane / 32) + j
+  return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(k1_s16x4, a), __builtin_bit_cast(k1_s16x4, b), c, 0, 0, 0);
+}
+
+template <int NP, bool GATE, int CT, int PW>
+__global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
+    const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w,
+    const float* __restrict__ V, float* __restrict__ C, float* __restrict__ P,
+    const float* __restrict__ gr, const float* __restrict__ gbias,
+    int B, int T, int N, int H, int Ds, int TT, int tiles, int dbg) {
+  constexpr int NT = 128 * PW;                       // PW producer + PW consumer waves
+  constexpr int SUB = 8;                             // rows per sub-tile
+  constexpr int RPW = SUB / PW;                      // rows per producer wave and sub-tile (one after the other)
+  constexpr int PP = 36;
+  constexpr bool K8 = NP > 16 && NP <= 24;           // words 16 .. 23 as ONE 32x32x8 k step (2-register operands) instead of a 32x32x16
+  constexpr int KS = NP > 16 && !K8 ? 2 : 1;         // full 16-word k steps
+  constexpr int CC = 8 * CT / PW;                    // 32-column tiles per consumer wave (Ds / PW columns)
+  const int HP = roundup256(H);
+  extern __shared__ __align__(16) float lds[];
+  float* Es = lds;                       // [NP][HP]
+  float* Wl = lds + NP * HP;             // [HP]   -2*w
+  float* Pl = Wl + HP;                   // [2][SUB][PP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+  const int jl = lane & 31, hh = lane >> 5;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x, tiles);
+  const int b = bid / tiles, tile = bid % tiles;
+  const int t_tile = tile * TT;
+  const float* ab = a + (size_t)b * T * H;
+  const int nsub = TT / SUB;
+
+  // ---- prologue (all waves): Es = exp(2 s[b]), -2w, zeroed P tiles
+  const float* sb = s + (size_t)b * N * H;
+  const int hp4 = HP / 4, total4 = NP * hp4;
+  constexpr int PU = PW == 4 ? 12 : 6;
+  for (int base = tid; base < total4; base += PU * NT) {
+    float4 v[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int idx = base + u * NT;
+      const int n = idx / hp4, k = (idx % hp4) * 4;
+      v[u] = (idx < total4 && n < N && k < H) ? *reinterpret_cast<const float4*>(sb + (size_t)n * H + k) : make_float4(-1e30f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int idx = base + u * NT;
+      if (idx < total4) {
+        const int n = idx / hp4, k = (idx % hp4) * 4;
+        float4 e = exp2x4(v[u]);
+        if (v[u].x == -1e30f) e = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Es + n * HP + k) = e;
+      }
+    }
+  }
+  for (int k = tid * 4; k < HP; k += 4 * NT) {
+    float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < H) wq = *reinterpret_cast<const float4*>(w + k);
+    *reinterpret_cast<float4*>(Wl + k) = make_float4(-2.f * wq.x, -2.f * wq.y, -2.f * wq.z, -2.f * wq.w);
+  }
+  for (int i = tid; i < 2 * SUB * PP; i += NT) Pl[i] = 0.f;
+
+  if (wv < PW) {
+    // =================================== producer: rows t0 + RPW wv .. =====================================================
+    __builtin_amdgcn_s_setprio(2);                         // the score loop is the critical path of the CU
+    // The wave's current row lives in CT float4; chunk c of the row it scores NEXT (its next row of this sub-tile, or its first of
+    // the next one) is requested into slot c as soon as the score loop has consumed it, unconditionally (clamped address).
+    float4 q[CT];
+    auto row_ptr = [&](int t) { return ab + (size_t)(t < T ? t : T - 1) * H + lane * 4; };
+    {
+      const float* row = row_ptr(t_tile + RPW * wv);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) q[c] = *reinterpret_cast<const float4*>(row + c * 256);
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) asm volatile("" : "+v"(q[c].x), "+v"(q[c].y), "+v"(q[c].z), "+v"(q[c].w));
+    lds_barrier();
+    auto score_row = [&](float* Pcur, int tl, int t, const float* nrow) {
+      float acc[1][NP];
+#pragma unroll
+      for (int n = 0; n < NP; ++n) acc[0][n] = 0.f;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int k = 256 * c + lane * 4;
+        const float4 wq = *reinterpret_cast<const float4*>(Wl + k);
+        const float w2[4] = {wq.x, wq.y, wq.z, wq.w};
+        float Ea[1][4];
+        const float4 e = exp2x4(q[c]);
+        Ea[0][0] = e.x; Ea[0][1] = e.y; Ea[0][2] = e.z; Ea[0][3] = e.w;
+        q[c] = *reinterpret_cast<const float4*>(nrow + 256 * c);
+        scdm_chunk_step<NP, 1, 2>(Ea, Es + k, HP, w2, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // land the next row ahead of the P stores (vmcnt counts loads and stores together, in order)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) asm volatile("" : "+v"(q[c].x), "+v"(q[c].y), "+v"(q[c].z), "+v"(q[c].w));
+      float z[NP / 4];
+      wave_transpose_sum<NP>(acc[0], z);
+      const int qd = lane >> 4;
+      const int nq = ((qd & 1) << 1) | (qd >> 1);
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < NP / 4; ++j) {
+        if (4 * j + nq >= N) z[j] = -INFINITY;
+        m = fmaxf(m, z[j]);
+      }
+      m = xrow_max(m);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < NP / 4; ++j) {
+        z[j] = fast_exp2((z[j] - m) * kLog2e);
+        sum += z[j];
+      }
+      const float inv = 1.f / xrow_sum(sum);
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < NP / 4; ++j) {
+          const int n = 4 * j + nq;
+          const float pv = z[j] * inv;
+          Pcur[tl * PP + n] = pv;
+          if (n < N && t < T) P[((size_t)b * T + t) * N + n] = pv;
+        }
+      }
+    };
+#pragma unroll 1
+    for (int st = 0; st < nsub; ++st) {
+      const int t0 = t_tile + st * SUB + RPW * wv;
+      float* Pcur = Pl + (st & 1) * SUB * PP;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r)
+        score_row(Pcur, RPW * wv + r, t0 + r, row_ptr(r + 1 < RPW ? t0 + r + 1 : t0 + SUB));
+      lds_barrier();                                       // hand-over #st: the sub-tile's P rows are in LDS
+    }
+  } else {
+    // =================================== consumer: phase 2 of the sub-tile handed over last ================================
+    const int col0 = (wv - PW) * 32 * CC;
+    lds_barrier();                                         // (prologue barrier first: the producers do not wait for the VW loads below)
+    const float* Vb = V + (size_t)b * N * Ds + col0 + jl;
+    k1_u32x4 vh[CC][KS], vl[CC][KS];
+    k1_u32x2 vh8[CC], vl8[CC];
+    float gb[CC];
+#pragma unroll
+    for (int ct = 0; ct < CC; ++ct) {
+      gb[ct] = GATE ? -kLog2e * gbias[col0 + 32 * ct + jl] : 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int n = 16 * ks + 8 * hh + j;
+          e[j] = Vb[(size_t)(n < N ? n : 0) * Ds + 32 * ct];
+          if (n >= N) e[j] = 0.f;
+        }
+        k1_split8(e, vh[ct][ks], vl[ct][ks]);
+      }
+      if (K8) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = 16 + 4 * hh + j;
+          e[j] = Vb[(size_t)(n < N ? n : 0) * Ds + 32 * ct];
+          if (n >= N) e[j] = 0.f;
+        }
+        unsigned h0, l0, h1, l1;
+        k1_split_pair(e[0], e[1], h0, l0); k1_split_pair(e[2], e[3], h1, l1);
+        vh8[ct] = (k1_u32x2){h0, h1}; vl8[ct] = (k1_u32x2){l0, l1};
+      }
+    }
+    const unsigned lane_off = (unsigned)(4 * hh) * (unsigned)Ds + (unsigned)(col0 + jl);
+    const unsigned lane_col = (unsigned)(col0 + jl);
+    float rr[CC][4];
+    auto load_rr = [&](int t0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int u = min(t0 + i, T - 1);
+        const float* base = gr + ((size_t)b * T + u) * Ds;
+        const unsigned off = u + 4 < T ? lane_off : lane_col;
+#pragma unroll
+        for (int ct = 0; ct < CC; ++ct) rr[ct][i] = (base + 32 * ct)[off];
+      }
+    };
+    if (GATE) load_rr(t_tile);
+#pragma unroll 1
+    for (int st = 0; st < nsub; ++st) {
+      const int t0 = t_tile + st * SUB;
+      const float* Pcur = Pl + (st & 1) * SUB * PP;
+      lds_barrier();                                       // hand-over #st
+      // land the r rows HERE (requested a whole score loop ago), before any of this sub-tile's stores is issued: a wait placed after
+      // them would be vmcnt(0) (the stores sit under row predicates, the compiler cannot count them) and drain the store queue
+      if (GATE) {
+#pragma unroll
+        for (int ct = 0; ct < CC; ++ct)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(rr[ct][i]));
+      }
+      k1_u32x4 ph[KS], pl[KS];
+      k1_u32x2 ph8, pl8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float* pr = Pcur + (jl & 7) * PP + 16 * ks + 8 * hh;
+        float4 x = *reinterpret_cast<const float4*>(pr), y = *reinterpret_cast<const float4*>(pr + 4);
+        if (jl >= 8) { x = make_float4(0.f, 0.f, 0.f, 0.f); y = x; }
+        const float e[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        k1_split8(e, ph[ks], pl[ks]);
+      }
+      if (K8) {
+        float4 x = *reinterpret_cast<const float4*>(Pcur + (jl & 7) * PP + 16 + 4 * hh);
+        if (jl >= 8) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned h0, l0, h1, l1;
+        k1_split_pair(x.x, x.y, h0, l0); k1_split_pair(x.z, x.w, h1, l1);
+        ph8 = (k1_u32x2){h0, h1}; pl8 = (k1_u32x2){l0, l1};
+      }
+#pragma unroll
+      for (int ct = 0; ct < CC; ++ct) {
+        k1_f32x16 o;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          o = k1_mfma(ph[ks], vh[ct][ks], o);
+          o = k1_mfma(ph[ks], vl[ct][ks], o);
+          o = k1_mfma(pl[ks], vh[ct][ks], o);
+        }
+        if (K8) {
+          o = k1_mfma8(ph8, vh8[ct], o);
+          o = k1_mfma8(ph8, vl8[ct], o);
+          o = k1_mfma8(pl8, vh8[ct], o);
+        }
+        float* dst = C + ((size_t)b * T + t0) * Ds + 32 * ct;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = o[i];
+          if (GATE) v = rr[ct][i] * fast_rcp(1.f + fast_exp2(fmaf(v, -kLog2e, gb[ct])));
+          if (t0 + i + 4 * hh < T) (dst + (size_t)i * Ds)[lane_off] = v;
+        }
+      }
+      if (GATE) load_rr(t0 + SUB);                         // the next sub-tile's r rows: a whole score loop of cover
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward, kernel 1: de[b,t,n] = P*(dP - <P,dP>),  dP[t,n] = <dC[t,:], sent[b,n,:]>
 // Workgroup = (b, 32 clips), 8 waves = (column group cg, row slot rs) exactly as forward phase 2:
 // the wave's sent[b,:,cols] slice stays in registers, its dC rows stream through (next row in
@@ -1689,10 +1947,30 @@ int launch_fwd_mm(const float* a, const float* s, const float* w, const float* V
   const int tiles = cdiv(T, TT);
   const size_t lds = sizeof(float) * ((size_t)(NP + 1) * roundup256(H) + (size_t)2 * 8 * 36);
   if (lds > (size_t)kLdsBytes) return -1000;
-  auto kern = Ds == 1024 ? scdm_fwd_mm_kernel<NP, GATE, 4> : Ds == 512 ? scdm_fwd_mm_kernel<NP, GATE, 2> : scdm_fwd_mm_kernel<NP, GATE, 1>;
+  static const bool mm_only = [] { const char* e = getenv("TSG_K1_FWD"); return e && e[0] == 'm'; }();   // A/B: time-shared roles
+  if (mm_only) {
+    auto kern = Ds == 1024 ? scdm_fwd_mm_kernel<NP, GATE, 4> : Ds == 512 ? scdm_fwd_mm_kernel<NP, GATE, 2> : scdm_fwd_mm_kernel<NP, GATE, 1>;
+    hipError_t e = allow_lds(kern, lds);
+    if (e != hipSuccess) return set_error((int)e, "scdm_attn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kFwdThreads), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
+    return check_launch("scdm_attn_fwd");
+  }
+  // role-specialised waves: 8 producers + 8 consumers (two score waves per SIMD) while the consumer's VW strip fits 128 VGPRs
+  // (N <= 24), else 4 + 4.  TSG_K1_PW=4 forces the latter (A/B timing).
+  static const int pw_env = [] { const char* e = getenv("TSG_K1_PW"); return e ? atoi(e) : 0; }();
+  constexpr bool kCanPw8 = NP > 8 && NP <= 24;          // (NP = 8 at 1024 threads spills: 4 + 4 there)
+  const bool pw8 = kCanPw8 && pw_env != 4;
+  void (*kern)(const float*, const float*, const float*, const float*, float*, float*, const float*, const float*,
+               int, int, int, int, int, int, int, int);
+  if constexpr (kCanPw8) {
+    if (pw8) kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 8> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 8> : scdm_fwd_ws_kernel<NP, GATE, 1, 8>;
+    else kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 4> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 4> : scdm_fwd_ws_kernel<NP, GATE, 1, 4>;
+  } else {
+    kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 4> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 4> : scdm_fwd_ws_kernel<NP, GATE, 1, 4>;
+  }
   hipError_t e = allow_lds(kern, lds);
   if (e != hipSuccess) return set_error((int)e, "scdm_attn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
-  hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kFwdThreads), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
+  hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(pw8 ? 1024 : 512), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
   return check_launch("scdm_attn_fwd");
 }
 
