@@ -544,7 +544,11 @@ def main():
             entry = {"mean_us": round(us, 2), "median_us": round(med, 2), "launches": n, "dims": list(dims)}
             key = {"tsg_scdm_attn_fwd": "scdm_fwd", "tsg_scdm_attn_bwd": "scdm_bwd",
                    "tsg_scdm_gate_fwd": "scdm_gate_fwd", "tsg_scdm_gate_bwd": "scdm_gate_bwd",
-                   "tsg_boundary_score_fwd": "boundary_fwd", "tsg_boundary_score_bwd": "boundary_bwd"}.get(name)
+                   "tsg_boundary_score_fwd": "boundary_fwd", "tsg_boundary_score_bwd": "boundary_bwd",
+                   "tsg_boundary_score_bwd_ws": "boundary_bwd"}.get(name)
+            if name == "tsg_boundary_score_bwd_ws":       # (ws_bytes, B, T, Hm, dtype): the workspace size is not a shape
+                dims = dims[1:]
+                entry["dims"] = list(dims)
             esz = 2 if (dims and dims[-1] == 1) else 4    # last integer argument = dtype: TSG_BF16 (1) stores activations in 2 bytes
             if key and key.startswith("scdm"):            # dims = (B, T, N, H, Ds, dtype)
                 by = alg_bytes(key, dims[0], dims[1], dims[2], dims[3], e=esz)

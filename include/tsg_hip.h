@@ -37,8 +37,9 @@
 extern "C" {
 #endif
 
-#define TSG_VERSION 3   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points
-                           3: tsg_error_word (device-side expiry report); dtype TSG_BF16 (bf16 storage) in K1 / K1g / K2 / K3 / LSTM */
+#define TSG_VERSION 4   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points
+                           3: tsg_error_word (device-side expiry report); dtype TSG_BF16 (bf16 storage) in K1 / K1g / K2 / K3 / LSTM
+                           4: tsg_boundary_score_bwd_ws (K3 backward in one launch) */
 #define TSG_F32 0
 #define TSG_BF16 1   /* bf16 storage of the activations, fp32 arithmetic (see Conventions)                               */
 #define TSG_F32S 2   /* fp32 storage; matrix products as split-precision bf16 MFMAs (x = hi + lo; hi*hi + hi*lo + lo*hi,
@@ -116,6 +117,17 @@ int tsg_boundary_score_bwd(const void* y, const void* cs, const void* b1, const 
                            const void* dp_start, const void* dp_end, void* dy, void* dcs, void* db1_part,
                            void* dw2_part, void* db2_part, void* dgate, void* dl_ws, int B, int T, int Hm,
                            int dtype, void* stream);
+/* Same in ONE launch (ABI revision 4).  ws: caller-owned
+ * workspace of tsg_boundary_score_bwd_ws_bytes(B,T,Hm) bytes, 16-byte aligned, whose first B 32-bit words (one ticket counter per
+ * batch item) must be ZERO when the call is enqueued; the kernel leaves them zero, so one workspace zeroed once serves every later
+ * call on the same stream (its other contents are scratch).  The T-sums are added in a fixed order: results are run-to-run
+ * identical (the two-kernel entry point above accumulates dcs / db1_part / dw2_part with float atomics).                      */
+long long tsg_boundary_score_bwd_ws_bytes(int B, int T, int Hm);
+int tsg_boundary_score_bwd_ws(const void* y, const void* cs, const void* b1, const void* w2, const void* gate,
+                              const int32_t* mask, const void* p_start, const void* p_end,
+                              const void* dp_start, const void* dp_end, void* dy, void* dcs, void* db1_part,
+                              void* dw2_part, void* db2_part, void* dgate, void* ws, long long ws_bytes,
+                              int B, int T, int Hm, int dtype, void* stream);
 
 /* ---- K2: multi-head dot-product attention between the wq/wk/wv projections and wo
  * (Attention.forward networks/attention.py:45-55, MultiHead.forward / A_forward :71-97).

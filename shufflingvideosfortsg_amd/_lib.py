@@ -33,6 +33,8 @@ _SIGNATURES = {
                        _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _I, _I, _P],
     "tsg_boundary_score_fwd": [_P] * 9 + [_I] * 4 + [_P],
     "tsg_boundary_score_bwd": [_P] * 17 + [_I] * 4 + [_P],
+    "tsg_boundary_score_bwd_ws_bytes": [_I] * 3,
+    "tsg_boundary_score_bwd_ws": [_P] * 17 + [c_longlong] + [_I] * 4 + [_P],
     "tsg_mha_fwd": [_P] * 7 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
     "tsg_mha_fwd_rng": [_P] * 7 + [_I] * 6 + [c_float, _I, c_float, _P, _I, _P],
     "tsg_mha_bwd_rng": [_P] * 10 + [_I] * 6 + [c_float, _I, c_float, _P, _I, _P],
@@ -61,7 +63,7 @@ _SIGNATURES = {
     "tsg_mha_bwd": [_P] * 10 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
 }
 _RESTYPE = {"tsg_last_error": c_char_p, "tsg_lstm_bwd_ws_bytes": c_longlong, "tsg_scdm_bwd_ws_bytes": c_longlong,
-             "tsg_wgrad_f32s_ws_bytes": c_longlong}
+             "tsg_wgrad_f32s_ws_bytes": c_longlong, "tsg_boundary_score_bwd_ws_bytes": c_longlong}
 
 
 class TsgLibraryError(RuntimeError):
@@ -86,8 +88,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)            # AttributeError here = header / library mismatch
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, c_int)
-    if lib.tsg_version() != 3:
-        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 3 expected by the Python host code")
+    if lib.tsg_version() != 4:
+        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 4 expected by the Python host code")
     _lib = lib
     return lib
 

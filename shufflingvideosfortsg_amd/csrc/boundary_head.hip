@@ -13,6 +13,8 @@
 // (all requested up front), lanes own hidden columns (coalesced float4 rows of y), the two dot
 // products are wave reductions; a second tiny kernel does the T-softmax in LDS.
 // HBM-bound: reads y once (T*J*4 B per pair), writes 2T probabilities.
+// (Round 3 measured a ONE-launch forward -- a 16-wave workgroup per item keeping the logits in LDS for the softmax -- at 18 us per
+// launch against 9.6 + 3 us for the two kernels at [64,128,256]: 64 workgroups cannot keep enough of the 17 MB in flight.  Dropped.)
 #include "tsg_common.h"
 
 namespace tsg {
@@ -267,6 +269,169 @@ __global__ __launch_bounds__(kThreads) void boundary_bwd_kernel(
   }
 }
 
+// ---- backward, ONE launch (tsg_boundary_score_bwd_ws).  Workgroup = (batch item, 128 hidden columns), ALL T rows: the per-column
+// sums over T (dcs, db1, dw2) are complete inside the workgroup -- direct stores, no float atomics, nothing to zero -- and so is db2
+// (column group 0 writes it).  Every workgroup recomputes the two softmax dot products <p, dp> and dl for the T rows (no dl pass).
+// What crosses workgroups is the per-ROW sum dgate[b,t] over all J columns (GMD gate only): each column group writes its partial
+// row (agent-scope write-through stores) and takes a ticket from the item's counter; the group that draws the last ticket adds the
+// partial rows in group order (deterministic) and puts the counter back to 0 -- the state the NEXT call on the stream expects: the
+// counters are zeroed once, when the caller creates the workspace.  Nobody waits for anybody: no co-residency requirement.
+// A wave covers two rows per instruction (32 lanes x 4 columns each); 8 row pairs per wave are in flight (at T = 128: the whole tile).
+constexpr int kCG = 128;                         // columns per workgroup
+constexpr int kBR = 8;                           // row pairs in flight per wave
+__device__ __forceinline__ void store_agent(float* p, float v) {          // write-through: visible to every XCD once acknowledged
+  asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ float4 load_agent_x4(const float* p0, const float* p1, const float* p2, const float* p3) {
+  float4 v;                                                               // four independent device-coherent loads, one wait
+  asm volatile("global_load_dword %0, %4, off sc1\n\tglobal_load_dword %1, %5, off sc1\n\t"
+               "global_load_dword %2, %6, off sc1\n\tglobal_load_dword %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(v.x), "=&v"(v.y), "=&v"(v.z), "=&v"(v.w) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+  return v;
+}
+
+template <typename ST>
+__global__ __launch_bounds__(kThreads) void boundary_bwd_one_kernel(
+    const ST* __restrict__ y, const float* __restrict__ cs, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ gate, const int* __restrict__ mask,
+    const float* __restrict__ ps, const float* __restrict__ pe, const float* __restrict__ dps, const float* __restrict__ dpe,
+    ST* __restrict__ dy, float* __restrict__ dcs, float* __restrict__ db1p, float* __restrict__ dw2p, float* __restrict__ db2p,
+    float* __restrict__ dgate, float* part, unsigned* cnt, int B, int T, int Hm, int cgs) {
+  extern __shared__ float lds[];
+  float* dl = lds;                               // [T][2]
+  float* red = lds + 2 * (size_t)T;              // [2 kWaves][3][kCG]
+  __shared__ float sc[4 * kWaves];
+  __shared__ unsigned last_one;
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+  const int half = lane >> 5, l32 = lane & 31;
+  const int b = blockIdx.x / cgs, cg = blockIdx.x % cgs;
+  const int J = 2 * Hm;
+  const int col = cg * kCG + l32 * 4;
+  const bool cok = col < J;                      // J % 4 == 0: a lane's four columns exist together
+  const int r0 = 2 * wv + half;                  // this half wave's rows: r0 + 16 k
+  typedef typename Raw4T<ST>::type Raw4;
+  const ST* yb = y + (size_t)b * T * J + (cok ? col : 0);
+  Raw4 yv[kBR];
+#pragma unroll
+  for (int u = 0; u < kBR; ++u) yv[u] = ldraw4(yb + (size_t)min(r0 + 16 * u, T - 1) * J);      // clamped: never used beyond T
+
+  // <p, dp> of both branches over the item's T clips, then dl of every row (LDS) and the db2 sums
+  float d0 = 0.f, d1 = 0.f;
+  for (int t = tid; t < T; t += kThreads) {
+    d0 = fmaf(ps[(size_t)b * T + t], dps[(size_t)b * T + t], d0);
+    d1 = fmaf(pe[(size_t)b * T + t], dpe[(size_t)b * T + t], d1);
+  }
+  d0 = wave_allsum(d0); d1 = wave_allsum(d1);
+  if (lane == 0) { sc[wv] = d0; sc[kWaves + wv] = d1; }
+  __syncthreads();
+  d0 = 0.f; d1 = 0.f;
+#pragma unroll
+  for (int u = 0; u < kWaves; ++u) { d0 += sc[u]; d1 += sc[kWaves + u]; }
+  float s0 = 0.f, s1 = 0.f;
+  for (int t = tid; t < T; t += kThreads) {
+    const float m = mask ? (float)mask[(size_t)b * T + t] : 1.f;
+    const float a0 = ps[(size_t)b * T + t] * (dps[(size_t)b * T + t] - d0) * m;
+    const float a1 = pe[(size_t)b * T + t] * (dpe[(size_t)b * T + t] - d1) * m;
+    dl[2 * t] = a0; dl[2 * t + 1] = a1;
+    s0 += a0; s1 += a1;
+  }
+  if (cg == 0) {                                 // workgroup-uniform
+    s0 = wave_allsum(s0); s1 = wave_allsum(s1);
+    if (lane == 0) { sc[2 * kWaves + wv] = s0; sc[3 * kWaves + wv] = s1; }
+  }
+  float c[4], bb[4], ww[4], acs[4], ab1[4], aw2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    c[q] = cok ? cs[(size_t)b * J + col + q] : 0.f;
+    bb[q] = cok ? b1[col + q] : 0.f;
+    ww[q] = cok ? w2[col + q] : 0.f;
+    acs[q] = 0.f; ab1[q] = 0.f; aw2[q] = 0.f;
+  }
+  __syncthreads();                               // dl, sc
+  if (cg == 0 && tid == 0) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int u = 0; u < kWaves; ++u) { t0 += sc[2 * kWaves + u]; t1 += sc[3 * kWaves + u]; }
+    db2p[(size_t)b * 2] = t0; db2p[(size_t)b * 2 + 1] = t1;
+  }
+  const bool many = cgs > 1;
+  float* mypart = part + ((size_t)b * cgs + cg) * T;
+  for (int k0 = 0; k0 * 16 < T; k0 += kBR) {
+#pragma unroll
+    for (int u = 0; u < kBR; ++u) {
+      const int t = r0 + 16 * (k0 + u);
+      const float4 v = cvt4(yv[u]);
+      yv[u] = ldraw4(yb + (size_t)min(t + 16 * kBR, T - 1) * J);          // refill the slot (unconditional, clamped)
+      if (t < T) {                               // uniform per half wave
+        const float g = gate ? gate[(size_t)b * T + t] : 1.f;
+        const float dl0 = dl[2 * t], dl1 = dl[2 * t + 1];
+        const float v4[4] = {v.x, v.y, v.z, v.w};
+        float o[4], dg = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float pre = v4[q] + c[q];
+          const float uu = tanh_fast(fmaf(g, pre, bb[q]));
+          const float dlv = (col + q < Hm) ? dl0 : dl1;
+          const float dz = dlv * ww[q] * (1.f - uu * uu);                  // ww = 0 beyond J
+          o[q] = g * dz;
+          acs[q] += o[q];
+          ab1[q] += dz;
+          aw2[q] = fmaf(dlv, uu, aw2[q]);
+          dg = fmaf(dz, pre, dg);
+        }
+        if (cok) st4(dy + ((size_t)b * T + t) * J + col, make_float4(o[0], o[1], o[2], o[3]));
+        if (dgate) {
+          dg += __shfl_xor(dg, 16, 64); dg += __shfl_xor(dg, 8, 64); dg += __shfl_xor(dg, 4, 64);
+          dg += __shfl_xor(dg, 2, 64); dg += __shfl_xor(dg, 1, 64);          // over the 32 lanes of the row
+          if (l32 == 0) {
+            if (many) store_agent(mypart + t, dg); else dgate[(size_t)b * T + t] = dg;
+          }
+        }
+      }
+    }
+  }
+  // per-column sums over the 16 row slots of the workgroup, then straight to the outputs
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    red[((2 * wv + half) * 3 + 0) * kCG + l32 * 4 + q] = acs[q];
+    red[((2 * wv + half) * 3 + 1) * kCG + l32 * 4 + q] = ab1[q];
+    red[((2 * wv + half) * 3 + 2) * kCG + l32 * 4 + q] = aw2[q];
+  }
+  __syncthreads();
+  if (tid < 3 * kCG) {
+    const int which = tid / kCG, j = tid % kCG;
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2 * kWaves; ++u) s += red[(u * 3 + which) * kCG + j];
+    float* dst = which == 0 ? dcs : (which == 1 ? db1p : dw2p);
+    if (cg * kCG + j < J) dst[(size_t)b * J + cg * kCG + j] = s;
+  }
+  if (!dgate || !many) return;
+  // ticket: the partial rows above are acknowledged (write-through) before the counter moves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) last_one = __hip_atomic_fetch_add(cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(cgs - 1);
+  __syncthreads();
+  if (!last_one) return;                         // workgroup-uniform
+  const float* all = part + (size_t)b * cgs * T;
+  for (int t = tid; t < T; t += kThreads) {
+    float s = 0.f;
+    for (int g0 = 0; g0 < cgs; g0 += 4) {        // column groups in order, four loads in flight
+      const float4 v = load_agent_x4(all + (size_t)min(g0, cgs - 1) * T + t, all + (size_t)min(g0 + 1, cgs - 1) * T + t,
+                                     all + (size_t)min(g0 + 2, cgs - 1) * T + t, all + (size_t)min(g0 + 3, cgs - 1) * T + t);
+      s += v.x;
+      if (g0 + 1 < cgs) s += v.y;
+      if (g0 + 2 < cgs) s += v.z;
+      if (g0 + 3 < cgs) s += v.w;
+    }
+    dgate[(size_t)b * T + t] = s;
+  }
+  if (tid == 0) __hip_atomic_store(cnt + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+inline long long bwd_ws_bytes(int B, int T, int Hm) {
+  return (long long)sizeof(float) * (roundup(B, 4) + (long long)B * cdiv(2 * Hm, kCG) * T);
+}
+
 int check(const char* fn, int B, int T, int Hm, int dtype) {
   if (dtype != TSG_F32 && dtype != TSG_BF16)
     return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32, or TSG_BF16 = y / dy stored as bf16)", fn, dtype);
@@ -344,6 +509,51 @@ extern "C" int tsg_boundary_score_bwd(const void* y, const void* cs, const void*
     hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kThreads), lds, st, (const float*)y, (const float*)cs, (const float*)b1,
                        (const float*)w2, (const float*)gate, (const float*)dl_ws, (float*)dy, (float*)dcs, (float*)db1_part,
                        (float*)dw2_part, (float*)dgate, B, T, Hm, tiles);
+  }
+  return check_launch(fn);
+}
+
+extern "C" long long tsg_boundary_score_bwd_ws_bytes(int B, int T, int Hm) {
+  if (B <= 0 || T <= 0 || Hm <= 0) return -1;
+  return bwd_ws_bytes(B, T, Hm);
+}
+
+extern "C" int tsg_boundary_score_bwd_ws(const void* y, const void* cs, const void* b1, const void* w2, const void* gate,
+                                         const int32_t* mask, const void* p_start, const void* p_end,
+                                         const void* dp_start, const void* dp_end, void* dy, void* dcs, void* db1_part,
+                                         void* dw2_part, void* db2_part, void* dgate, void* ws, long long ws_bytes,
+                                         int B, int T, int Hm, int dtype, void* stream) {
+  const char* fn = "tsg_boundary_score_bwd_ws";
+  for (const void* p : {y, cs, b1, w2, p_start, p_end, dp_start, dp_end, (const void*)dy, (const void*)dcs,
+                        (const void*)db1_part, (const void*)dw2_part, (const void*)db2_part, (const void*)ws})
+    if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+  if (!aligned16(y) || !aligned16(dy) || !aligned16(ws)) return set_error(TSG_E_ALIGN, "%s: y / dy / ws not 16-byte aligned", fn);
+  int rc = check(fn, B, T, Hm, dtype);
+  if (rc) return rc;
+  if (ws_bytes < bwd_ws_bytes(B, T, Hm))
+    return set_error(TSG_E_SHAPE, "%s: workspace of %lld B < %lld B (tsg_boundary_score_bwd_ws_bytes)", fn, ws_bytes, bwd_ws_bytes(B, T, Hm));
+  auto st = static_cast<hipStream_t>(stream);
+  const int cgs = cdiv(2 * Hm, kCG);
+  const size_t lds = sizeof(float) * (2 * (size_t)T + (size_t)2 * kWaves * 3 * kCG);
+  if (lds > (size_t)kLdsBytes - 1024) return set_error(TSG_E_LDS, "%s: needs %zu B of LDS", fn, lds);
+  unsigned* cnt = static_cast<unsigned*>(ws);
+  float* part = static_cast<float*>(ws) + roundup(B, 4);
+  if (dtype == TSG_BF16) {
+    auto kern = boundary_bwd_one_kernel<bf16_t>;
+    hipError_t e = allow_lds(kern, lds);
+    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(B * cgs), dim3(kThreads), lds, st, (const bf16_t*)y, (const float*)cs, (const float*)b1,
+                       (const float*)w2, (const float*)gate, mask, (const float*)p_start, (const float*)p_end,
+                       (const float*)dp_start, (const float*)dp_end, (bf16_t*)dy, (float*)dcs, (float*)db1_part,
+                       (float*)dw2_part, (float*)db2_part, (float*)dgate, part, cnt, B, T, Hm, cgs);
+  } else {
+    auto kern = boundary_bwd_one_kernel<float>;
+    hipError_t e = allow_lds(kern, lds);
+    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(B * cgs), dim3(kThreads), lds, st, (const float*)y, (const float*)cs, (const float*)b1,
+                       (const float*)w2, (const float*)gate, mask, (const float*)p_start, (const float*)p_end,
+                       (const float*)dp_start, (const float*)dp_end, (float*)dy, (float*)dcs, (float*)db1_part,
+                       (float*)dw2_part, (float*)db2_part, (float*)dgate, part, cnt, B, T, Hm, cgs);
   }
   return check_launch(fn);
 }

@@ -674,6 +674,12 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_mm_kernel(
 // are used and its stores have as long to drain; a producer issues no stores but the 80-byte P rows.  Cost: the score loop runs on one
 // wave per SIMD (tools/ubench: 18.2 instead of 16.1 cycles per fma-rcp-fma triple when nothing else fills the gaps).
 // ------------------------------------------------------------------------------------------
+#ifndef TSG_WS_PRIO_P
+#define TSG_WS_PRIO_P 2                                   // wave priorities of the two roles (tuning: tools/build_variant.sh)
+#endif
+#ifndef TSG_WS_PRIO_C
+#define TSG_WS_PRIO_C 0
+#endif
 typedef short k1_s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned k1_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ k1_f32x16 k1_mfma8(k1_u32x2 a, k1_u32x2 b, k1_f32x16 c) {      // 32x32x8: k = 4 (lane / 32) + j
@@ -709,7 +715,7 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
 
   // ---- prologue (all waves): Es = exp(2 s[b]), -2w, zeroed P tiles
   const float* sb = s + (size_t)b * N * H;
-  const int hp4 = HP / 4, total4 = NP * hp4;
+  const int hp4 = HP / 4, total4 = TSG_SKIP(8) ? 0 : NP * hp4;
   constexpr int PU = PW == 4 ? 12 : 6;
   for (int base = tid; base < total4; base += PU * NT) {
     float4 v[PU];
@@ -739,7 +745,7 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
 
   if (wv < PW) {
     // =================================== producer: rows t0 + RPW wv .. =====================================================
-    __builtin_amdgcn_s_setprio(2);                         // the score loop is the critical path of the CU
+    __builtin_amdgcn_s_setprio(TSG_WS_PRIO_P);             // the score loop is the critical path of the CU
     // The wave's current row lives in CT float4; chunk c of the row it scores NEXT (its next row of this sub-tile, or its first of
     // the next one) is requested into slot c as soon as the score loop has consumed it, unconditionally (clamped address).
     float4 q[CT];
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
         const float4 e = exp2x4(q[c]);
         Ea[0][0] = e.x; Ea[0][1] = e.y; Ea[0][2] = e.z; Ea[0][3] = e.w;
         q[c] = *reinterpret_cast<const float4*>(nrow + 256 * c);
-        scdm_chunk_step<NP, 1, 2>(Ea, Es + k, HP, w2, acc);
+        if (!TSG_SKIP(1)) scdm_chunk_step<NP, 1, 2>(Ea, Es + k, HP, w2, acc);
         __builtin_amdgcn_sched_barrier(0);
       }
       // land the next row ahead of the P stores (vmcnt counts loads and stores together, in order)
@@ -810,6 +816,7 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
     }
   } else {
     // =================================== consumer: phase 2 of the sub-tile handed over last ================================
+    if (TSG_WS_PRIO_C) __builtin_amdgcn_s_setprio(TSG_WS_PRIO_C);
     const int col0 = (wv - PW) * 32 * CC;
     lds_barrier();                                         // (prologue barrier first: the producers do not wait for the VW loads below)
     const float* Vb = V + (size_t)b * N * Ds + col0 + jl;
@@ -870,6 +877,7 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
 #pragma unroll
           for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(rr[ct][i]));
       }
+      if (TSG_SKIP(4)) continue;
       k1_u32x4 ph[KS], pl[KS];
       k1_u32x2 ph8, pl8;
 #pragma unroll

@@ -455,6 +455,25 @@ def scdm_gate(a, s, w, VW, gbias, r):
     return _ScdmGate.apply(a, s, w.reshape(-1), VW, gbias, r)
 
 
+_k3_ws = {}        # (device, stream) -> uint8 workspace of the one-launch K3 backward; its ticket counters are zero between calls
+
+
+def _k3_workspace(device, B: int, T: int, Hm: int):
+    """Workspace of tsg_boundary_score_bwd_ws (include/tsg_hip.h): zeroed when created, left zeroed by every call, so one buffer per
+    (device, stream) serves all calls enqueued on that stream.  A buffer created while the stream is being captured belongs to the
+    graph's pool and is zeroed by a captured fill on every replay: it is handed out once and not kept."""
+    nb = int(load().tsg_boundary_score_bwd_ws_bytes(B, T, Hm))
+    if nb <= 0:
+        raise ValueError(f"boundary_score: bad shape B={B} T={T} Hm={Hm}")
+    key = (_cuda_device(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _k3_ws.get(key)
+    if ws is None or ws.numel() < nb:
+        ws = torch.zeros(nb, device=device, dtype=torch.uint8)
+        if not torch.cuda.is_current_stream_capturing():     # (the warm-up steps before a capture run on the capture stream: kept)
+            _k3_ws[key] = ws
+    return ws, nb
+
+
 class _BoundaryScore(torch.autograd.Function):
     """K3: (y=[B,T,2Hm], cs=[B,2Hm], b1=[2Hm], w2=[2Hm], b2=[2], gate=[B,T]|None, mask=[B,T] int|None)
     -> (p_start, p_end) [B,T]."""
@@ -497,13 +516,13 @@ class _BoundaryScore(torch.autograd.Function):
         dw2p = torch.empty_like(db1p)
         db2p = torch.empty(B, 2, device=y.device, dtype=torch.float32)
         dgate = torch.empty(B, T, device=y.device, dtype=torch.float32) if gate is not None else None
-        dl = torch.empty(B, T, 2, device=y.device, dtype=torch.float32)
-        _call("tsg_boundary_score_bwd", y, ptr(y), ptr(cs), ptr(b1), ptr(w2),
-                                            ptr(gate) if gate is not None else None,
-                                            ptr(mask) if mask is not None else None,
-                                            ptr(ps), ptr(pe), ptr(dps), ptr(dpe), ptr(dy), ptr(dcs), ptr(db1p),
-                                            ptr(dw2p), ptr(db2p), ptr(dgate) if dgate is not None else None, ptr(dl),
-                                            B, T, J // 2, ctx.dt)
+        ws, nb = _k3_workspace(y.device, B, T, J // 2)
+        _call("tsg_boundary_score_bwd_ws", y, ptr(y), ptr(cs), ptr(b1), ptr(w2),
+                                               ptr(gate) if gate is not None else None,
+                                               ptr(mask) if mask is not None else None,
+                                               ptr(ps), ptr(pe), ptr(dps), ptr(dpe), ptr(dy), ptr(dcs), ptr(db1p),
+                                               ptr(dw2p), ptr(db2p), ptr(dgate) if dgate is not None else None, ptr(ws), nb,
+                                               B, T, J // 2, ctx.dt)
         return dy, dcs, db1p.sum(0), dw2p.sum(0), db2p.sum(0), dgate, None
 
 

@@ -24,6 +24,6 @@ for dt in (0, 2):
     e1.record(); torch.cuda.synchronize()
     print("mask", os.environ.get("TSG_ABLATE_MASK", "0"), "dtype", dt, "%%.1f us" %% (e0.elapsed_time(e1) / 200 * 1e3), flush=True)
 ''' % root
-for mask in ("0", "1", "4", "5", "0"):
+for mask in ("0", "1", "4", "5", "8", "13", "0"):
     env = dict(os.environ, TSG_HIP_LIB=os.path.join(root, "tools", "_ablate", "k1abl.so"), TSG_ABLATE_MASK=mask)
     subprocess.run([sys.executable, "-c", code, B], env=env)
