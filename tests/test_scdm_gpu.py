@@ -110,11 +110,12 @@ def test_scdm_gate_parity(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 15, 512), (32, 64, 20, 512), (64, 128, 20, 1024), (3, 200, 25, 1024), (5, 100, 32, 256),
-                                   (130, 100, 20, 256), (2, 70, 9, 1024), (1, 3, 4, 256)])
+                                   (130, 100, 20, 256), (2, 70, 9, 1024), (1, 3, 4, 256), (2, 40, 8, 512), (3, 50, 24, 1024)])
 def test_scdm_split_precision_forward(shape, request):
-    """The "f32s" mode's forward (dtype TSG_F32S: scdm_fwd_mm_kernel, phase 2 = P @ VW on the bf16 matrix pipe as hi*hi + hi*lo +
-    lo*hi with fp32 accumulation, output columns 256 / 512 / 1024; ragged last tiles, 8- to 64-row workgroups, N <= 16 (one k step)
-    and N > 16 (two)) vs the oracle at the UNCHANGED fp32 tolerance, gate-fused and plain; the backward is the fp32 kernel."""
+    """The "f32s" mode's forward (dtype TSG_F32S: scdm_fwd_ws_kernel -- producer waves score, consumer waves run phase 2 = P @ VW on the
+    bf16 matrix pipe as hi*hi + hi*lo + lo*hi with fp32 accumulation; output columns 256 / 512 / 1024; ragged last tiles, 8- to 64-row
+    workgroups; 8 + 8 waves with N <= 16 (one 32x32x16 k step) and 16 < N <= 24 (+ one 32x32x8 step), 4 + 4 waves for N <= 8 and
+    N > 24 (two 32x32x16 steps)) vs the oracle at the UNCHANGED fp32 tolerance, gate-fused and plain; the backward is the fp32 kernel."""
     from shufflingvideosfortsg_amd import engine, functional as F
     engine.precision("f32s")
     request.addfinalizer(lambda: engine.precision(None))
@@ -147,3 +148,33 @@ def test_scdm_split_precision_forward(shape, request):
     engine.precision(None)
     out2 = F.scdm_gate(a.detach(), s.detach(), pd["w"].detach(), lin(wd, pd["Wl"]).detach(), pd["bl"].detach(), rd.detach())
     torch.testing.assert_close(out1.detach(), out2, atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("env", [{"TSG_K1_FWD": "mm"}, {"TSG_K1_PW": "4"}])
+def test_scdm_split_precision_forward_ab_variants(env):
+    """The A/B switches of the f32s forward (TSG_K1_FWD=mm: time-shared roles, scdm_fwd_mm_kernel; TSG_K1_PW=4: 4 + 4 waves) are read
+    once per process, so each runs in a child: gate-fused and plain outputs against the fp32 VALU kernel on the same operands."""
+    import os, subprocess, sys
+    code = r'''
+import torch
+from shufflingvideosfortsg_amd import _lib
+from shufflingvideosfortsg_amd._lib import ptr, TSG_F32, TSG_F32S
+lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+torch.manual_seed(3)
+for (B, T, N, d) in ((5, 100, 20, 1024), (3, 37, 25, 512)):
+    A = torch.randn(B, T, d, device="cuda"); S = torch.randn(B, N, d, device="cuda"); w = torch.randn(d, device="cuda") / d ** 0.5
+    VW = torch.randn(B, N, d, device="cuda"); gb = torch.randn(d, device="cuda") * 0.1; r = torch.randn(B, T, d, device="cuda")
+    res = {}
+    for dt in (TSG_F32, TSG_F32S):
+        out = torch.empty_like(A); C = torch.empty_like(A); P = torch.empty(B, T, N, device="cuda")
+        assert lib.tsg_scdm_gate_fwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(gb), ptr(r), ptr(out), ptr(P), B, T, N, d, d, dt, st) == 0
+        assert lib.tsg_scdm_attn_fwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(C), ptr(P), B, T, N, d, d, dt, st) == 0
+        res[dt] = (out, C, P)
+    torch.cuda.synchronize()
+    for x, y in zip(res[TSG_F32], res[TSG_F32S]):
+        torch.testing.assert_close(x, y, atol=3e-5, rtol=3e-5)
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=root, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
