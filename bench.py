@@ -572,7 +572,7 @@ def main():
         k1bf = bool(k1.get("dims")) and k1["dims"][-1] == 1
         tr, tr_src = pmc_traffic("scdm_fwd_kernel[gate]" if gate else "scdm_fwd_kernel", 64, a.T, a.N, a.d, launch_B=k1B,
                                  dtype="bf16" if k1bf else "f32")                               # PMC passes at B=64 (+ exact ones)
-        k1split = bool(k1.get("dims")) and k1["dims"][-1] == 2          # TSG_F32S: the role-specialised matrix-pipe kernel (H = Ds = 256 CT)
+        k1split = bool(k1.get("dims")) and k1["dims"][-1] in (1, 2)     # TSG_F32S / TSG_BF16: the role-specialised matrix-pipe kernel (H = Ds = 256 CT)
         roof = {"kernel": "%s<GATE=%s> (%s)" % ("scdm_fwd_ws_kernel" if k1split and a.d in (256, 512, 1024) else "scdm_fwd_kernel",
                                                 "true" if gate else "false", k1name.split("[")[0]), "bound": "hbm",
                 "achieved": k1.get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -686,11 +686,13 @@ __device__ __forceinline__ k1_f32x16 k1_mfma8(k1_u32x2 a, k1_u32x2 b, k1_f32x16 
   return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(k1_s16x4, a), __builtin_bit_cast(k1_s16x4, b), c, 0, 0, 0);
 }
 
-template <int NP, bool GATE, int CT, int PW>
+// ST = bf16_t (dtype TSG_BF16): a, s, V, gr, C are bf16 in HBM; the rows are kept as raw 8-byte pieces until the score loop consumes them,
+// VW is exact in bf16 so its lo plane (and the third MFMA of every k step) drops out, r / out are one 2-byte element per lane.
+template <int NP, bool GATE, int CT, int PW, typename ST>
 __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
-    const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w,
-    const float* __restrict__ V, float* __restrict__ C, float* __restrict__ P,
-    const float* __restrict__ gr, const float* __restrict__ gbias,
+    const ST* __restrict__ a, const ST* __restrict__ s, const float* __restrict__ w,
+    const ST* __restrict__ V, ST* __restrict__ C, float* __restrict__ P,
+    const ST* __restrict__ gr, const float* __restrict__ gbias,
     int B, int T, int N, int H, int Ds, int TT, int tiles, int dbg) {
   constexpr int NT = 128 * PW;                       // PW producer + PW consumer waves
   constexpr int SUB = 8;                             // rows per sub-tile
@@ -710,11 +712,12 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
   const int bid = xcd_remap(blockIdx.x, gridDim.x, tiles);
   const int b = bid / tiles, tile = bid % tiles;
   const int t_tile = tile * TT;
-  const float* ab = a + (size_t)b * T * H;
+  constexpr bool BF = storage_is_bf16<ST>::value;
+  const ST* ab = a + (size_t)b * T * H;
   const int nsub = TT / SUB;
 
   // ---- prologue (all waves): Es = exp(2 s[b]), -2w, zeroed P tiles
-  const float* sb = s + (size_t)b * N * H;
+  const ST* sb = s + (size_t)b * N * H;
   const int hp4 = HP / 4, total4 = TSG_SKIP(8) ? 0 : NP * hp4;
   constexpr int PU = PW == 4 ? 12 : 6;
   for (int base = tid; base < total4; base += PU * NT) {
@@ -723,7 +726,7 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
     for (int u = 0; u < PU; ++u) {
       const int idx = base + u * NT;
       const int n = idx / hp4, k = (idx % hp4) * 4;
-      v[u] = (idx < total4 && n < N && k < H) ? *reinterpret_cast<const float4*>(sb + (size_t)n * H + k) : make_float4(-1e30f, 0.f, 0.f, 0.f);
+      v[u] = (idx < total4 && n < N && k < H) ? ld4(sb + (size_t)n * H + k) : make_float4(-1e30f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < PU; ++u) {
@@ -748,17 +751,24 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
     __builtin_amdgcn_s_setprio(TSG_WS_PRIO_P);             // the score loop is the critical path of the CU
     // The wave's current row lives in CT float4; chunk c of the row it scores NEXT (its next row of this sub-tile, or its first of
     // the next one) is requested into slot c as soon as the score loop has consumed it, unconditionally (clamped address).
-    float4 q[CT];
+    typedef typename Raw4T<ST>::type Raw4;
+    Raw4 q[CT];
     auto row_ptr = [&](int t) { return ab + (size_t)(t < T ? t : T - 1) * H + lane * 4; };
+    auto land = [&]() {                                    // (an empty asm per piece: the wait for the requests lands HERE)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if constexpr (BF) asm volatile("" : "+v"(q[c].x), "+v"(q[c].y));
+        else asm volatile("" : "+v"(q[c].x), "+v"(q[c].y), "+v"(q[c].z), "+v"(q[c].w));
+      }
+    };
     {
-      const float* row = row_ptr(t_tile + RPW * wv);
+      const ST* row = row_ptr(t_tile + RPW * wv);
 #pragma unroll
-      for (int c = 0; c < CT; ++c) q[c] = *reinterpret_cast<const float4*>(row + c * 256);
+      for (int c = 0; c < CT; ++c) q[c] = ldraw4(row + c * 256);
     }
-#pragma unroll
-    for (int c = 0; c < CT; ++c) asm volatile("" : "+v"(q[c].x), "+v"(q[c].y), "+v"(q[c].z), "+v"(q[c].w));
+    land();
     lds_barrier();
-    auto score_row = [&](float* Pcur, int tl, int t, const float* nrow) {
+    auto score_row = [&](float* Pcur, int tl, int t, const ST* nrow) {
       float acc[1][NP];
 #pragma unroll
       for (int n = 0; n < NP; ++n) acc[0][n] = 0.f;
@@ -768,15 +778,14 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
         const float4 wq = *reinterpret_cast<const float4*>(Wl + k);
         const float w2[4] = {wq.x, wq.y, wq.z, wq.w};
         float Ea[1][4];
-        const float4 e = exp2x4(q[c]);
+        const float4 e = exp2x4(cvt4(q[c]));
         Ea[0][0] = e.x; Ea[0][1] = e.y; Ea[0][2] = e.z; Ea[0][3] = e.w;
-        q[c] = *reinterpret_cast<const float4*>(nrow + 256 * c);
+        q[c] = ldraw4(nrow + 256 * c);
         if (!TSG_SKIP(1)) scdm_chunk_step<NP, 1, 2>(Ea, Es + k, HP, w2, acc);
         __builtin_amdgcn_sched_barrier(0);
       }
       // land the next row ahead of the P stores (vmcnt counts loads and stores together, in order)
-#pragma unroll
-      for (int c = 0; c < CT; ++c) asm volatile("" : "+v"(q[c].x), "+v"(q[c].y), "+v"(q[c].z), "+v"(q[c].w));
+      land();
       float z[NP / 4];
       wave_transpose_sum<NP>(acc[0], z);
       const int qd = lane >> 4;
@@ -819,7 +828,7 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
     if (TSG_WS_PRIO_C) __builtin_amdgcn_s_setprio(TSG_WS_PRIO_C);
     const int col0 = (wv - PW) * 32 * CC;
     lds_barrier();                                         // (prologue barrier first: the producers do not wait for the VW loads below)
-    const float* Vb = V + (size_t)b * N * Ds + col0 + jl;
+    const ST* Vb = V + (size_t)b * N * Ds + col0 + jl;
     k1_u32x4 vh[CC][KS], vl[CC][KS];
     k1_u32x2 vh8[CC], vl8[CC];
     float gb[CC];
@@ -832,7 +841,7 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int n = 16 * ks + 8 * hh + j;
-          e[j] = Vb[(size_t)(n < N ? n : 0) * Ds + 32 * ct];
+          e[j] = ld1(Vb + (size_t)(n < N ? n : 0) * Ds + 32 * ct);
           if (n >= N) e[j] = 0.f;
         }
         k1_split8(e, vh[ct][ks], vl[ct][ks]);
@@ -842,7 +851,7 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = 16 + 4 * hh + j;
-          e[j] = Vb[(size_t)(n < N ? n : 0) * Ds + 32 * ct];
+          e[j] = ld1(Vb + (size_t)(n < N ? n : 0) * Ds + 32 * ct);
           if (n >= N) e[j] = 0.f;
         }
         unsigned h0, l0, h1, l1;
@@ -857,10 +866,10 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int u = min(t0 + i, T - 1);
-        const float* base = gr + ((size_t)b * T + u) * Ds;
+        const ST* base = gr + ((size_t)b * T + u) * Ds;
         const unsigned off = u + 4 < T ? lane_off : lane_col;
 #pragma unroll
-        for (int ct = 0; ct < CC; ++ct) rr[ct][i] = (base + 32 * ct)[off];
+        for (int ct = 0; ct < CC; ++ct) rr[ct][i] = ld1(base + 32 * ct + off);
       }
     };
     if (GATE) load_rr(t_tile);
@@ -903,20 +912,20 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           o = k1_mfma(ph[ks], vh[ct][ks], o);
-          o = k1_mfma(ph[ks], vl[ct][ks], o);
+          if constexpr (!BF) o = k1_mfma(ph[ks], vl[ct][ks], o);            // (bf16 storage: VW has no lo part)
           o = k1_mfma(pl[ks], vh[ct][ks], o);
         }
         if (K8) {
           o = k1_mfma8(ph8, vh8[ct], o);
-          o = k1_mfma8(ph8, vl8[ct], o);
+          if constexpr (!BF) o = k1_mfma8(ph8, vl8[ct], o);
           o = k1_mfma8(pl8, vh8[ct], o);
         }
-        float* dst = C + ((size_t)b * T + t0) * Ds + 32 * ct;
+        ST* dst = C + ((size_t)b * T + t0) * Ds + 32 * ct;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float v = o[i];
           if (GATE) v = rr[ct][i] * fast_rcp(1.f + fast_exp2(fmaf(v, -kLog2e, gb[ct])));
-          if (t0 + i + 4 * hh < T) (dst + (size_t)i * Ds)[lane_off] = v;
+          if (t0 + i + 4 * hh < T) st1(dst + (size_t)i * Ds + lane_off, v);
         }
       }
       if (GATE) load_rr(t0 + SUB);                         // the next sub-tile's r rows: a whole score loop of cover
@@ -1941,6 +1950,10 @@ int launch_fwd(const ST* a, const ST* s, const float* w, const ST* V, ST* C, flo
   return check_launch("scdm_attn_fwd");
 }
 
+template <int NP, bool GATE, typename ST>
+int launch_fwd_ws(const ST* a, const ST* s, const float* w, const ST* V, ST* C, float* P, const ST* gr, const float* gbias,
+                  int B, int T, int N, int H, int Ds, int TT, int tiles, size_t lds, hipStream_t st);
+
 // dtype TSG_F32S, fp32 storage: the forward with phase 2 on the bf16 matrix pipe where its tiling applies (Ds = 256, 512, 1024);
 // TSG_K1_FWD=valu in the environment keeps the VALU kernel (A/B timing).  Returns -1000 when the shape is not covered.
 template <int NP, bool GATE>
@@ -1963,23 +1976,45 @@ int launch_fwd_mm(const float* a, const float* s, const float* w, const float* V
     hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kFwdThreads), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
     return check_launch("scdm_attn_fwd");
   }
-  // role-specialised waves: 8 producers + 8 consumers (two score waves per SIMD) while the consumer's VW strip fits 128 VGPRs
-  // (N <= 24), else 4 + 4.  TSG_K1_PW=4 forces the latter (A/B timing).
+  return launch_fwd_ws<NP, GATE, float>(a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, lds, st);
+}
+
+// role-specialised waves: 8 producers + 8 consumers (two score waves per SIMD) while the consumer's VW strip fits 128 VGPRs
+// (8 < N <= 24), else 4 + 4.  TSG_K1_PW=4 forces the latter (A/B timing).  ST = float (TSG_F32S) or bf16_t (TSG_BF16).
+template <int NP, bool GATE, typename ST>
+int launch_fwd_ws(const ST* a, const ST* s, const float* w, const ST* V, ST* C, float* P, const ST* gr, const float* gbias,
+                  int B, int T, int N, int H, int Ds, int TT, int tiles, size_t lds, hipStream_t st) {
   static const int pw_env = [] { const char* e = getenv("TSG_K1_PW"); return e ? atoi(e) : 0; }();
   constexpr bool kCanPw8 = NP > 8 && NP <= 24;          // (NP = 8 at 1024 threads spills: 4 + 4 there)
   const bool pw8 = kCanPw8 && pw_env != 4;
-  void (*kern)(const float*, const float*, const float*, const float*, float*, float*, const float*, const float*,
-               int, int, int, int, int, int, int, int);
+  void (*kern)(const ST*, const ST*, const float*, const ST*, ST*, float*, const ST*, const float*, int, int, int, int, int, int, int, int);
   if constexpr (kCanPw8) {
-    if (pw8) kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 8> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 8> : scdm_fwd_ws_kernel<NP, GATE, 1, 8>;
-    else kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 4> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 4> : scdm_fwd_ws_kernel<NP, GATE, 1, 4>;
+    if (pw8) kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 8, ST> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 8, ST> : scdm_fwd_ws_kernel<NP, GATE, 1, 8, ST>;
+    else kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 4, ST> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 4, ST> : scdm_fwd_ws_kernel<NP, GATE, 1, 4, ST>;
   } else {
-    kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 4> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 4> : scdm_fwd_ws_kernel<NP, GATE, 1, 4>;
+    kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 4, ST> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 4, ST> : scdm_fwd_ws_kernel<NP, GATE, 1, 4, ST>;
   }
   hipError_t e = allow_lds(kern, lds);
   if (e != hipSuccess) return set_error((int)e, "scdm_attn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
   hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(pw8 ? 1024 : 512), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
   return check_launch("scdm_attn_fwd");
+}
+
+// dtype TSG_BF16: the same kernel on bf16 storage where its tiling applies (H = Ds = 256, 512, 1024); -1000 otherwise (the VALU kernel runs).
+// TSG_K1_FWD=valu keeps the VALU kernel (A/B timing).
+template <int NP, bool GATE>
+int launch_fwd_ws_bf16(const bf16_t* a, const bf16_t* s, const float* w, const bf16_t* V, bf16_t* C, float* P,
+                       const bf16_t* gr, const float* gbias, int B, int T, int N, int H, int Ds, hipStream_t st) {
+  static const bool valu_only = [] { const char* e = getenv("TSG_K1_FWD"); return e && e[0] == 'v'; }();
+  if (valu_only || H != Ds || (Ds != 256 && Ds != 512 && Ds != 1024)) return -1000;
+  int TT = 64;
+  while (TT > 8 && (long)B * cdiv(T, TT) < 256) TT >>= 1;
+  static const int tt_env = [] { const char* e = getenv("TSG_K1_TT"); return e ? atoi(e) : 0; }();
+  if (tt_env >= 8 && tt_env % 8 == 0) TT = tt_env;
+  const int tiles = cdiv(T, TT);
+  const size_t lds = sizeof(float) * ((size_t)(NP + 1) * roundup256(H) + (size_t)2 * 8 * 36);
+  if (lds > (size_t)kLdsBytes) return -1000;
+  return launch_fwd_ws<NP, GATE, bf16_t>(a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, lds, st);
 }
 
 // Two-kernel path (kept for shapes whose P / de tiles do not fit the fused kernel's LDS, and for A/B timing with
@@ -2097,6 +2132,12 @@ extern "C" int tsg_scdm_attn_fwd(const void* a, const void* s, const void* w, co
   auto st = static_cast<hipStream_t>(stream);
   if (dtype == TSG_BF16) {
     using S = bf16_t;
+    auto ws = [&]() -> int {
+      TSG_DISPATCH_NP(np, (launch_fwd_ws_bf16<NP, false>((const S*)a, (const S*)s, (const float*)w, (const S*)sent,
+                                                         (S*)C, (float*)P, nullptr, nullptr, B, T, N, H, Ds, st)));
+    };
+    rc = ws();
+    if (rc != -1000) return rc;
     TSG_DISPATCH_NP(np, (launch_fwd<NP, false, S>((const S*)a, (const S*)s, (const float*)w, (const S*)sent,
                                                   (S*)C, (float*)P, nullptr, nullptr, B, T, N, H, Ds, st)));
   }
@@ -2159,6 +2200,12 @@ extern "C" int tsg_scdm_gate_fwd(const void* a, const void* s, const void* w, co
   auto st = static_cast<hipStream_t>(stream);
   if (dtype == TSG_BF16) {
     using S = bf16_t;
+    auto ws = [&]() -> int {
+      TSG_DISPATCH_NP(np, (launch_fwd_ws_bf16<NP, true>((const S*)a, (const S*)s, (const float*)w, (const S*)VW,
+                                                        (S*)out, (float*)P, (const S*)r, (const float*)gbias, B, T, N, H, Ds, st)));
+    };
+    rc = ws();
+    if (rc != -1000) return rc;
     TSG_DISPATCH_NP(np, (launch_fwd<NP, true, S>((const S*)a, (const S*)s, (const float*)w, (const S*)VW,
                                                  (S*)out, (float*)P, (const S*)r, (const float*)gbias, B, T, N, H, Ds, st)));
   }
