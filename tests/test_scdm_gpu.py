@@ -178,3 +178,45 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=root, **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_scdm_ws_forward_random_shape_sweep():
+    """The role-specialised forward (dtype TSG_F32S, and TSG_BF16 on bf16 copies) against the fp32 VALU kernel over 40 random shapes:
+    every N in 1..32 (8 + 8 waves for 8 < N <= 24, 4 + 4 otherwise; one / two 32x32x16 k steps, the 32x32x8 step), T from 1 to 300
+    (ragged sub-tiles and tiles, 8- to 64-row workgroups), Ds = H in {256, 512, 1024}; gate-fused and plain; P bit-equal in f32s."""
+    from shufflingvideosfortsg_amd import _lib
+    from shufflingvideosfortsg_amd._lib import ptr, TSG_F32, TSG_F32S, TSG_BF16
+    lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(2024)
+    ns = list(range(1, 33)) + [20, 25, 15, 24, 9, 8, 17, 28]
+    for it, N in enumerate(ns):
+        d = (256, 512, 1024)[int(torch.randint(0, 3, (1,), generator=g))]
+        T = int(torch.randint(1, 301, (1,), generator=g)) if it % 4 else (1, 7, 8, 9, 63, 64, 65, 128, 200, 257)[it // 4 % 10]
+        B = int(torch.randint(1, 9, (1,), generator=g)) if T > 64 else int(torch.randint(1, 70, (1,), generator=g))
+        A = torch.randn(B, T, d, generator=g).cuda(); S = torch.randn(B, N, d, generator=g).cuda()
+        w = (torch.randn(d, generator=g) / d ** 0.5).cuda(); VW = torch.randn(B, N, d, generator=g).cuda()
+        gb = (torch.randn(d, generator=g) * 0.1).cuda(); r = torch.randn(B, T, d, generator=g).cuda()
+        res = {}
+        for dt, cast in ((TSG_F32, torch.float32), (TSG_F32S, torch.float32), (TSG_BF16, torch.bfloat16)):
+            a_, s_, vw_, r_ = (x.to(cast).contiguous() for x in (A, S, VW, r))
+            out = torch.empty_like(a_); C = torch.empty_like(a_); P = torch.empty(B, T, N, device="cuda"); P2 = torch.empty_like(P)
+            assert lib.tsg_scdm_gate_fwd(ptr(a_), ptr(s_), ptr(w), ptr(vw_), ptr(gb), ptr(r_), ptr(out), ptr(P), B, T, N, d, d, dt, st) == 0, lib.tsg_last_error()
+            assert lib.tsg_scdm_attn_fwd(ptr(a_), ptr(s_), ptr(w), ptr(vw_), ptr(C), ptr(P2), B, T, N, d, d, dt, st) == 0, lib.tsg_last_error()
+            res[dt] = (out.float(), C.float(), P, P2)
+        torch.cuda.synchronize()
+        tag = f"shape B={B} T={T} N={N} d={d}"
+        o0, c0, p0, q0 = res[TSG_F32]
+        o1, c1, p1, q1 = res[TSG_F32S]
+        assert torch.equal(p0, p1) and torch.equal(q0, q1), tag                   # the score phase is the same arithmetic
+        torch.testing.assert_close(o1, o0, atol=3e-5, rtol=3e-5, msg=lambda m: f"{tag} gate: {m}")
+        torch.testing.assert_close(c1, c0, atol=3e-5, rtol=3e-5, msg=lambda m: f"{tag} plain: {m}")
+        # bf16 storage: against the fp32 kernel on the bf16-rounded operands, within the rounding of the stored output
+        ab, sb, vb, rb = (x.to(torch.bfloat16).float() for x in (A, S, VW, r))
+        ob = torch.empty_like(ab); cb = torch.empty_like(ab); pb = torch.empty(B, T, N, device="cuda")
+        assert lib.tsg_scdm_gate_fwd(ptr(ab), ptr(sb), ptr(w), ptr(vb), ptr(gb), ptr(rb), ptr(ob), ptr(pb), B, T, N, d, d, TSG_F32, st) == 0
+        assert lib.tsg_scdm_attn_fwd(ptr(ab), ptr(sb), ptr(w), ptr(vb), ptr(cb), ptr(pb), B, T, N, d, d, TSG_F32, st) == 0
+        torch.cuda.synchronize()
+        o2, c2, p2, _ = res[TSG_BF16]
+        torch.testing.assert_close(o2, ob, atol=2e-2, rtol=1e-2, msg=lambda m: f"{tag} bf16 gate: {m}")
+        torch.testing.assert_close(c2, cb, atol=2e-2, rtol=1e-2, msg=lambda m: f"{tag} bf16 plain: {m}")
+        torch.testing.assert_close(p2, pb, atol=1e-5, rtol=1e-4, msg=lambda m: f"{tag} bf16 P: {m}")
