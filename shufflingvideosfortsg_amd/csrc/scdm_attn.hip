@@ -1429,6 +1429,29 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
     Pl[idx] = (n < N && r < T) ? P[((size_t)b * T + r) * N + n] : 0.f;
   }
 
+  // Publish this part's partial dP rows (De complete, workgroup met) and count it in: called right after the row loop, BEFORE the
+  // T-sum epilogue of the row phase (dVW stores, dbias atomics), so that the partners' round trip runs under that epilogue.
+  // The rows are agent-scope (write-through) stores and the barrier waits for their acknowledgement (s_waitcnt vmcnt(0)): they are
+  // visible device-wide before the counter moves.  No release fence: a fence here is an L2 WRITE-BACK (buffer_wbl2), and at this
+  // point the L2 holds this workgroup's 256 KiB of freshly stored dr rows -- every workgroup of the XCD would stall on flushing
+  // them in the middle of the kernel (173 -> 147 us per launch at [128,128,20,1024]; -DTSG_K1_XCH_FENCE builds keep the fences: A/B).
+  auto publish_dp = [&]() {
+    if (parts <= 1) return;
+    float* mine = xch + ((size_t)b * parts + pt) * T * NP;
+    for (int idx = tid; idx < T * NP; idx += kFusedThreads)
+      __hip_atomic_store(mine + idx, De[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+      xch_failed = 0u;
+#ifdef TSG_K1_XCH_FENCE
+      __threadfence();
+      __hip_atomic_fetch_add(cnt + b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+      __hip_atomic_fetch_add(cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
+  };
+
   // ---------------- row phase ------------------------------------------------------------------
   if constexpr (MROW) {
     // The row phase is three small GEMMs per 32-row tile and 32-column tile of the wave's slice -- G = P VW (K = N words),
@@ -1567,6 +1590,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
       }
       lds_barrier();
     }
+    publish_dp();
     // T-sums of the row phase.  The accumulator tiles hold dVW[n = rho(v, kk)][column jl]; row splits rq > 0 hand theirs to
     // rq = 0 through LDS (over the VW slices, which are dead now), in fixed order.
     float* redm = Wk + kFusedWaves * kMrowWk;                      // [RS-1][SP][CTW][16][64]
@@ -1704,6 +1728,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
       }
       lds_barrier();
     }
+    publish_dp();
     // T-sums of the row phase: dVW and the gate bias gradient.  Row splits rq > 0 hand theirs to rq = 0 through LDS.
     for (int q = 1; q < RS; ++q) {
       if (rq == q) {
@@ -1747,17 +1772,15 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
   }
 
   // ---------------- exchange: dP over ALL columns, then de -------------------------------------
+  // (published right after the row loop, before the T-sum epilogue above: `publish_dp`)
   if (parts > 1) {
-    float* mine = xch + ((size_t)b * parts + pt) * T * NP;
-    for (int idx = tid; idx < T * NP; idx += kFusedThreads)
-      __hip_atomic_store(mine + idx, De[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
     if (tid == 0) {
-      xch_failed = 0u;
-      __threadfence();
-      __hip_atomic_fetch_add(cnt + b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       unsigned spins = 0;
+#ifdef TSG_K1_XCH_FENCE
       while (!TSG_SKIP(64) && __hip_atomic_load(cnt + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)parts) {
+#else
+      while (!TSG_SKIP(64) && __hip_atomic_load(cnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)parts) {
+#endif
         if (++spins > kXchSpinLimit) {
           report_expiry(esink);                  // host sink + device word (the optimizer's guard reads the latter)
           xch_failed = 1u;
@@ -1765,7 +1788,11 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
         }
         __builtin_amdgcn_s_sleep(8);
       }
+#ifdef TSG_K1_XCH_FENCE
       __threadfence();
+#else
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // invalidate only (buffer_inv): the partners' rows are read after this; no write-back
+#endif
     }
     __syncthreads();
     // every part's partial in part order (deterministic).  Plain loads: thread 0's agent-scope acquire followed by the

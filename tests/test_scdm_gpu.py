@@ -220,3 +220,44 @@ def test_scdm_ws_forward_random_shape_sweep():
         torch.testing.assert_close(o2, ob, atol=2e-2, rtol=1e-2, msg=lambda m: f"{tag} bf16 gate: {m}")
         torch.testing.assert_close(c2, cb, atol=2e-2, rtol=1e-2, msg=lambda m: f"{tag} bf16 plain: {m}")
         torch.testing.assert_close(p2, pb, atol=1e-5, rtol=1e-4, msg=lambda m: f"{tag} bf16 P: {m}")
+
+
+@pytest.mark.parametrize("B,gate", [(4, True), (24, True), (9, False)])
+def test_scdm_bwd_exchange_is_reproducible(B, gate):
+    """The fused backward at small B cuts an item's columns into up to 16 parts that publish partial dP rows (agent-scope stores, one
+    counter per item, no release fence) and sum them in part order: 60 launches on the same operands, the direct outputs (da, ds, dVW /
+    dsent, dr) bit-identical from launch to launch -- a partial row read before it was visible would show up as a different bit pattern."""
+    from shufflingvideosfortsg_amd import _lib
+    from shufflingvideosfortsg_amd._lib import ptr, TSG_F32
+    lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+    T, N, d = 128, 20, 1024
+    g = torch.Generator().manual_seed(77)
+    A = torch.randn(B, T, d, generator=g).cuda(); S = torch.randn(B, N, d, generator=g).cuda(); w = (torch.randn(d, generator=g) / d ** 0.5).cuda()
+    VW = torch.randn(B, N, d, generator=g).cuda(); gb = (torch.randn(d, generator=g) * 0.1).cuda(); r = torch.randn(B, T, d, generator=g).cuda()
+    dout = torch.randn(B, T, d, generator=g).cuda()
+    out = torch.empty_like(A); P = torch.empty(B, T, N, device="cuda")
+    if gate:
+        assert lib.tsg_scdm_gate_fwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(gb), ptr(r), ptr(out), ptr(P), B, T, N, d, d, TSG_F32, st) == 0
+    else:
+        assert lib.tsg_scdm_attn_fwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(out), ptr(P), B, T, N, d, d, TSG_F32, st) == 0
+    nb = int(lib.tsg_scdm_bwd_ws_bytes(B, T, N, d, d, int(gate)))
+    first = None
+    for it in range(60):
+        da, ds, dw, dvw = torch.empty_like(A), torch.empty_like(S), torch.empty_like(w), torch.empty_like(VW)
+        dgb, dr = torch.empty_like(gb), torch.empty_like(r)
+        ws = torch.empty(nb // 4 + 4, device="cuda")
+        if gate:
+            rc = lib.tsg_scdm_gate_bwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(gb), ptr(r), ptr(P), ptr(dout), ptr(da), ptr(ds), ptr(dw), ptr(dvw),
+                                       ptr(dgb), ptr(dr), ptr(ws), nb, B, T, N, d, d, TSG_F32, st)
+        else:
+            rc = lib.tsg_scdm_attn_bwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(P), ptr(dout), ptr(da), ptr(ds), ptr(dw), ptr(dvw), ptr(ws), nb,
+                                       B, T, N, d, d, TSG_F32, st)
+        assert rc == 0, lib.tsg_last_error()
+        cur = (da, ds, dvw) + ((dr,) if gate else ())
+        if first is None:
+            torch.cuda.synchronize()
+            first = cur
+            assert all(bool(torch.isfinite(x).all()) for x in cur)
+        else:
+            for a0, a1 in zip(first, cur):
+                assert torch.equal(a0, a1), f"launch {it} differs"
