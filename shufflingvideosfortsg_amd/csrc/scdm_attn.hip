@@ -1342,7 +1342,8 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
 //               dG = dout*r*sg*(1-sg);  dVW += P[t,:]^T dG;  dbias += dG;  partial dP[t,n] = <dG, VW[n,:]> over the
 //               wave's columns (swap reduction), folded over the part's slices in LDS  (GATE = false: dG = dC)
 //   exchange    the dot products need ALL columns: the `parts` workgroups of an item publish their partial dP
-//               ([T][NP] floats, agent-scope stores), meet on a counter and each sums the partials in part order
+//               ([T][NP] floats, agent-scope write-through stores, acknowledged before a RELAXED counter add: no release fence =
+//               no L2 write-back of the dr rows just stored), meet on the counter and each sums the partials in part order
 //               (deterministic).  de = P (dP - <P,dP>) -> LDS.  Co-dispatched neighbours (consecutive block ids),
 //               bounded spin; 10 KiB per workgroup instead of the 1 MiB dG round trip.
 //   column phase per row t, columns k of the wave: r = 1/(Ea Es[n]+1), q = r - r^2:
