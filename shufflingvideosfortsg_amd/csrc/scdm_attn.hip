@@ -2013,7 +2013,8 @@ template <int NP, bool GATE, typename ST>
 int launch_fwd_ws(const ST* a, const ST* s, const float* w, const ST* V, ST* C, float* P, const ST* gr, const float* gbias,
                   int B, int T, int N, int H, int Ds, int TT, int tiles, size_t lds, hipStream_t st) {
   static const int pw_env = [] { const char* e = getenv("TSG_K1_PW"); return e ? atoi(e) : 0; }();
-  constexpr bool kCanPw8 = NP > 8 && NP <= 24;          // (NP = 8 at 1024 threads spills: 4 + 4 there)
+  // (NP = 8 at 1024 threads spills: 4 + 4 there; bf16 storage has no VW lo plane and 8-byte row pieces: 28 slots -- N = 25 -- still fit)
+  constexpr bool kCanPw8 = NP > 8 && (NP <= 24 || (storage_is_bf16<ST>::value && NP <= 28));
   const bool pw8 = kCanPw8 && pw_env != 4;
   void (*kern)(const ST*, const ST*, const float*, const ST*, ST*, float*, const ST*, const float*, int, int, int, int, int, int, int, int);
   if constexpr (kCanPw8) {
