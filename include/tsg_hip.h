@@ -39,7 +39,7 @@ extern "C" {
 
 #define TSG_VERSION 4   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points
                            3: tsg_error_word (device-side expiry report); dtype TSG_BF16 (bf16 storage) in K1 / K1g / K2 / K3 / LSTM
-                           4: tsg_boundary_score_bwd_ws (K3 backward in one launch) */
+                           4: tsg_boundary_score_bwd_ws (K3 backward in one launch); tsg_gemm_f32s */
 #define TSG_F32 0
 #define TSG_BF16 1   /* bf16 storage of the activations, fp32 arithmetic (see Conventions)                               */
 #define TSG_F32S 2   /* fp32 storage; matrix products as split-precision bf16 MFMAs (x = hi + lo; hi*hi + hi*lo + lo*hi,
@@ -272,6 +272,13 @@ int tsg_match_head_bwd(const void* y, const void* cs, const void* w2, const void
  * (SCDM W_a / W_s attention.py:104-106, sent_linear VideoEncoder.py:48, MultiHead wq/wk/wv/wo attention.py:63-66, the
  * first boundary Linear SpanPredictor.py:62-67).  Exact fp32 (v_mfma_f32_32x32x2_f32).  K % 4 == 0.                 */
 int tsg_linear_fwd(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int dtype, void* stream);
+
+/* The same product in the split-precision ("f32s") arithmetic with the operands converted ON LOAD (ABI revision 4): every element is
+ * split into hi = rne_bf16(x), lo = rne_bf16(x - hi) in registers and hi*hi + hi*lo + lo*hi is accumulated in fp32 on the bf16
+ * MFMA -- tsg_split_bf16x3 + a bf16 GEMM over the 3x longer contraction, without the operand planes in memory.  fp32 in / out,
+ * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL).  M % 256 == 0, N % 256 == 0, K % 32 == 0 (TSG_E_SHAPE otherwise).  The input
+ * gradient dX = dY W of the same Linears is this call with the weight passed transposed ([K,N] contiguous).                       */
+int tsg_gemm_f32s(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, void* stream);
 
 /* ---- split-precision operand preparation (optional "f32s" GEMM mode) ------------------------------------------------
  * Not a reference function: the reference's Linears / LSTM input GEMMs (torch.nn.Linear, nn.LSTM; e.g.

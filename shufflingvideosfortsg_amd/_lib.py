@@ -53,6 +53,7 @@ _SIGNATURES = {
     "tsg_lstm_bwd_ws_persistent": [_I, _I, _I, c_longlong],
     "tsg_lstm_bwd_ws_bytes": [_I, _I, _I],
     "tsg_linear_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "tsg_gemm_f32s": [_P] * 4 + [_I] * 3 + [_P],
     "tsg_split_bf16x3": [_P, _P, c_longlong, c_longlong, c_longlong, c_longlong, _I, _P],
     "tsg_split_bf16x3_shift": [_P, c_longlong, c_longlong, c_longlong, _P, c_longlong, c_longlong, c_longlong, c_longlong, _I, _P],
     "tsg_split_bf16x3_t": [_P, c_longlong, c_longlong, c_longlong, _P, c_longlong, c_longlong, c_longlong, c_longlong, _I, c_longlong, _P],

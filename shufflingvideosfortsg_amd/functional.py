@@ -310,13 +310,45 @@ def _split_operand(m: torch.Tensor, k_dim: int, right: bool) -> torch.Tensor:
     return split_bf16x3(m.contiguous(), k_dim, right)
 
 
+_OWN_GEMM = os.environ.get("TSG_GEMM", "1") != "0"          # A/B switch: 0 = operand planes + the library's bf16 GEMM everywhere
+
+
+def gemm_f32s_ok(M: int, N: int, K: int) -> bool:
+    """Shapes tsg_gemm_f32s takes AND is the faster path for (include/tsg_hip.h): whole 256 x 256 tiles, at least 100 of them
+    (with few tiles the library's smaller ones win: 63 vs 41 us at [2560 x 1024] x [1024 x 1024] = 40 tiles; 133 vs 171 us at 128 tiles).
+    The LSTM input GEMM ([T*B, I] x [8h, I]: 450 vs 436-454 us at 1024 tiles, and its W planes are needed by the backward anyway) stays
+    on the library path."""
+    return _OWN_GEMM and M % 256 == 0 and N % 256 == 0 and K % 32 == 0 and (M // 256) * (N // 256) >= 100
+
+
+def gemm_f32s(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
+    """y [M,N] = x [M,K] @ w [N,K]^T (+ bias) in the split-precision arithmetic with the operands converted on load
+    (tsg_gemm_f32s, csrc/gemm_f32s.hip): no operand planes in memory.  x, w fp32 contiguous."""
+    require_device(x, w, bias)
+    x, w = _f32c(x), _f32c(w)
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"gemm_f32s: x{tuple(x.shape)} w{tuple(w.shape)}")
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _call("tsg_gemm_f32s", x, ptr(x), ptr(w), ptr(_f32c(bias)) if bias is not None else None, ptr(y), M, N, K)
+    return y
+
+
 def _mm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """fp32 [M,K] @ [K,N] -> fp32, through rocBLAS/hipBLASLt in the configured GEMM precision."""
+    """fp32 [M,K] @ [K,N] -> fp32 in the configured GEMM precision: rocBLAS / hipBLASLt, or -- "f32s", whole 256-tiles -- the
+    hand-written split-on-load GEMM (the right operand is taken as [N,K] contiguous: a weight's `.t()` view as it is, a [K,N]
+    contiguous matrix through one transposed copy, which for the path's weights is a few MB)."""
     if _GEMM_DTYPE is None:
         return a @ b
     if _GEMM_DTYPE == "f32s":
         if a.shape[1] % 4 or a.shape[0] % 4 or b.shape[1] % 4:
             return a @ b
+        if a.is_cuda and a.is_contiguous() and gemm_f32s_ok(a.shape[0], b.shape[1], a.shape[1]):
+            if b.t().is_contiguous():
+                return gemm_f32s(a, b.t())
+            if b.is_contiguous() and b.numel() <= (1 << 24):         # [K,N] weight: transpose once (<= 64 MB), then the same kernel
+                return gemm_f32s(a, b.t().contiguous())
         return torch.mm(_split_operand(a, 1, False), _split_operand(b, 0, True), out_dtype=torch.float32)
     # bf16 operands, fp32 accumulate AND fp32 output straight from the GEMM (no bf16 round trip of the result, no cast kernel)
     return torch.mm(a.to(_BF), b.to(_BF), out_dtype=torch.float32)
@@ -793,9 +825,12 @@ class _LinearSplit(torch.autograd.Function):
     @_fwd
     def forward(ctx, x, w, b):
         x2 = _f32c(x).view(-1, x.shape[-1])
-        y = _mm(x2, w.t())
-        if b is not None:
-            y += b
+        if _GEMM_DTYPE == "f32s" and x2.is_cuda and w.is_contiguous() and gemm_f32s_ok(x2.shape[0], w.shape[0], w.shape[1]):
+            y = gemm_f32s(x2, w, b)                                           # bias in the GEMM's epilogue
+        else:
+            y = _mm(x2, w.t())
+            if b is not None:
+                y += b
         ctx.save_for_backward(x2, w)
         ctx.has_bias = b is not None
         return y.view(*x.shape[:-1], w.shape[0])
