@@ -242,6 +242,17 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
         fl = 3 * 2.0 * M * Nn * Kk
         out[name].update(bound="mfma", mfma_flops=fl, achieved_TFLOPs=round(fl / out[name]["mean_us"] / 1e6, 1),
                          mfma_frac=round(fl / out[name]["mean_us"] / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4))
+    # the hand-written split-on-load projection GEMM (csrc/gemm_f32s.hip) at the two shapes the step runs it on most (W_a forward /
+    # input gradient; the heads' first Linear): same accounting
+    for (M, Nn, Kk) in ((2 * B * T, d, d), (2 * B * T, 512, 2 * d)):
+        if M % 256 or Nn % 256 or Kk % 32:
+            continue
+        Xg = torch.randn(M, Kk, device=dev); Wg = torch.randn(Nn, Kk, device=dev) / Kk ** 0.5; Yg = torch.empty(M, Nn, device=dev)
+        name = f"tsg_gemm_f32s[{M}x{Kk} . ({Nn}x{Kk})^T]"
+        run(name, lambda: lib.tsg_gemm_f32s(ptr(Xg), ptr(Wg), None, ptr(Yg), M, Nn, Kk, st), (M * Kk + Nn * Kk + M * Nn) * e)
+        fl = 3 * 2.0 * M * Nn * Kk
+        out[name].update(bound="mfma", mfma_flops=fl, achieved_TFLOPs=round(fl / out[name]["mean_us"] / 1e6, 1),
+                         mfma_frac=round(fl / out[name]["mean_us"] / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4))
     return out
 
 
