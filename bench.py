@@ -377,9 +377,10 @@ def main():
     def train_step():
         dp.zero_grad()
         loss = forward()
-        loss.backward()
-        dp.finish()
-        engine.optimizer_step(opt, loss)          # the update is skipped ON THE DEVICE if the loss is not finite (no sync)
+        loss.backward()                           # runs in the forward's mode (saved in the autograd contexts)
+        guard = engine.step_guard(loss)           # this rank's skip flag (non-finite loss / expired bounded wait), on the device
+        dp.finish(guard=guard)                    # ... reduced over the ranks inside the gradient all-reduce
+        engine.optimizer_step(opt, loss, dp=dp, guard=guard)   # the update is skipped ON THE DEVICE, on every rank alike (no sync)
         return loss
 
     def fwd_step():

@@ -37,9 +37,11 @@
 extern "C" {
 #endif
 
-#define TSG_VERSION 4   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points
+#define TSG_VERSION 5   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points
                            3: tsg_error_word (device-side expiry report); dtype TSG_BF16 (bf16 storage) in K1 / K1g / K2 / K3 / LSTM
-                           4: tsg_boundary_score_bwd_ws (K3 backward in one launch); tsg_gemm_f32s */
+                           4: tsg_boundary_score_bwd_ws (K3 backward in one launch); tsg_gemm_f32s
+                           5: tsg_scdm_bwd_mode / tsg_scdm_bwd_fused_ok (path selection as a call and a predicate instead of an
+                              environment variable and an error code); per-device error words */
 #define TSG_F32 0
 #define TSG_BF16 1   /* bf16 storage of the activations, fp32 arithmetic (see Conventions)                               */
 #define TSG_F32S 2   /* fp32 storage; matrix products as split-precision bf16 MFMAs (x = hi + lo; hi*hi + hi*lo + lo*hi,
@@ -73,6 +75,14 @@ int tsg_scdm_attn_fwd(const void* a, const void* s, const void* w, const void* s
  * `ws`: caller-owned workspace of at least tsg_scdm_bwd_ws_bytes(B,T,N,H,Ds,gate) bytes, contents irrelevant.
  * (TSG_K1_BWD=split in the environment selects the two-kernel path of revision 1, which moves dG / de through `ws`.)   */
 long long tsg_scdm_bwd_ws_bytes(int B, int T, int N, int H, int Ds, int gate);
+/* Path selection of the K1 / K1g backward (ABI revision 5).  tsg_scdm_bwd_mode(mode): 0 = automatic (the one-launch kernel where its
+ * plan fits, else the two kernels), 1 = always the two-kernel path (no cross-workgroup exchange), 2 = one launch with the row phase
+ * on the VALU; any other value only queries.  Returns the previous mode (initialised from TSG_K1_BWD = split / valu).
+ * tsg_scdm_bwd_fused_ok: 1 when the current mode runs this shape in the one-launch kernel on the current device -- the only
+ * backward dtype TSG_BF16 takes (the host code decides with this predicate whether to go through fp32 copies; it does not
+ * probe with a failing call).                                                                                                  */
+int tsg_scdm_bwd_mode(int mode);
+int tsg_scdm_bwd_fused_ok(int B, int T, int N, int H, int Ds);
 int tsg_scdm_attn_bwd(const void* a, const void* s, const void* w, const void* sent, const void* P,
                       const void* dC, void* da, void* ds, void* dw, void* dsent, void* ws, long long ws_bytes,
                       int B, int T, int N, int H, int Ds, int dtype, void* stream);
@@ -205,7 +215,9 @@ int tsg_error_sink(void* flag);          /* the same sink under its general name
  * 1 on expiry, in addition to the host sink.  It exists for guards that run on the device -- the host code ORs it into the fused
  * optimizer's found_inf input, so the update of a step whose backward was corrupted by an expired wait is skipped even when the
  * step is replayed from a HIP graph and no host code runs between its launches.  On expiry the K1 backward also poisons the
- * affected item's da / ds / dw with NaN instead of summing incomplete partials.  NULL (default) disables it.               */
+ * affected item's da / ds / dw with NaN instead of summing incomplete partials.  NULL (default) disables it.  ONE WORD PER DEVICE
+ * (ABI revision 5): the call registers the word for the current HIP device, and a launch reports into the word of the device it
+ * runs on.                                                                                                                   */
 int tsg_error_word(void* device_flag);
 /* Allow (default, TSG_LSTM_L2X) or forbid the exchange that stays inside one XCD's L2 (plain stores when a group's one-XCD
  * placement is verified); forbidden = write-through stores always.  The Python host turns it off when its start-up self-test

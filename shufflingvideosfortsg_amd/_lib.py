@@ -22,6 +22,8 @@ _SIGNATURES = {
     "tsg_scdm_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsg_scdm_attn_bwd": [_P] * 11 + [c_longlong] + [_I] * 6 + [_P],
     "tsg_scdm_bwd_ws_bytes": [_I] * 6,
+    "tsg_scdm_bwd_mode": [_I],
+    "tsg_scdm_bwd_fused_ok": [_I] * 5,
     "tsg_error_sink": [_P],
     "tsg_error_word": [_P],
     "tsg_scdm_gate_fwd": [_P] * 8 + [_I] * 6 + [_P],
@@ -89,8 +91,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)            # AttributeError here = header / library mismatch
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, c_int)
-    if lib.tsg_version() != 4:
-        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 4 expected by the Python host code")
+    if lib.tsg_version() != 5:
+        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 5 expected by the Python host code")
     _lib = lib
     return lib
 

@@ -34,6 +34,7 @@
 //              Es for the slice lives in registers (NP*4 per lane); de / P rows are wave-uniform.
 #include "tsg_common.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1432,15 +1433,21 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
 
   // Publish this part's partial dP rows (De complete, workgroup met) and count it in: called right after the row loop, BEFORE the
   // T-sum epilogue of the row phase (dVW stores, dbias atomics), so that the partners' round trip runs under that epilogue.
-  // The rows are agent-scope (write-through) stores and the barrier waits for their acknowledgement (s_waitcnt vmcnt(0)): they are
-  // visible device-wide before the counter moves.  No release fence: a fence here is an L2 WRITE-BACK (buffer_wbl2), and at this
+  // The rows are agent-scope (write-through, sc1) stores; EVERY thread waits for the acknowledgement of its own stores with an
+  // explicit `s_waitcnt vmcnt(0)` before the workgroup barrier -- the barrier's workgroup-scope fence is `s_waitcnt lgkmcnt(0)` only
+  // on gfx950 and does NOT wait for vector stores (round-3 review: the shipped ISA had store -> s_barrier -> atomic with no vmcnt
+  // wait, so a partner could count this part in and read rows that had not reached L2).  With the wait the rows are visible
+  // device-wide before the counter moves.  Still no release fence: a fence here is an L2 WRITE-BACK (buffer_wbl2), and at this
   // point the L2 holds this workgroup's 256 KiB of freshly stored dr rows -- every workgroup of the XCD would stall on flushing
   // them in the middle of the kernel (173 -> 147 us per launch at [128,128,20,1024]; -DTSG_K1_XCH_FENCE builds keep the fences: A/B).
+  // tests/test_isa_cpu.py disassembles the built code object and asserts the vmcnt(0) wait between the last sc1 store and the
+  // counter's atomic in every instantiation.
   auto publish_dp = [&]() {
     if (parts <= 1) return;
     float* mine = xch + ((size_t)b * parts + pt) * T * NP;
     for (int idx = tid; idx < T * NP; idx += kFusedThreads)
       __hip_atomic_store(mine + idx, De[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // acknowledgement of THIS thread's partial rows (write-through to L2 / memory)
     __syncthreads();
     if (tid == 0) {
       xch_failed = 0u;
@@ -2069,9 +2076,40 @@ int launch_bwd_split(const float* a, const float* s, const float* w, const float
   return check_launch("scdm_attn_bwd(cols)");
 }
 
-static bool want_split() {
-  static const bool v = [] { const char* e = getenv("TSG_K1_BWD"); return e && e[0] == 's'; }();
+// Backward path selection: 0 = automatic (one fused launch where the plan fits, else the two kernels), 1 = always the two-kernel
+// path ("split": no cross-workgroup exchange at all), 2 = fused with the row phase on the VALU.  Initialised from TSG_K1_BWD
+// (s.. / v..), changed at run time by tsg_scdm_bwd_mode (the exchange stress test compares the fused result with the split one in
+// one process).
+static std::atomic<int> g_bwd_mode{-1};
+static int bwd_mode() {
+  int v = g_bwd_mode.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("TSG_K1_BWD");
+    v = (e && e[0] == 's') ? 1 : ((e && e[0] == 'v') ? 2 : 0);
+    g_bwd_mode.store(v, std::memory_order_relaxed);
+  }
   return v;
+}
+static bool want_split() { return bwd_mode() == 1; }
+
+// The plan launch_bwd runs for a shape: which fused variant, and whether the one-launch kernel takes it at all.
+struct BwdChoice { FusedPlan plan; bool mrow; bool fused; };
+template <int NP>
+BwdChoice choose_bwd(int B, int T, int N, int H, int Ds) {
+  const bool valu_rows = bwd_mode() == 2;                           // A/B: row phase on the VALU
+  const FusedPlan pm = fused_plan<NP, true>(B, T, N, H, Ds), pv = fused_plan<NP, false>(B, T, N, H, Ds);
+  // the MFMA row phase pays when its 64-column slices do not force more column parts per item than the 128-column
+  // slices of the VALU variant would need (measured at [., 128, 20, 1024]: 128 pairs 183 vs 188 us gate-fused, 132 vs 158 us
+  // plain; 256 pairs -- 2 parts instead of 1 -- 355 vs 326 us)
+  const bool mrow = pm.ok && !valu_rows && (!pv.ok || pm.parts <= pv.parts);
+  const FusedPlan& pl = mrow ? pm : pv;
+  // The parts of an item wait for each other (bounded spin).  They are `parts` block ids inside a window of 8*(parts-1)+1
+  // consecutive ids (xcd_remap keeps an item on one XCD); with in-order dispatch the oldest resident workgroup's partners
+  // are all dispatched as long as that window fits the workgroups the chip holds at once (one per CU).  Half the CUs is the
+  // margin kept for CUs a collective or another stream occupies; beyond it the two-kernel path (no waiting) runs.
+  const bool window_ok = pl.parts == 1 || 8 * (pl.parts - 1) + 1 <= device_cu_count() / 2;
+  const bool ds_ok = Ds <= (NP <= 20 ? 2048 : 1024);
+  return BwdChoice{pl, mrow, ds_ok && pl.ok && window_ok && !want_split()};
 }
 
 inline long long split_ws_bytes(int B, int T, int N, int Ds, bool gate) {
@@ -2085,19 +2123,10 @@ int launch_bwd(const ST* a, const ST* s, const float* w, const ST* V, const floa
   const char* fn = GATE ? "tsg_scdm_gate_bwd" : "tsg_scdm_attn_bwd";
   if (Ds > (NP <= 20 ? 2048 : 1024))
     return set_error(TSG_E_SHAPE, "%s: Ds=%d (max %d at N=%d) not supported", fn, Ds, NP <= 20 ? 2048 : 1024, N);
-  static const bool valu_rows = [] { const char* e = getenv("TSG_K1_BWD"); return e && e[0] == 'v'; }();   // A/B: row phase on the VALU
-  const FusedPlan pm = fused_plan<NP, true>(B, T, N, H, Ds), pv = fused_plan<NP, false>(B, T, N, H, Ds);
-  // the MFMA row phase pays when its 64-column slices do not force more column parts per item than the 128-column
-  // slices of the VALU variant would need (measured at [., 128, 20, 1024]: 128 pairs 183 vs 188 us gate-fused, 132 vs 158 us
-  // plain; 256 pairs -- 2 parts instead of 1 -- 355 vs 326 us)
-  const bool mrow = pm.ok && !valu_rows && (!pv.ok || pm.parts <= pv.parts);
-  const FusedPlan& pl = mrow ? pm : pv;
-  // The parts of an item wait for each other (bounded spin).  They are `parts` block ids inside a window of 8*(parts-1)+1
-  // consecutive ids (xcd_remap keeps an item on one XCD); with in-order dispatch the oldest resident workgroup's partners
-  // are all dispatched as long as that window fits the workgroups the chip holds at once (one per CU).  Half the CUs is the
-  // margin kept for CUs a collective or another stream occupies; beyond it the two-kernel path (no waiting) runs.
-  const bool window_ok = pl.parts == 1 || 8 * (pl.parts - 1) + 1 <= device_cu_count() / 2;
-  if (pl.ok && window_ok && !want_split()) {
+  const BwdChoice ch = choose_bwd<NP>(B, T, N, H, Ds);
+  const FusedPlan& pl = ch.plan;
+  const bool mrow = ch.mrow;
+  if (ch.fused) {
     if (ws_bytes < pl.ws_bytes) return set_error(TSG_E_SHAPE, "%s: workspace of %lld B < %lld B (tsg_scdm_bwd_ws_bytes)", fn, ws_bytes, pl.ws_bytes);
     float* xch = static_cast<float*>(ws);
     unsigned* cnt = reinterpret_cast<unsigned*>(xch + (size_t)B * pl.parts * T * NP);
@@ -2198,6 +2227,18 @@ extern "C" long long tsg_scdm_bwd_ws_bytes(int B, int T, int N, int H, int Ds, i
     default: fused = std::max(fused_plan<32, true>(B, T, N, H, Ds).ws_bytes, fused_plan<32, false>(B, T, N, H, Ds).ws_bytes); break;
   }
   return fused > split ? fused : split;       // either path can run in it
+}
+
+extern "C" int tsg_scdm_bwd_mode(int mode) {
+  const int prev = bwd_mode();
+  if (mode >= 0 && mode <= 2) g_bwd_mode.store(mode, std::memory_order_relaxed);
+  return prev;
+}
+
+extern "C" int tsg_scdm_bwd_fused_ok(int B, int T, int N, int H, int Ds) {
+  if (B <= 0 || T <= 0 || N <= 0 || N > 32 || H <= 0 || Ds <= 0 || H % 4 || Ds % 4) return 0;
+  const int np = roundup(N, 4);
+  TSG_DISPATCH_NP(np, (choose_bwd<NP>(B, T, N, H, Ds).fused ? 1 : 0));
 }
 
 extern "C" int tsg_scdm_attn_bwd(const void* a, const void* s, const void* w, const void* sent,

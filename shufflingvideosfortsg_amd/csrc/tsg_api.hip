@@ -10,10 +10,18 @@ namespace tsg {
 namespace {
 thread_local char g_err[512] = "";
 std::atomic<unsigned*> g_error_sink{nullptr};
-std::atomic<unsigned*> g_error_word{nullptr};
+std::atomic<unsigned*> g_error_word[64];       // one device word PER DEVICE (ABI revision 5; ADVICE r3: with one global word a launch on
+                                                // device 0 reported into device 1's memory after a second device had registered)
+int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  return dev;
+}
 }
 
-ErrSink error_sink() { return ErrSink{g_error_sink.load(std::memory_order_relaxed), g_error_word.load(std::memory_order_relaxed)}; }
+ErrSink error_sink() {
+  return ErrSink{g_error_sink.load(std::memory_order_relaxed), g_error_word[current_device()].load(std::memory_order_relaxed)};
+}
 
 hipError_t ensure_lds(const void* kernel, size_t bytes) {
   static std::mutex mu;
@@ -62,6 +70,10 @@ extern "C" int tsg_error_sink(void* p) { tsg::g_error_sink.store(static_cast<uns
 extern "C" int tsg_lstm_error_sink(void* p) { return tsg_error_sink(p); }
 // The same report into DEVICE memory (a 4-byte word the caller owns and clears): what a device-side guard -- the optimizer's
 // found_inf input -- can read without the host, e.g. between the two graphs of a replayed train step.
-extern "C" int tsg_error_word(void* p) { tsg::g_error_word.store(static_cast<unsigned*>(p), std::memory_order_relaxed); return 0; }
+// Registered for the CURRENT device (hipGetDevice at the time of the call); launches on a device report into that device's word.
+extern "C" int tsg_error_word(void* p) {
+  tsg::g_error_word[tsg::current_device()].store(static_cast<unsigned*>(p), std::memory_order_relaxed);
+  return 0;
+}
 extern "C" int tsg_version(void) { return TSG_VERSION; }
 extern "C" const char* tsg_last_error(void) { return tsg::g_err; }

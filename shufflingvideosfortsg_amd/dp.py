@@ -45,7 +45,12 @@ class FlatGradAllReduce:
         order = list(reversed(self.params))
         self._numel = sum(p.numel() for p in order)
         self._esize = torch.empty(0, dtype=dt).element_size()
-        self.flat = torch.zeros(self._numel, device=dev, dtype=dt) if self.active else None
+        # one extra element behind the gradients: the GUARD slot.  A rank that wants the optimizer update skipped (non-finite loss, an
+        # expired bounded wait in one of its kernels) writes 1 there before the exchange; after the (sum / mean) all-reduce the slot is
+        # non-zero on EVERY rank, so all replicas skip the same update and stay identical (the guard used to be rank-local
+        # while the gradients -- including a corrupted rank's -- were averaged into everyone).  It rides in the gradient all-reduce: no
+        # extra collective on the default (exchange-after-backward) and graph-replay protocols.
+        self.flat = torch.zeros(self._numel + 1, device=dev, dtype=dt) if self.active else None
         self.buckets = []          # (start, end, [params])
         cap = max(1, int(bucket_mb * (1 << 20) / self._esize))
         off = start = 0
@@ -108,14 +113,31 @@ class FlatGradAllReduce:
         if self._ready[b] == len(self.buckets[b][2]) and not self._launched[b]:
             self._launch(b)
 
-    def finish(self):
-        """Complete the gradient exchange: afterwards every rank holds the mean gradient."""
+    def _set_guard(self, guard):
+        slot = self.flat[self._numel:]
+        if guard is None:
+            slot.zero_()
+        else:
+            slot.copy_(guard.detach().reshape(1).to(slot.dtype))
+
+    @property
+    def guard(self):
+        """After ``finish`` / ``exchange_static``: a 1-element view that is non-zero iff ANY rank passed a non-zero ``guard`` in
+        (None when there is no exchange).  ``engine.optimizer_step(..., dp=dp)`` ORs it into the fused optimizer's skip flag."""
+        return self.flat[self._numel:] if self.active else None
+
+    def finish(self, guard=None):
+        """Complete the gradient exchange: afterwards every rank holds the mean gradient.  ``guard``: this rank's skip flag (a
+        1-element tensor, non-zero = skip the update), reduced across the ranks with the gradients (see ``guard``)."""
         if not self.active:
             return
+        self._set_guard(guard)
         if self.overlap:
             for b in range(len(self.buckets)):             # buckets with parameters that received no gradient
                 if not self._launched[b]:
                     self._launch(b)
+            # the buckets are already in flight: the guard slot goes in a collective of its own (4 bytes)
+            self._handles.append(dist.all_reduce(self.flat[self._numel:], op=self._op, group=self.group, async_op=True))
         else:
             for b in range(len(self.buckets)):
                 self._gather(b)
@@ -126,15 +148,18 @@ class FlatGradAllReduce:
             self.flat.div_(self.world)
 
     # -- graph-replay protocol (engine.GraphedTrainStep) ---------------------------------------
-    def adopt(self, grads):
+    def adopt(self, grads, guard=None):
         """Called once after the backward has been captured: ``grads`` are the graph's static gradient tensors (in
         ``self.params`` order).  Gathers and exchanges them once and leaves ``.grad`` of every parameter pointing into the flat
         buffer, which is what the captured optimizer update then reads on every replay."""
-        self.exchange_static(grads)
+        self.exchange_static(grads, guard)
 
-    def exchange_static(self, grads):
+    def exchange_static(self, grads, guard=None):
         """static gradient tensors -> flat buffer (one multi-tensor copy; zeros where there is no gradient), ONE all-reduce of the
-        whole buffer (the backward has finished: nothing to overlap with), ``.grad`` re-pointed at the flat views."""
+        whole buffer incl. the guard slot (the backward has finished: nothing to overlap with), ``.grad`` re-pointed at the flat
+        views.  A parameter without a gradient on THIS rank contributes zeros, so a parameter that received a gradient on one rank
+        only still gets the mean over all ranks everywhere."""
+        self._set_guard(guard)
         have = [(self._view[id(p)], g) for p, g in zip(self.params, grads) if g is not None]
         none = [self._view[id(p)] for p, g in zip(self.params, grads) if g is None]
         if have:

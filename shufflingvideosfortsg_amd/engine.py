@@ -59,19 +59,46 @@ def build_model(kind: str, params: Dict, logger=LOG) -> torch.nn.Module:
     return cls(*copy.deepcopy(make_settings(params)), logger, params["dropout"])
 
 
-def precision(gemm_dtype=None):
-    """Context for one forward.  ``None`` / fp32 = strict fp32 (parity mode); ``"f32s"`` = split-precision bf16 MFMA products,
-    fp32 storage (the headline mode: fp32-level error); ``"bf16"`` = bf16 STORAGE mode (BASELINE configs 2 / 4): activations and
-    their gradients live in HBM as bf16, the hand-written kernels run with dtype TSG_BF16 (fp32 arithmetic inside), the GEMMs are
-    plain bf16 MFMA GEMMs, parameters / weight gradients / optimizer state stay fp32 -- no autocast involved;
-    ``torch.bfloat16`` = the older operands-only mode: every library GEMM (nn.Linear projections via autocast, the LSTM GEMMs via
-    functional.set_gemm_dtype) takes bf16 operands with fp32 accumulation while the HIP kernels and all storage stay fp32."""
-    import contextlib
+def set_precision(gemm_dtype=None):
+    """Set the process-wide arithmetic mode of the path (see ``precision``) and return the previous one.  For code that cannot use
+    a ``with`` block (test fixtures with finalizers); everything else uses ``precision``."""
     from . import functional as TF
+    prev = TF.get_gemm_dtype()
     TF.set_gemm_dtype(gemm_dtype)
-    if gemm_dtype in (None, torch.float32, "f32s", "bf16"):
-        return contextlib.nullcontext()
-    return torch.autocast("cuda", dtype=gemm_dtype)
+    return prev
+
+
+class precision:
+    """Context manager for the arithmetic mode of the path; the previous mode is RESTORED on exit (round-3 review: it used to set a
+    process global and return a null context, so the mode leaked past the block).  ``None`` / fp32 = strict fp32 (parity mode);
+    ``"f32s"`` = split-precision bf16 MFMA products, fp32 storage (the headline mode: fp32-level error); ``"bf16"`` = bf16 STORAGE
+    mode (BASELINE configs 2 / 4): activations and their gradients live in HBM as bf16, the hand-written kernels run with dtype
+    TSG_BF16 (fp32 arithmetic inside), the GEMMs are plain bf16 MFMA GEMMs, parameters / weight gradients / optimizer state stay
+    fp32 -- no autocast involved; ``torch.bfloat16`` = the older operands-only mode: every library GEMM (nn.Linear projections via
+    autocast, the LSTM GEMMs via functional.set_gemm_dtype) takes bf16 operands with fp32 accumulation while the HIP kernels and
+    all storage stay fp32.  A backward runs in the mode of ITS forward (saved in the autograd context), so ``loss.backward()`` may
+    sit outside the block."""
+
+    def __init__(self, gemm_dtype=None):
+        self.mode = gemm_dtype
+        self._prev = None
+        self._autocast = None
+
+    def __enter__(self):
+        self._prev = set_precision(self.mode)
+        if self.mode not in (None, torch.float32, "f32s", "bf16"):
+            self._autocast = torch.autocast("cuda", dtype=self.mode)
+            self._autocast.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            if self._autocast is not None:
+                self._autocast.__exit__(*exc)
+        finally:
+            self._autocast = None
+            set_precision(self._prev)
+        return False
 
 
 def make_optimizer(model, params, capturable=False):
@@ -84,28 +111,44 @@ def make_optimizer(model, params, capturable=False):
                             capturable=bool(capturable and fused))
 
 
-def optimizer_step(opt, loss):
-    """``opt.step()`` guarded on the DEVICE: the fused Adam kernel skips the update -- its ``found_inf`` input, the GradScaler
-    mechanism -- when the loss is not finite (a persistent LSTM forward whose bounded wait expired leaves NaN sentinels in its
-    output; an overflow) OR when any kernel of the step reported an expired bounded wait into the device error word
-    (``functional.error_word``: the persistent LSTM backward and the K1 backward's partner exchange run AFTER the loss is
-    known to be finite -- ADVICE r2: the loss alone did not cover them; the K1 backward additionally poisons the affected
-    gradients with NaN).  So the parameters and the Adam moments are not corrupted by a step the host has already enqueued, also
-    when the step is replayed from HIP graphs.  No synchronisation; the host-side report follows at the next
-    ``functional.check_kernel_errors()`` (every LSTM call, every graph replay).  With a non-fused optimizer (CPU tests) it is a
-    plain ``opt.step()``."""
-    fused = any(g.get("fused") for g in opt.param_groups)
-    if fused:
+def step_guard(loss):
+    """This rank's skip flag for the step that produced ``loss``, computed ON THE DEVICE after the backward has been enqueued: 1.0
+    when the loss is not finite (a persistent LSTM forward whose bounded wait expired leaves NaN sentinels in its output; an
+    overflow) OR when any kernel of the step reported an expired bounded wait into the device error word
+    (``functional.error_word``: the persistent LSTM backward and the K1 backward's partner exchange run AFTER the loss is known to
+    be finite; the K1 backward additionally poisons the affected gradients with NaN).  float32 [1]; no synchronisation."""
+    bad = ~torch.isfinite(loss.detach()).reshape(())
+    if loss.is_cuda:
         from . import functional as TF
-        bad = ~torch.isfinite(loss.detach()).reshape(())
-        if loss.is_cuda:
-            bad = bad | (TF.error_word(loss.device)[0] != 0)
-        opt.found_inf = bad.to(torch.float32).reshape(())
-    try:
-        opt.step()
-    finally:
-        if fused:
+        bad = bad | (TF.error_word(loss.device)[0] != 0)
+    return bad.to(torch.float32).reshape(1)
+
+
+def optimizer_step(opt, loss, dp=None, guard=None):
+    """``opt.step()`` guarded on the DEVICE: the fused Adam kernel skips the update -- its ``found_inf`` input, the GradScaler
+    mechanism -- when ``step_guard(loss)`` is set on this rank OR, with a gradient exchange ``dp`` (FlatGradAllReduce), on ANY rank:
+    the flag is reduced across the ranks inside the gradient all-reduce (``dp.finish(guard=step_guard(loss))`` /
+    ``dp.exchange_static(grads, guard)``), because the averaged gradient a healthy rank holds contains the corrupted rank's
+    contribution -- with a rank-local guard the replicas would diverge.  So the parameters and the Adam moments are not
+    corrupted by a step the host has already enqueued, also when the step is replayed from HIP graphs.  No synchronisation; the
+    host-side report follows at the next ``functional.check_kernel_errors()`` (every LSTM call, every graph replay).  With a
+    non-fused optimizer (CPU tests) the flag is read on the host instead (one ``.item()``), so the skip semantics are the same there.
+    ``guard``: the local flag if the caller has already computed it (it must be the tensor handed to ``dp.finish``)."""
+    fused = any(g.get("fused") for g in opt.param_groups)
+    bad = step_guard(loss) if guard is None else guard.reshape(1).to(torch.float32)
+    if dp is not None and getattr(dp, "active", False) and dp.guard is not None:
+        bad = torch.maximum(bad, (dp.guard != 0).to(torch.float32))
+    if fused:
+        opt.found_inf = bad.reshape(())
+        try:
+            opt.step()
+        finally:
             opt.found_inf = None
+    elif dp is not None and getattr(dp, "active", False):
+        if float(bad.item()) == 0.0:                       # host-side optimizers (the gloo CPU tests): same rule, read on the host
+            opt.step()
+    else:
+        opt.step()
 
 
 class GraphedTrainStep:
@@ -136,9 +179,10 @@ class GraphedTrainStep:
                 self._zero()
                 loss = step_fn(model, batch)
                 loss.backward()
+                g = step_guard(loss)
                 if dp is not None:
-                    dp.finish()
-                optimizer_step(opt, loss)
+                    dp.finish(guard=g)
+                optimizer_step(opt, loss, dp=dp, guard=g)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         TF.check_lstm_errors()
@@ -150,11 +194,12 @@ class GraphedTrainStep:
             self._zero()
             self.loss = step_fn(model, batch)
             self.loss.backward()
+            self.guard = step_guard(self.loss)              # this rank's skip flag: the last node of graph A (after the backward)
         self.grads = [p.grad for p in self.params]          # the graph's static gradient tensors (None: no gradient)
         if dp is not None and dp.active:
-            dp.adopt(self.grads)                            # gather + exchange once: .grad now points into the flat buffer
+            dp.adopt(self.grads, self.guard)                # gather + exchange once: .grad now points into the flat buffer
         with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=side):
-            optimizer_step(opt, self.loss)
+            optimizer_step(opt, self.loss, dp=dp, guard=self.guard)   # reads the REDUCED flag (dp.guard: static memory of the flat buffer)
 
     def _zero(self):
         for p in self.params:
@@ -170,7 +215,7 @@ class GraphedTrainStep:
         TF.check_kernel_errors()
         self.graph_a.replay()
         if self.dp is not None and self.dp.active:
-            self.dp.exchange_static(self.grads)
+            self.dp.exchange_static(self.grads, self.guard)
         self.graph_b.replay()
         return self.loss
 

@@ -68,8 +68,9 @@ def _register_error_channels(device) -> None:
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _err_words:
         _err_words[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
-        # one process drives one GPU (one rank per device): the library keeps ONE device word, that of the last device used
-        check(lib.tsg_error_word(_err_words[idx].data_ptr()), "tsg_error_word")
+        # the library keeps one word per device, registered for the CURRENT device of the call (ABI revision 5)
+        with torch.cuda.device(idx):
+            check(lib.tsg_error_word(_err_words[idx].data_ptr()), "tsg_error_word")
 
 
 def error_word(device=None) -> torch.Tensor:
@@ -175,6 +176,11 @@ def set_gemm_dtype(dtype=None):
     if dtype not in (None, torch.float32, torch.bfloat16, "f32s", "bf16"):
         raise ValueError("gemm dtype must be None/float32, bfloat16 (library-GEMM operands only), 'f32s' or 'bf16' (bf16 storage)")
     _GEMM_DTYPE = None if dtype in (None, torch.float32) else dtype
+
+
+def get_gemm_dtype():
+    """The current mode as ``set_gemm_dtype`` takes it (None = strict fp32)."""
+    return _GEMM_DTYPE
 
 
 def bf16_storage() -> bool:
@@ -335,13 +341,17 @@ def gemm_f32s(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None) -> to
     return y
 
 
-def _mm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """fp32 [M,K] @ [K,N] -> fp32 in the configured GEMM precision: rocBLAS / hipBLASLt, or -- "f32s", whole 256-tiles -- the
+_AUTO = object()          # "the mode that is current now" (forward); a backward passes the mode its forward saved in ctx
+
+
+def _mm(a: torch.Tensor, b: torch.Tensor, mode=_AUTO) -> torch.Tensor:
+    """fp32 [M,K] @ [K,N] -> fp32 in the GEMM precision ``mode`` (default: the configured one): rocBLAS / hipBLASLt, or -- "f32s", whole 256-tiles -- the
     hand-written split-on-load GEMM (the right operand is taken as [N,K] contiguous: a weight's `.t()` view as it is, a [K,N]
     contiguous matrix through one transposed copy, which for the path's weights is a few MB)."""
-    if _GEMM_DTYPE is None:
+    mode = _GEMM_DTYPE if mode is _AUTO else mode
+    if mode is None:
         return a @ b
-    if _GEMM_DTYPE == "f32s":
+    if mode == "f32s":
         if a.shape[1] % 4 or a.shape[0] % 4 or b.shape[1] % 4:
             return a @ b
         if a.is_cuda and a.is_contiguous() and gemm_f32s_ok(a.shape[0], b.shape[1], a.shape[1]):
@@ -381,6 +391,12 @@ def _act(t: torch.Tensor, bf: bool) -> torch.Tensor:
     return _bfc(t) if bf else _f32c(t)
 
 
+def scdm_bwd_fused_ok(B: int, T: int, N: int, H: int, Ds: int) -> bool:
+    """True when the K1 / K1g backward of this shape runs as the one-launch kernel on the current device (the only backward the
+    bf16 storage dtype takes): the library's own plan (tsg_scdm_bwd_fused_ok, include/tsg_hip.h), not a probe with a failing call."""
+    return bool(load().tsg_scdm_bwd_fused_ok(B, T, N, H, Ds))
+
+
 class _ScdmAttn(torch.autograd.Function):
     """K1: (a=[B,T,H], s=[B,N,H], w=[H], sent=[B,N,Ds]) -> (C=[B,T,Ds], P=[B,T,N])."""
 
@@ -415,13 +431,12 @@ class _ScdmAttn(torch.autograd.Function):
         dw = torch.empty_like(w); dsent = torch.empty_like(sent)
         nb = int(load().tsg_scdm_bwd_ws_bytes(B, T, N, H, Ds, 0))
         ws = torch.empty(nb // 4 + 4, device=a.device, dtype=torch.float32)
-        try:
+        if ctx.dt != TSG_BF16 or scdm_bwd_fused_ok(B, T, N, H, Ds):
             _call("tsg_scdm_attn_bwd", a, ptr(a), ptr(s), ptr(w), ptr(sent), ptr(P), ptr(dC), ptr(da), ptr(ds),
                                            ptr(dw), ptr(dsent), ptr(ws), nb, B, T, N, H, Ds, ctx.dt)
-        except RuntimeError:
-            if ctx.dt != TSG_BF16:
-                raise
-            # a shape only the two-kernel (fp32-storage) backward takes: fp32 copies through it, results rounded to bf16
+        else:
+            # a shape only the two-kernel (fp32-storage) backward takes (decided by the library's predicate, not by a failing
+            # call): fp32 copies through it, results rounded to bf16
             af, sf, vf, gf = a.float(), s.float(), sent.float(), dC.float()
             daf, dsf, dvf = torch.empty_like(af), torch.empty_like(sf), torch.empty_like(vf)
             _call("tsg_scdm_attn_bwd", af, ptr(af), ptr(sf), ptr(w), ptr(vf), ptr(P), ptr(gf), ptr(daf), ptr(dsf),
@@ -468,12 +483,10 @@ class _ScdmGate(torch.autograd.Function):
         dVW = torch.empty_like(VW); dgb = torch.empty_like(gbias); dr = torch.empty_like(r)
         nb = int(load().tsg_scdm_bwd_ws_bytes(B, T, N, H, Ds, 1))
         ws = torch.empty(nb // 4 + 4, device=a.device, dtype=torch.float32)
-        try:
+        if ctx.dt != TSG_BF16 or scdm_bwd_fused_ok(B, T, N, H, Ds):
             _call("tsg_scdm_gate_bwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(r), ptr(P), ptr(dout),
                   ptr(da), ptr(ds), ptr(dw), ptr(dVW), ptr(dgb), ptr(dr), ptr(ws), nb, B, T, N, H, Ds, ctx.dt)
-        except RuntimeError:
-            if ctx.dt != TSG_BF16:
-                raise
+        else:
             af, sf, vf, rf, gf = a.float(), s.float(), VW.float(), r.float(), dout.float()
             daf, dsf, dvf, drf = torch.empty_like(af), torch.empty_like(sf), torch.empty_like(vf), torch.empty_like(rf)
             _call("tsg_scdm_gate_bwd", af, ptr(af), ptr(sf), ptr(w), ptr(vf), ptr(gbias), ptr(rf), ptr(P), ptr(gf),
@@ -487,21 +500,25 @@ def scdm_gate(a, s, w, VW, gbias, r):
     return _ScdmGate.apply(a, s, w.reshape(-1), VW, gbias, r)
 
 
-_k3_ws = {}        # (device, stream) -> uint8 workspace of the one-launch K3 backward; its ticket counters are zero between calls
+_k3_ws = {}        # (device, stream, B, T, Hm) -> uint8 workspace of the one-launch K3 backward; its ticket counters are zero between calls
 
 
 def _k3_workspace(device, B: int, T: int, Hm: int):
-    """Workspace of tsg_boundary_score_bwd_ws (include/tsg_hip.h): zeroed when created, left zeroed by every call, so one buffer per
-    (device, stream) serves all calls enqueued on that stream.  A buffer created while the stream is being captured belongs to the
-    graph's pool and is zeroed by a captured fill on every replay: it is handed out once and not kept."""
+    """Workspace of tsg_boundary_score_bwd_ws (include/tsg_hip.h): [roundup(B,4) ticket counters | partial rows], zeroed when created,
+    its counters left zeroed by every call.  That invariant holds per LAYOUT only -- with another B the counter words of one call
+    overlap the partial rows of another (B=64,T=128 then B=128,T=32 left counters 64..127 non-zero and dgate unwritten)
+    -- so the cache is keyed on the shape as well as on (device, stream).  A buffer created while the stream is being captured belongs
+    to the graph's pool and is zeroed by a captured fill on every replay: it is handed out once and not kept."""
     nb = int(load().tsg_boundary_score_bwd_ws_bytes(B, T, Hm))
     if nb <= 0:
         raise ValueError(f"boundary_score: bad shape B={B} T={T} Hm={Hm}")
-    key = (_cuda_device(device), torch.cuda.current_stream(device).cuda_stream)
+    key = (_cuda_device(device), torch.cuda.current_stream(device).cuda_stream, B, T, Hm)
     ws = _k3_ws.get(key)
     if ws is None or ws.numel() < nb:
         ws = torch.zeros(nb, device=device, dtype=torch.uint8)
         if not torch.cuda.is_current_stream_capturing():     # (the warm-up steps before a capture run on the capture stream: kept)
+            if len(_k3_ws) >= 64:                            # bounded: a sweep over many shapes does not pile buffers up
+                _k3_ws.clear()
             _k3_ws[key] = ws
     return ws, nb
 
@@ -825,6 +842,7 @@ class _LinearSplit(torch.autograd.Function):
     @_fwd
     def forward(ctx, x, w, b):
         x2 = _f32c(x).view(-1, x.shape[-1])
+        ctx.mode = _GEMM_DTYPE                                                # the backward runs in the forward's mode, whatever is current then
         if _GEMM_DTYPE == "f32s" and x2.is_cuda and w.is_contiguous() and gemm_f32s_ok(x2.shape[0], w.shape[0], w.shape[1]):
             y = gemm_f32s(x2, w, b)                                           # bias in the GEMM's epilogue
         else:
@@ -840,16 +858,17 @@ class _LinearSplit(torch.autograd.Function):
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         dy2 = _f32c(dy).view(-1, w.shape[0])
-        dx = _mm(dy2, w).view(*dy.shape[:-1], w.shape[1]) if ctx.needs_input_grad[0] else None
+        mode = ctx.mode
+        dx = _mm(dy2, w, mode).view(*dy.shape[:-1], w.shape[1]) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             M, (N, K) = x2.shape[0], w.shape
-            if _GEMM_DTYPE == "f32s" and _WGRAD_KERNEL and wgrad_f32s_ok(M, N, K):
+            if mode == "f32s" and _WGRAD_KERNEL and wgrad_f32s_ok(M, N, K):
                 # dY^T X in the same split-precision arithmetic by the hand-written kernel that converts the fp32 rows on load:
                 # 132 us at [1024 x 16384] x [16384 x 1024] against 290 us for the fp32 library GEMM and 340 us for operand planes
                 # + the library's bf16 GEMM (tools/wgrad_time.py)
                 dw = wgrad_f32s(dy2, x2)[0]
-            elif _GEMM_DTYPE == "f32s" and N * K >= 2048 * 2048 and M % 16 == 0 and N % 4 == 0 and K % 4 == 0:
+            elif mode == "f32s" and N * K >= 2048 * 2048 and M % 16 == 0 and N % 4 == 0 and K % 4 == 0:
                 # a LARGE weight gradient (the 2048 x 2048 projections of the self-attention head: 69 GFLOP each, 0.49 ms as an
                 # fp32 GEMM) as a split-precision GEMM over the row contraction: both operands K-contiguous from the transposing
                 # split, as in the LSTM weight gradients
@@ -923,27 +942,28 @@ class _BiLSTMLayer(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, x, W_ih, bias, W_hh, bm=False):
+    def forward(ctx, x, W_ih, bias, W_hh, bm=False, mode=_AUTO):
         require_device(x, W_ih, bias, W_hh)
+        mode = ctx.mode = _GEMM_DTYPE if mode is _AUTO else mode      # kept for the backward (it used to read the global)
         x, W_ih, bias, W_hh = _f32c(x), _f32c(W_ih), _f32c(bias), _f32c(W_hh)
         (B, T, I) = x.shape if bm else (x.shape[1], x.shape[0], x.shape[2])
         h = W_hh.shape[2]
         if W_ih.shape != (8 * h, I) or W_hh.shape != (2, 4 * h, h) or bias.numel() != 8 * h:
             raise ValueError(f"bilstm: shape mismatch x{tuple(x.shape)} W_ih{tuple(W_ih.shape)} W_hh{tuple(W_hh.shape)}")
         ctx.Ws = None
-        if _GEMM_DTYPE is None:
+        if mode is None:
             Gx, kbias = torch.addmm(bias, x.view(T * B, I), W_ih.t()), None   # [rows,2,4h]; bias in the GEMM epilogue
-        elif _GEMM_DTYPE == "f32s" and (T * B) % 4 == 0 and I % 4 == 0 and h % 4 == 0:
+        elif mode == "f32s" and (T * B) % 4 == 0 and I % 4 == 0 and h % 4 == 0:
             ctx.Ws = split_bf16x3(W_ih, 1, True)                              # [8h, 3I] (hi, lo, hi): kept for the backward's dX
             Gx, kbias = torch.mm(split_bf16x3(x.view(T * B, I), 1, False), ctx.Ws.t(), out_dtype=torch.float32), bias
         else:
-            Gx, kbias = _mm(x.view(T * B, I), W_ih.t()), bias                 # bias added inside the recurrence kernel
+            Gx, kbias = _mm(x.view(T * B, I), W_ih.t(), mode), bias           # bias added inside the recurrence kernel
         out = torch.empty((B, T, 2 * h) if bm else (T, B, 2 * h), device=x.device, dtype=torch.float32)
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=torch.float32)
         Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
         sync = torch.empty(512, device=x.device, dtype=torch.int32)         # TSG_LSTM_SYNC_BYTES: persistent-kernel sync words
         # outside the strict-fp32 mode the recurrence's W_hh products are split-precision bf16 MFMAs as well (TSG_F32S)
-        ctx.rec_dtype = TSG_F32 if _GEMM_DTYPE is None else TSG_F32S
+        ctx.rec_dtype = TSG_F32 if mode is None else TSG_F32S
         check_lstm_errors()
         _call("tsg_lstm_fwd_bias", x, ptr(Gx), ptr(kbias) if kbias is not None else None, ptr(W_hh), ptr(out), ptr(R), ptr(Cs),
               ptr(sync), B, T, h, ctx.rec_dtype, int(bm))
@@ -974,8 +994,9 @@ class _BiLSTMLayer(torch.autograd.Function):
         _call("tsg_lstm_bwd_ws_layout", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC),
               ptr(ws) if ws is not None else None, nb, ptr(dbias) if fused_db else None, B, T, h, ctx.rec_dtype, int(bm))
         dGf = dG.view(TB, 8 * h)
-        fast = _GEMM_DTYPE == "f32s" and T > 1 and TB % 16 == 0 and h % 4 == 0 and I % 4 == 0
-        dx = _mm(dGf, W_ih).view(x.shape) if (ctx.needs_input_grad[0] and not fast) else None
+        mode = ctx.mode
+        fast = mode == "f32s" and T > 1 and TB % 16 == 0 and h % 4 == 0 and I % 4 == 0
+        dx = _mm(dGf, W_ih, mode).view(x.shape) if (ctx.needs_input_grad[0] and not fast) else None
         if dbias is None:
             dbias = dGf.sum(0)
         # dW_hh[d] = sum_t dG_t[d]^T h_{t-1}[d] (h_{t+1} for the reverse direction): in row terms the partner of row r is
@@ -983,7 +1004,7 @@ class _BiLSTMLayer(torch.autograd.Function):
         shift, period = (1, T) if bm else (B, 0)
         x2, o2 = x.view(TB, I), out.view(TB, 2 * h)
         if T == 1:
-            dW_ih = _mm(dGf.t(), x2)
+            dW_ih = _mm(dGf.t(), x2, mode)
             dW_hh = torch.zeros_like(W_hh)
         elif fast:
             # ONE batched GEMM over the two directions: D[d] = dG[d]^T [x | h_{t-+1}[d]] holds dW_ih[d] and dW_hh[d].  (Three
@@ -1009,15 +1030,15 @@ class _BiLSTMLayer(torch.autograd.Function):
             dW_hh = D[:, :, I:].contiguous()                                # cuts from them are taken over as they are (no clones)
         else:
             # the step whose partner is the zero state drops out, so both operands are plain strided VIEWS
-            dW_ih = _mm(dGf.t(), x2)
+            dW_ih = _mm(dGf.t(), x2, mode)
             if bm:
                 gf, hf = dG[:, 1:, 0].reshape(B * (T - 1), 4 * h), out[:, :-1, :h].reshape(B * (T - 1), h)
                 gr, hr = dG[:, :-1, 1].reshape(B * (T - 1), 4 * h), out[:, 1:, h:].reshape(B * (T - 1), h)
             else:
                 gf, hf = dG[1:, :, 0].reshape((T - 1) * B, 4 * h), out[:-1, :, :h].reshape((T - 1) * B, h)
                 gr, hr = dG[:-1, :, 1].reshape((T - 1) * B, 4 * h), out[1:, :, h:].reshape((T - 1) * B, h)
-            dW_hh = torch.stack([_mm(gf.t(), hf), _mm(gr.t(), hr)])
-        return dx, dW_ih, dbias, dW_hh, None
+            dW_hh = torch.stack([_mm(gf.t(), hf, mode), _mm(gr.t(), hr, mode)])
+        return dx, dW_ih, dbias, dW_hh, None, None
 
 
 def lstm_bf16_ok(T: int, h: int) -> bool:
@@ -1096,11 +1117,7 @@ def bilstm_layer(x, W_ih, bias, W_hh, batch_major=False):
         T, h = (x.shape[1] if batch_major else x.shape[0]), W_hh.shape[2]
         if batch_major and lstm_bf16_ok(T, h):
             return _BiLSTMLayerBf16.apply(x, W_ih, bias, W_hh)
-        global _GEMM_DTYPE
-        _GEMM_DTYPE = "f32s"                                   # forward of the fallback; its backward reads ctx, not the global
-        try:
-            out, Cs = _BiLSTMLayer.apply(x.float(), W_ih, bias, W_hh, batch_major)
-        finally:
-            _GEMM_DTYPE = "bf16"
+        # the fp32-storage layer in the f32s arithmetic: the mode is an ARGUMENT (saved in ctx for the backward), not a flip of the global
+        out, Cs = _BiLSTMLayer.apply(x.float(), W_ih, bias, W_hh, batch_major, "f32s")
         return out.to(_BF), Cs
     return _BiLSTMLayer.apply(x, W_ih, bias, W_hh, batch_major)

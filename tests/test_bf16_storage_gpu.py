@@ -162,8 +162,8 @@ def test_bilstm_bf16_storage(B, T, I, h, request):
     from shufflingvideosfortsg_amd import engine, functional as TF
     from shufflingvideosfortsg_amd.model.networks.RNN import BiLSTM
     from test_lstm_gpu import _params
-    engine.precision("bf16")
-    request.addfinalizer(lambda: engine.precision(None))
+    engine.set_precision("bf16")
+    request.addfinalizer(lambda: engine.set_precision(None))
     g = torch.Generator().manual_seed(11)
     p = {k: v.requires_grad_(True) for k, v in _params(I, h, 2, g).items()}
     x = _r(torch.randn(B, T, I, generator=g)).requires_grad_(True)
@@ -194,8 +194,8 @@ def test_bilstm_bf16_storage(B, T, I, h, request):
 def test_linear_bf16_storage(request):
     """functional.linear in the storage mode: bf16 in / out, fp32 weight and bias gradients."""
     from shufflingvideosfortsg_amd import engine, functional as TF
-    engine.precision("bf16")
-    request.addfinalizer(lambda: engine.precision(None))
+    engine.set_precision("bf16")
+    request.addfinalizer(lambda: engine.set_precision(None))
     g = torch.Generator().manual_seed(12)
     x = _r(torch.randn(6, 50, 96, generator=g)).requires_grad_(True)
     w = _r(torch.randn(64, 96, generator=g) / 10).requires_grad_(True)
@@ -286,8 +286,8 @@ def test_gmd_golden_in_bf16_storage_mode(golden, losses, request):
     from shufflingvideosfortsg_amd import engine
     from shufflingvideosfortsg_amd.model import GMD
     from test_models_gpu import _sets
-    engine.precision("bf16")
-    request.addfinalizer(lambda: engine.precision(None))
+    engine.set_precision("bf16")
+    request.addfinalizer(lambda: engine.set_precision(None))
     g = golden("gmd")
     m = GMD(*_sets(24, 8, 12, 16), logging.getLogger("t"), 0.0)
     m.load_state_dict(g.weights)

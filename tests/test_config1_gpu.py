@@ -122,7 +122,7 @@ def test_model_forward_config1_vs_oracle(kind):
         else:
             ref = O.baseline_forward(sd, cpu["video"][:NREF], cpu["query"][:NREF], cpu["video_mask"][:NREF])
     model = model.cuda().eval()
-    engine.precision(None)
+    engine.set_precision(None)
     fwd = model.eval_forward if kind == "gmd" else model
     with torch.no_grad():
         out = fwd(cpu["video"].cuda(), cpu["query"].cuda(), cpu["video_mask"].cuda(), cpu["query_mask"].cuda())

@@ -75,8 +75,8 @@ def test_k2_self_t512_vs_oracle(d, heads):
 def test_lstm_t512_vs_float64(mode, request):
     """one BiLSTM layer at (B=32, T=512, h=512), 512 sequential steps, vs a float64 recurrence."""
     from shufflingvideosfortsg_amd import engine, functional as TF
-    engine.precision(None if mode == "f32" else "f32s")
-    request.addfinalizer(lambda: engine.precision(None))
+    engine.set_precision(None if mode == "f32" else "f32s")
+    request.addfinalizer(lambda: engine.set_precision(None))
     B, T, h, I = 32, T4, 512, 256
     g = torch.Generator().manual_seed(12)
     x = torch.randn(B, T, I, generator=g) * 0.5
@@ -149,8 +149,8 @@ def test_lstm_256_rows_run_persistent_in_chunks(dt, bm):
 def test_gmd_config4_step_vs_oracle(request):
     """GMD train step at T=512, N=25, d=1024 (B=2 for the CPU oracle), split-precision mode, vs the oracle."""
     from shufflingvideosfortsg_amd import data, engine, functional as TF
-    engine.precision("f32s")
-    request.addfinalizer(lambda: engine.precision(None))
+    engine.set_precision("f32s")
+    request.addfinalizer(lambda: engine.set_precision(None))
     params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, dropout=0.0, video_len=T4, sent_len=N4)
     torch.manual_seed(0)
     model = engine.build_model("gmd", params)
@@ -179,8 +179,8 @@ def test_gmd_config4_full_batch_properties(request):
     """B=128 per GPU at T=512 (256 batched encoder rows, the chunked persistent LSTM): one full train step is finite, softmax
     rows sum to one, and duplicated items give bit-identical rows."""
     from shufflingvideosfortsg_amd import data, engine, functional as TF
-    engine.precision("f32s")
-    request.addfinalizer(lambda: engine.precision(None))
+    engine.set_precision("f32s")
+    request.addfinalizer(lambda: engine.set_precision(None))
     B = 128
     params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, dropout=0.0, video_len=T4, sent_len=N4)
     torch.manual_seed(0)

@@ -1,0 +1,165 @@
+"""BASELINE config 5 in ITS OWN dtype: ActivityNet-CD [B=128, T_clip=512, T_word=25, d=1024] **bf16** (cfgs/anet_cd_i3d.yml:17-25 give
+N = 25; the config pushes T to 512) -- the bf16 STORAGE mode (dtype TSG_BF16) at that length.  Round-3 review: the T=512 / N=25 shape
+was oracle-checked in `f32s` only (tests/test_config4_gpu.py); the bf16 LSTM at T=512, the K1g bf16 backward at N=25 / T=512 and the
+whole bf16 step at that length had a bench line but no parity or property test.
+
+Tolerances are the bf16-storage ones of tests/test_bf16_storage_gpu.py / test_fullsize_gpu.py[bf16-storage]: the kernels compute in
+fp32, every stored activation is rounded once to bf16 (2^-9 relative), the oracle is fed the same bf16-valued inputs."""
+import pytest
+import torch
+
+from oracle import tsg_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+T5, N5, D5 = 512, 25, 1024
+
+
+def _r(t):
+    return t.to(BF).float()
+
+
+def _close(got, want, name, rel=1e-2, tight=None):
+    rel = tight if tight is not None else rel
+    scale = max(1.0, float(want.abs().max()))
+    torch.testing.assert_close(got.float().cpu(), want, atol=rel * scale, rtol=rel, msg=lambda m: f"{name}: {m}")
+
+
+def test_k1g_bf16_storage_at_T512_N25():
+    """K1g forward + backward (tsg_scdm_gate_fwd / _bwd, TSG_BF16) at [2, 512, 25, 1024] vs the oracle's SCDM attention + gate tail
+    (attention.py:109-121, VideoEncoder.py:65-72) on the same bf16-valued inputs.  T=512 rows of P / de in LDS is the largest tile the
+    fused backward holds; the predicate (not a failing call) decides whether it runs natively."""
+    from shufflingvideosfortsg_amd import functional as F
+    B, T, N, d = 2, T5, N5, D5
+    g = torch.Generator().manual_seed(5)
+    a, s, VW, r = (_r(torch.randn(*sh, generator=g)).requires_grad_(True) for sh in ((B, T, d), (B, N, d), (B, N, d), (B, T, d)))
+    w = (torch.randn(d, generator=g) / d ** 0.5).requires_grad_(True)
+    gb = (torch.randn(d, generator=g) * 0.1).requires_grad_(True)
+    gout = _r(torch.randn(B, T, d, generator=g))
+    C, P = O.scdm_core(a, s, w, VW)                         # P @ VW  (VW = sent W_l^T: sent_linear reassociated onto the word rows)
+    out0 = r * torch.sigmoid(C + gb)
+    out0.backward(gout)
+    ad, sd_, vd, rd = (x.detach().to(BF).cuda().requires_grad_(True) for x in (a, s, VW, r))
+    wd, gbd = w.detach().cuda().requires_grad_(True), gb.detach().cuda().requires_grad_(True)
+    out1 = F.scdm_gate(ad, sd_, wd, vd, gbd, rd)
+    assert out1.dtype == BF
+    out1.backward(gout.to(BF).cuda())
+    torch.cuda.synchronize()
+    F.check_kernel_errors()
+    _close(out1.detach(), out0.detach(), "out")
+    for got, want, name in ((ad.grad, a.grad, "da"), (sd_.grad, s.grad, "ds"), (vd.grad, VW.grad, "dVW"), (rd.grad, r.grad, "dr")):
+        assert got.dtype == BF
+        _close(got, want, name)
+    _close(wd.grad, w.grad, "dw", tight=5e-3)
+    _close(gbd.grad, gb.grad, "dgbias", tight=5e-3)
+
+
+def test_bilstm_bf16_storage_at_T512(request):
+    """The 2-layer BiLSTM (RNN.py:26-48) in the bf16 storage mode at T = 512, h = 512 (config 5's encoder width) vs the oracle's fp32
+    recurrence on the same bf16-valued input.  512 steps of a recurrence that feeds its own bf16-rounded h back: outputs within 5e-2
+    abs (|h| <= 1), gradients within 8e-2 of their scale (T=128 in test_bf16_storage_gpu.py: 3e-2 / 5e-2)."""
+    from shufflingvideosfortsg_amd import engine, functional as TF
+    from shufflingvideosfortsg_amd.model.networks.RNN import BiLSTM
+    from test_lstm_gpu import _params
+    engine.set_precision("bf16")
+    request.addfinalizer(lambda: engine.set_precision(None))
+    B, T, I, h = 3, T5, 1024, 512
+    g = torch.Generator().manual_seed(13)
+    p = {k: v.requires_grad_(True) for k, v in _params(I, h, 2, g).items()}
+    x = _r(torch.randn(B, T, I, generator=g)).requires_grad_(True)
+    go = _r(torch.randn(B, T, 2 * h, generator=g))
+    out0, hn0, cn0 = O.bilstm(x, p, 2)
+    (out0 * go).sum().backward()
+    m = BiLSTM(I, h, 2, 0.0)
+    m.load_state_dict({k: v.detach() for k, v in p.items()})
+    m.cuda().train()
+    xd = x.detach().to(BF).cuda().requires_grad_(True)
+    assert TF.lstm_bf16_ok(T, h)
+    out1, hn1, cn1 = m(xd)
+    assert out1.dtype == BF
+    (out1.float() * go.cuda()).sum().backward()
+    torch.cuda.synchronize(); TF.check_lstm_errors()
+    torch.testing.assert_close(out1.float().cpu(), out0.detach(), atol=5e-2, rtol=5e-2)
+    torch.testing.assert_close(hn1.float().cpu(), hn0.detach(), atol=5e-2, rtol=5e-2)
+    _close(xd.grad, x.grad, "dx", rel=8e-2)
+    for k, v in m.named_parameters():
+        assert v.grad.dtype == torch.float32
+        _close(v.grad, p[k].grad, k, rel=8e-2)
+
+
+def _to_dev(cpu, bf16_video=True):
+    dev = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in cpu.items() if not isinstance(v, dict)}
+    if bf16_video:
+        dev["video"], dev["pseudo_video"] = dev["video"].to(BF), dev["pseudo_video"].to(BF)
+    for gt in ("gt", "pseudo_gt"):
+        dev[gt] = {k: (v.cuda() if isinstance(v, torch.Tensor) else torch.tensor(v, dtype=torch.long).cuda()) for k, v in cpu[gt].items()}
+    return dev
+
+
+def test_gmd_config5_bf16_step_vs_oracle(request):
+    """GMD train step (SpanGroundMatchDisc.py:60-100 + the four losses, train.py:142-165) at T=512, N=25, d=1024 in the bf16 storage
+    mode, B=2 for the CPU oracle: boundary scores / losses within the bf16 tolerance of test_fullsize_gpu.py[bf16-storage] (1e-2 abs,
+    2e-2 rel), parameter gradients within 5e-2 x scale (four times the sequence length of that test: its 3e-2 widened)."""
+    from shufflingvideosfortsg_amd import data, engine, functional as TF
+    engine.set_precision("bf16")
+    request.addfinalizer(lambda: engine.set_precision(None))
+    params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, dropout=0.0, video_len=T5, sent_len=N5)
+    torch.manual_seed(0)
+    model = engine.build_model("gmd", params)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    b = data.synthetic_batch(2, T5, N5, seed=19, pair=True)
+    b["video"], b["pseudo_video"] = _r(b["video"]), _r(b["pseudo_video"])          # the oracle sees the stored (bf16) clip features
+    g, pg = b["gt"], b["pseudo_gt"]
+    ref = O.gmd_forward(sd, b["query"], b["video"], b["video_mask"], b["pseudo_video"], b["video_mask"],
+                        g["temporal_labels"], g["fore_masks"], g["back_masks"], pg["temporal_labels"], pg["fore_masks"], pg["back_masks"])
+    ref_loss, _ = O.gmd_losses(ref, b["video_mask"], b["video_mask"], g, pg)
+    ref_loss.backward()
+    model = model.cuda().train()
+    model.tod.dropout.p = 0.0
+    d = _to_dev(b)
+    loss, _, span = engine.gmd_step(model, d, params)
+    loss.backward()
+    torch.cuda.synchronize(); TF.check_lstm_errors()
+    tol = dict(atol=1e-2, rtol=2e-2)
+    torch.testing.assert_close(span["start"].float().detach().cpu(), ref[0]["start"].detach(), **tol)
+    torch.testing.assert_close(span["end"].float().detach().cpu(), ref[0]["end"].detach(), **tol)
+    torch.testing.assert_close(loss.float().detach().cpu(), ref_loss.detach(), atol=5e-2, rtol=2e-2)
+    for k, p in model.named_parameters():
+        want = sd[k].grad
+        assert p.grad.dtype == torch.float32
+        torch.testing.assert_close(p.grad.cpu(), want, atol=5e-2 * max(1.0, float(want.abs().max())), rtol=2e-1, msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("B", [16, 128])
+def test_gmd_config5_bf16_properties(B, request):
+    """Config 5 at its full per-GPU batches -- B = 128 (the named batch on one GPU: 256 batched encoder rows, the chunked persistent
+    LSTM) and B = 16 (its 8-GPU shard) -- in the bf16 storage mode: one full train step is finite, the boundary softmax rows sum to
+    one (fp32 probabilities), a duplicated item gives bit-identical rows wherever it sits in the batch, every parameter gradient is
+    finite fp32, and a second identical step reproduces the loss bit for bit up to the float-atomic sums (1e-3 relative)."""
+    from shufflingvideosfortsg_amd import data, engine, functional as TF
+    engine.set_precision("bf16")
+    request.addfinalizer(lambda: engine.set_precision(None))
+    params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, dropout=0.0, video_len=T5, sent_len=N5)
+    torch.manual_seed(0)
+    model = engine.build_model("gmd", params).cuda().train()
+    model.tod.dropout.p = 0.0
+    d = data.synthetic_batch(B, T5, N5, seed=23, pair=True, device="cuda")
+    for k in ("video", "query", "video_mask", "pseudo_video"):
+        d[k][B - 1] = d[k][0]                               # item 0 again, in the LAST row
+    for gt in ("gt", "pseudo_gt"):
+        for k, v in d[gt].items():
+            v[B - 1] = v[0]
+    d["video"], d["pseudo_video"] = d["video"].to(BF), d["pseudo_video"].to(BF)
+    loss, _, span = engine.gmd_step(model, d, params)
+    loss.backward()
+    torch.cuda.synchronize(); TF.check_lstm_errors()
+    assert torch.isfinite(loss)
+    for p in (span["start"], span["end"]):
+        assert p.dtype == torch.float32
+        torch.testing.assert_close(p.sum(1), torch.ones(B, device="cuda"), atol=1e-4, rtol=0)
+        assert torch.equal(p[0], p[B - 1]), "batch items are not independent"
+    assert all(p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all() for p in model.parameters())
+    model.zero_grad(set_to_none=True)
+    loss2, _, _ = engine.gmd_step(model, d, params)
+    torch.cuda.synchronize(); TF.check_lstm_errors()
+    torch.testing.assert_close(loss2.detach(), loss.detach(), atol=0, rtol=1e-3)

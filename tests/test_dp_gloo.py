@@ -96,3 +96,87 @@ def test_shard_batch():
     assert sum(p["video"].shape[0] for p in parts) == 8
     assert torch.equal(torch.cat([p["video"] for p in parts]), b["video"])
     assert sum((p["gt"]["framestps"] for p in parts), []) == b["gt"]["framestps"]
+
+
+# ---- world 4: unequal gradient presence across ranks, and the rank-reduced optimizer guard (round-3 review item 9) ----
+class Branchy(nn.Module):
+    """A parameter (`only0`) that takes part in the loss on rank 0 only: every other rank leaves its .grad as None."""
+
+    def __init__(self):
+        super().__init__()
+        self.shared = nn.Linear(6, 4)
+        self.only0 = nn.Linear(4, 4)
+        self.never = nn.Linear(2, 2)
+
+    def forward(self, x, use_branch):
+        y = torch.tanh(self.shared(x))
+        if use_branch:
+            y = y + self.only0(y)
+        return y.pow(2).mean()
+
+
+def _worker4(rank, world, port, protocol, poison_rank, out):
+    import copy
+    from shufflingvideosfortsg_amd import engine
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7)
+    model = Branchy()
+    dp = FlatGradAllReduce(model, bucket_mb=0.0001, overlap=(protocol == "overlap"))
+    opt = torch.optim.Adam(model.parameters(), lr=0.1)          # host optimizer: engine.optimizer_step reads the reduced flag on the host
+    before = copy.deepcopy(model.state_dict())
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(8, 6, generator=g)[2 * rank:2 * rank + 2]
+    dp.zero_grad()
+    loss = model(x, use_branch=(rank == 0))
+    loss.backward()
+    if rank == poison_rank:
+        loss = loss * float("nan")                                # this rank's step went wrong (what an expired wait leaves behind)
+    guard = engine.step_guard(loss)
+    if protocol == "static":
+        grads = [p.grad for p in dp.params]
+        dp.exchange_static(grads, guard)
+    else:
+        dp.finish(guard=guard)
+    flag = float(dp.guard.item())
+    engine.optimizer_step(opt, loss, dp=dp, guard=guard)
+    moved = any(not torch.equal(before[k], v) for k, v in model.state_dict().items())
+    out.put((rank, {k: p.grad.numpy().copy() for k, p in model.named_parameters()}, flag, moved))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("protocol", ["after", "overlap", "static"])
+@pytest.mark.parametrize("poison_rank", [None, 2])
+def test_world4_unequal_gradient_presence_and_reduced_guard(protocol, poison_rank):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    world = 4
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, protocol, poison_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get() for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # reference: the mean over the four ranks' local gradients, a missing gradient counting as zeros
+    torch.manual_seed(7)
+    ref = Branchy()
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(8, 6, generator=g)
+    acc = {k: torch.zeros_like(p) for k, p in ref.named_parameters()}
+    for r in range(world):
+        ref.zero_grad()
+        ref(X[2 * r:2 * r + 2], use_branch=(r == 0)).backward()
+        for k, p in ref.named_parameters():
+            if p.grad is not None:
+                acc[k] += p.grad / world
+    assert acc["only0.weight"].abs().max() > 0
+    for rank, grads, flag, moved in got:
+        for k, want in acc.items():
+            torch.testing.assert_close(torch.from_numpy(grads[k]), want, atol=1e-6, rtol=1e-5, msg=lambda m, k=k, r=rank: f"rank {r} {k}: {m}")
+        # the guard: set on one rank -> seen by ALL ranks, and ALL of them skip the update (replicas stay identical)
+        assert (flag != 0.0) == (poison_rank is not None), (rank, flag)
+        assert moved == (poison_rank is None), (rank, moved)

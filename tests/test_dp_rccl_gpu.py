@@ -37,8 +37,9 @@ with engine.precision("f32s"):
         dp.zero_grad()
         loss, _, _ = engine.gmd_step(model, batch, params)
         loss.backward()
-        dp.finish()
-        engine.optimizer_step(opt, loss)
+        g = engine.step_guard(loss)
+        dp.finish(guard=g)
+        engine.optimizer_step(opt, loss, dp=dp, guard=g)
         losses.append(float(loss))
 torch.cuda.synchronize()
 TF.check_lstm_errors()

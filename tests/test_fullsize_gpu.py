@@ -45,7 +45,7 @@ def test_full_size_gmd_step_vs_oracle(gemm, request):
     mode = "bf16" if storage else (torch.bfloat16 if bf16 else gemm)
     tol = BF16_TOL if bf16 else TOL
     precision = lambda: engine.precision(mode)
-    request.addfinalizer(lambda: engine.precision(None))
+    request.addfinalizer(lambda: engine.set_precision(None))
     B, T, N = 64, 128, 20
     params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, dropout=0.0, video_len=T, sent_len=N)
     torch.manual_seed(0)

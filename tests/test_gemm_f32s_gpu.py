@@ -39,8 +39,8 @@ def test_linear_f32s_uses_the_kernel_and_matches_fp32(request):
     """functional.linear in the "f32s" mode at a shape the kernel takes (25 600 rows: 100 tiles): forward and all three gradients
     against torch.nn.functional.linear in fp32 at the fp32 tolerance of the mode."""
     from shufflingvideosfortsg_amd import engine, functional as F
-    engine.precision("f32s")
-    request.addfinalizer(lambda: engine.precision(None))
+    engine.set_precision("f32s")
+    request.addfinalizer(lambda: engine.set_precision(None))
     g = torch.Generator().manual_seed(5)
     x = torch.randn(100, 256, 512, generator=g).cuda().requires_grad_(True)
     w = (torch.randn(256, 512, generator=g) / 512 ** 0.5).cuda().requires_grad_(True)

@@ -1,0 +1,124 @@
+"""ISA gate (CPU suite): the cross-workgroup publications of the shipped gfx950 code objects wait for their stores.
+
+Round-3 review: `scdm_bwd_fused_kernel`'s partner exchange (csrc/scdm_attn.hip `publish_dp`; the gradient of the reference's
+`SCDM_Attention.forward`, networks/attention.py:109-121) stored its partial dP rows with agent-scope stores and then bumped the item's
+counter after a workgroup barrier -- but on gfx950 the barrier's fence is `s_waitcnt lgkmcnt(0)` only, so the shipped ISA was
+`global_store_dword ... sc1 ; s_barrier ; global_atomic_add` with no `vmcnt(0)`: a partner could count the part in and read rows that
+had not reached L2.  The fix is an explicit `s_waitcnt vmcnt(0)` in every thread before the barrier.  This test disassembles the
+code objects inside the built `libtsg_hip.so` and asserts, for every instantiation of the kernels that publish through
+"stores -> barrier -> counter atomic", that a `vmcnt(0)` wait sits between the last agent-scope store and the barrier in front of the
+counter's atomic.  No GPU needed (hipcc cross-compiles; llvm-objdump reads the bundle).
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "shufflingvideosfortsg_amd", "libtsg_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+# kernels whose cross-workgroup protocol is "agent-scope stores, workgroup barrier, one integer atomic on a counter"
+PUBLISHERS = ("scdm_bwd_fused_kernel", "boundary_bwd_one_kernel")
+
+
+def _disassemble(tmp_path):
+    """-> {mangled kernel name: [instruction text, ...]} for every gfx950 bundle in the shipped library."""
+    if not os.path.exists(LIB):
+        from shufflingvideosfortsg_amd import build
+        build.build()
+    work = tmp_path / "isa"
+    work.mkdir()
+    so = work / "lib.so"
+    shutil.copy(LIB, so)
+    subprocess.run([OBJDUMP, "--offloading", str(so)], check=True, capture_output=True, cwd=work)   # writes the bundles beside the copy
+    kernels = {}
+    for f in sorted(os.listdir(work)):
+        if "gfx950" not in f:
+            continue
+        want = subprocess.run(["grep", "-c", "-a", "-E", "|".join(PUBLISHERS), str(work / f)], capture_output=True, text=True)
+        if want.stdout.strip() in ("", "0"):
+            continue                                     # bundle without a publishing kernel: skip the (slow) disassembly
+        txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", str(work / f)], check=True, capture_output=True, text=True).stdout
+        cur = None
+        for line in txt.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                cur = m.group(1)
+                kernels[cur] = []
+            elif cur is not None and line.startswith("\t"):
+                kernels[cur].append(line.split("//")[0].strip())
+    return kernels
+
+
+def _counter_atomics(ins):
+    """Indices of integer global atomics (the counters / tickets); float atomics (dw, dbias sums) are not publications."""
+    return [i for i, t in enumerate(ins) if re.match(r"global_atomic_(add|inc|or)(_u32|_x2)?\s", t) and "_f32" not in t]
+
+
+def _check_kernel(name, ins):
+    """Every agent-scope (sc1, not the system-scope `sc0 sc1` error sink) store that precedes a counter atomic must be followed by a
+    `s_waitcnt` containing vmcnt(0) before the next s_barrier.  Returns the number of publication sites verified."""
+    sites = 0
+    atomics = _counter_atomics(ins)
+    assert atomics, f"{name}: no counter atomic found -- the protocol changed, update this gate"
+    stores = [i for i, t in enumerate(ins) if t.startswith("global_store") and re.search(r"\bsc1\b", t) and not re.search(r"\bsc0\b", t)]
+    for a in atomics:
+        before = [i for i in stores if i < a]
+        if not before:
+            continue
+        last = before[-1]
+        barrier = next((i for i in range(last, a) if ins[i].startswith("s_barrier")), None)
+        if barrier is None:
+            continue                                     # this atomic is not a publication of those stores (no barrier between them)
+        waits = [i for i in range(last + 1, barrier) if ins[i].startswith("s_waitcnt") and "vmcnt(0)" in ins[i]]
+        assert waits, (f"{name}: agent-scope store at instruction {last} is followed by s_barrier ({barrier}) and the counter atomic "
+                       f"({a}) with no s_waitcnt vmcnt(0) in between:\n  " + "\n  ".join(ins[last:barrier + 1][-12:]))
+        sites += 1
+    return sites
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    return _disassemble(tmp_path_factory.mktemp("isa"))
+
+
+def test_k1_backward_publication_waits_for_its_stores(kernels):
+    names = [k for k in kernels if "scdm_bwd_fused_kernel" in k]
+    assert len(names) >= 16, f"expected every (NP, GATE, MROW, storage) instantiation, found {len(names)}"
+    total = 0
+    for k in names:
+        n = _check_kernel(k, kernels[k])
+        assert n >= 1, f"{k}: no publication site recognised (stores -> barrier -> counter atomic)"
+        total += n
+    assert total >= len(names)
+
+
+def test_k3_one_launch_backward_publication_waits_for_its_stores(kernels):
+    names = [k for k in kernels if "boundary_bwd_one_kernel" in k]
+    assert names
+    for k in names:
+        ins = kernels[k]
+        # K3's ticket: plain partial-row stores (write-through is not needed: the explicit wait + the loads' sc1 do the work)
+        atomics = _counter_atomics(ins)
+        assert atomics, k
+        a = atomics[0]
+        barrier = max(i for i in range(a) if ins[i].startswith("s_barrier"))
+        stores = [i for i in range(barrier) if ins[i].startswith("global_store")]
+        assert stores
+        last = stores[-1]
+        assert any(ins[i].startswith("s_waitcnt") and "vmcnt(0)" in ins[i] for i in range(last + 1, barrier)), k
+
+
+def test_gate_detects_the_round3_sequence():
+    """The checker itself: the sequence the round-3 library shipped must fail, the fixed one must pass."""
+    bad = ["global_store_dword v[34:35], v38, off sc1", "s_waitcnt lgkmcnt(0)", "s_barrier", "global_atomic_add v34, v35, s[4:5]"]
+    good = ["global_store_dword v[34:35], v38, off sc1", "s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_barrier",
+            "global_atomic_add v34, v35, s[4:5]"]
+    with pytest.raises(AssertionError):
+        _check_kernel("bad", bad)
+    assert _check_kernel("good", good) == 1

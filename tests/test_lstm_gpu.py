@@ -35,8 +35,8 @@ def test_bilstm_parity(B, T, I, h, gemm, request):
     GEMMs in the split-precision mode, at the same tolerances."""
     from shufflingvideosfortsg_amd import engine
     from shufflingvideosfortsg_amd.model.networks.RNN import BiLSTM
-    engine.precision(gemm)
-    request.addfinalizer(lambda: engine.precision(None))
+    engine.set_precision(gemm)
+    request.addfinalizer(lambda: engine.set_precision(None))
     g = torch.Generator().manual_seed(9)
     p = {k: v.requires_grad_(True) for k, v in _params(I, h, 2, g).items()}
     x = torch.randn(B, T, I, generator=g, requires_grad=True)

@@ -142,8 +142,8 @@ def test_baseline_golden(golden, tag, gemm, request):
     gradient equal to the reference's -- in the strict-fp32 and in the split-precision GEMM mode, same tolerances."""
     from shufflingvideosfortsg_amd import engine
     from shufflingvideosfortsg_amd import loss as L
-    engine.precision(gemm)
-    request.addfinalizer(lambda: engine.precision(None))
+    engine.set_precision(gemm)
+    request.addfinalizer(lambda: engine.set_precision(None))
     from shufflingvideosfortsg_amd.model import Baseline
     g = golden("baseline_" + tag)
     m = Baseline(*_sets(24, 8, 12, 16, tag == "mask"), LOG, 0.0)
@@ -168,8 +168,8 @@ def test_gmd_golden(golden, gemm, losses, request):
     LSTM GEMMs in split-precision mode ("f32s"), which must meet the SAME fp32 tolerances.  losses: the collate's lists of
     frame stamps select the torch formulation of the four losses, resident index tensors the fused kernel K4."""
     from shufflingvideosfortsg_amd import engine
-    engine.precision(gemm)
-    request.addfinalizer(lambda: engine.precision(None))
+    engine.set_precision(gemm)
+    request.addfinalizer(lambda: engine.set_precision(None))
     from shufflingvideosfortsg_amd.model import GMD
     g = golden("gmd")
     m = GMD(*_sets(24, 8, 12, 16), LOG, 0.0)
@@ -266,7 +266,7 @@ def test_bf16_gemm_mode_tracks_fp32(golden):
             loss = L.span_ground_loss(out["start"], out["end"], g.a["framestps"])
         loss.backward()
     finally:
-        engine.precision(None)
+        engine.set_precision(None)
     assert out["start"].dtype == torch.float32
     torch.testing.assert_close(out["start"].detach().cpu(), g.t("start"), atol=2e-2, rtol=5e-2)
     torch.testing.assert_close(loss.detach().cpu(), g.t("loss"), atol=5e-2, rtol=5e-2)
@@ -279,8 +279,8 @@ def test_gmd_large_config_vs_oracle(gemm, request):
     instantiation, d=1024), batch reduced for the CPU oracle: full GMD step, default init, vs the oracle
     (fp32 GEMMs and the split-precision "f32s" GEMM mode, same tolerances)."""
     from shufflingvideosfortsg_amd import data, engine
-    engine.precision(gemm)
-    request.addfinalizer(lambda: engine.precision(None))
+    engine.set_precision(gemm)
+    request.addfinalizer(lambda: engine.set_precision(None))
     params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, dropout=0.0, video_len=256, sent_len=25)
     torch.manual_seed(0)
     model = engine.build_model("gmd", params)
@@ -342,7 +342,7 @@ def test_graphed_train_step_matches_eager():
     batch = data.synthetic_batch(32, 32, 15, video_dim=256, seed=3, pair=True, device="cuda")
     other = data.synthetic_batch(32, 32, 15, video_dim=256, seed=4, pair=True, device="cuda")
     step_fn = lambda m, b: engine.gmd_step(m, b, params)[0]
-    engine.precision("f32s")
+    engine.set_precision("f32s")
     try:
         m, opt = build()
         eager = []
@@ -372,7 +372,7 @@ def test_graphed_train_step_matches_eager():
         torch.cuda.synchronize()
         TF.check_lstm_errors()
     finally:
-        engine.precision(None)
+        engine.set_precision(None)
     for a, b in zip(got, eager):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (got, eager)
     assert abs(got[3] - eager[3]) <= 1e-4 * max(1.0, abs(eager[3]))

@@ -117,8 +117,8 @@ def test_scdm_split_precision_forward(shape, request):
     workgroups; 8 + 8 waves with N <= 16 (one 32x32x16 k step) and 16 < N <= 24 (+ one 32x32x8 step), 4 + 4 waves for N <= 8 and
     N > 24 (two 32x32x16 steps)) vs the oracle at the UNCHANGED fp32 tolerance, gate-fused and plain; the backward is the fp32 kernel."""
     from shufflingvideosfortsg_amd import engine, functional as F
-    engine.precision("f32s")
-    request.addfinalizer(lambda: engine.precision(None))
+    engine.set_precision("f32s")
+    request.addfinalizer(lambda: engine.set_precision(None))
     lin = torch.nn.functional.linear
     B, T, N, d = shape
     g = torch.Generator().manual_seed(14)
@@ -145,7 +145,7 @@ def test_scdm_split_precision_forward(shape, request):
         atol = 3e-4 * max(1.0, float(want.abs().max()))
         torch.testing.assert_close(got.grad.cpu(), want, atol=atol, rtol=2e-3, msg=lambda m, n=name: f"d{n}: {m}")
     # the matrix-pipe forward against the VALU forward on the same operands: the split-precision product is at fp32-GEMM level
-    engine.precision(None)
+    engine.set_precision(None)
     out2 = F.scdm_gate(a.detach(), s.detach(), pd["w"].detach(), lin(wd, pd["Wl"]).detach(), pd["bl"].detach(), rd.detach())
     torch.testing.assert_close(out1.detach(), out2, atol=2e-5, rtol=2e-5)
 
@@ -222,42 +222,79 @@ def test_scdm_ws_forward_random_shape_sweep():
         torch.testing.assert_close(p2, pb, atol=1e-5, rtol=1e-4, msg=lambda m: f"{tag} bf16 P: {m}")
 
 
-@pytest.mark.parametrize("B,gate", [(4, True), (24, True), (9, False)])
-def test_scdm_bwd_exchange_is_reproducible(B, gate):
-    """The fused backward at small B cuts an item's columns into up to 16 parts that publish partial dP rows (agent-scope stores, one
-    counter per item, no release fence) and sum them in part order: 60 launches on the same operands, the direct outputs (da, ds, dVW /
-    dsent, dr) bit-identical from launch to launch -- a partial row read before it was visible would show up as a different bit pattern."""
-    from shufflingvideosfortsg_amd import _lib
+def _k1_bwd_exchange_run(lib, B, gate, launches, T=128, N=20, d=1024, dirty_every=0):
+    """The fused K1 / K1g backward with its partner exchange under the conditions that can expose a publication race (round-3 review):
+    the exchange workspace is POISONED with NaN before every launch (a partial row read before its store was visible is then a NaN, not
+    the bit-identical stale row of the previous launch), two operand sets ALTERNATE (a stale row of the previous launch belongs to the
+    other set), and the reference is the two-kernel path (tsg_scdm_bwd_mode(1): no cross-workgroup exchange at all) on the same
+    operands -- the first fused launch of each set must agree with it, every later launch must be bit-identical to the first.
+    -> number of launches checked."""
     from shufflingvideosfortsg_amd._lib import ptr, TSG_F32
-    lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
-    T, N, d = 128, 20, 1024
-    g = torch.Generator().manual_seed(77)
-    A = torch.randn(B, T, d, generator=g).cuda(); S = torch.randn(B, N, d, generator=g).cuda(); w = (torch.randn(d, generator=g) / d ** 0.5).cuda()
-    VW = torch.randn(B, N, d, generator=g).cuda(); gb = (torch.randn(d, generator=g) * 0.1).cuda(); r = torch.randn(B, T, d, generator=g).cuda()
-    dout = torch.randn(B, T, d, generator=g).cuda()
-    out = torch.empty_like(A); P = torch.empty(B, T, N, device="cuda")
-    if gate:
-        assert lib.tsg_scdm_gate_fwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(gb), ptr(r), ptr(out), ptr(P), B, T, N, d, d, TSG_F32, st) == 0
-    else:
-        assert lib.tsg_scdm_attn_fwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(out), ptr(P), B, T, N, d, d, TSG_F32, st) == 0
+    st = torch.cuda.current_stream().cuda_stream
     nb = int(lib.tsg_scdm_bwd_ws_bytes(B, T, N, d, d, int(gate)))
-    first = None
-    for it in range(60):
-        da, ds, dw, dvw = torch.empty_like(A), torch.empty_like(S), torch.empty_like(w), torch.empty_like(VW)
-        dgb, dr = torch.empty_like(gb), torch.empty_like(r)
-        ws = torch.empty(nb // 4 + 4, device="cuda")
+    sets = []
+    for seed in (77, 78):
+        g = torch.Generator().manual_seed(seed + B)
+        A = torch.randn(B, T, d, generator=g).cuda(); S = torch.randn(B, N, d, generator=g).cuda(); w = (torch.randn(d, generator=g) / d ** 0.5).cuda()
+        VW = torch.randn(B, N, d, generator=g).cuda(); gb = (torch.randn(d, generator=g) * 0.1).cuda(); r = torch.randn(B, T, d, generator=g).cuda()
+        dout = torch.randn(B, T, d, generator=g).cuda()
+        out = torch.empty_like(A); P = torch.empty(B, T, N, device="cuda")
         if gate:
-            rc = lib.tsg_scdm_gate_bwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(gb), ptr(r), ptr(P), ptr(dout), ptr(da), ptr(ds), ptr(dw), ptr(dvw),
-                                       ptr(dgb), ptr(dr), ptr(ws), nb, B, T, N, d, d, TSG_F32, st)
+            assert lib.tsg_scdm_gate_fwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(gb), ptr(r), ptr(out), ptr(P), B, T, N, d, d, TSG_F32, st) == 0
         else:
-            rc = lib.tsg_scdm_attn_bwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(P), ptr(dout), ptr(da), ptr(ds), ptr(dw), ptr(dvw), ptr(ws), nb,
-                                       B, T, N, d, d, TSG_F32, st)
+            assert lib.tsg_scdm_attn_fwd(ptr(A), ptr(S), ptr(w), ptr(VW), ptr(out), ptr(P), B, T, N, d, d, TSG_F32, st) == 0
+        sets.append(dict(A=A, S=S, w=w, VW=VW, gb=gb, r=r, dout=dout, P=P))
+
+    ws = torch.empty(nb // 4 + 4, device="cuda")
+
+    def launch(o):
+        da, ds, dw, dvw = torch.empty_like(o["A"]), torch.empty_like(o["S"]), torch.empty_like(o["w"]), torch.empty_like(o["VW"])
+        dgb, dr = torch.empty_like(o["gb"]), torch.empty_like(o["r"])
+        ws.fill_(float("nan"))                                       # poison: counters included (the launch zeroes its counters itself)
+        if gate:
+            rc = lib.tsg_scdm_gate_bwd(ptr(o["A"]), ptr(o["S"]), ptr(o["w"]), ptr(o["VW"]), ptr(o["gb"]), ptr(o["r"]), ptr(o["P"]), ptr(o["dout"]),
+                                       ptr(da), ptr(ds), ptr(dw), ptr(dvw), ptr(dgb), ptr(dr), ptr(ws), nb, B, T, N, d, d, TSG_F32, st)
+        else:
+            rc = lib.tsg_scdm_attn_bwd(ptr(o["A"]), ptr(o["S"]), ptr(o["w"]), ptr(o["VW"]), ptr(o["P"]), ptr(o["dout"]), ptr(da), ptr(ds), ptr(dw),
+                                       ptr(dvw), ptr(ws), nb, B, T, N, d, d, TSG_F32, st)
         assert rc == 0, lib.tsg_last_error()
-        cur = (da, ds, dvw) + ((dr,) if gate else ())
-        if first is None:
+        return (da, ds, dvw) + ((dr,) if gate else ())
+
+    prev = lib.tsg_scdm_bwd_mode(1)                                  # reference: the two-kernel path (no exchange)
+    try:
+        refs = [launch(o) for o in sets]
+        torch.cuda.synchronize()
+    finally:
+        lib.tsg_scdm_bwd_mode(prev)
+    assert lib.tsg_scdm_bwd_fused_ok(B, T, N, d, d) == 1, "the shape must run the one-launch kernel for this test to mean anything"
+    big = torch.empty(256 << 20, device="cuda", dtype=torch.uint8) if dirty_every else None
+    first = [None, None]
+    for it in range(launches):
+        k = it & 1
+        if dirty_every and it % dirty_every == 0:
+            big.fill_(it & 255)                                      # evict L2 / the Infinity Cache between some launches
+        cur = launch(sets[k])
+        if first[k] is None:
             torch.cuda.synchronize()
-            first = cur
-            assert all(bool(torch.isfinite(x).all()) for x in cur)
+            first[k] = cur
+            for x, y in zip(cur, refs[k]):
+                assert bool(torch.isfinite(x).all())
+                scale = float(y.abs().max())
+                torch.testing.assert_close(x, y, atol=2e-5 * max(1.0, scale), rtol=2e-4)
         else:
-            for a0, a1 in zip(first, cur):
-                assert torch.equal(a0, a1), f"launch {it} differs"
+            for a0, a1 in zip(first[k], cur):
+                assert torch.equal(a0, a1), f"launch {it} (operand set {k}) differs from that set's first launch"
+    torch.cuda.synchronize()
+    return launches
+
+
+@pytest.mark.parametrize("B,gate", [(4, True), (24, True), (9, False), (128, True)])
+def test_scdm_bwd_exchange_is_reproducible(B, gate):
+    """The fused backward at small B cuts an item's columns into up to 16 parts that publish partial dP rows (agent-scope stores, an
+    explicit vmcnt(0) wait in every thread, the workgroup barrier, one relaxed counter per item -- no release fence) and sum them in part
+    order.  80 launches per shape with a NaN-poisoned exchange workspace and two alternating operand sets: first launch of each set
+    against the two-kernel path, all later ones bit-identical (see _k1_bwd_exchange_run; tools/k1_bwd_stress.py runs 2 000+ launches
+    per batch size, and tests/test_isa_cpu.py gates the vmcnt(0) wait in the shipped ISA)."""
+    from shufflingvideosfortsg_amd import _lib
+    lib = _lib.load()
+    assert _k1_bwd_exchange_run(lib, B, gate, 80, dirty_every=16) == 80

@@ -30,7 +30,7 @@ for name, mode in [("f32", None), ("f32+1ulp", None), ("f32s", "f32s"), ("bf16",
             loss, _, _ = engine.gmd_step(model, batches[it % 4], params)
         loss.backward(); dp.finish(); opt.step()
         losses.append(float(loss))
-    engine.precision(None)
+    engine.set_precision(None)
     curves[name] = losses
 ref = curves["f32"]
 for name in ("f32+1ulp", "f32s", "bf16"):
