@@ -279,6 +279,16 @@ int tsg_match_head_fwd(const void* y, const void* cs, const void* w2, const void
 int tsg_match_head_bwd(const void* y, const void* cs, const void* w2, const void* dlogits, void* dy, void* dcs,
                        void* dw2, void* db2, int B, int T, int H, int activation, int dtype, void* stream);
 
+/* ---- MomentPooling's masked means (temporal-order discriminator of the GMD, components/TemporalOrderDiscriminator.py:29-46;
+ * ABI revision 5): pooled[b,k,:] = sum_t m_k[b,t] feat[b,t,:] / (sum_t m_k[b,t] + 1e-6) for the target / fore / back clip ranges
+ * (k = 0, 1, 2) in ONE pass over feat [B,T,D]; masks float [B,T]; pooled fp32 [B,3,D].  The backward writes dfeat [B,T,D] from
+ * dpooled [B,3,D] (the masks are labels: no gradient).  D % 4 == 0.  dtype TSG_F32, or TSG_BF16 = feat / dfeat stored as bf16.
+ * Sums in a fixed order: run-to-run identical.                                                                              */
+int tsg_moment_pool_fwd(const void* feat, const void* m_target, const void* m_fore, const void* m_back, void* pooled,
+                        int B, int T, int D, int dtype, void* stream);
+int tsg_moment_pool_bwd(const void* dpooled, const void* m_target, const void* m_fore, const void* m_back, void* dfeat,
+                        int B, int T, int D, int dtype, void* stream);
+
 /* ---- dense projection GEMM on the fp32 matrix cores ("tsg_gemm_*" of SURVEY section 8b) ------------------------------
  * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL): torch.nn.Linear's layout, i.e. the d x d projections of the path
  * (SCDM W_a / W_s attention.py:104-106, sent_linear VideoEncoder.py:48, MultiHead wq/wk/wv/wo attention.py:63-66, the
@@ -291,6 +301,35 @@ int tsg_linear_fwd(const void* x, const void* w, const void* bias, void* y, int 
  * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL).  M % 256 == 0, N % 256 == 0, K % 32 == 0 (TSG_E_SHAPE otherwise).  The input
  * gradient dX = dY W of the same Linears is this call with the weight passed transposed ([K,N] contiguous).                       */
 int tsg_gemm_f32s(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, void* stream);
+/* The same with row strides (in elements, multiples of 4) for x, w and y: a column slice of a row-major matrix is an operand as it
+ * stands (ABI revision 5) -- the video half W[:, :Dv] of a head's [H, Dv + Ds] first Linear, or a slice of a wider output.        */
+int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, long long ldw, const void* bias, void* y, long long ldy,
+                     int M, int N, int K, void* stream);
+
+/* ---- the heads as the EPILOGUE of their own first-Linear GEMM (ABI revision 5; round-3 review: SURVEY 8f #2 "split-W Linear + ReLU
+ * + dot epilogue").  Same f32s arithmetic and tiling as tsg_gemm_f32s (row tiles of 256 / 128 / 64 so that a narrow head still
+ * covers the chip); the accumulator tile goes through the head's tail in registers and only [rows]-sized logits leave the kernel.
+ * Rows are (b, t) pairs: M = B*T, row = b*T + t.  `y` [M,N] (the pre-activation GEMM output the backward kernels
+ * tsg_match_head_bwd / tsg_boundary_score_bwd_ws read) is written only when non-NULL: under no_grad it never exists.
+ * ws: caller-owned workspace of tsg_head_gemm_ws_bytes(M, N, heads) bytes (tickets + per-tile partial rows of a head wider than one
+ * 256-column tile), contents irrelevant (the call zeroes its tickets).  Sums are formed in a fixed order: run-to-run identical.
+ *
+ * tsg_match_head_gemm (K5; VideoTextSemanticMatch, components/DistributionAlign.py:83-118):
+ *   logits[row] = w2 . act(x[row,:] @ w^T + cs[b,:]) + b2      x [M,K] (ldx), w [N,K] (ldw: the slice W1[:, :Dv]), cs [B,N] = q @ W1[:, Dv:]^T
+ *   + b1, w2 [N], b2 [1]; activation 0 relu / 1 tanh / 2 sigmoid.  M % 64 == 0, N % 256 == 0, K % 32 == 0.
+ * tsg_boundary_head_gemm (K3; VideoSentenceConcat + MLP_predictor, CrossModalInteraction.py:44-47, SpanPredictor.py:71-85, gate
+ *   SpanGroundMatchDisc.py:86): the start and the end head's first Linears are read in place as two row segments (w_start, w_end:
+ *   [Hm,K] slices with row stride ldw); cs [B,2Hm], b1 / w2 [2Hm], b2 [2], gate [B,T] or NULL, mask int32 [B,T] or NULL:
+ *   z = gate (x @ w^T + cs) + b1;  l = w2 . tanh(z) + b2 per head;  mask_logits;  p_start, p_end = softmax over T (the second,
+ *   [B,T]-sized kernel of tsg_boundary_score_fwd).  Hm % 256 == 0, (B*T) % 64 == 0, K % 32 == 0, T <= 8192.                     */
+long long tsg_head_gemm_ws_bytes(int M, int N, int heads);
+int tsg_match_head_gemm(const void* x, long long ldx, const void* w, long long ldw, const void* cs, const void* w2, const void* b2,
+                        void* y, void* logits, void* ws, long long ws_bytes, int M, int T, int N, int K, int activation, void* stream);
+int tsg_boundary_head_gemm(const void* x, long long ldx, const void* w_start, const void* w_end, long long ldw, const void* cs,
+                           const void* b1, const void* w2, const void* b2, const void* gate, const int32_t* mask, void* y,
+                           void* p_start, void* p_end, void* ws, long long ws_bytes, int B, int T, int Hm, int K, void* stream);
+/* softmax over T of two [B,T] logit tensors, in place (the second kernel of tsg_boundary_score_fwd, exported for the fused head) */
+int tsg_boundary_softmax(void* p_start, void* p_end, int B, int T, void* stream);
 
 /* ---- split-precision operand preparation (optional "f32s" GEMM mode) ------------------------------------------------
  * Not a reference function: the reference's Linears / LSTM input GEMMs (torch.nn.Linear, nn.LSTM; e.g.

@@ -473,6 +473,15 @@ extern "C" int tsg_boundary_score_fwd(const void* y, const void* cs, const void*
   return check_launch(fn);
 }
 
+extern "C" int tsg_boundary_softmax(void* p_start, void* p_end, int B, int T, void* stream) {
+  const char* fn = "tsg_boundary_softmax";
+  if (!p_start || !p_end) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+  if (B <= 0 || T <= 0 || T > 8192) return set_error(TSG_E_SHAPE, "%s: bad B=%d T=%d", fn, B, T);
+  const size_t lds = sizeof(float) * (2 * (size_t)T + 2 * kWaves);
+  hipLaunchKernelGGL(boundary_softmax_kernel, dim3(B), dim3(kThreads), lds, static_cast<hipStream_t>(stream), (float*)p_start, (float*)p_end, T);
+  return check_launch(fn);
+}
+
 extern "C" int tsg_boundary_score_bwd(const void* y, const void* cs, const void* b1, const void* w2, const void* gate,
                                       const int32_t* mask, const void* p_start, const void* p_end,
                                       const void* dp_start, const void* dp_end, void* dy, void* dcs, void* db1_part,

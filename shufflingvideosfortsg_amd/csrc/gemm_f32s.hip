@@ -31,6 +31,24 @@
 #include "tsg_common.h"
 #include <type_traits>
 
+// ---- Round 4: one kernel template, three epilogues -------------------------------------------------------------------------------
+//   * the M tile is a template parameter (TM = 256 / 128 / 64 rows; the N tile stays 256 columns, 8 waves as 2 (M) x 4 (N)): a head GEMM
+//     with few output columns ([8192 x 1024] x [512 x 1024]^T: 64 tiles of 256 x 256) still covers the chip with 64-row tiles;
+//   * X and W take row strides (ldx, ldw) and W may come as TWO row segments (w0: columns < nseg, w1: the rest): the video half of a
+//     head's first Linear is the column slice W[:, :Dv] of the [Hm, Dv + Ds] parameter, and the boundary head stacks two such
+//     parameters (start | end) -- both are read in place, no sliced or concatenated copies;
+//   * the epilogue is a functor on the accumulator tile:
+//       EpiStore     Y = acc + bias                                                     (tsg_gemm_f32s, as before)
+//       EpiMatch     K5, the matching head (DistributionAlign.py:83-118):  logits[row] = w2 . act(acc + cs[b,:]) + b2
+//       EpiBoundary  K3, the boundary head (SpanPredictor.py:71-85, gate SpanGroundMatchDisc.py:86):
+//                    l[branch][row] = w2 . tanh(gate[row] (acc + cs[b,:]) + b1) + b2[branch], mask_logits; softmax over T by the
+//                    existing boundary_softmax kernel
+//     The head epilogues reduce over the tile's 256 columns in registers (DPP) and LDS, in a fixed order; a head wider than one N tile
+//     (K5: 1024 hidden columns = 4 tiles) publishes per-tile partial rows (write-through stores, vmcnt(0), barrier, one relaxed ticket
+//     per M tile: the K3-backward / K1-backward recipe) and the last arrival adds them in tile order: run-to-run identical, no float
+//     atomics.  `y` (the pre-activation GEMM output the backward kernels read) is written only when the caller asks for it
+//     (training); under no_grad it never exists.
+
 namespace tsg {
 namespace {
 
@@ -41,9 +59,10 @@ typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned g_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kGT = 512;                       // threads
-constexpr int kTM = 256, kTN = 256, kBK = 32;  // workgroup tile, fp32 columns per chunk
-constexpr int kPlane = kTM * kBK / 2;           // dwords of one bf16 plane of an operand tile: 256 rows x 16 dwords (16 KiB)
-constexpr size_t kGemmLds = sizeof(unsigned) * 2 * 4 * kPlane;  // [2 buffers][X hi | X lo | W hi | W lo] = 128 KiB
+constexpr int kTN = 256, kBK = 32;             // N tile, fp32 columns per chunk
+constexpr int kPlaneW = kTN * kBK / 2;          // dwords of one bf16 plane of the W tile: 256 rows x 16 dwords (16 KiB)
+template <int TM> constexpr int plane_x() { return TM * kBK / 2; }
+template <int TM> constexpr size_t gemm_lds() { return sizeof(unsigned) * 2 * (2 * plane_x<TM>() + 2 * kPlaneW); }   // [2 buffers][X hi | X lo | W hi | W lo]
 
 __device__ __forceinline__ unsigned g_pk(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector((g_f32x2){a, b}, g_bf16x2));
@@ -56,59 +75,210 @@ __device__ __forceinline__ g_f32x16 g_mfma(g_u32x4 a, g_u32x4 b, g_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g_bf16x8, a), __builtin_bit_cast(g_bf16x8, b), c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restrict__ X, const float* __restrict__ W,
-                                                           const float* __restrict__ bias, float* __restrict__ Y,
+// Sum over the 32 lanes of each wave half (lanes 0..31 / 32..63); every lane of a half receives its half's total.
+__device__ __forceinline__ float half_allsum(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
+  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));  // xor 16
+  return v;
+}
+__device__ __forceinline__ void g_store_agent(float* p, float v) {          // write-through: visible to every XCD once acknowledged
+  asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ float g_load_agent(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ float g_tanh(float x) {        // 1 - 2/(exp(2x)+1), as K3's tanh_fast
+  const float e = fast_exp2(clampf(x, -44.f, 44.f) * k2Log2e);
+  return 1.f - 2.f * fast_rcp(e + 1.f);
+}
+template <int ACT> __device__ __forceinline__ float g_act(float z) {          // 0 relu, 1 tanh, 2 sigmoid (as K5's act_f)
+  if (ACT == 0) return fmaxf(z, 0.f);
+  if (ACT == 1) return g_tanh(z);
+  return fast_rcp(1.f + fast_exp2(-z * kLog2e));
+}
+
+// Where a lane's accumulator elements sit in the workgroup tile (32x32x16 C/D map): element r of tile (i, j) is
+// row wm + 32 i + 4 kg + (r & 3) + 8 (r >> 2), column wn + 32 j + jl.
+struct TilePos { int m0, n0, wm, wn, jl, kg, tid; };
+__device__ __forceinline__ int acc_row(const TilePos& p, int i, int r) { return p.wm + 32 * i + 4 * p.kg + (r & 3) + 8 * (r >> 2); }
+
+// ---- epilogue: plain store ------------------------------------------------------------------------------------------------------
+struct EpiStore {
+  const float* bias; float* Y; long long ldy;
+  static constexpr bool kUsesLds = false;
+  template <int MI>
+  __device__ __forceinline__ void run(const g_f32x16 (&acc)[MI][2], const TilePos& p, float* /*lds*/) const {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = p.n0 + p.wn + 32 * j + p.jl;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        float* yp = Y + (size_t)(p.m0 + p.wm + 32 * i + 4 * p.kg) * ldy + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r] + bv;
+      }
+    }
+  }
+};
+
+// ---- epilogue: a head.  HEAD = 0: matching head (K5), HEAD = 1: boundary head (K3).
+// Rows are (batch item b = row / T, clip t = row % T); cs [Bn, N] is the per-item sentence half of the first Linear.
+// lds (reused after the K loop, behind a barrier): red [4 N-waves][TM] partial row sums + one flag word.
+struct HeadArgs {
+  const float* cs;       // [M / T, N]
+  const float* b1;       // K3: [N] first-Linear bias (K5 carries it inside cs); else NULL
+  const float* w2;       // [N]
+  const float* b2;       // K5: [1]; K3: [2]
+  const float* gate;     // K3: [M] or NULL
+  const int* mask;       // K3: [M] or NULL
+  float* Y;              // [M, N] pre-activation GEMM output for the backward, or NULL
+  float* out0;           // K5: logits [M]; K3: start logits [M]
+  float* out1;           // K3: end logits [M]
+  float* part;           // [tiles per head][M] partial rows (only when a head spans several N tiles)
+  unsigned* cnt;         // [M / TM] tickets, zero at launch
+  int M, N, T, Hm;       // Hm: columns per head (K5: N; K3: N / 2), a multiple of 256
+  float invT;
+};
+
+template <int HEAD, int ACT>
+struct EpiHead {
+  HeadArgs a;
+  static constexpr bool kUsesLds = true;
+  template <int MI>
+  __device__ __forceinline__ void run(const g_f32x16 (&acc)[MI][2], const TilePos& p, float* lds) const {
+    constexpr int TM = 64 * MI;
+    float* red = lds;                       // [4][TM]
+    unsigned* flag = reinterpret_cast<unsigned*>(lds + 4 * TM);
+    const int colg[2] = {p.n0 + p.wn + p.jl, p.n0 + p.wn + 32 + p.jl};
+    float w2v[2], b1v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { w2v[j] = a.w2[colg[j]]; b1v[j] = (HEAD == 1 && a.b1) ? a.b1[colg[j]] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int r_first = p.m0 + p.wm + 32 * i;                              // first row of this 32-row MFMA tile (wave-uniform)
+      const int bA = (int)(((float)r_first + 0.5f) * a.invT), bB = (int)(((float)(r_first + 31) + 0.5f) * a.invT);
+      const bool two = bB - bA <= 1;                                          // the tile spans at most two batch items (T >= 32)
+      float cA[2], cB[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        cA[j] = a.cs[(size_t)bA * a.N + colg[j]];
+        cB[j] = a.cs[(size_t)(two ? bB : bA) * a.N + colg[j]];
+      }
+      const int boundary = (bA + 1) * a.T;                                    // first row of item bA + 1
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = acc_row(p, i, r), row = p.m0 + rl;
+        float c0, c1;
+        if (two) { const bool hi = row >= boundary; c0 = hi ? cB[0] : cA[0]; c1 = hi ? cB[1] : cA[1]; }
+        else { const int b = (int)(((float)row + 0.5f) * a.invT); c0 = a.cs[(size_t)b * a.N + colg[0]]; c1 = a.cs[(size_t)b * a.N + colg[1]]; }
+        const float y0 = acc[i][0][r], y1 = acc[i][1][r];
+        if (a.Y) { a.Y[(size_t)row * a.N + colg[0]] = y0; a.Y[(size_t)row * a.N + colg[1]] = y1; }
+        float v;
+        if (HEAD == 0) {
+          v = w2v[0] * g_act<ACT>(y0 + c0) + w2v[1] * g_act<ACT>(y1 + c1);
+        } else {
+          const float g = a.gate ? a.gate[row] : 1.f;
+          v = w2v[0] * g_tanh(fmaf(g, y0 + c0, b1v[0])) + w2v[1] * g_tanh(fmaf(g, y1 + c1, b1v[1]));
+        }
+        v = half_allsum(v);                                                    // over the wave's 64 columns of this row
+        if (p.jl == 0) red[(p.wn >> 6) * TM + rl] = v;
+      }
+    }
+    __syncthreads();
+    const int tiles_h = a.Hm / kTN;                                           // N tiles per head
+    const int head = p.n0 / a.Hm, q = (p.n0 % a.Hm) / kTN;                    // which head this tile belongs to, which of its tiles
+    float* out = (HEAD == 1 && head == 1) ? a.out1 : a.out0;
+    const float bias2 = a.b2[HEAD == 1 ? head : 0];
+    auto finish = [&](float s, int row) {
+      s += bias2;
+      if (HEAD == 1 && a.mask) { const float m = (float)a.mask[row]; s = s * m + (-1e30f) * (1.f - m); }   // mask_logits, attention.py:129-133
+      out[row] = s;
+    };
+    if (tiles_h == 1) {
+      if (p.tid < TM) finish(red[p.tid] + red[TM + p.tid] + red[2 * TM + p.tid] + red[3 * TM + p.tid], p.m0 + p.tid);
+    } else {
+      float* mine = a.part + ((size_t)(head * tiles_h + q)) * a.M;
+      if (p.tid < TM) g_store_agent(mine + p.m0 + p.tid, red[p.tid] + red[TM + p.tid] + red[2 * TM + p.tid] + red[3 * TM + p.tid]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the partial rows are acknowledged before the ticket moves
+      __syncthreads();
+      if (p.tid == 0)
+        *flag = __hip_atomic_fetch_add(a.cnt + (size_t)head * (a.M / TM) + p.m0 / TM, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(tiles_h - 1);
+      __syncthreads();
+      if (*flag && p.tid < TM) {                                              // last arrival: the head's tiles in order
+        float s = 0.f;
+        for (int t = 0; t < tiles_h; ++t) s += g_load_agent(a.part + ((size_t)(head * tiles_h + t)) * a.M + p.m0 + p.tid);
+        finish(s, p.m0 + p.tid);
+      }
+    }
+    __syncthreads();                                                           // red / flag are free again before the next tile's chunks land
+  }
+};
+
+template <int TM, typename Epi>
+__global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ W0,
+                                                           const float* __restrict__ W1, int nseg, long long ldw, Epi epi,
                                                            int M, int N, int K, int tiles_n) {
-  extern __shared__ __align__(16) unsigned lds[];                   // [2 buffers][X hi | X lo | W hi | W lo], each [256 rows][16 dwords]
+  constexpr int MI = TM / 64, PX = TM / 64;                         // MFMA row tiles per wave; staging passes over the X tile
+  constexpr int kPlaneX = plane_x<TM>();
+  constexpr int kBuf = 2 * kPlaneX + 2 * kPlaneW;
+  extern __shared__ __align__(16) unsigned lds[];                   // [2 buffers][X hi | X lo | W hi | W lo]
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = (wv >> 2) * 128, wn = (wv & 3) * 64;
+  const int wm = (wv >> 2) * (TM / 2), wn = (wv & 3) * 64;
   const int jl = lane & 31, kg = lane >> 5;
-  const int ntiles = (M / kTM) * tiles_n;
+  const int ntiles = (M / TM) * tiles_n;
   // Persistent workgroups: workgroup w walks the tiles w, w + grid, ...: the fp32 stores of a finished tile drain under the next
   // tile's chunks (a 256 x 256 tile is 256 KiB of output: 15-20 us of store tail per tile when nothing runs beside it).
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   const int bid = xcd_remap(tile, ntiles, tiles_n);                 // the N tiles of one M tile share an XCD (X rows stay in its L2)
-  const int m0 = (bid / tiles_n) * kTM, n0 = (bid % tiles_n) * kTN;
+  const int m0 = (bid / tiles_n) * TM, n0 = (bid % tiles_n) * kTN;
 
-  // staging role: 8 threads per row (8 float4 = one 128-byte row segment), 64 rows per pass, 4 passes per operand
+  // staging role: 8 threads per row (8 float4 = one 128-byte row segment), 64 rows per pass
   const int sr = tid >> 3, sq = tid & 7;
-  const float* xsrc = X + (size_t)(m0 + sr) * K + 4 * sq;
-  const float* wsrc = W + (size_t)(n0 + sr) * K + 4 * sq;
-  const size_t pass = (size_t)64 * K;
-  float4 rx[4], rw[4];
+  const float* xsrc = X + (size_t)(m0 + sr) * ldx + 4 * sq;
+  const float* wbase = n0 < nseg ? W0 + (size_t)n0 * ldw : W1 + (size_t)(n0 - nseg) * ldw;     // a tile lies inside one segment (nseg % 256 == 0)
+  const float* wsrc = wbase + (size_t)sr * ldw + 4 * sq;
+  const size_t passx = (size_t)64 * ldx, passw = (size_t)64 * ldw;
+  float4 rx[PX], rw[4];
   auto request = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      rx[p] = *reinterpret_cast<const float4*>(xsrc + p * pass + k0);
-      rw[p] = *reinterpret_cast<const float4*>(wsrc + p * pass + k0);
-    }
+    for (int p = 0; p < PX; ++p) rx[p] = *reinterpret_cast<const float4*>(xsrc + p * passx + k0);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) rw[p] = *reinterpret_cast<const float4*>(wsrc + p * passw + k0);
   };
   // split once, here, and write the bf16 planes: row r, 16-byte piece (sq >> 1) ^ ((r >> 2) & 3), 8-byte half sq & 1
   auto write_planes = [&](int buf) {
-    unsigned* base = lds + buf * 4 * kPlane;
+    unsigned* base = lds + buf * kBuf;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int r = sr + 64 * p;
       const int o = r * 16 + (((sq >> 1) ^ ((r >> 2) & 3)) << 2) + ((sq & 1) << 1);
       unsigned h0, l0, h1, l1;
-      g_split_pair(rx[p].x, rx[p].y, h0, l0); g_split_pair(rx[p].z, rx[p].w, h1, l1);
-      *reinterpret_cast<uint2*>(base + o) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(base + kPlane + o) = make_uint2(l0, l1);
+      if (p < PX) {
+        g_split_pair(rx[p < PX ? p : 0].x, rx[p < PX ? p : 0].y, h0, l0); g_split_pair(rx[p < PX ? p : 0].z, rx[p < PX ? p : 0].w, h1, l1);
+        *reinterpret_cast<uint2*>(base + o) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(base + kPlaneX + o) = make_uint2(l0, l1);
+      }
       g_split_pair(rw[p].x, rw[p].y, h0, l0); g_split_pair(rw[p].z, rw[p].w, h1, l1);
-      *reinterpret_cast<uint2*>(base + 2 * kPlane + o) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(base + 3 * kPlane + o) = make_uint2(l0, l1);
+      *reinterpret_cast<uint2*>(base + 2 * kPlaneX + o) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(base + 2 * kPlaneX + kPlaneW + o) = make_uint2(l0, l1);
     }
   };
   // fragment of k step s: 8 consecutive k (one 16-byte piece 2 s + kg, swizzled) of row r, from the hi and the lo plane
-  auto frag = [&](const unsigned* hi_plane, int r, int s, g_u32x4& hi, g_u32x4& lo) {
+  auto frag = [&](const unsigned* hi_plane, int plane, int r, int s, g_u32x4& hi, g_u32x4& lo) {
     const int o = r * 16 + (((2 * s + kg) ^ ((r >> 2) & 3)) << 2);
     hi = *reinterpret_cast<const g_u32x4*>(hi_plane + o);
-    lo = *reinterpret_cast<const g_u32x4*>(hi_plane + kPlane + o);
+    lo = *reinterpret_cast<const g_u32x4*>(hi_plane + plane + o);
   };
 
-  g_f32x16 acc[4][2];
+  g_f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -126,25 +296,25 @@ __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restri
     lds_barrier();                                                   // chunk ks is in LDS; nobody reads the other buffer any more
     if (WRITE) write_planes((ks + 1) & 1);
     if (REQ) request((ks + 2) * kBK);
-    const unsigned* xt = lds + (ks & 1) * 4 * kPlane;
-    const unsigned* wt = xt + 2 * kPlane;
+    const unsigned* xt = lds + (ks & 1) * kBuf;
+    const unsigned* wt = xt + 2 * kPlaneX;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       g_u32x4 bh[2], bl[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) frag(wt, wn + 32 * j + jl, s, bh[j], bl[j]);
+      for (int j = 0; j < 2; ++j) frag(wt, kPlaneW, wn + 32 * j + jl, s, bh[j], bl[j]);
       g_u32x4 ah, al, nh, nl;
-      frag(xt, wm + jl, s, ah, al);
+      frag(xt, kPlaneX, wm + jl, s, ah, al);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (i < 3) frag(xt, wm + 32 * (i + 1) + jl, s, nh, nl);     // the next X tile's fragment flies under this tile's MFMAs
+      for (int i = 0; i < MI; ++i) {
+        if (i < MI - 1) frag(xt, kPlaneX, wm + 32 * (i + 1) + jl, s, nh, nl);     // the next X tile's fragment flies under this tile's MFMAs
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           acc[i][j] = g_mfma(ah, bh[j], acc[i][j]);
           acc[i][j] = g_mfma(ah, bl[j], acc[i][j]);
           acc[i][j] = g_mfma(al, bh[j], acc[i][j]);
         }
-        ah = nh; al = nl;
+        if (i < MI - 1) { ah = nh; al = nl; }
       }
     }
   };
@@ -154,20 +324,51 @@ __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restri
   for (; ks + 2 < nk; ++ks) chunk(ks, Y_{}, Y_{});
   if (ks + 1 < nk) { chunk(ks, Y_{}, N_{}); ++ks; }
   chunk(ks, N_{}, N_{});
-  // epilogue: accumulator register r of lane (jl, kg) = row (r & 3) + 8 (r >> 2) + 4 kg, column jl of the 32 x 32 tile
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn + 32 * j + jl;
-    const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float* yp = Y + (size_t)(m0 + wm + 32 * i + 4 * kg) * N + col;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * N] = acc[i][j][r] + bv;
-    }
+  if (Epi::kUsesLds) __syncthreads();                                // every wave is done with the last chunk's buffer: the epilogue reuses LDS
+  const TilePos pos{m0, n0, wm, wn, jl, kg, tid};
+  epi.template run<MI>(acc, pos, reinterpret_cast<float*>(lds));
+  if (!Epi::kUsesLds) lds_barrier();                                 // (the head epilogues end with their own barrier)
   }
-  lds_barrier();                                                     // every wave is done with the last chunk's buffer before the next tile overwrites it
+}
+
+template <int TM, typename Epi>
+int launch_gemm(const char* fn, const float* x, long long ldx, const float* w0, const float* w1, int nseg, long long ldw, const Epi& epi,
+                int M, int N, int K, hipStream_t st) {
+  auto kern = gemm_nt_f32s_kernel<TM, Epi>;
+  constexpr size_t lds = gemm_lds<TM>();
+  hipError_t e = allow_lds(kern, lds);
+  if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute(%zu): %s", fn, lds, hipGetErrorString(e));
+  const int tiles_n = N / kTN;
+  const int tiles = (M / TM) * tiles_n, cus = device_cu_count();
+  const int grid = tiles < cus ? tiles : cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kGT), lds, st, x, ldx, w0, w1, nseg, ldw, epi, M, N, K, tiles_n);
+  return check_launch(fn);
+}
+
+// M tile for a head GEMM: the largest of 256 / 128 / 64 that divides M and still gives every CU a tile (or the smallest that divides M)
+inline int pick_tm(int M, int N) {
+  const int cus = device_cu_count(), tiles_n = N / kTN;
+  for (int tm : {256, 128, 64})
+    if (M % tm == 0 && ((M / tm) * tiles_n >= cus || tm == 64)) return tm;
+  return M % 128 == 0 ? 128 : (M % 64 == 0 ? 64 : 0);
+}
+
+inline long long head_ws_bytes(int M, int N, int heads) {
+  const int tiles_h = N / heads / kTN;
+  const long long cnt = roundup((long long)heads * (M / 64), 4);              // tickets for the smallest M tile
+  return (long long)sizeof(float) * (cnt + (tiles_h > 1 ? (long long)(N / kTN) * M : 0));
+}
+
+int check_head(const char* fn, std::initializer_list<const void*> ptrs, int M, int T, int N, int K, long long ldx, long long ldw, int Hm) {
+  for (const void* p : ptrs) {
+    if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+    if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
   }
+  if (M <= 0 || T <= 0 || N <= 0 || K <= 0 || M % T) return set_error(TSG_E_SHAPE, "%s: bad dimensions M=%d T=%d N=%d K=%d (M must be B*T)", fn, M, T, N, K);
+  if (M % 64 || N % kTN || K % kBK || Hm % kTN || M > (1 << 23))
+    return set_error(TSG_E_SHAPE, "%s: M=%d must be a multiple of 64, N=%d and the head width %d of 256, K=%d of 32", fn, M, N, Hm, K);
+  if (ldx < K || ldw < K || ldx % 4 || ldw % 4) return set_error(TSG_E_ALIGN, "%s: ldx=%lld / ldw=%lld must be >= K and multiples of 4", fn, ldx, ldw);
+  return 0;
 }
 
 }  // namespace
@@ -178,21 +379,86 @@ using namespace tsg;
 // Y[M,N] = X[M,K] W[N,K]^T (+ bias, may be NULL) in the split-precision arithmetic, operands converted on load.
 // M % 256 == 0, N % 256 == 0, K % 32 == 0 (TSG_E_SHAPE otherwise: the caller uses tsg_split_bf16x3 + a bf16 GEMM).
 extern "C" int tsg_gemm_f32s(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, void* stream) {
+  return tsg_gemm_f32s_ld(x, K, w, K, bias, y, N, M, N, K, stream);
+}
+
+extern "C" int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, long long ldw, const void* bias, void* y, long long ldy,
+                                int M, int N, int K, void* stream) {
   const char* fn = "tsg_gemm_f32s";
   for (const void* p : {x, w, (const void*)y}) {
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
     if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
   }
   if (M <= 0 || N <= 0 || K <= 0) return set_error(TSG_E_SHAPE, "%s: non-positive dimension M=%d N=%d K=%d", fn, M, N, K);
-  if (M % kTM || N % kTN || K % kBK)
+  if (M % 256 || N % kTN || K % kBK)
     return set_error(TSG_E_SHAPE, "%s: M=%d, N=%d must be multiples of 256 and K=%d of 32", fn, M, N, K);
-  auto kern = gemm_nt_f32s_kernel;
-  hipError_t e = allow_lds(kern, kGemmLds);
-  if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute(%zu): %s", fn, kGemmLds, hipGetErrorString(e));
-  const int tiles_n = N / kTN;
-  const int tiles = (M / kTM) * tiles_n, cus = device_cu_count();
-  const int grid = tiles < cus ? tiles : cus;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kGT), kGemmLds, static_cast<hipStream_t>(stream), (const float*)x,
-                     (const float*)w, (const float*)bias, (float*)y, M, N, K, tiles_n);
-  return check_launch(fn);
+  if (ldx < K || ldw < K || ldy < N || ldx % 4 || ldw % 4) return set_error(TSG_E_ALIGN, "%s: leading dimensions ldx=%lld ldw=%lld ldy=%lld", fn, ldx, ldw, ldy);
+  const EpiStore epi{(const float*)bias, (float*)y, ldy};
+  return launch_gemm<256>(fn, (const float*)x, ldx, (const float*)w, (const float*)w, N, ldw, epi, M, N, K, static_cast<hipStream_t>(stream));
+}
+
+extern "C" long long tsg_head_gemm_ws_bytes(int M, int N, int heads) {
+  if (M <= 0 || N <= 0 || heads < 1 || heads > 2 || N % (heads * kTN) || M % 64) return -1;
+  return head_ws_bytes(M, N, heads);
+}
+
+extern "C" int tsg_match_head_gemm(const void* x, long long ldx, const void* w, long long ldw, const void* cs, const void* w2, const void* b2,
+                                   void* y, void* logits, void* ws, long long ws_bytes, int M, int T, int N, int K, int activation,
+                                   void* stream) {
+  const char* fn = "tsg_match_head_gemm";
+  int rc = check_head(fn, {x, w, cs, w2, b2, (const void*)logits, (const void*)ws}, M, T, N, K, ldx, ldw, N);
+  if (rc) return rc;
+  if (y && !aligned16(y)) return set_error(TSG_E_ALIGN, "%s: y not 16-byte aligned", fn);
+  if (activation < 0 || activation > 2) return set_error(TSG_E_SHAPE, "%s: activation %d (0 relu, 1 tanh, 2 sigmoid)", fn, activation);
+  if (ws_bytes < head_ws_bytes(M, N, 1)) return set_error(TSG_E_SHAPE, "%s: workspace of %lld B < %lld B (tsg_head_gemm_ws_bytes)", fn, ws_bytes, head_ws_bytes(M, N, 1));
+  auto st = static_cast<hipStream_t>(stream);
+  const int tm = pick_tm(M, N);
+  const long long cntw = roundup((long long)(M / 64), 4);
+  unsigned* cnt = static_cast<unsigned*>(ws);
+  float* part = static_cast<float*>(ws) + cntw;
+  if (N / kTN > 1) {
+    hipError_t e = zero_async(cnt, sizeof(unsigned) * cntw, st);
+    if (e != hipSuccess) return set_error((int)e, "%s: zero fill: %s", fn, hipGetErrorString(e));
+  }
+  const HeadArgs a{(const float*)cs, nullptr, (const float*)w2, (const float*)b2, nullptr, nullptr, (float*)y, (float*)logits, nullptr,
+                   part, cnt, M, N, T, N, 1.f / (float)T};
+  const float* xf = (const float*)x; const float* wf = (const float*)w;
+#define TSG_MH(TMV, ACTV) launch_gemm<TMV>(fn, xf, ldx, wf, wf, N, ldw, EpiHead<0, ACTV>{a}, M, N, K, st)
+#define TSG_MH_TM(ACTV) (tm == 256 ? TSG_MH(256, ACTV) : (tm == 128 ? TSG_MH(128, ACTV) : TSG_MH(64, ACTV)))
+  if (activation == 0) return TSG_MH_TM(0);
+  if (activation == 1) return TSG_MH_TM(1);
+  return TSG_MH_TM(2);
+#undef TSG_MH_TM
+#undef TSG_MH
+}
+
+extern "C" int tsg_boundary_head_gemm(const void* x, long long ldx, const void* w_start, const void* w_end, long long ldw, const void* cs,
+                                      const void* b1, const void* w2, const void* b2, const void* gate, const int32_t* mask, void* y,
+                                      void* p_start, void* p_end, void* ws, long long ws_bytes, int B, int T, int Hm, int K, void* stream) {
+  const char* fn = "tsg_boundary_head_gemm";
+  if (B <= 0 || T <= 0 || (long long)B * T > (1 << 23)) return set_error(TSG_E_SHAPE, "%s: bad B=%d T=%d", fn, B, T);
+  const int M = B * T, N = 2 * Hm;
+  int rc = check_head(fn, {x, w_start, w_end, cs, b1, w2, b2, (const void*)p_start, (const void*)p_end, (const void*)ws}, M, T, N, K, ldx, ldw, Hm);
+  if (rc) return rc;
+  if (y && !aligned16(y)) return set_error(TSG_E_ALIGN, "%s: y not 16-byte aligned", fn);
+  if (T > 8192) return set_error(TSG_E_SHAPE, "%s: T=%d > 8192 not supported", fn, T);
+  if (ws_bytes < head_ws_bytes(M, N, 2)) return set_error(TSG_E_SHAPE, "%s: workspace of %lld B < %lld B (tsg_head_gemm_ws_bytes)", fn, ws_bytes, head_ws_bytes(M, N, 2));
+  auto st = static_cast<hipStream_t>(stream);
+  const int tm = pick_tm(M, N);
+  const long long cntw = roundup((long long)2 * (M / 64), 4);
+  unsigned* cnt = static_cast<unsigned*>(ws);
+  float* part = static_cast<float*>(ws) + cntw;
+  if (Hm / kTN > 1) {
+    hipError_t e = zero_async(cnt, sizeof(unsigned) * cntw, st);
+    if (e != hipSuccess) return set_error((int)e, "%s: zero fill: %s", fn, hipGetErrorString(e));
+  }
+  const HeadArgs a{(const float*)cs, (const float*)b1, (const float*)w2, (const float*)b2, (const float*)gate, mask, (float*)y,
+                   (float*)p_start, (float*)p_end, part, cnt, M, N, T, Hm, 1.f / (float)T};
+  const EpiHead<1, 1> epi{a};
+  const float* xf = (const float*)x;
+  if (tm == 256) rc = launch_gemm<256>(fn, xf, ldx, (const float*)w_start, (const float*)w_end, Hm, ldw, epi, M, N, K, st);
+  else if (tm == 128) rc = launch_gemm<128>(fn, xf, ldx, (const float*)w_start, (const float*)w_end, Hm, ldw, epi, M, N, K, st);
+  else rc = launch_gemm<64>(fn, xf, ldx, (const float*)w_start, (const float*)w_end, Hm, ldw, epi, M, N, K, st);
+  if (rc) return rc;
+  return tsg_boundary_softmax(p_start, p_end, B, T, stream);       // softmax over T, in place (csrc/boundary_head.hip)
 }

@@ -1442,11 +1442,17 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
   // them in the middle of the kernel (173 -> 147 us per launch at [128,128,20,1024]; -DTSG_K1_XCH_FENCE builds keep the fences: A/B).
   // tests/test_isa_cpu.py disassembles the built code object and asserts the vmcnt(0) wait between the last sc1 store and the
   // counter's atomic in every instantiation.
+  // Two steps (round 4).  publish_dp: the stores, right after the row loop.  count_in: the wait + barrier + ticket, AFTER the T-sum
+  // epilogue of the row phase -- vmcnt counts loads and stores together and in order, so the acknowledgement wait also drains the
+  // wave's queue of dr row stores (256 KiB per workgroup, just issued): placed straight behind the row loop it stalled every wave on
+  // that drain (165 vs 146 us per launch at [128,128,20,1024]); behind the epilogue the queue has drained under the epilogue's LDS work.
   auto publish_dp = [&]() {
     if (parts <= 1) return;
     float* mine = xch + ((size_t)b * parts + pt) * T * NP;
     for (int idx = tid; idx < T * NP; idx += kFusedThreads)
       __hip_atomic_store(mine + idx, De[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto count_in = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // acknowledgement of THIS thread's partial rows (write-through to L2 / memory)
     __syncthreads();
     if (tid == 0) {
@@ -1780,8 +1786,9 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
   }
 
   // ---------------- exchange: dP over ALL columns, then de -------------------------------------
-  // (published right after the row loop, before the T-sum epilogue above: `publish_dp`)
+  // (partial rows stored right after the row loop: `publish_dp`; counted in here, behind the T-sum epilogue: `count_in`)
   if (parts > 1) {
+    count_in();
     if (tid == 0) {
       unsigned spins = 0;
 #ifdef TSG_K1_XCH_FENCE

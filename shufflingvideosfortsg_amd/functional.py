@@ -779,6 +779,188 @@ def match_head(y, cs, w2, b2, activation="relu"):
     return _MatchHead.apply(y, cs, w2.reshape(-1), b2.reshape(-1), _ACTS[activation])
 
 
+def head_gemm_ok(M: int, N: int, K: int, T: int, head_width: int) -> bool:
+    """Shapes the fused head GEMMs (tsg_match_head_gemm / tsg_boundary_head_gemm, include/tsg_hip.h) take; the modules use them in the
+    "f32s" mode (their arithmetic) and keep GEMM + K3 / K5 otherwise."""
+    return (_GEMM_DTYPE == "f32s" and _OWN_GEMM and M > 0 and M % 64 == 0 and N % 256 == 0 and head_width % 256 == 0 and K % 32 == 0
+            and 0 < T <= 8192 and M % T == 0 and M <= (1 << 23))
+
+
+def _dx_f32s(dy2: torch.Tensor, w_rows: torch.Tensor) -> torch.Tensor:
+    """dX [M,K] = dY [M,N] @ W [N,K] in the f32s arithmetic: the own GEMM with the (small) weight transposed once where its tile
+    constraints hold, else the generic split-precision product."""
+    M, N = dy2.shape
+    K = w_rows.shape[1]
+    if gemm_f32s_ok(M, K, N):
+        return gemm_f32s(dy2, w_rows.t().contiguous())
+    return _mm(dy2, w_rows, "f32s")
+
+
+def _dw_f32s(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """dW [N,K] = dY [M,N]^T @ X [M,K] in the f32s arithmetic (tsg_wgrad_f32s where its tiles fit, else fp32)."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    if _WGRAD_KERNEL and wgrad_f32s_ok(M, N, K):
+        return wgrad_f32s(dy2, x2)[0]
+    return dy2.t() @ x2
+
+
+class _MatchHeadGemm(torch.autograd.Function):
+    """K5 as the epilogue of its own first-Linear GEMM (tsg_match_head_gemm): x [B,T,K], w = W1[:, :K] (a column-slice VIEW of the
+    [H, K + Kq] parameter, read in place), cs [B,H] = query half + bias, w2 [H], b2 [1] -> matching logits [B,T].  The pre-activation
+    y = x w^T is written only when a gradient is needed (the backward kernel tsg_match_head_bwd reads it)."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, x, w, cs, w2, b2, act):
+        require_device(x, w, cs, w2, b2)
+        x = _f32c(x)
+        B, T, K = x.shape
+        H = w.shape[0]
+        if w.stride(1) != 1 or w.stride(0) % 4 or w.data_ptr() % 16 or w.shape[1] != K:
+            raise ValueError("match_head_gemm: w must be a row-major matrix or a column slice of one (16-byte aligned rows)")
+        cs, w2, b2 = _f32p(cs), _f32p(w2).view(-1), _f32p(b2).view(-1)
+        M = B * T
+        need_y = any(ctx.needs_input_grad[:4])
+        y = torch.empty(B, T, H, device=x.device, dtype=torch.float32) if need_y else None
+        out = torch.empty(B, T, device=x.device, dtype=torch.float32)
+        nb = int(load().tsg_head_gemm_ws_bytes(M, H, 1))
+        ws = torch.empty(max(nb, 16), device=x.device, dtype=torch.uint8)
+        _call("tsg_match_head_gemm", x, ptr(x), K, ptr(w), w.stride(0), ptr(cs), ptr(w2), ptr(b2), ptr(y) if need_y else None, ptr(out),
+              ptr(ws), nb, M, T, H, K, int(act))
+        if need_y:
+            ctx.save_for_backward(x, w, y, cs, w2)
+        ctx.act = int(act)
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dl):
+        x, w, y, cs, w2 = ctx.saved_tensors
+        B, T, H = y.shape
+        K = x.shape[2]
+        dl = _f32p(dl)
+        dy = torch.empty_like(y)
+        dcs = torch.empty_like(cs); dw2 = torch.empty_like(w2); db2 = torch.empty(1, device=y.device, dtype=torch.float32)
+        _call("tsg_match_head_bwd", y, ptr(y), ptr(cs), ptr(w2), ptr(dl), ptr(dy), ptr(dcs), ptr(dw2), ptr(db2), B, T, H, ctx.act, TSG_F32)
+        dy2, x2 = dy.view(B * T, H), x.view(B * T, K)
+        dx = _dx_f32s(dy2, w).view(B, T, K) if ctx.needs_input_grad[0] else None
+        dw = _dw_f32s(dy2, x2) if ctx.needs_input_grad[1] else None
+        return dx, dw, dcs, dw2, db2, None
+
+
+def match_head_gemm(x, w, cs, w2, b2, activation="relu"):
+    """Matching head fused into its first-Linear GEMM (include/tsg_hip.h: tsg_match_head_gemm)."""
+    return _MatchHeadGemm.apply(x, w, cs, w2.reshape(-1), b2.reshape(-1), _ACTS[activation])
+
+
+class _BoundaryHeadGemm(torch.autograd.Function):
+    """K3 as the epilogue of its own first-Linear GEMM (tsg_boundary_head_gemm): x [B,T,K]; ws_, we_ = the video-half column slices of
+    the start / end head's first Linear ([Hm, K] views, read in place as two row segments: no stacked copy); cs [B,2Hm], b1 / w2 [2Hm],
+    b2 [2], gate [B,T] | None, mask [B,T] int | None -> (p_start, p_end) [B,T]."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, x, ws_, we_, cs, b1, w2, b2, gate, mask):
+        require_device(x, ws_, we_, cs, b1, w2, b2, gate, mask)
+        x = _f32c(x)
+        B, T, K = x.shape
+        Hm = ws_.shape[0]
+        for w in (ws_, we_):
+            if w.shape != (Hm, K) or w.stride(1) != 1 or w.stride(0) != ws_.stride(0) or w.stride(0) % 4 or w.data_ptr() % 16:
+                raise ValueError("boundary_head_gemm: the two first-Linear slices must be [Hm,K] row-major views with one row stride")
+        cs, b1, w2, b2 = _f32p(cs), _f32p(b1), _f32p(w2), _f32p(b2)
+        gate_c = _f32p(gate) if gate is not None else None
+        mask_c = mask.to(torch.int32).contiguous() if mask is not None else None
+        need_y = any(ctx.needs_input_grad[:7]) or (gate is not None and ctx.needs_input_grad[7])
+        J = 2 * Hm
+        y = torch.empty(B, T, J, device=x.device, dtype=torch.float32) if need_y else None
+        ps = torch.empty(B, T, device=x.device, dtype=torch.float32)
+        pe = torch.empty_like(ps)
+        nb = int(load().tsg_head_gemm_ws_bytes(B * T, J, 2))
+        wsb = torch.empty(max(nb, 16), device=x.device, dtype=torch.uint8)
+        _call("tsg_boundary_head_gemm", x, ptr(x), K, ptr(ws_), ptr(we_), ws_.stride(0), ptr(cs), ptr(b1), ptr(w2), ptr(b2),
+              ptr(gate_c) if gate_c is not None else None, ptr(mask_c) if mask_c is not None else None, ptr(y) if need_y else None,
+              ptr(ps), ptr(pe), ptr(wsb), nb, B, T, Hm, K)
+        if need_y:
+            ctx.save_for_backward(x, ws_, we_, y, cs, b1, w2, ps, pe, *([gate_c] if gate_c is not None else []),
+                                  *([mask_c] if mask_c is not None else []))
+        ctx.has_gate, ctx.has_mask = gate_c is not None, mask_c is not None
+        return ps, pe
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dps, dpe):
+        saved = list(ctx.saved_tensors)
+        x, ws_, we_, y, cs, b1, w2, ps, pe = saved[:9]
+        rest = saved[9:]
+        gate = rest.pop(0) if ctx.has_gate else None
+        mask = rest.pop(0) if ctx.has_mask else None
+        B, T, J = y.shape
+        K, Hm = x.shape[2], J // 2
+        dps = _f32p(dps) if dps is not None else torch.zeros_like(ps)
+        dpe = _f32p(dpe) if dpe is not None else torch.zeros_like(pe)
+        dy = torch.empty_like(y); dcs = torch.empty_like(cs)
+        db1p = torch.empty(B, J, device=y.device, dtype=torch.float32)
+        dw2p = torch.empty_like(db1p)
+        db2p = torch.empty(B, 2, device=y.device, dtype=torch.float32)
+        dgate = torch.empty(B, T, device=y.device, dtype=torch.float32) if gate is not None else None
+        wk, nb = _k3_workspace(y.device, B, T, Hm)
+        _call("tsg_boundary_score_bwd_ws", y, ptr(y), ptr(cs), ptr(b1), ptr(w2),
+              ptr(gate) if gate is not None else None, ptr(mask) if mask is not None else None,
+              ptr(ps), ptr(pe), ptr(dps), ptr(dpe), ptr(dy), ptr(dcs), ptr(db1p), ptr(dw2p), ptr(db2p),
+              ptr(dgate) if dgate is not None else None, ptr(wk), nb, B, T, Hm, TSG_F32)
+        dy2, x2 = dy.view(B * T, J), x.view(B * T, K)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _dx_f32s(dy2, torch.cat([ws_, we_], 0)).view(B, T, K)
+        dws = dwe = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dW = _dw_f32s(dy2, x2)                                     # [2Hm, K]: rows of the start head, then of the end head
+            dws, dwe = dW[:Hm], dW[Hm:]
+        return dx, dws, dwe, dcs, db1p.sum(0), dw2p.sum(0), db2p.sum(0), dgate, None
+
+
+def boundary_head_gemm(x, w_start, w_end, cs, b1, w2, b2, gate=None, mask=None):
+    """Boundary head fused into its first-Linear GEMM (include/tsg_hip.h: tsg_boundary_head_gemm)."""
+    return _BoundaryHeadGemm.apply(x, w_start, w_end, cs, b1, w2, b2, gate, mask)
+
+
+class _MomentPool(torch.autograd.Function):
+    """MomentPooling's three masked means in one pass (tsg_moment_pool_fwd / _bwd): feat [B,T,D] (fp32, or bf16 in the storage
+    mode), masks float [B,T] x 3 -> pooled fp32 [B,3,D]."""
+
+    @staticmethod
+    def forward(ctx, feat, m_target, m_fore, m_back):
+        require_device(feat, m_target, m_fore, m_back)
+        bf = feat.dtype == _BF
+        feat = _act(feat, bf)
+        ms = tuple(_f32p(m) for m in (m_target, m_fore, m_back))
+        B, T, D = feat.shape
+        if any(m.shape != (B, T) for m in ms):
+            raise ValueError(f"moment_pool: masks must be [{B},{T}]")
+        pooled = torch.empty(B, 3, D, device=feat.device, dtype=torch.float32)
+        ctx.dt = TSG_BF16 if bf else TSG_F32
+        _call("tsg_moment_pool_fwd", feat, ptr(feat), ptr(ms[0]), ptr(ms[1]), ptr(ms[2]), ptr(pooled), B, T, D, ctx.dt)
+        ctx.save_for_backward(*ms)
+        ctx.shape = (B, T, D)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        ms = ctx.saved_tensors
+        B, T, D = ctx.shape
+        dpooled = _f32p(dpooled)
+        dfeat = torch.empty(B, T, D, device=dpooled.device, dtype=_BF if ctx.dt == TSG_BF16 else torch.float32)
+        _call("tsg_moment_pool_bwd", dpooled, ptr(dpooled), ptr(ms[0]), ptr(ms[1]), ptr(ms[2]), ptr(dfeat), B, T, D, ctx.dt)
+        return dfeat, None, None, None
+
+
+def moment_pool(feat, m_target, m_fore, m_back):
+    """-> [B,3,D]: masked means of feat over the target / fore / back ranges (include/tsg_hip.h: tsg_moment_pool_fwd)."""
+    return _MomentPool.apply(feat, m_target, m_fore, m_back)
+
+
 class _GmdLosses(torch.autograd.Function):
     """The four GMD training losses (K4, csrc/losses.hip) -> (parts[4] = span, matching BCE, matching KL, order CE, all
     un-weighted; total = span + lam[0] BCE + lam[1] KL + lam[2] CE)."""

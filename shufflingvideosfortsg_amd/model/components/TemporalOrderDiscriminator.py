@@ -1,9 +1,11 @@
 """Temporal-order discriminator (reference components/TemporalOrderDiscriminator.py), GMD only:
 masked means over the target / fore / back clip ranges -> small MLPs -> 2-way logits
-(original vs shuffled video).  Training-only auxiliary head; torch ops."""
+(original vs shuffled video).  Training-only auxiliary head: the three masked means are ONE HIP pass over the clip features
+(tsg_moment_pool_fwd / _bwd, csrc/moment_pool.hip); the two small Linears on the [B, 2d] / [B, 3d] pooled rows stay torch ops."""
 import torch
 import torch.nn as nn
 
+from ... import functional as TF
 from ..networks.attention import mask_logits
 
 
@@ -32,7 +34,10 @@ class MomentPooling(nn.Module):
         return torch.bmm(M, feat) / (M.sum(2, keepdim=True) + 1e-6)               # [B,K,D]
 
     def forward(self, feat, target_mask, fore_mask, back_mask):
-        if feat.dim() == 3 and target_mask.dim() == 2:
+        if feat.is_cuda and feat.dim() == 3 and target_mask.dim() == 2 and feat.size(-1) % 4 == 0 and feat.dtype in (torch.float32, torch.bfloat16):
+            pooled = TF.moment_pool(feat, target_mask, fore_mask, back_mask)                    # [B,3,D] fp32, one pass over feat
+            tgt, fore_avg, back_avg = pooled[:, 0], pooled[:, 1], pooled[:, 2]
+        elif feat.dim() == 3 and target_mask.dim() == 2:
             pooled = self.average_masks(feat, (target_mask, fore_mask, back_mask)).float()      # [B,3,D]: the small MLPs stay fp32
             tgt, fore_avg, back_avg = pooled[:, 0], pooled[:, 1], pooled[:, 2]
         else:

@@ -21,7 +21,7 @@ LIB = os.path.join(ROOT, "shufflingvideosfortsg_amd", "libtsg_hip.so")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 # kernels whose cross-workgroup protocol is "agent-scope stores, workgroup barrier, one integer atomic on a counter"
-PUBLISHERS = ("scdm_bwd_fused_kernel", "boundary_bwd_one_kernel")
+PUBLISHERS = ("scdm_bwd_fused_kernel", "boundary_bwd_one_kernel", "gemm_nt_f32s_kernel")
 
 
 def _disassemble(tmp_path):
@@ -70,12 +70,14 @@ def _check_kernel(name, ins):
         if not before:
             continue
         last = before[-1]
-        barrier = next((i for i in range(last, a) if ins[i].startswith("s_barrier")), None)
-        if barrier is None:
+        barriers = [i for i in range(last, a) if ins[i].startswith("s_barrier")]
+        if not barriers:
             continue                                     # this atomic is not a publication of those stores (no barrier between them)
+        barrier = barriers[-1]                           # the barrier the counter's atomic sits behind (other work -- the row phase's
+        # T-sum epilogue, with barriers of its own -- may lie between the stores and it: round 4 moved the wait behind that epilogue)
         waits = [i for i in range(last + 1, barrier) if ins[i].startswith("s_waitcnt") and "vmcnt(0)" in ins[i]]
         assert waits, (f"{name}: agent-scope store at instruction {last} is followed by s_barrier ({barrier}) and the counter atomic "
-                       f"({a}) with no s_waitcnt vmcnt(0) in between:\n  " + "\n  ".join(ins[last:barrier + 1][-12:]))
+                       f"({a}) with no s_waitcnt vmcnt(0) in between:\n  " + "\n  ".join(ins[max(last, barrier - 12):barrier + 1]))
         sites += 1
     return sites
 
@@ -112,6 +114,15 @@ def test_k3_one_launch_backward_publication_waits_for_its_stores(kernels):
         assert stores
         last = stores[-1]
         assert any(ins[i].startswith("s_waitcnt") and "vmcnt(0)" in ins[i] for i in range(last + 1, barrier)), k
+
+
+def test_head_gemm_ticket_waits_for_its_partial_rows(kernels):
+    """The fused heads (csrc/gemm_f32s.hip, EpiHead): a head wider than one column tile publishes per-tile partial rows (sc1 stores) and
+    takes a ticket -- the same protocol, the same gate."""
+    names = [k for k in kernels if "gemm_nt_f32s_kernel" in k and "EpiHead" in k]
+    assert len(names) >= 12, names                        # 3 row-tile sizes x (3 activations of K5 + K3)
+    for k in names:
+        assert _check_kernel(k, kernels[k]) >= 1, k
 
 
 def test_gate_detects_the_round3_sequence():

@@ -1,0 +1,87 @@
+"""MomentPooling (temporal-order discriminator of the GMD, reference components/TemporalOrderDiscriminator.py:29-46): the three masked
+means as one HIP pass (tsg_moment_pool_fwd / _bwd) and the module on top of it, against the CPU oracle's `moment_pooling` --
+the reference formulation (mask_logits(feat, m, 0).sum(1) / (m.sum(1) + 1e-6) per range, then the two small Linears)."""
+import pytest
+import torch
+
+from oracle import tsg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _masks(B, T, g):
+    """target / fore / back ranges as the datasets build them (charades.py:167-170: inclusive ends, fore includes the start clip, back
+    the end clip); one item with an EMPTY fore range (moment starts at clip 0 ... handled by the +1e-6) and one full-length moment."""
+    tgt, fore, back = torch.zeros(B, T), torch.zeros(B, T), torch.zeros(B, T)
+    for b in range(B):
+        n = int(torch.randint(max(2, T // 2), T + 1, (1,), generator=g))
+        s = int(torch.randint(0, n - 1, (1,), generator=g)); e = int(torch.randint(s + 1, n, (1,), generator=g))
+        if b == 0:
+            s, e = 0, n - 1
+        tgt[b, s:e + 1] = 1; fore[b, :s + 1] = 1; back[b, e:n] = 1
+    fore[1 % B] = 0                                     # an empty range: 0 / (0 + 1e-6) = 0
+    return tgt, fore, back
+
+
+@pytest.mark.parametrize("B,T,D", [(3, 17, 24), (4, 128, 1024), (130, 64, 512), (2, 300, 260)])
+def test_moment_pool_kernel_vs_oracle(B, T, D):
+    from shufflingvideosfortsg_amd import functional as TF
+    g = torch.Generator().manual_seed(B + T)
+    feat = torch.randn(B, T, D, generator=g, requires_grad=True)
+    tgt, fore, back = _masks(B, T, g)
+    gp = torch.randn(B, 3, D, generator=g)
+    avg = lambda m: O.mask_logits(feat, m, 0.0).sum(1) / (m.sum(1, keepdim=True) + 1e-6)
+    ref = torch.stack([avg(tgt), avg(fore), avg(back)], 1)
+    ref.backward(gp)
+    fd = feat.detach().cuda().requires_grad_(True)
+    out = TF.moment_pool(fd, tgt.cuda(), fore.cuda(), back.cuda())
+    out.backward(gp.cuda())
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(fd.grad.cpu(), feat.grad, atol=1e-6, rtol=1e-5)
+    out2 = TF.moment_pool(fd.detach(), tgt.cuda(), fore.cuda(), back.cuda())
+    assert torch.equal(out2, out.detach())              # fixed-order sums
+
+
+def test_moment_pool_bf16_storage():
+    from shufflingvideosfortsg_amd import functional as TF
+    B, T, D = 4, 128, 1024
+    g = torch.Generator().manual_seed(4)
+    feat = torch.randn(B, T, D, generator=g).to(torch.bfloat16).float().requires_grad_(True)
+    tgt, fore, back = _masks(B, T, g)
+    gp = torch.randn(B, 3, D, generator=g)
+    avg = lambda m: (feat * m.unsqueeze(2)).sum(1) / (m.sum(1, keepdim=True) + 1e-6)
+    ref = torch.stack([avg(tgt), avg(fore), avg(back)], 1)
+    ref.backward(gp)
+    fd = feat.detach().to(torch.bfloat16).cuda().requires_grad_(True)
+    out = TF.moment_pool(fd, tgt.cuda(), fore.cuda(), back.cuda())
+    assert out.dtype == torch.float32
+    out.backward(gp.cuda())
+    assert fd.grad.dtype == torch.bfloat16
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), atol=1e-5, rtol=1e-5)       # fp32 sums of the same bf16 values
+    torch.testing.assert_close(fd.grad.float().cpu(), feat.grad, atol=1e-2 * float(feat.grad.abs().max()), rtol=1e-2)
+
+
+@pytest.mark.parametrize("B,T,D", [(3, 40, 64), (4, 128, 1024)])
+def test_moment_pooling_module_vs_oracle(B, T, D):
+    import logging
+    from shufflingvideosfortsg_amd.model.components.TemporalOrderDiscriminator import MomentPooling
+    torch.manual_seed(1)
+    m = MomentPooling(D, logging.getLogger("t"))
+    m.dropout.p = 0.0
+    g = torch.Generator().manual_seed(7)
+    feat = torch.randn(B, T, D, generator=g, requires_grad=True)
+    tgt, fore, back = _masks(B, T, g)
+    w = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref = O.moment_pooling(feat, tgt, fore, back, w)
+    gl = torch.randn(B, 2, generator=g)
+    ref.backward(gl)
+    m = m.cuda().train()
+    fd = feat.detach().cuda().requires_grad_(True)
+    out = m(fd, tgt.cuda(), fore.cuda(), back.cuda())
+    out.backward(gl.cuda())
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(fd.grad.cpu(), feat.grad, atol=2e-5, rtol=2e-3)
+    for k, p in m.named_parameters():
+        want = w[k].grad
+        torch.testing.assert_close(p.grad.cpu(), want, atol=2e-4 * max(1.0, float(want.abs().max())), rtol=2e-3, msg=lambda s, k=k: f"{k}: {s}")
