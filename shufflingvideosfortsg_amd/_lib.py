@@ -59,7 +59,7 @@ _SIGNATURES = {
     "tsg_gemm_f32s_ld": [_P, c_longlong, _P, c_longlong, _P, _P, c_longlong, _I, _I, _I, _P],
     "tsg_head_gemm_ws_bytes": [_I, _I, _I],
     "tsg_match_head_gemm": [_P, c_longlong, _P, c_longlong, _P, _P, _P, _P, _P, _P, c_longlong, _I, _I, _I, _I, _I, _P],
-    "tsg_boundary_head_gemm": [_P, c_longlong, _P, _P, c_longlong] + [_P] * 11 + [c_longlong, _I, _I, _I, _I, _P],
+    "tsg_boundary_head_gemm": [_P, c_longlong, _P, _P, c_longlong] + [_P] * 10 + [c_longlong, _I, _I, _I, _I, _P],
     "tsg_boundary_softmax": [_P, _P, _I, _I, _P],
     "tsg_moment_pool_fwd": [_P] * 5 + [_I] * 4 + [_P],
     "tsg_moment_pool_bwd": [_P] * 5 + [_I] * 4 + [_P],
