@@ -561,6 +561,15 @@ def main():
             if name == "tsg_boundary_score_bwd_ws":       # (ws_bytes, B, T, Hm, dtype): the workspace size is not a shape
                 dims = dims[1:]
                 entry["dims"] = list(dims)
+            if name == "tsg_boundary_head_gemm":          # (ldx, ldw, ws_bytes, B, T, Hm, K): K3 as the epilogue of its own GEMM -- MFMA work
+                Bq, Tq, Hmq, Kq = dims[-4:]
+                fl = 2.0 * Bq * Tq * 2 * Hmq * Kq * 3     # three bf16 products per fp32 product (hi*hi + hi*lo + lo*hi)
+                entry.update(dims=[Bq, Tq, Hmq, Kq], bound="mfma", mfma_flops=fl, achieved_TFLOPs=round(fl / us / 1e6, 1),
+                             frac=round(fl / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4),
+                             note="boundary head fused into its first-Linear GEMM (split-precision, 64/128/256-row tiles): GEMM + tanh + "
+                                  "w2-dot + masked softmax; y is written for the backward in training")
+                kern[f"{name}{[Bq, Tq, Hmq, Kq]}"] = entry
+                continue
             esz = 2 if (dims and dims[-1] == 1) else 4    # last integer argument = dtype: TSG_BF16 (1) stores activations in 2 bytes
             if key and key.startswith("scdm"):            # dims = (B, T, N, H, Ds, dtype)
                 by = alg_bytes(key, dims[0], dims[1], dims[2], dims[3], e=esz)
@@ -593,7 +602,14 @@ def main():
                                    "profile citation, not observed by this run") if tr_src else None,
                 "pairs_per_launch": k1B,
                 "alg_bytes_per_launch": k1.get("alg_bytes"), "alg_bytes_formula": k1.get("alg_bytes_formula"),
-                "mean_launch_us": k1.get("mean_us"), "launches_timed": k1.get("launches")}
+                "mean_launch_us": k1.get("mean_us"), "launches_timed": k1.get("launches"),
+                # round-3 review: state the kernel's own ceiling instead of chasing the last 10 %
+                "ceiling_note": ("fp32 / f32s arithmetic: one v_rcp_f32 + 2 v_fma_f32 per (t,n,k) element = 14.5-16 cycles per 64 elements on "
+                                 "1024 SIMDs -> 40-44 us of VALU issue per 128-pair launch = an upper bound of 0.64-0.70 of the 8 TB/s "
+                                 "roofline for this arithmetic; with the ~15 us ramp of a single wave of 256 workgroups the kernel's own "
+                                 "ceiling is 0.50-0.52 (DESIGN.md section 4, K1g).  bf16 storage: the score loop is packed f16 (two Newton "
+                                 "steps instead of v_rcp_f32: 8 packed instructions per element pair), half the bytes at half the loop time")
+                if gate else None}
         what = "fwd-only" if a.fwd_only else "fwd+bwd"
         wl = (f"{a.model}_forward: fwd+losses under no_grad, " if a.fwd_only else
               f"{a.model}_train_step: fwd+losses+bwd+grad-allreduce+Adam, ")

@@ -102,59 +102,6 @@ __device__ __forceinline__ void scdm_chunk_step(const float (&Ea)[R][4], const f
   }
 }
 
-// ---- bf16 STORAGE mode (dtype TSG_BF16): the score loop in PACKED f16 arithmetic (round-3 review item 6; tolerance of the mode: 1e-2).
-// The fp32 loop costs fma + v_rcp_f32 (quarter rate) + fma = 16 cycles per 64 elements and runs at the VALU floor; bf16 inputs do not
-// need it.  Here two elements share every instruction (v_pk_*_f16 run at the full rate) and the reciprocal is two Newton steps from an
-// integer first guess, so no transcendental is issued per element:
-//     x  = min(Ea*Es + 1, 16384)                 v_pk_fma_f16, v_pk_min_f16     (E = exp(2(a+s)); a, s clamped to +-5: Ea, Es <= 22026 < 65504)
-//     r0 = bits(0x777E) - bits(x)                v_pk_sub_u16                   (|r0 x - 1| <= 12 %)
-//     r  = r + r (1 - x r)   twice               2 x (v_pk_fma_f16, v_pk_fma_f16)  (|r x - 1| <= 7.6e-4 over 1 <= x <= 16384, simulated in f16)
-//     acc += (-2w) r                             v_pk_fma_f16
-// = 8 packed instructions per element PAIR = 16 cycles per 128 elements, half the fp32 loop.  Per-element error of tanh = 1 - 2r:
-// <= 2e-3 (f16 roundings of Ea, Es and the Newton steps); a lane accumulates 8 terms per accumulator half in f16, the sums over the
-// lanes, the softmax and everything after it stay fp32.  The clamp at 16384 is tanh(4.85) = 0.99988.
-typedef _Float16 k1_h2 __attribute__((ext_vector_type(2)));
-typedef unsigned short k1_us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ k1_h2 k1_rcp_h2(k1_h2 x) {
-  const k1_us2 magic = {0x777E, 0x777E};
-  k1_h2 r = __builtin_bit_cast(k1_h2, (k1_us2)(magic - __builtin_bit_cast(k1_us2, x)));
-  const k1_h2 one = {(_Float16)1.f, (_Float16)1.f};
-  k1_h2 e = one - x * r;
-  r = r + r * e;
-  e = one - x * r;
-  r = r + r * e;
-  return r;
-}
-__device__ __forceinline__ k1_h2 k1_pack_h2(float a, float b) { return (k1_h2){(_Float16)a, (_Float16)b}; }
-// One wave-level chunk step: 4 columns per lane as two element pairs (lo: columns 0,1; hi: columns 2,3).  esp: f16 Es rows, HP halves
-// per word.  acc[n] += sum over the 4 columns of (-2w) / (Ea Es[n] + 1), two packed halves.
-template <int NP, int G = 4>
-__device__ __forceinline__ void scdm_chunk_step_h(k1_h2 EaLo, k1_h2 EaHi, const _Float16* __restrict__ esp, int HP, k1_h2 wLo, k1_h2 wHi,
-                                                  k1_h2 (&acc)[NP]) {
-  static_assert(NP % G == 0, "word groups");
-  const k1_h2 one = {(_Float16)1.f, (_Float16)1.f}, cap = {(_Float16)16384.f, (_Float16)16384.f};
-  uint2 cur[G], nxt[G];
-#pragma unroll
-  for (int u = 0; u < G; ++u) cur[u] = *reinterpret_cast<const uint2*>(esp + u * HP);
-#pragma unroll
-  for (int n0 = 0; n0 < NP; n0 += G) {
-    if (n0 + G < NP) {
-#pragma unroll
-      for (int u = 0; u < G; ++u) nxt[u] = *reinterpret_cast<const uint2*>(esp + (n0 + G + u) * HP);
-    }
-#pragma unroll
-    for (int u = 0; u < G; ++u) {
-      const k1_h2 eLo = __builtin_bit_cast(k1_h2, cur[u].x), eHi = __builtin_bit_cast(k1_h2, cur[u].y);
-      const k1_h2 xl = __builtin_elementwise_min(EaLo * eLo + one, cap), xh = __builtin_elementwise_min(EaHi * eHi + one, cap);
-      acc[n0 + u] = wLo * k1_rcp_h2(xl) + acc[n0 + u];
-      acc[n0 + u] = wHi * k1_rcp_h2(xh) + acc[n0 + u];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < G; ++u) cur[u] = nxt[u];
-  }
-}
-
 // Sum NP per-lane partials over the 64 lanes with the gfx950 swap instructions: v_permlane32_swap
 // folds the two wave halves of TWO values at once, v_permlane16_swap the two 16-lane rows of each
 // half, then 4 DPP steps finish inside a row.  NP values -> NP/4 registers; afterwards register j,
@@ -771,10 +718,6 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
   const int nsub = TT / SUB;
 
   // ---- prologue (all waves): Es = exp(2 s[b]), -2w, zeroed P tiles
-  // (bf16 storage: both as f16 -- the packed score loop below -- in the first half of the same LDS blocks; a, s clamped to +-5)
-  _Float16* Es16 = reinterpret_cast<_Float16*>(Es);     // [NP][HP] halves
-  _Float16* Wl16 = reinterpret_cast<_Float16*>(Wl);     // [HP] halves: -2w
-  constexpr float kClampH = 5.f;
   const ST* sb = s + (size_t)b * N * H;
   const int hp4 = HP / 4, total4 = TSG_SKIP(8) ? 0 : NP * hp4;
   constexpr int PU = PW == 4 ? 12 : 6;
@@ -791,29 +734,16 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
       const int idx = base + u * NT;
       if (idx < total4) {
         const int n = idx / hp4, k = (idx % hp4) * 4;
-        if constexpr (BF) {
-          float4 e = make_float4(fast_exp2(clampf(v[u].x, -kClampH, kClampH) * k2Log2e), fast_exp2(clampf(v[u].y, -kClampH, kClampH) * k2Log2e),
-                                 fast_exp2(clampf(v[u].z, -kClampH, kClampH) * k2Log2e), fast_exp2(clampf(v[u].w, -kClampH, kClampH) * k2Log2e));
-          if (v[u].x == -1e30f) e = make_float4(0.f, 0.f, 0.f, 0.f);
-          const k1_h2 lo = k1_pack_h2(e.x, e.y), hi = k1_pack_h2(e.z, e.w);
-          *reinterpret_cast<uint2*>(Es16 + n * HP + k) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
-        } else {
-          float4 e = exp2x4(v[u]);
-          if (v[u].x == -1e30f) e = make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(Es + n * HP + k) = e;
-        }
+        float4 e = exp2x4(v[u]);
+        if (v[u].x == -1e30f) e = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Es + n * HP + k) = e;
       }
     }
   }
   for (int k = tid * 4; k < HP; k += 4 * NT) {
     float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < H) wq = *reinterpret_cast<const float4*>(w + k);
-    if constexpr (BF) {
-      const k1_h2 lo = k1_pack_h2(-2.f * wq.x, -2.f * wq.y), hi = k1_pack_h2(-2.f * wq.z, -2.f * wq.w);
-      *reinterpret_cast<uint2*>(Wl16 + k) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
-    } else {
-      *reinterpret_cast<float4*>(Wl + k) = make_float4(-2.f * wq.x, -2.f * wq.y, -2.f * wq.z, -2.f * wq.w);
-    }
+    *reinterpret_cast<float4*>(Wl + k) = make_float4(-2.f * wq.x, -2.f * wq.y, -2.f * wq.z, -2.f * wq.w);
   }
   for (int i = tid; i < 2 * SUB * PP; i += NT) Pl[i] = 0.f;
 
@@ -841,40 +771,19 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
     lds_barrier();
     auto score_row = [&](float* Pcur, int tl, int t, const ST* nrow) {
       float acc[1][NP];
-      if constexpr (BF) {
-        // packed f16 score loop (scdm_chunk_step_h): no transcendental per element, two elements per instruction
-        k1_h2 acch[NP];
 #pragma unroll
-        for (int n = 0; n < NP; ++n) acch[n] = (k1_h2){(_Float16)0.f, (_Float16)0.f};
+      for (int n = 0; n < NP; ++n) acc[0][n] = 0.f;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          const int k = 256 * c + lane * 4;
-          const uint2 wq = *reinterpret_cast<const uint2*>(Wl16 + k);
-          const float4 av = cvt4(q[c]);
-          const k1_h2 EaLo = k1_pack_h2(fast_exp2(clampf(av.x, -kClampH, kClampH) * k2Log2e), fast_exp2(clampf(av.y, -kClampH, kClampH) * k2Log2e));
-          const k1_h2 EaHi = k1_pack_h2(fast_exp2(clampf(av.z, -kClampH, kClampH) * k2Log2e), fast_exp2(clampf(av.w, -kClampH, kClampH) * k2Log2e));
-          q[c] = ldraw4(nrow + 256 * c);
-          if (!TSG_SKIP(1))
-            scdm_chunk_step_h<NP, (NP % 4 == 0 ? 4 : 2)>(EaLo, EaHi, Es16 + k, HP, __builtin_bit_cast(k1_h2, wq.x), __builtin_bit_cast(k1_h2, wq.y), acch);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int n = 0; n < NP; ++n) acc[0][n] = (float)acch[n].x + (float)acch[n].y;
-      } else {
-#pragma unroll
-        for (int n = 0; n < NP; ++n) acc[0][n] = 0.f;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          const int k = 256 * c + lane * 4;
-          const float4 wq = *reinterpret_cast<const float4*>(Wl + k);
-          const float w2[4] = {wq.x, wq.y, wq.z, wq.w};
-          float Ea[1][4];
-          const float4 e = exp2x4(cvt4(q[c]));
-          Ea[0][0] = e.x; Ea[0][1] = e.y; Ea[0][2] = e.z; Ea[0][3] = e.w;
-          q[c] = ldraw4(nrow + 256 * c);
-          if (!TSG_SKIP(1)) scdm_chunk_step<NP, 1, 2>(Ea, Es + k, HP, w2, acc);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+      for (int c = 0; c < CT; ++c) {
+        const int k = 256 * c + lane * 4;
+        const float4 wq = *reinterpret_cast<const float4*>(Wl + k);
+        const float w2[4] = {wq.x, wq.y, wq.z, wq.w};
+        float Ea[1][4];
+        const float4 e = exp2x4(cvt4(q[c]));
+        Ea[0][0] = e.x; Ea[0][1] = e.y; Ea[0][2] = e.z; Ea[0][3] = e.w;
+        q[c] = ldraw4(nrow + 256 * c);
+        if (!TSG_SKIP(1)) scdm_chunk_step<NP, 1, 2>(Ea, Es + k, HP, w2, acc);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // land the next row ahead of the P stores (vmcnt counts loads and stores together, in order)
       land();
@@ -1534,9 +1443,10 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
   // tests/test_isa_cpu.py disassembles the built code object and asserts the vmcnt(0) wait between the last sc1 store and the
   // counter's atomic in every instantiation.
   // Two steps (round 4).  publish_dp: the stores, right after the row loop.  count_in: the wait + barrier + ticket, AFTER the T-sum
-  // epilogue of the row phase -- vmcnt counts loads and stores together and in order, so the acknowledgement wait also drains the
-  // wave's queue of dr row stores (256 KiB per workgroup, just issued): placed straight behind the row loop it stalled every wave on
-  // that drain (165 vs 146 us per launch at [128,128,20,1024]); behind the epilogue the queue has drained under the epilogue's LDS work.
+  // epilogue of the row phase -- vmcnt counts loads and stores together and in order, so the acknowledgement wait also covers the
+  // wave's queue of dr row stores; behind the epilogue that queue has drained under the epilogue's LDS work.  A/B on one box
+  // (tools/gpu_jobs/r4c.sh, -DTSG_K1_NO_ACK = the round-3 protocol without the wait): 165.4 / 166.4 us with the wait, 166.1 / 164.3
+  // without, at [128,128,20,1024] -- the acknowledgement wait is free.
   auto publish_dp = [&]() {
     if (parts <= 1) return;
     float* mine = xch + ((size_t)b * parts + pt) * T * NP;

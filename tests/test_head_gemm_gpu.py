@@ -180,4 +180,5 @@ def test_gemm_f32s_ld_slices(f32s):
     assert lib.tsg_gemm_f32s_ld(ptr(Xw), K + 32, ptr(Ww), 2 * K, ptr(bias), ptr(Yw), N + 64, M, N, K, st) == 0, lib.tsg_last_error()
     torch.cuda.synchronize()
     assert torch.equal(Yw[:, :N], y) and float(Yw[:, N:].abs().max()) == 0.0
-    torch.testing.assert_close(y, x.double().mm(w.double().t()).float() + bias, atol=1e-4, rtol=1e-4)
+    # (split-precision product of N(0,1) operands: ~2^-16 relative per term; the equality above is the point of this test)
+    torch.testing.assert_close(y, x.double().mm(w.double().t()).float() + bias, atol=1e-3, rtol=1e-3)
