@@ -302,11 +302,9 @@ int tsg_linear_fwd(const void* x, const void* w, const void* bias, void* y, int 
  * gradient dX = dY W of the same Linears is this call with the weight passed transposed ([K,N] contiguous).                       */
 int tsg_gemm_f32s(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, void* stream);
 /* The same with row strides (in elements, multiples of 4) for x, w and y: a column slice of a row-major matrix is an operand as it
- * stands (ABI revision 5) -- the video half W[:, :Dv] of a head's [H, Dv + Ds] first Linear, or a slice of a wider output -- and an
- * optional ADDEND [M,N] (row stride ldy, may be y itself): y = x w^T + bias + addend, i.e. a gradient accumulated into an existing
- * one in the GEMM's epilogue instead of by a separate elementwise pass (dr += da W_a in the recalibration block's backward).        */
-int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, long long ldw, const void* bias, const void* addend, void* y,
-                     long long ldy, int M, int N, int K, void* stream);
+ * stands (ABI revision 5) -- the video half W[:, :Dv] of a head's [H, Dv + Ds] first Linear, or a slice of a wider output.        */
+int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, long long ldw, const void* bias, void* y, long long ldy,
+                     int M, int N, int K, void* stream);
 
 /* ---- the heads as the EPILOGUE of their own first-Linear GEMM (ABI revision 5; round-3 review: SURVEY 8f #2 "split-W Linear + ReLU
  * + dot epilogue").  Same f32s arithmetic and tiling as tsg_gemm_f32s (row tiles of 256 / 128 / 64 so that a narrow head still

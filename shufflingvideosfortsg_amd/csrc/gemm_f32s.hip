@@ -115,8 +115,6 @@ __device__ __forceinline__ int acc_row(const TilePos& p, int i, int r) { return 
 // ---- epilogue: plain store ------------------------------------------------------------------------------------------------------
 struct EpiStore {
   const float* bias; float* Y; long long ldy;
-  const float* addend;     // [M, N] with Y's row stride, or NULL: Y = acc + bias + addend (may alias Y: each element is read and then
-                           // written by the same lane) -- a gradient ACCUMULATED into an existing one instead of a separate add pass
   static constexpr bool kUsesLds = false;
   template <int MI>
   __device__ __forceinline__ void run(const g_f32x16 (&acc)[MI][2], const TilePos& p, float* /*lds*/) const {
@@ -127,17 +125,8 @@ struct EpiStore {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         float* yp = Y + (size_t)(p.m0 + p.wm + 32 * i + 4 * p.kg) * ldy + col;
-        if (addend) {
-          const float* ap = addend + (size_t)(p.m0 + p.wm + 32 * i + 4 * p.kg) * ldy + col;
-          float av[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) av[r] = ap[(size_t)((r & 3) + 8 * (r >> 2)) * ldy];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r] + bv + av[r];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r] + bv;
-        }
+        for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r] + bv;
       }
     }
   }
@@ -506,11 +495,11 @@ using namespace tsg;
 // Y[M,N] = X[M,K] W[N,K]^T (+ bias, may be NULL) in the split-precision arithmetic, operands converted on load.
 // M % 256 == 0, N % 256 == 0, K % 32 == 0 (TSG_E_SHAPE otherwise: the caller uses tsg_split_bf16x3 + a bf16 GEMM).
 extern "C" int tsg_gemm_f32s(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, void* stream) {
-  return tsg_gemm_f32s_ld(x, K, w, K, bias, nullptr, y, N, M, N, K, stream);
+  return tsg_gemm_f32s_ld(x, K, w, K, bias, y, N, M, N, K, stream);
 }
 
-extern "C" int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, long long ldw, const void* bias, const void* addend, void* y,
-                                long long ldy, int M, int N, int K, void* stream) {
+extern "C" int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, long long ldw, const void* bias, void* y, long long ldy,
+                                int M, int N, int K, void* stream) {
   const char* fn = "tsg_gemm_f32s";
   for (const void* p : {x, w, (const void*)y}) {
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
@@ -521,7 +510,7 @@ extern "C" int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, lon
     return set_error(TSG_E_SHAPE, "%s: M=%d, N=%d must be multiples of 256 and K=%d of 32", fn, M, N, K);
   if (ldx < K || ldw < K || ldy < N || ldx % 4 || ldw % 4) return set_error(TSG_E_ALIGN, "%s: leading dimensions ldx=%lld ldw=%lld ldy=%lld", fn, ldx, ldw, ldy);
   static const bool m16 = [] { const char* e = getenv("TSG_GEMM_MFMA16"); return e && atoi(e) != 0; }();     // A/B: the 16x16x32 variant
-  if (m16 && !addend) {
+  if (m16) {
     auto kern = gemm_nt_f32s_m16_kernel<256>;
     constexpr size_t lds = gemm_lds<256>();
     hipError_t e = allow_lds(kern, lds);
@@ -531,7 +520,7 @@ extern "C" int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, lon
                        (const float*)w, ldw, (const float*)bias, (float*)y, ldy, M, N, K, tiles_n);
     return check_launch(fn);
   }
-  const EpiStore epi{(const float*)bias, (float*)y, ldy, (const float*)addend};
+  const EpiStore epi{(const float*)bias, (float*)y, ldy};
   return launch_gemm<256>(fn, (const float*)x, ldx, (const float*)w, (const float*)w, N, ldw, epi, M, N, K, static_cast<hipStream_t>(stream));
 }
 

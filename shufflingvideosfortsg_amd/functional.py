@@ -495,65 +495,6 @@ class _ScdmGate(torch.autograd.Function):
         return da, ds, dw, dVW, dgb, dr
 
 
-class _RecalBlock(torch.autograd.Function):
-    """The attention part of rnn_recalibration_layer.forward (components/VideoEncoder.py:61-74) as ONE autograd node in the f32s mode:
-    a = r W_a^T (own split-precision GEMM), out = K1g(a, s, w, VW, gbias, r).  r feeds both the projection and the gate, so its
-    gradient is a sum of two terms; as separate nodes autograd materialises da W_a and adds it to the gate's dr in an extra pass over
-    [B,T,d] (4 launches of 16.8 M elements per step); here the projection's input gradient is ACCUMULATED into dr in the epilogue of
-    its GEMM (tsg_gemm_f32s_ld with addend = output)."""
-
-    @staticmethod
-    @_fwd
-    def forward(ctx, r, Wa, s, w, VW, gbias):
-        require_device(r, Wa, s, w, VW, gbias)
-        r, Wa, s, w, VW, gbias = _f32c(r), _f32c(Wa), _f32c(s), _f32p(w), _f32c(VW), _f32p(gbias)
-        B, T, D = r.shape
-        H = Wa.shape[0]
-        _, N, Ds = VW.shape
-        if Wa.shape[1] != D or s.shape != (B, N, H) or w.numel() != H or Ds != D or gbias.numel() != Ds:
-            raise ValueError(f"recal_block: shape mismatch r{tuple(r.shape)} Wa{tuple(Wa.shape)} s{tuple(s.shape)} VW{tuple(VW.shape)}")
-        a = gemm_f32s(r.view(B * T, D), Wa).view(B, T, H)
-        out = torch.empty(B, T, Ds, device=r.device, dtype=torch.float32)
-        P = torch.empty(B, T, N, device=r.device, dtype=torch.float32)
-        _call("tsg_scdm_gate_fwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(r), ptr(out), ptr(P), B, T, N, H, Ds, TSG_F32S)
-        ctx.save_for_backward(r, Wa, a, s, w, VW, gbias, P)
-        return out
-
-    @staticmethod
-    @_bwd
-    def backward(ctx, dout):
-        r, Wa, a, s, w, VW, gbias, P = ctx.saved_tensors
-        dout = _f32c(dout)
-        B, T, H = a.shape
-        _, N, Ds = VW.shape
-        D = r.shape[2]
-        da = torch.empty_like(a); ds = torch.empty_like(s); dw = torch.empty_like(w)
-        dVW = torch.empty_like(VW); dgb = torch.empty_like(gbias); dr = torch.empty_like(r)
-        nb = int(load().tsg_scdm_bwd_ws_bytes(B, T, N, H, Ds, 1))
-        ws = torch.empty(nb // 4 + 4, device=a.device, dtype=torch.float32)
-        _call("tsg_scdm_gate_bwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(r), ptr(P), ptr(dout),
-              ptr(da), ptr(ds), ptr(dw), ptr(dVW), ptr(dgb), ptr(dr), ptr(ws), nb, B, T, N, H, Ds, TSG_F32S)
-        M = B * T
-        da2, r2 = da.view(M, H), r.view(M, D)
-        dWa = _dw_f32s(da2, r2) if ctx.needs_input_grad[1] else None
-        if ctx.needs_input_grad[0]:
-            Wt = Wa.t().contiguous()                                   # [D, H]: dr[M,D] += da[M,H] Wa[H,D] as an NT product
-            _call("tsg_gemm_f32s_ld", da2, ptr(da2), H, ptr(Wt), H, None, ptr(dr), ptr(dr), D, M, D, H)
-        return dr, dWa, ds, dw, dVW, dgb
-
-
-def recal_block_ok(B: int, T: int, D: int, H: int, Ds: int) -> bool:
-    """Shapes the fused recalibration node takes (f32s mode; whole 256-tiles for both GEMMs; K1g's role-specialised kernel widths)."""
-    M = B * T
-    return (_GEMM_DTYPE == "f32s" and _OWN_GEMM and D == Ds and gemm_f32s_ok(M, H, D) and gemm_f32s_ok(M, D, H) and H % 32 == 0
-            and os.environ.get("TSG_RECAL_FUSED", "1") != "0")
-
-
-def recal_block(r, Wa, s, w, VW, gbias):
-    """-> r * sigmoid(P @ VW + gbias) with P = softmax_n(w . tanh(r W_a^T + s)): projection + K1g as one node (see _RecalBlock)."""
-    return _RecalBlock.apply(r, Wa, s, w.reshape(-1), VW, gbias)
-
-
 def scdm_gate(a, s, w, VW, gbias, r):
     """SCDM attention fused with the recalibration gate (see include/tsg_hip.h, K1g)."""
     return _ScdmGate.apply(a, s, w.reshape(-1), VW, gbias, r)

@@ -57,15 +57,6 @@ class rnn_recalibration_layer(nn.Module):
             # fused tail: sent_linear(P @ words) = P @ (words W_l^T) + b_l, so the Linear runs on the N word rows
             # instead of the T clip rows and bias / sigmoid / gate are the attention kernel's epilogue
             VW = TF.linear(word_feat, self.sent_linear.weight)
-            B, T, D = rnn_output.shape
-            if (rnn_output.is_cuda and rnn_output.dtype == torch.float32 and word_feat.dtype == torch.float32
-                    and TF.recal_block_ok(B, T, D, att.W_a.weight.size(0), VW.size(-1))):
-                # projection + attention + gate as ONE autograd node: the projection's input gradient is accumulated into the
-                # gate's dr inside its GEMM (functional._RecalBlock)
-                s = TF.linear(word_feat, att.W_s.weight, None)
-                if att.W_a.bias is not None:
-                    s = s + att.W_a.bias
-                return TF.recal_block(rnn_output, att.W_a.weight, s, att.w.weight, VW, self.sent_linear.bias)
             a, s = att.projections(rnn_output, word_feat)
             return TF.scdm_gate(a, s, att.w.weight, VW, self.sent_linear.bias, rnn_output)
         # un-fused tail (another attention class, or a word width sent_linear was not built for)

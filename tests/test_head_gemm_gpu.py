@@ -177,59 +177,8 @@ def test_gemm_f32s_ld_slices(f32s):
     x, w = Xw[:, :K].contiguous(), Ww[:, :K].contiguous()
     y = torch.empty(M, N, device="cuda")
     assert lib.tsg_gemm_f32s(ptr(x), ptr(w), ptr(bias), ptr(y), M, N, K, st) == 0, lib.tsg_last_error()
-    assert lib.tsg_gemm_f32s_ld(ptr(Xw), K + 32, ptr(Ww), 2 * K, ptr(bias), None, ptr(Yw), N + 64, M, N, K, st) == 0, lib.tsg_last_error()
+    assert lib.tsg_gemm_f32s_ld(ptr(Xw), K + 32, ptr(Ww), 2 * K, ptr(bias), ptr(Yw), N + 64, M, N, K, st) == 0, lib.tsg_last_error()
     torch.cuda.synchronize()
     assert torch.equal(Yw[:, :N], y) and float(Yw[:, N:].abs().max()) == 0.0
-    # accumulate into an existing tensor (the addend IS the output): y2 <- y2 + x w^T
-    y2 = torch.randn(M, N, generator=g).cuda(); want = y2 + (y - bias)
-    assert lib.tsg_gemm_f32s_ld(ptr(x), K, ptr(w), K, None, ptr(y2), ptr(y2), N, M, N, K, st) == 0, lib.tsg_last_error()
-    torch.testing.assert_close(y2, want, atol=1e-5, rtol=1e-5)
     # (split-precision product of N(0,1) operands: ~2^-16 relative per term; the equality above is the point of this test)
     torch.testing.assert_close(y, x.double().mm(w.double().t()).float() + bias, atol=1e-3, rtol=1e-3)
-
-
-def test_recal_block_fused_node_vs_unfused_and_oracle(f32s):
-    """rnn_recalibration_layer's attention part as ONE autograd node (functional._RecalBlock: projection GEMM + K1g, the projection's
-    input gradient accumulated into the gate's dr in the GEMM epilogue) against (i) the oracle's un-fused formulation
-    (attention.py:109-121 + VideoEncoder.py:65-72 on the LSTM output r) and (ii) the two-node HIP path, on the same operands."""
-    from shufflingvideosfortsg_amd import functional as TF
-    B, T, N, d = 50, 128, 20, 1024                      # M = 6400 rows = 25 x 4 = 100 tiles of 256 x 256: the smallest eligible launch
-    assert TF.recal_block_ok(B, T, d, d, d)
-    g = torch.Generator().manual_seed(31)
-    r = torch.randn(B, T, d, generator=g) * 0.5
-    Wa = torch.randn(d, d, generator=g) / d ** 0.5; ba = torch.randn(d, generator=g) * 0.1
-    Ws = torch.randn(d, d, generator=g) / d ** 0.5; w = torch.randn(1, d, generator=g) / d ** 0.5
-    Wl = torch.randn(d, d, generator=g) / d ** 0.5; bl = torch.randn(d, generator=g) * 0.1
-    words = torch.randn(B, N, d, generator=g) * 0.5
-    go = torch.randn(B, T, d, generator=g)
-    # oracle on 2 items (the CPU cannot run 50 in seconds): the reference's un-fused math
-    r0 = r[:2].clone().requires_grad_(True)
-    p0 = {k: v.clone().requires_grad_(True) for k, v in dict(Wa=Wa, ba=ba, Ws=Ws, w=w, Wl=Wl, bl=bl).items()}
-    C0 = O.scdm_attention(r0, words[:2], p0["Ws"], p0["Wa"], p0["ba"], p0["w"])
-    C0 = C0[0] if isinstance(C0, tuple) else C0
-    out0 = r0 * torch.sigmoid(torch.nn.functional.linear(C0, p0["Wl"], p0["bl"]))
-    out0.backward(go[:2])
-
-    def run(fused):
-        rd = r.cuda().requires_grad_(True)
-        pd = {k: v.cuda().requires_grad_(True) for k, v in dict(Wa=Wa, ba=ba, Ws=Ws, w=w, Wl=Wl, bl=bl).items()}
-        wd = words.cuda()
-        VW = TF.linear(wd, pd["Wl"])
-        s = TF.linear(wd, pd["Ws"], None) + pd["ba"]
-        if fused:
-            out = TF.recal_block(rd, pd["Wa"], s, pd["w"], VW, pd["bl"])
-        else:
-            out = TF.scdm_gate(TF.linear(rd, pd["Wa"], None), s, pd["w"], VW, pd["bl"], rd)
-        out.backward(go.cuda())
-        torch.cuda.synchronize()
-        return out.detach(), rd.grad, {k: v.grad for k, v in pd.items()}
-
-    out1, dr1, g1 = run(True)
-    out2, dr2, g2 = run(False)
-    torch.testing.assert_close(out1, out2, atol=2e-5, rtol=2e-5)
-    torch.testing.assert_close(dr1, dr2, atol=2e-5 * max(1.0, float(dr2.abs().max())), rtol=2e-4)
-    for k in g1:
-        torch.testing.assert_close(g1[k], g2[k], atol=2e-4 * max(1.0, float(g2[k].abs().max())), rtol=2e-3, msg=lambda m, k=k: f"d{k}: {m}")
-    torch.testing.assert_close(out1[:2].cpu(), out0.detach(), **TOL)
-    # the oracle's gradient of r for items 0..1 (upstream gradient restricted to them is what the full backward sees for those rows)
-    torch.testing.assert_close(dr1[:2].cpu(), r0.grad, atol=3e-4, rtol=2e-3)
