@@ -75,10 +75,6 @@ __device__ __forceinline__ void g_split_pair(float a, float b, unsigned& hi, uns
 __device__ __forceinline__ g_f32x16 g_mfma(g_u32x4 a, g_u32x4 b, g_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g_bf16x8, a), __builtin_bit_cast(g_bf16x8, b), c, 0, 0, 0);
 }
-typedef float g_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ g_f32x4 g_mfma16(g_u32x4 a, g_u32x4 b, g_f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g_bf16x8, a), __builtin_bit_cast(g_bf16x8, b), c, 0, 0, 0);
-}
 
 // Sum over the 32 lanes of each wave half (lanes 0..31 / 32..63); every lane of a half receives its half's total.
 __device__ __forceinline__ float half_allsum(float v) {
@@ -336,116 +332,11 @@ __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restri
   }
 }
 
-// ---- the same GEMM on v_mfma_f32_16x16x32_bf16 (plain-store epilogue).  MI355X_MICROARCH.md, DVFS give-back item 7: at about equal cycles
-// per FLOP the chip holds a higher clock on the 16x16x32 shape than on 32x32x16 (bare loops: 1.12-1.15 x the FLOP/s).  One MFMA consumes a
-// whole 32-deep chunk of 16 rows: lane l reads row l & 15, 16-byte piece l >> 4 of the plane row.  LDS image: piece p of row r sits at
-// slot p ^ h((r >> 2) & 3), h = {0, 3, 2, 1}: every 16-lane group of the ds_read_b128 (lanes {0-3, 12-15, 20-27}, ...) then touches 16
-// distinct 16-byte slots of the 256-byte bank row, and the staging writes (two rows of 64 bytes per 16 lanes) stay conflict-free.
-// C/D map: column lane & 15, rows 4 (lane >> 4) + reg.
-__device__ __forceinline__ int g_h16(int r) { return (0x1230 >> (4 * ((r >> 2) & 3))) & 3; }     // h = {0, 3, 2, 1}
-
-template <int TM>
-__global__ __launch_bounds__(kGT) void gemm_nt_f32s_m16_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ W, long long ldw,
-                                                               const float* __restrict__ bias, float* __restrict__ Y, long long ldy,
-                                                               int M, int N, int K, int tiles_n) {
-  constexpr int MI = TM / 32, NJ = 4, PX = TM / 64;                 // 16-row tiles per wave (wave tile = TM/2 rows x 64 columns)
-  constexpr int kPlaneX = plane_x<TM>();
-  constexpr int kBuf = 2 * kPlaneX + 2 * kPlaneW;
-  extern __shared__ __align__(16) unsigned lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = (wv >> 2) * (TM / 2), wn = (wv & 3) * 64;
-  const int rl = lane & 15, pc = lane >> 4;
-  const int ntiles = (M / TM) * tiles_n;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  const int bid = xcd_remap(tile, ntiles, tiles_n);
-  const int m0 = (bid / tiles_n) * TM, n0 = (bid % tiles_n) * kTN;
-  const int sr = tid >> 3, sq = tid & 7;
-  const float* xsrc = X + (size_t)(m0 + sr) * ldx + 4 * sq;
-  const float* wsrc = W + (size_t)(n0 + sr) * ldw + 4 * sq;
-  const size_t passx = (size_t)64 * ldx, passw = (size_t)64 * ldw;
-  float4 rx[PX], rw[4];
-  auto request = [&](int k0) {
-#pragma unroll
-    for (int p = 0; p < PX; ++p) rx[p] = *reinterpret_cast<const float4*>(xsrc + p * passx + k0);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) rw[p] = *reinterpret_cast<const float4*>(wsrc + p * passw + k0);
-  };
-  auto write_planes = [&](int buf) {
-    unsigned* base = lds + buf * kBuf;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int r = sr + 64 * p;
-      const int o = r * 16 + (((sq >> 1) ^ g_h16(r)) << 2) + ((sq & 1) << 1);
-      unsigned h0, l0, h1, l1;
-      if (p < PX) {
-        g_split_pair(rx[p < PX ? p : 0].x, rx[p < PX ? p : 0].y, h0, l0); g_split_pair(rx[p < PX ? p : 0].z, rx[p < PX ? p : 0].w, h1, l1);
-        *reinterpret_cast<uint2*>(base + o) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(base + kPlaneX + o) = make_uint2(l0, l1);
-      }
-      g_split_pair(rw[p].x, rw[p].y, h0, l0); g_split_pair(rw[p].z, rw[p].w, h1, l1);
-      *reinterpret_cast<uint2*>(base + 2 * kPlaneX + o) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(base + 2 * kPlaneX + kPlaneW + o) = make_uint2(l0, l1);
-    }
-  };
-  auto frag = [&](const unsigned* hi_plane, int plane, int r0, g_u32x4& hi, g_u32x4& lo) {     // 16 rows from r0: lane -> (row r0 + rl, piece pc)
-    const int r = r0 + rl;
-    const int o = r * 16 + ((pc ^ g_h16(r)) << 2);
-    hi = *reinterpret_cast<const g_u32x4*>(hi_plane + o);
-    lo = *reinterpret_cast<const g_u32x4*>(hi_plane + plane + o);
-  };
-  g_f32x4 acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
-  const int nk = K / kBK;
-  request(0);
-  write_planes(0);
-  if (nk > 1) request(kBK);
-  auto chunk = [&](int ks, auto w_tag, auto r_tag) {
-    constexpr bool WRITE = decltype(w_tag)::value, REQ = decltype(r_tag)::value;
-    lds_barrier();
-    if (WRITE) write_planes((ks + 1) & 1);
-    if (REQ) request((ks + 2) * kBK);
-    const unsigned* xt = lds + (ks & 1) * kBuf;
-    const unsigned* wt = xt + 2 * kPlaneX;
-    g_u32x4 bh[NJ], bl[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) frag(wt, kPlaneW, wn + 16 * j, bh[j], bl[j]);
-    g_u32x4 ah, al, nh, nl;
-    frag(xt, kPlaneX, wm, ah, al);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      if (i < MI - 1) frag(xt, kPlaneX, wm + 16 * (i + 1), nh, nl);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        acc[i][j] = g_mfma16(ah, bh[j], acc[i][j]);
-        acc[i][j] = g_mfma16(ah, bl[j], acc[i][j]);
-        acc[i][j] = g_mfma16(al, bh[j], acc[i][j]);
-      }
-      if (i < MI - 1) { ah = nh; al = nl; }
-    }
-  };
-  typedef std::true_type Y_; typedef std::false_type N_;
-  int ks = 0;
-#pragma unroll 1
-  for (; ks + 2 < nk; ++ks) chunk(ks, Y_{}, Y_{});
-  if (ks + 1 < nk) { chunk(ks, Y_{}, N_{}); ++ks; }
-  chunk(ks, N_{}, N_{});
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int col = n0 + wn + 16 * j + rl;
-    const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      float* yp = Y + (size_t)(m0 + wm + 16 * i + 4 * pc) * ldy + col;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) yp[(size_t)r * ldy] = acc[i][j][r] + bv;
-    }
-  }
-  lds_barrier();
-  }
-}
+// (Round 4, measured and removed: the same kernel on v_mfma_f32_16x16x32_bf16 -- MI355X_MICROARCH.md reports a higher sustained clock for
+// that shape in bare MFMA loops.  Here, with the conversion VALU beside the MFMAs, it is a tie: 387-431 vs 396-438 us at
+// [16384 x 1024] x [4096 x 1024]^T, 94-96 vs 94-101 us at [16384 x 1024] x [1024 x 1024]^T, two processes each, alternating:
+// profiles/r4/gemm_f32s_mfma_shape_ab_v1.txt.  The LDS image for its fragment reads: piece p of row r at slot p ^ h((r >> 2) & 3),
+// h = {0, 3, 2, 1}, conflict-free for both the b128 reads and the staging writes.)
 
 template <int TM, typename Epi>
 int launch_gemm(const char* fn, const float* x, long long ldx, const float* w0, const float* w1, int nseg, long long ldw, const Epi& epi,
@@ -509,17 +400,6 @@ extern "C" int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, lon
   if (M % 256 || N % kTN || K % kBK)
     return set_error(TSG_E_SHAPE, "%s: M=%d, N=%d must be multiples of 256 and K=%d of 32", fn, M, N, K);
   if (ldx < K || ldw < K || ldy < N || ldx % 4 || ldw % 4) return set_error(TSG_E_ALIGN, "%s: leading dimensions ldx=%lld ldw=%lld ldy=%lld", fn, ldx, ldw, ldy);
-  static const bool m16 = [] { const char* e = getenv("TSG_GEMM_MFMA16"); return e && atoi(e) != 0; }();     // A/B: the 16x16x32 variant
-  if (m16) {
-    auto kern = gemm_nt_f32s_m16_kernel<256>;
-    constexpr size_t lds = gemm_lds<256>();
-    hipError_t e = allow_lds(kern, lds);
-    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute(%zu): %s", fn, lds, hipGetErrorString(e));
-    const int tiles_n = N / kTN, tiles = (M / 256) * tiles_n, cus = device_cu_count();
-    hipLaunchKernelGGL(kern, dim3(tiles < cus ? tiles : cus), dim3(kGT), lds, static_cast<hipStream_t>(stream), (const float*)x, ldx,
-                       (const float*)w, ldw, (const float*)bias, (float*)y, ldy, M, N, K, tiles_n);
-    return check_launch(fn);
-  }
   const EpiStore epi{(const float*)bias, (float*)y, ldy};
   return launch_gemm<256>(fn, (const float*)x, ldx, (const float*)w, (const float*)w, N, ldw, epi, M, N, K, static_cast<hipStream_t>(stream));
 }
