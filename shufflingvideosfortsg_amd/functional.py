@@ -317,6 +317,12 @@ def _split_operand(m: torch.Tensor, k_dim: int, right: bool) -> torch.Tensor:
 
 
 _OWN_GEMM = os.environ.get("TSG_GEMM", "1") != "0"          # A/B switch: 0 = operand planes + the library's bf16 GEMM everywhere
+# The LSTM layers' three products (input projection, dX, [dW_ih | dW_hh]) on the hand-written split-on-load kernels (tsg_gemm_f32s,
+# tsg_wgrad_f32s) instead of operand planes + the library's bf16 GEMM: the default since round 4.  In the step it is a tie in time
+# (14.295 / 14.297 / 14.304 ms own vs 14.278 / 14.314 / 14.320 ms library, alternating processes on one box:
+# profiles/r4/bench_lstm_own_gemm_ab_v1.txt) -- and it takes the operand-plane passes (1.59 -> 0.24 ms per step) and the library's bf16
+# GEMMs (4.92 -> 0.60 ms) out of the step: all matrix work of the path is hand-written now.  TSG_LSTM_GEMM=lib keeps the old path (A/B).
+_LSTM_OWN_GEMM = os.environ.get("TSG_LSTM_GEMM", "own") != "lib"
 
 
 def gemm_f32s_ok(M: int, N: int, K: int) -> bool:
@@ -1133,8 +1139,14 @@ class _BiLSTMLayer(torch.autograd.Function):
         if W_ih.shape != (8 * h, I) or W_hh.shape != (2, 4 * h, h) or bias.numel() != 8 * h:
             raise ValueError(f"bilstm: shape mismatch x{tuple(x.shape)} W_ih{tuple(W_ih.shape)} W_hh{tuple(W_hh.shape)}")
         ctx.Ws = None
+        ctx.own = False
         if mode is None:
             Gx, kbias = torch.addmm(bias, x.view(T * B, I), W_ih.t()), None   # [rows,2,4h]; bias in the GEMM epilogue
+        elif mode == "f32s" and _LSTM_OWN_GEMM and x.is_cuda and gemm_f32s_ok(T * B, 8 * h, I):
+            # the LSTM's matrix work on the hand-written kernels, operands converted on load: no operand planes in HBM at all
+            # (forward: tsg_gemm_f32s; backward: tsg_gemm_f32s for dX, tsg_wgrad_f32s for [dW_ih | dW_hh] of both directions)
+            ctx.own = True
+            Gx, kbias = gemm_f32s(x.view(T * B, I), W_ih), bias
         elif mode == "f32s" and (T * B) % 4 == 0 and I % 4 == 0 and h % 4 == 0:
             ctx.Ws = split_bf16x3(W_ih, 1, True)                              # [8h, 3I] (hi, lo, hi): kept for the backward's dX
             Gx, kbias = torch.mm(split_bf16x3(x.view(T * B, I), 1, False), ctx.Ws.t(), out_dtype=torch.float32), bias
@@ -1185,6 +1197,13 @@ class _BiLSTMLayer(torch.autograd.Function):
         # row r -+ B of `out` (time-major) or row r -+ 1 of the same sequence (batch-major), zero at the sequence ends
         shift, period = (1, T) if bm else (B, 0)
         x2, o2 = x.view(TB, I), out.view(TB, 2 * h)
+        if ctx.own and T > 1 and wgrad_f32s_ok(TB, 4 * h, I, h) and gemm_f32s_ok(TB, I, 8 * h):
+            # own kernels, no operand planes: dX = dG W_ih (the weight transposed once: 16 MB), and ONE tsg_wgrad_f32s launch for
+            # D[d] = dG[d]^T [x | h_{t-+1}[d]] of both directions, the shifted h rows read straight from `out`
+            if ctx.needs_input_grad[0]:
+                dx = gemm_f32s(dGf, W_ih.t().contiguous()).view(x.shape)
+            D = wgrad_f32s(dGf, x2, N=4 * h, groups=2, a_group_stride=4 * h, B1=o2, K1=h, b1_group_stride=h, shift=shift, period=period)
+            return dx, D[:, :, :I].contiguous().view(8 * h, I), dbias, D[:, :, I:].contiguous(), None, None
         if T == 1:
             dW_ih = _mm(dGf.t(), x2, mode)
             dW_hh = torch.zeros_like(W_hh)
