@@ -332,6 +332,10 @@ __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restri
   }
 }
 
+// (Round 4, measured and removed: STAGGERED SIMD partners -- waves 4..7 run each barrier interval in the other order (MFMAs first, the
+// next chunk's conversion behind them; MI355X_MICROARCH.md "Two waves per SIMD" item 9): step 14.13 / 14.06 / 14.09 ms vs 14.11 / 14.08 /
+// 14.07 ms lock-step, stand-alone 454-459 vs 452-455 us at [16384 x 1024] x [4096 x 1024]^T: profiles/r4/gemm_f32s_stagger_ab_v1.txt.
+// hipcc already interleaves the conversion with the MFMAs inside the one basic block of the steady-state chunk.)
 // (Round 4, measured and removed: the same kernel on v_mfma_f32_16x16x32_bf16 -- MI355X_MICROARCH.md reports a higher sustained clock for
 // that shape in bare MFMA loops.  Here, with the conversion VALU beside the MFMAs, it is a tie: 387-431 vs 396-438 us at
 // [16384 x 1024] x [4096 x 1024]^T, 94-96 vs 94-101 us at [16384 x 1024] x [1024 x 1024]^T, two processes each, alternating:
