@@ -30,6 +30,11 @@
 // L2 streams one row range of A and B once.
 // B can have two column segments: [0,K0) from B0, [K0,K0+K1) from B1 with a ROW SHIFT (source row m - shift, zeros outside the
 // row's sequence; group 1 uses -shift): the h_{t-1} / h_{t+1} operand of dW_hh straight from the LSTM output, no shifted copy.
+// (Round 4, measured and removed: a 256 x 256 tile variant with 128 x 64 wave tiles -- the main loop of tsg_gemm_f32s behind this kernel's
+// transposing stage: 32 instead of 24 converted elements and 24 instead of 16 fragment reads per thread and chunk for 48 instead of 24
+// MFMAs.  Slower: the LSTM layer's [2][2048 x 16384] x [16384 x 1536] 796-805 vs 776-777 us, [1024 x 16384] x [16384 x 1024] 126-128 vs
+// 121-124 us, the step 14.60-14.65 vs 14.36-14.43 ms (profiles/r4/wgrad_tile256_ab_v1.txt): fewer, larger tiles need twice the row
+// ranges (partial-tile traffic) and lose the sched_group_barrier interleave below, which is worth more than the geometry.)
 #include "tsg_common.h"
 #include <cstdlib>
 
