@@ -433,7 +433,7 @@ def main():
         log(f"warm-up step {i} done")
     # event pairs around the hot-path kernel launches (K1 / K1g / K3; K2 when it is in the step) -- not around the LSTM and
     # operand-split launches, whose barrier packets would cost milliseconds per step (rocprof has their times)
-    functional.kernel_timer.enable(only=None if a.time_all else ("tsg_scdm", "tsg_boundary", "tsg_mha"))
+    functional.kernel_timer.enable(only=None if a.time_all else ("tsg_scdm", "tsg_boundary", "tsg_mha", "tsg_match_head", "tsg_moment_pool"))
     dt, t_enq, loss = timed(step, a.steps)                # t_enq: host time to enqueue the K steps (== dt when the host is the limit)
     functional.kernel_timer.disable()
     ms_ = torch.cuda.memory_stats()
@@ -561,6 +561,22 @@ def main():
             if name == "tsg_boundary_score_bwd_ws":       # (ws_bytes, B, T, Hm, dtype): the workspace size is not a shape
                 dims = dims[1:]
                 entry["dims"] = list(dims)
+            if name == "tsg_match_head_gemm":             # (ldx, ldw, ws_bytes, M, T, N, K, act): K5 as the epilogue of its own GEMM -- MFMA work
+                Mq, Tq, Nq, Kq = dims[-5:-1]
+                fl = 2.0 * Mq * Nq * Kq * 3               # three bf16 products per fp32 product (hi*hi + hi*lo + lo*hi)
+                entry.update(dims=[Mq, Tq, Nq, Kq], bound="mfma", mfma_flops=fl, achieved_TFLOPs=round(fl / us / 1e6, 1),
+                             frac=round(fl / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4),
+                             note="matching head fused into its first-Linear GEMM (split-precision, 256-row tiles, 4 column tiles per row tile "
+                                  "meeting at a ticket): GEMM + relu + w2-dot; y is written for the backward in training")
+                kern[f"{name}{[Mq, Tq, Nq, Kq]}"] = entry
+                continue
+            if name in ("tsg_moment_pool_fwd", "tsg_moment_pool_bwd"):      # (B, T, D, dtype): one pass over feat / dfeat
+                Bq, Tq, Dq, dtq = dims[-4:]
+                by = Bq * Tq * Dq * (2 if dtq == 1 else 4)
+                entry.update(dims=[Bq, Tq, Dq], alg_bytes=by, alg_bytes_formula="B*T*D*e  [one pass over the clip features]", achieved_GBs=round(by / us / 1e3, 1),
+                             frac=round(by / us / 1e3 / HBM_PEAK_GBS, 4))
+                kern[f"{name}{[Bq, Tq, Dq]}"] = entry
+                continue
             if name == "tsg_boundary_head_gemm":          # (ldx, ldw, ws_bytes, B, T, Hm, K): K3 as the epilogue of its own GEMM -- MFMA work
                 Bq, Tq, Hmq, Kq = dims[-4:]
                 fl = 2.0 * Bq * Tq * 2 * Hmq * Kq * 3     # three bf16 products per fp32 product (hi*hi + hi*lo + lo*hi)

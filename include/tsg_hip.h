@@ -306,6 +306,13 @@ int tsg_gemm_f32s(const void* x, const void* w, const void* bias, void* y, int M
 int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, long long ldw, const void* bias, void* y, long long ldy,
                      int M, int N, int K, void* stream);
 
+/* The same arithmetic with the right operand stored CONTRACTION-major: y[M,N] = x[M,K] w[K,N] (+ bias), w row-major with row stride ldw,
+ * optionally as two row segments (w0: rows < kseg, w1: the rest; kseg = K, w1 = NULL for one matrix).  This is the input gradient
+ * dX = dY W of a Linear with W as the parameter stores it ([N_out][K_in]; the boundary head's two first Linears as two segments): no
+ * transposed copy of the weight per call.  M % 256 == 0, N % 256 == 0, K % 32 == 0, kseg % 32 == 0 (ABI revision 5).                 */
+int tsg_gemm_f32s_nn(const void* x, long long ldx, const void* w0, const void* w1, int kseg, long long ldw, const void* bias,
+                     void* y, long long ldy, int M, int N, int K, void* stream);
+
 /* ---- the heads as the EPILOGUE of their own first-Linear GEMM (ABI revision 5; round-3 review: SURVEY 8f #2 "split-W Linear + ReLU
  * + dot epilogue").  Same f32s arithmetic and tiling as tsg_gemm_f32s (row tiles of 256 / 128 / 64 so that a narrow head still
  * covers the chip); the accumulator tile goes through the head's tail in registers and only [rows]-sized logits leave the kernel.
@@ -373,6 +380,13 @@ int tsg_wgrad_f32s(const void* A, long long lda, long long a_group_stride, const
                    const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift, long long period,
                    void* C, long long ldc, long long c_group_stride, void* ws, long long ws_bytes,
                    long long M, int N, int groups, void* stream);
+
+/* The same with TWO outputs (ABI revision 5): the B0 segment's columns to C (C[g][n][k], k < K0, ldc >= K0), the B1 segment's to C1
+ * (C1[g][n][k - K0], ldc1 >= K1): nn.LSTM's dW_ih [2][4h][I] and dW_hh [2][4h][h] as the two parameter-shaped tensors.             */
+int tsg_wgrad_f32s_out2(const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
+                        const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift, long long period,
+                        void* C, long long ldc, long long c_group_stride, void* C1, long long ldc1, long long c1_group_stride,
+                        void* ws, long long ws_bytes, long long M, int N, int groups, void* stream);
 
 /* The same product with bf16 OPERANDS (the bf16 storage mode, ABI revision 3): A, B0, B1 are bf16 matrices (strides in elements,
  * multiples of 4; 16-byte aligned bases), C and ws fp32 as above (workspace size: tsg_wgrad_f32s_ws_bytes).  One bf16 MFMA per

@@ -31,6 +31,8 @@ _SIGNATURES = {
     "tsg_wgrad_f32s_ws_bytes": [c_longlong] + [_I] * 4,
     "tsg_wgrad_f32s": [_P, c_longlong, c_longlong, _P, c_longlong, _I, _P, c_longlong, c_longlong, _I, c_longlong, c_longlong,
                        _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _I, _I, _P],
+    "tsg_wgrad_f32s_out2": [_P, c_longlong, c_longlong, _P, c_longlong, _I, _P, c_longlong, c_longlong, _I, c_longlong, c_longlong,
+                            _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _I, _I, _P],
     "tsg_wgrad_bf16": [_P, c_longlong, c_longlong, _P, c_longlong, _I, _P, c_longlong, c_longlong, _I, c_longlong, c_longlong,
                        _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _I, _I, _P],
     "tsg_boundary_score_fwd": [_P] * 9 + [_I] * 4 + [_P],
@@ -57,6 +59,7 @@ _SIGNATURES = {
     "tsg_linear_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "tsg_gemm_f32s": [_P] * 4 + [_I] * 3 + [_P],
     "tsg_gemm_f32s_ld": [_P, c_longlong, _P, c_longlong, _P, _P, c_longlong, _I, _I, _I, _P],
+    "tsg_gemm_f32s_nn": [_P, c_longlong, _P, _P, _I, c_longlong, _P, _P, c_longlong, _I, _I, _I, _P],
     "tsg_head_gemm_ws_bytes": [_I, _I, _I],
     "tsg_match_head_gemm": [_P, c_longlong, _P, c_longlong, _P, _P, _P, _P, _P, _P, c_longlong, _I, _I, _I, _I, _I, _P],
     "tsg_boundary_head_gemm": [_P, c_longlong, _P, _P, c_longlong] + [_P] * 10 + [c_longlong, _I, _I, _I, _I, _P],

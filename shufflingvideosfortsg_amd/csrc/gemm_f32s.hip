@@ -88,9 +88,11 @@ __device__ __forceinline__ float half_allsum(float v) {
 __device__ __forceinline__ void g_store_agent(float* p, float v) {          // write-through: visible to every XCD once acknowledged
   asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ float g_load_agent(const float* p) {
-  float v;
-  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+__device__ __forceinline__ float4 g_load_agent_x4(const float* p0, const float* p1, const float* p2, const float* p3) {
+  float4 v;                                                               // four independent device-coherent loads, one wait
+  asm volatile("global_load_dword %0, %4, off sc1\n\tglobal_load_dword %1, %5, off sc1\n\t"
+               "global_load_dword %2, %6, off sc1\n\tglobal_load_dword %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(v.x), "=&v"(v.y), "=&v"(v.z), "=&v"(v.w) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
   return v;
 }
 __device__ __forceinline__ float g_tanh(float x) {        // 1 - 2/(exp(2x)+1), as K3's tanh_fast
@@ -212,8 +214,18 @@ struct EpiHead {
         *flag = __hip_atomic_fetch_add(a.cnt + (size_t)head * (a.M / TM) + p.m0 / TM, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(tiles_h - 1);
       __syncthreads();
       if (*flag && p.tid < TM) {                                              // last arrival: the head's tiles in order
+        // four device-coherent loads in flight per wait (one dependent round trip per group instead of one per tile: the serial
+        // form cost the last arriver 4 x 1-2 us at K5's four tiles)
+        const float* base = a.part + (size_t)head * tiles_h * a.M + p.m0 + p.tid;
         float s = 0.f;
-        for (int t = 0; t < tiles_h; ++t) s += g_load_agent(a.part + ((size_t)(head * tiles_h + t)) * a.M + p.m0 + p.tid);
+        for (int t = 0; t < tiles_h; t += 4) {
+          const float4 v = g_load_agent_x4(base + (size_t)min(t, tiles_h - 1) * a.M, base + (size_t)min(t + 1, tiles_h - 1) * a.M,
+                                           base + (size_t)min(t + 2, tiles_h - 1) * a.M, base + (size_t)min(t + 3, tiles_h - 1) * a.M);
+          s += v.x;
+          if (t + 1 < tiles_h) s += v.y;
+          if (t + 2 < tiles_h) s += v.z;
+          if (t + 3 < tiles_h) s += v.w;
+        }
         finish(s, p.m0 + p.tid);
       }
     }
@@ -221,7 +233,12 @@ struct EpiHead {
   }
 };
 
-template <int TM, typename Epi>
+// WT = true: the right operand is stored CONTRACTION-major -- W[K][N] row-major (row stride ldw), y = x W -- as the weight of a Linear is
+// for its input gradient dX = dY W ([N_out][K_in]: the contraction index N_out is the row).  Its 32 (k) x 256 (n) chunk is loaded
+// row-wise as 4 x 4 blocks and TRANSPOSED on the way into the same LDS image (four 8-byte pieces per thread and plane: the staging of
+// the weight-gradient kernel, csrc/wgrad_split.hip); nothing else changes.  It replaces a transposed copy of the weight per call
+// (16 MB for an LSTM layer's W_ih, 4 MB for a d x d projection).  In this mode the two segments (W0 | W1, nseg) split the ROWS.
+template <int TM, typename Epi, bool WT = false>
 __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ W0,
                                                            const float* __restrict__ W1, int nseg, long long ldw, Epi epi,
                                                            int M, int N, int K, int tiles_n) {
@@ -245,12 +262,21 @@ __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restri
   const float* wbase = n0 < nseg ? W0 + (size_t)n0 * ldw : W1 + (size_t)(n0 - nseg) * ldw;     // a tile lies inside one segment (nseg % 256 == 0)
   const float* wsrc = wbase + (size_t)sr * ldw + 4 * sq;
   const size_t passx = (size_t)64 * ldx, passw = (size_t)64 * ldw;
+  // WT staging role: a 4 (k) x 4 (n) block; lane bits [1:0] = column quad inside a 64-byte segment, [4:2] = row group, [5..8] = segment
+  const int tmg = (tid >> 2) & 7, tc4 = (tid & 3) + 4 * (tid >> 5);
   float4 rx[PX], rw[4];
   auto request = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < PX; ++p) rx[p] = *reinterpret_cast<const float4*>(xsrc + p * passx + k0);
+    if constexpr (WT) {
+      const int kr = k0 + 4 * tmg;                                    // a chunk lies inside one row segment (nseg % 32 == 0)
+      const float* wt = (kr < nseg ? W0 + (size_t)kr * ldw : W1 + (size_t)(kr - nseg) * ldw) + n0 + 4 * tc4;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) rw[p] = *reinterpret_cast<const float4*>(wsrc + p * passw + k0);
+      for (int p = 0; p < 4; ++p) rw[p] = *reinterpret_cast<const float4*>(wt + (size_t)p * ldw);
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) rw[p] = *reinterpret_cast<const float4*>(wsrc + p * passw + k0);
+    }
   };
   // split once, here, and write the bf16 planes: row r, 16-byte piece (sq >> 1) ^ ((r >> 2) & 3), 8-byte half sq & 1
   auto write_planes = [&](int buf) {
@@ -265,9 +291,20 @@ __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restri
         *reinterpret_cast<uint2*>(base + o) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(base + kPlaneX + o) = make_uint2(l0, l1);
       }
-      g_split_pair(rw[p].x, rw[p].y, h0, l0); g_split_pair(rw[p].z, rw[p].w, h1, l1);
-      *reinterpret_cast<uint2*>(base + 2 * kPlaneX + o) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(base + 2 * kPlaneX + kPlaneW + o) = make_uint2(l0, l1);
+      if constexpr (WT) {
+        // column j = p of the thread's 4 x 4 block = plane row 4 tc4 + p; its k = 4 tmg .. + 3 = half (tmg & 1) of 16-byte piece tmg >> 1
+        const int rt = 4 * tc4 + p;
+        const int ot = rt * 16 + ((((tmg >> 1) ^ ((rt >> 2) & 3))) << 2) + ((tmg & 1) << 1);
+        const float e0 = p == 0 ? rw[0].x : p == 1 ? rw[0].y : p == 2 ? rw[0].z : rw[0].w, e1 = p == 0 ? rw[1].x : p == 1 ? rw[1].y : p == 2 ? rw[1].z : rw[1].w;
+        const float e2 = p == 0 ? rw[2].x : p == 1 ? rw[2].y : p == 2 ? rw[2].z : rw[2].w, e3 = p == 0 ? rw[3].x : p == 1 ? rw[3].y : p == 2 ? rw[3].z : rw[3].w;
+        g_split_pair(e0, e1, h0, l0); g_split_pair(e2, e3, h1, l1);
+        *reinterpret_cast<uint2*>(base + 2 * kPlaneX + ot) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(base + 2 * kPlaneX + kPlaneW + ot) = make_uint2(l0, l1);
+      } else {
+        g_split_pair(rw[p].x, rw[p].y, h0, l0); g_split_pair(rw[p].z, rw[p].w, h1, l1);
+        *reinterpret_cast<uint2*>(base + 2 * kPlaneX + o) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(base + 2 * kPlaneX + kPlaneW + o) = make_uint2(l0, l1);
+      }
     }
   };
   // fragment of k step s: 8 consecutive k (one 16-byte piece 2 s + kg, swizzled) of row r, from the hi and the lo plane
@@ -342,10 +379,10 @@ __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restri
 // profiles/r4/gemm_f32s_mfma_shape_ab_v1.txt.  The LDS image for its fragment reads: piece p of row r at slot p ^ h((r >> 2) & 3),
 // h = {0, 3, 2, 1}, conflict-free for both the b128 reads and the staging writes.)
 
-template <int TM, typename Epi>
+template <int TM, typename Epi, bool WT = false>
 int launch_gemm(const char* fn, const float* x, long long ldx, const float* w0, const float* w1, int nseg, long long ldw, const Epi& epi,
                 int M, int N, int K, hipStream_t st) {
-  auto kern = gemm_nt_f32s_kernel<TM, Epi>;
+  auto kern = gemm_nt_f32s_kernel<TM, Epi, WT>;
   constexpr size_t lds = gemm_lds<TM>();
   hipError_t e = allow_lds(kern, lds);
   if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute(%zu): %s", fn, lds, hipGetErrorString(e));
@@ -406,6 +443,25 @@ extern "C" int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, lon
   if (ldx < K || ldw < K || ldy < N || ldx % 4 || ldw % 4) return set_error(TSG_E_ALIGN, "%s: leading dimensions ldx=%lld ldw=%lld ldy=%lld", fn, ldx, ldw, ldy);
   const EpiStore epi{(const float*)bias, (float*)y, ldy};
   return launch_gemm<256>(fn, (const float*)x, ldx, (const float*)w, (const float*)w, N, ldw, epi, M, N, K, static_cast<hipStream_t>(stream));
+}
+
+// y[M,N] = x[M,K] w[K,N] (+ bias): the right operand contraction-major, optionally as two ROW segments (w0: rows < kseg, w1: the rest;
+// kseg = K and w1 = NULL for one matrix) -- the input gradient dX = dY W of a Linear with its weight as it is stored.
+extern "C" int tsg_gemm_f32s_nn(const void* x, long long ldx, const void* w0, const void* w1, int kseg, long long ldw, const void* bias,
+                                void* y, long long ldy, int M, int N, int K, void* stream) {
+  const char* fn = "tsg_gemm_f32s_nn";
+  for (const void* p : {x, w0, (const void*)y}) {
+    if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
+    if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
+  }
+  if (M <= 0 || N <= 0 || K <= 0) return set_error(TSG_E_SHAPE, "%s: non-positive dimension M=%d N=%d K=%d", fn, M, N, K);
+  if (M % 256 || N % kTN || K % kBK) return set_error(TSG_E_SHAPE, "%s: M=%d, N=%d must be multiples of 256 and K=%d of 32", fn, M, N, K);
+  if (kseg <= 0 || kseg > K || kseg % kBK || (kseg < K && (!w1 || !aligned16(w1))))
+    return set_error(TSG_E_SHAPE, "%s: kseg=%d must be a multiple of 32 in (0, K] and w1 given when kseg < K", fn, kseg);
+  if (ldx < K || ldw < N || ldy < N || ldx % 4 || ldw % 4) return set_error(TSG_E_ALIGN, "%s: leading dimensions ldx=%lld ldw=%lld ldy=%lld", fn, ldx, ldw, ldy);
+  const EpiStore epi{(const float*)bias, (float*)y, ldy};
+  return launch_gemm<256, EpiStore, true>(fn, (const float*)x, ldx, (const float*)w0, (const float*)(w1 ? w1 : w0), kseg, ldw, epi, M, N, K,
+                                          static_cast<hipStream_t>(stream));
 }
 
 extern "C" long long tsg_head_gemm_ws_bytes(int M, int N, int heads) {

@@ -55,6 +55,7 @@ struct WgradArgs {                                      // A / B0 / B1: fp32 (ts
   const void* B0; long ldb0; int K0;
   const void* B1; long ldb1; long b1_gs; int K1; long shift; long period;
   float* C; long ldc; long c_gs;                        // output (splits == 1) ...
+  float* C1; long ldc1; long c1_gs;                     // optional second output for the columns k >= K0 (the B1 segment), else NULL: C1[g][n][k - K0]
   float* ws;                                            // ... or partials [splits][groups][N][K0+K1]
   long M; int N; int groups; int splits; int cps;       // cps = chunks (of 32 rows) per split
 };
@@ -292,8 +293,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
   }
 
   // epilogue: accumulator (row = n, column = k on the lanes) -> C or this split's partial tile
-  float* out = a.splits == 1 ? a.C + g * a.c_gs : a.ws + ((size_t)split * a.groups + g) * (size_t)a.N * K;
-  const long ldo = a.splits == 1 ? a.ldc : K;
+  // (a tile lies inside one column segment: K0 % 128 == 0; with a second output the B1 segment's tiles go to C1, columns from 0)
+  const bool to1 = a.splits == 1 && a.C1 && k0 >= a.K0;
+  float* out = a.splits == 1 ? (to1 ? a.C1 + g * a.c1_gs - a.K0 : a.C + g * a.c_gs) : a.ws + ((size_t)split * a.groups + g) * (size_t)a.N * K;
+  const long ldo = a.splits == 1 ? (to1 ? a.ldc1 : a.ldc) : K;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -325,7 +328,8 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_split_kernel(const WgradAr
 
 // C[g][n][k] = sum_s ws[s][g][n][k], float4 per thread
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc, long c_gs,
-                                                           int N, int K, int groups, int splits) {
+                                                           int N, int K, int groups, int splits, float* __restrict__ C1, long ldc1,
+                                                           long c1_gs, int K0) {
   const long per = (long)N * K / 4, total = per * groups;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
     const int g = (int)(i / per);
@@ -335,7 +339,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       const float4 t = *reinterpret_cast<const float4*>(ws + ((size_t)p * groups + g) * (size_t)N * K + e);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    *reinterpret_cast<float4*>(C + g * c_gs + n * ldc + k) = s;
+    if (C1 && k >= K0) *reinterpret_cast<float4*>(C1 + g * c1_gs + n * ldc1 + (k - K0)) = s;      // the B1 segment's columns: second output
+    else *reinterpret_cast<float4*>(C + g * c_gs + n * ldc + k) = s;
   }
 }
 
@@ -404,14 +409,16 @@ extern "C" long long tsg_wgrad_f32s_ws_bytes(long long M, int N, int K0, int K1,
 static int wgrad_impl(const char* fn, bool bf, const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
                       const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift,
                       long long period, void* C, long long ldc, long long c_group_stride, void* ws, long long ws_bytes,
-                      long long M, int N, int groups, void* stream) {
+                      long long M, int N, int groups, void* stream, void* C1 = nullptr, long long ldc1 = 0, long long c1_group_stride = 0) {
   int rc = check_args(fn, M, N, K0, K1, groups);
+  if (C1 && (K1 <= 0 || (ldc1 & 3) || (c1_group_stride & 3) || ldc1 < K1 || ldc < K0 || !aligned16(C1)))
+    return set_error(TSG_E_SHAPE, "%s: second output needs K1 > 0, ldc1 >= K1, ldc >= K0, strides %% 4 == 0, 16-byte alignment", fn);
   if (rc) return rc;
   if (!A || !C || (K0 > 0 && !B0) || (K1 > 0 && !B1)) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
   const int K = K0 + K1;
   if ((lda & 3) || (ldb0 & 3) || (ldb1 & 3) || (ldc & 3) || (a_group_stride & 3) || (b1_group_stride & 3) || (c_group_stride & 3) ||
       lda < (groups - 1) * a_group_stride + N || (K0 > 0 && ldb0 < K0) || (K1 > 0 && ldb1 < (groups - 1) * b1_group_stride + K1) ||
-      ldc < K || period < 0)
+      ldc < (C1 ? K0 : K) || period < 0)
     return set_error(TSG_E_SHAPE, "%s: leading dimensions / group strides must be multiples of 4 and cover the operands", fn);
   if (period > 0 && M % period) return set_error(TSG_E_SHAPE, "%s: M=%lld is not a multiple of period=%lld", fn, M, period);
   if (M >= (1LL << 31) || shift >= (1LL << 31) || shift <= -(1LL << 31) || period >= (1LL << 31))
@@ -428,6 +435,7 @@ static int wgrad_impl(const char* fn, bool bf, const void* A, long long lda, lon
   a.B0 = B0; a.ldb0 = ldb0; a.K0 = K0;
   a.B1 = B1; a.ldb1 = ldb1; a.b1_gs = b1_group_stride; a.K1 = K1; a.shift = shift; a.period = period;
   a.C = (float*)C; a.ldc = ldc; a.c_gs = c_group_stride; a.ws = (float*)ws;
+  a.C1 = (float*)C1; a.ldc1 = ldc1; a.c1_gs = c1_group_stride;
   a.M = M; a.N = N; a.groups = groups; a.splits = p.splits; a.cps = (int)((chunks + p.splits - 1) / p.splits);
   if (bf) rc = p.tn == 256 ? launch<4, 2, bf16_t>(fn, a, p.tiles * p.splits, st) : launch<2, 2, bf16_t>(fn, a, p.tiles * p.splits, st);
   else rc = p.tn == 256 ? launch<4, 2, float>(fn, a, p.tiles * p.splits, st) : launch<2, 2, float>(fn, a, p.tiles * p.splits, st);
@@ -438,7 +446,7 @@ static int wgrad_impl(const char* fn, bool bf, const void* A, long long lda, lon
   const long total = (long)groups * N * K / 4;
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)ws, (float*)C, (long)ldc, (long)c_group_stride,
-                     N, K, groups, p.splits);
+                     N, K, groups, p.splits, (float*)C1, (long)ldc1, (long)c1_group_stride, K0);
   return check_launch(fn);
 }
 
@@ -448,6 +456,18 @@ extern "C" int tsg_wgrad_f32s(const void* A, long long lda, long long a_group_st
                               long long M, int N, int groups, void* stream) {
   return wgrad_impl("tsg_wgrad_f32s", false, A, lda, a_group_stride, B0, ldb0, K0, B1, ldb1, b1_group_stride, K1, shift, period, C, ldc,
                     c_group_stride, ws, ws_bytes, M, N, groups, stream);
+}
+
+// Two outputs: the columns of the B0 segment to C (C[g][n][k], k < K0, row stride ldc >= K0), those of the B1 segment to C1
+// (C1[g][n][k - K0], row stride ldc1 >= K1) -- the LSTM layer's dW_ih and dW_hh leave the kernel as the two parameter-shaped tensors
+// autograd wants, instead of one [2][4h][I + h] block the host then slices and copies (4 x 2 copies of 16 + 8 MB per step).
+extern "C" int tsg_wgrad_f32s_out2(const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
+                                   const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift,
+                                   long long period, void* C, long long ldc, long long c_group_stride, void* C1, long long ldc1,
+                                   long long c1_group_stride, void* ws, long long ws_bytes, long long M, int N, int groups, void* stream) {
+  if (!C1) return set_error(TSG_E_NULL, "tsg_wgrad_f32s_out2: NULL second output");
+  return wgrad_impl("tsg_wgrad_f32s_out2", false, A, lda, a_group_stride, B0, ldb0, K0, B1, ldb1, b1_group_stride, K1, shift, period, C, ldc,
+                    c_group_stride, ws, ws_bytes, M, N, groups, stream, C1, ldc1, c1_group_stride);
 }
 
 // The same product for the bf16 storage mode: A, B0, B1 are bf16 matrices (strides in elements; rows 8-byte aligned), C and the

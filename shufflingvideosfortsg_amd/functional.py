@@ -276,6 +276,24 @@ def wgrad_f32s(A: torch.Tensor, B0: torch.Tensor, N: int = None, groups: int = 1
     return C
 
 
+def wgrad_f32s_out2(A: torch.Tensor, B0: torch.Tensor, B1: torch.Tensor, N: int, K1: int, a_group_stride: int, b1_group_stride: int,
+                    shift: int, period: int):
+    """``wgrad_f32s`` with two groups and TWO outputs (tsg_wgrad_f32s_out2): -> (C0 [2, N, K0], C1 [2, N, K1]) -- the LSTM layer's
+    dW_ih and dW_hh of both directions from one launch, each in its parameter's shape (no slicing copies)."""
+    require_device(A, B0, B1)
+    A, B0, B1 = _rows2d(A), _rows2d(B0), _rows2d(B1)
+    M, K0 = B0.shape
+    C0 = torch.empty(2, N, K0, device=A.device, dtype=torch.float32)
+    C1 = torch.empty(2, N, K1, device=A.device, dtype=torch.float32)
+    nb = int(load().tsg_wgrad_f32s_ws_bytes(M, N, K0, K1, 2))
+    if nb < 0:
+        raise ValueError(f"wgrad_f32s_out2: unsupported shape M={M} N={N} K0={K0} K1={K1}")
+    ws = torch.empty(nb, device=A.device, dtype=torch.uint8) if nb else None
+    _call("tsg_wgrad_f32s_out2", A, ptr(A), A.stride(0), a_group_stride, ptr(B0), B0.stride(0), K0, ptr(B1), B1.stride(0), b1_group_stride, K1,
+          shift, period, ptr(C0), K0, N * K0, ptr(C1), K1, N * K1, ptr(ws) if ws is not None else None, nb, M, N, 2)
+    return C0, C1
+
+
 def _rows2d_bf(t: torch.Tensor) -> torch.Tensor:
     """bf16 2-D operand whose rows are contiguous (a column slice of a row-major matrix is taken as it is)."""
     if t.dtype != torch.bfloat16 or t.dim() != 2:
@@ -323,6 +341,16 @@ _OWN_GEMM = os.environ.get("TSG_GEMM", "1") != "0"          # A/B switch: 0 = op
 # profiles/r4/bench_lstm_own_gemm_ab_v1.txt) -- and it takes the operand-plane passes (1.59 -> 0.24 ms per step) and the library's bf16
 # GEMMs (4.92 -> 0.60 ms) out of the step: all matrix work of the path is hand-written now.  TSG_LSTM_GEMM=lib keeps the old path (A/B).
 _LSTM_OWN_GEMM = os.environ.get("TSG_LSTM_GEMM", "own") != "lib"
+# Two copy eliminations of round 4, measured separately in the step (profiles/r4/bench_no_copies_ab_v1.txt; 14.167-14.191 ms with neither):
+#   out2: the LSTM layer's dW_ih / dW_hh as two parameter-shaped outputs of ONE weight-gradient launch (tsg_wgrad_f32s_out2) instead of
+#         a [2][4h][I+h] block the host slices and copies: 14.134-14.141 ms -- adopted;
+#   nn:   the contraction-major GEMM operand (tsg_gemm_f32s_nn: dX = dY W with the weight as stored) instead of a transposed copy of the
+#         weight + tsg_gemm_f32s: 14.257-14.269 ms -- SLOWER: the transposing stage of the W tile costs each of the 13 GEMM launches more
+#         than the 4-16 MB copy it deletes.  Kept as an entry point (functional.gemm_f32s_nn), not used by default.
+# TSG_NO_COPIES = out2 (default) / nn / 1 (both) / 0 (neither).
+_NC = os.environ.get("TSG_NO_COPIES", "out2")
+_NO_COPIES = _NC in ("1", "nn")                               # the contraction-major GEMM operand
+_OUT2 = _NC in ("1", "out2")                                  # the two-output weight gradient
 
 
 def gemm_f32s_ok(M: int, N: int, K: int) -> bool:
@@ -350,6 +378,26 @@ def gemm_f32s(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None) -> to
 _AUTO = object()          # "the mode that is current now" (forward); a backward passes the mode its forward saved in ctx
 
 
+def gemm_f32s_nn(x: torch.Tensor, w: torch.Tensor, w1: torch.Tensor = None) -> torch.Tensor:
+    """y [M,N] = x [M,K] @ w [K,N] in the split-precision arithmetic with the RIGHT operand contraction-major (tsg_gemm_f32s_nn): the
+    input gradient dX = dY W of a Linear with the weight as the parameter stores it -- no transposed copy.  w may be a column slice of a
+    wider row-major matrix (row stride = its stride(0)); with ``w1`` the contraction rows are [w ; w1] (same row stride)."""
+    require_device(x, w, w1)
+    x = _f32c(x)
+    M, K = x.shape
+    k0, N = w.shape
+    k1 = w1.shape[0] if w1 is not None else 0
+    for t in (w, w1):
+        if t is not None and (t.dtype != torch.float32 or t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16 or t.shape[1] != N
+                              or t.stride(0) != w.stride(0)):
+            raise ValueError("gemm_f32s_nn: the right operand must be fp32 row-major (or a column slice of such a matrix), 16-byte aligned rows")
+    if k0 + k1 != K:
+        raise ValueError(f"gemm_f32s_nn: x{tuple(x.shape)} w{tuple(w.shape)}")
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _call("tsg_gemm_f32s_nn", x, ptr(x), K, ptr(w), ptr(w1) if w1 is not None else None, k0, w.stride(0), None, ptr(y), N, M, N, K)
+    return y
+
+
 def _mm(a: torch.Tensor, b: torch.Tensor, mode=_AUTO) -> torch.Tensor:
     """fp32 [M,K] @ [K,N] -> fp32 in the GEMM precision ``mode`` (default: the configured one): rocBLAS / hipBLASLt, or -- "f32s", whole 256-tiles -- the
     hand-written split-on-load GEMM (the right operand is taken as [N,K] contiguous: a weight's `.t()` view as it is, a [K,N]
@@ -363,7 +411,9 @@ def _mm(a: torch.Tensor, b: torch.Tensor, mode=_AUTO) -> torch.Tensor:
         if a.is_cuda and a.is_contiguous() and gemm_f32s_ok(a.shape[0], b.shape[1], a.shape[1]):
             if b.t().is_contiguous():
                 return gemm_f32s(a, b.t())
-            if b.is_contiguous() and b.numel() <= (1 << 24):         # [K,N] weight: transpose once (<= 64 MB), then the same kernel
+            if _NO_COPIES and b.stride(1) == 1 and b.stride(0) % 4 == 0 and b.data_ptr() % 16 == 0:   # [K,N] row-major (or a column slice):
+                return gemm_f32s_nn(a, b)                                                  # the contraction-major form of the kernel, no transposed copy
+            if b.is_contiguous() and b.numel() <= (1 << 24):
                 return gemm_f32s(a, b.t().contiguous())
         return torch.mm(_split_operand(a, 1, False), _split_operand(b, 0, True), out_dtype=torch.float32)
     # bf16 operands, fp32 accumulate AND fp32 output straight from the GEMM (no bf16 round trip of the result, no cast kernel)
@@ -797,6 +847,8 @@ def _dx_f32s(dy2: torch.Tensor, w_rows: torch.Tensor) -> torch.Tensor:
     constraints hold, else the generic split-precision product."""
     M, N = dy2.shape
     K = w_rows.shape[1]
+    if _NO_COPIES and gemm_f32s_ok(M, K, N) and w_rows.stride(1) == 1 and w_rows.stride(0) % 4 == 0 and w_rows.data_ptr() % 16 == 0:
+        return gemm_f32s_nn(dy2, w_rows)                           # the weight (slice) as it is stored: contraction-major operand
     if gemm_f32s_ok(M, K, N):
         return gemm_f32s(dy2, w_rows.t().contiguous())
     return _mm(dy2, w_rows, "f32s")
@@ -919,7 +971,10 @@ class _BoundaryHeadGemm(torch.autograd.Function):
         dy2, x2 = dy.view(B * T, J), x.view(B * T, K)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _dx_f32s(dy2, torch.cat([ws_, we_], 0)).view(B, T, K)
+            if _NO_COPIES and gemm_f32s_ok(B * T, K, J) and Hm % 32 == 0:
+                dx = gemm_f32s_nn(dy2, ws_, we_).view(B, T, K)          # [W_start ; W_end] as two row segments, read in place
+            else:
+                dx = _dx_f32s(dy2, torch.cat([ws_, we_], 0)).view(B, T, K)
         dws = dwe = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dW = _dw_f32s(dy2, x2)                                     # [2Hm, K]: rows of the start head, then of the end head
@@ -1198,10 +1253,14 @@ class _BiLSTMLayer(torch.autograd.Function):
         shift, period = (1, T) if bm else (B, 0)
         x2, o2 = x.view(TB, I), out.view(TB, 2 * h)
         if ctx.own and T > 1 and wgrad_f32s_ok(TB, 4 * h, I, h) and gemm_f32s_ok(TB, I, 8 * h):
-            # own kernels, no operand planes: dX = dG W_ih (the weight transposed once: 16 MB), and ONE tsg_wgrad_f32s launch for
-            # D[d] = dG[d]^T [x | h_{t-+1}[d]] of both directions, the shifted h rows read straight from `out`
+            # own kernels, no operand planes, no copies: dX = dG W_ih (tsg_gemm_f32s_nn: the weight as stored), and ONE weight-gradient
+            # launch for dG[d]^T [x | h_{t-+1}[d]] of both directions, the shifted h rows read straight from `out`, written as the two
+            # parameter-shaped tensors (tsg_wgrad_f32s_out2)
             if ctx.needs_input_grad[0]:
-                dx = gemm_f32s(dGf, W_ih.t().contiguous()).view(x.shape)
+                dx = (gemm_f32s_nn(dGf, W_ih) if _NO_COPIES else gemm_f32s(dGf, W_ih.t().contiguous())).view(x.shape)
+            if _OUT2:
+                dW_ih, dW_hh = wgrad_f32s_out2(dGf, x2, o2, N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h, shift=shift, period=period)
+                return dx, dW_ih.view(8 * h, I), dbias, dW_hh, None, None
             D = wgrad_f32s(dGf, x2, N=4 * h, groups=2, a_group_stride=4 * h, B1=o2, K1=h, b1_group_stride=h, shift=shift, period=period)
             return dx, D[:, :, :I].contiguous().view(8 * h, I), dbias, D[:, :, I:].contiguous(), None, None
         if T == 1:

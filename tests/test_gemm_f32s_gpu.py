@@ -53,3 +53,25 @@ def test_linear_f32s_uses_the_kernel_and_matches_fp32(request):
     y0 = torch.nn.functional.linear(x, w, b); y0.backward(gy)
     for a, r, name in zip(got, (y0.detach(), x.grad, w.grad, b.grad), ("y", "dx", "dw", "db")):
         torch.testing.assert_close(a, r, atol=3e-4 * max(1.0, float(r.abs().max())), rtol=2e-3, msg=lambda m, n=name: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("M,N,K,seg", [(512, 256, 96, None), (256, 512, 1024, None), (512, 256, 512, 256), (256, 1024, 4096, None)])
+def test_gemm_f32s_nn(M, N, K, seg):
+    """tsg_gemm_f32s_nn (round 4): y = x @ w with w [K,N] row-major (the contraction-major right operand: dX = dY W with the weight as
+    the parameter stores it), also as a column slice of a wider matrix and as two row segments -- bit-equal to tsg_gemm_f32s on the
+    explicitly transposed weight (the same products in the same order), and close to float64."""
+    from shufflingvideosfortsg_amd import functional as TF
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).cuda()
+    Ww = (torch.randn(K, N + 64, generator=g) / K ** 0.5).cuda()
+    w = Ww[:, 32:32 + N]                                   # a column slice: row stride N + 64 (offset 32 floats = 128 B: 16-byte aligned)
+    want = TF.gemm_f32s(x, w.t().contiguous())
+    if seg is None:
+        got = TF.gemm_f32s_nn(x, w)
+    else:
+        W2 = Ww.clone()                                    # two row segments with the same row stride
+        got = TF.gemm_f32s_nn(x, Ww[:seg, 32:32 + N], W2[seg:, 32:32 + N])
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    ref = x.double() @ w.double()
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-5

@@ -154,3 +154,19 @@ def test_wgrad_bf16_lstm_operands():
         gd = dG[:, d * 4 * h:(d + 1) * 4 * h].double()
         ref = torch.cat([gd.t() @ x.double(), gd.t() @ hp[:, d * h:(d + 1) * h]], 1)
         assert _rel(D[d], ref) < 2e-6, d
+
+
+@pytest.mark.parametrize("bm", [True, False])
+def test_wgrad_two_outputs_equal_the_sliced_single_output(bm):
+    """tsg_wgrad_f32s_out2 (round 4): the B0 / B1 column segments to two parameter-shaped outputs -- bit-equal to slicing the
+    single-output result (same kernel, same summation order), with row ranges (partial tiles + reduce) and without."""
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(9)
+    for Bn, T, I, h in ((8, 16, 128, 128), (64, 64, 256, 128)):        # 4 chunks: one range; 128 chunks: several ranges
+        TB = Bn * T
+        dG = torch.randn(TB, 8 * h, generator=g).cuda(); x = torch.randn(TB, I, generator=g).cuda(); out = torch.randn(TB, 2 * h, generator=g).cuda()
+        shift, period = (1, T) if bm else (Bn, 0)
+        D = F.wgrad_f32s(dG, x, N=4 * h, groups=2, a_group_stride=4 * h, B1=out, K1=h, b1_group_stride=h, shift=shift, period=period)
+        C0, C1 = F.wgrad_f32s_out2(dG, x, out, N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h, shift=shift, period=period)
+        assert C0.shape == (2, 4 * h, I) and C1.shape == (2, 4 * h, h)
+        assert torch.equal(C0, D[:, :, :I]) and torch.equal(C1, D[:, :, I:])
