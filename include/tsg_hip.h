@@ -289,6 +289,18 @@ int tsg_moment_pool_fwd(const void* feat, const void* m_target, const void* m_fo
 int tsg_moment_pool_bwd(const void* dpooled, const void* m_target, const void* m_fore, const void* m_back, void* dfeat,
                         int B, int T, int D, int dtype, void* stream);
 
+/* ---- LayerNorm over the channel axis: the final nn.LayerNorm(d), eps 1e-5, of QueryAwareEncoder.forward (components/VideoEncoder.py:96,112)
+ * on the [rows = 2B*T, d] encoder output (ABI revision 5).  y = (x - mean) * rstd * gamma + beta with the biased variance of the row, as
+ * torch.nn.LayerNorm; mean / rstd [rows] are kept for the backward.  The backward reads x and dy ONCE: dx, and dgamma / dbeta through one
+ * partial row per workgroup (ws of tsg_layer_norm_bwd_ws_bytes(rows, d) bytes) added in workgroup order by a second small kernel (no
+ * float atomics: run-to-run identical).  d % 4 == 0, d <= 2048.  dtype TSG_F32, or TSG_BF16 = x / y / dy / dx stored as bf16 (gamma, beta,
+ * the statistics and the sums fp32).                                                                                              */
+int tsg_layer_norm_fwd(const void* x, const void* gamma, const void* beta, void* y, void* mean, void* rstd,
+                       long long rows, int d, float eps, int dtype, void* stream);
+long long tsg_layer_norm_bwd_ws_bytes(long long rows, int d);
+int tsg_layer_norm_bwd(const void* x, const void* dy, const void* gamma, const void* mean, const void* rstd, void* dx,
+                       void* dgamma, void* dbeta, void* ws, long long ws_bytes, long long rows, int d, int dtype, void* stream);
+
 /* ---- dense projection GEMM on the fp32 matrix cores ("tsg_gemm_*" of SURVEY section 8b) ------------------------------
  * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL): torch.nn.Linear's layout, i.e. the d x d projections of the path
  * (SCDM W_a / W_s attention.py:104-106, sent_linear VideoEncoder.py:48, MultiHead wq/wk/wv/wo attention.py:63-66, the

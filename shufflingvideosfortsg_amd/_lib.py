@@ -64,6 +64,9 @@ _SIGNATURES = {
     "tsg_match_head_gemm": [_P, c_longlong, _P, c_longlong, _P, _P, _P, _P, _P, _P, c_longlong, _I, _I, _I, _I, _I, _P],
     "tsg_boundary_head_gemm": [_P, c_longlong, _P, _P, c_longlong] + [_P] * 10 + [c_longlong, _I, _I, _I, _I, _P],
     "tsg_boundary_softmax": [_P, _P, _I, _I, _P],
+    "tsg_layer_norm_fwd": [_P] * 6 + [c_longlong, _I, c_float, _I, _P],
+    "tsg_layer_norm_bwd_ws_bytes": [c_longlong, _I],
+    "tsg_layer_norm_bwd": [_P] * 9 + [c_longlong, c_longlong, _I, _I, _P],
     "tsg_moment_pool_fwd": [_P] * 5 + [_I] * 4 + [_P],
     "tsg_moment_pool_bwd": [_P] * 5 + [_I] * 4 + [_P],
     "tsg_split_bf16x3": [_P, _P, c_longlong, c_longlong, c_longlong, c_longlong, _I, _P],
@@ -76,7 +79,7 @@ _SIGNATURES = {
     "tsg_mha_bwd": [_P] * 10 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
 }
 _RESTYPE = {"tsg_last_error": c_char_p, "tsg_lstm_bwd_ws_bytes": c_longlong, "tsg_scdm_bwd_ws_bytes": c_longlong,
-             "tsg_wgrad_f32s_ws_bytes": c_longlong, "tsg_boundary_score_bwd_ws_bytes": c_longlong, "tsg_head_gemm_ws_bytes": c_longlong}
+             "tsg_wgrad_f32s_ws_bytes": c_longlong, "tsg_boundary_score_bwd_ws_bytes": c_longlong, "tsg_head_gemm_ws_bytes": c_longlong, "tsg_layer_norm_bwd_ws_bytes": c_longlong}
 
 
 class TsgLibraryError(RuntimeError):

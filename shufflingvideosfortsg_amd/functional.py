@@ -987,6 +987,48 @@ def boundary_head_gemm(x, w_start, w_end, cs, b1, w2, b2, gate=None, mask=None):
     return _BoundaryHeadGemm.apply(x, w_start, w_end, cs, b1, w2, b2, gate, mask)
 
 
+class _LayerNorm(torch.autograd.Function):
+    """LayerNorm over the last axis (tsg_layer_norm_fwd / _bwd): x [..., d] fp32 (or bf16 in the storage mode), gamma / beta [d] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        require_device(x, gamma, beta)
+        bf = x.dtype == _BF
+        x = _act(x, bf)
+        gamma, beta = _f32p(gamma), _f32p(beta)
+        d = x.shape[-1]
+        rows = x.numel() // d
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        ctx.dt = TSG_BF16 if bf else TSG_F32
+        _call("tsg_layer_norm_fwd", x, ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, d, float(eps), ctx.dt)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = _act(dy, ctx.dt == TSG_BF16)
+        d = x.shape[-1]
+        rows = x.numel() // d
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma); dbeta = torch.empty_like(gamma)
+        nb = int(load().tsg_layer_norm_bwd_ws_bytes(rows, d))
+        ws = torch.empty(nb, device=x.device, dtype=torch.uint8)
+        _call("tsg_layer_norm_bwd", x, ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), nb, rows, d, ctx.dt)
+        return dx, dgamma, dbeta, None
+
+
+def layer_norm_ok(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype in (torch.float32, _BF) and x.shape[-1] % 4 == 0 and x.shape[-1] <= 2048 and os.environ.get("TSG_LN", "1") != "0"
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    """nn.LayerNorm(d) on the hand-written kernels (include/tsg_hip.h: tsg_layer_norm_fwd / _bwd)."""
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
 class _MomentPool(torch.autograd.Function):
     """MomentPooling's three masked means in one pass (tsg_moment_pool_fwd / _bwd): feat [B,T,D] (fp32, or bf16 in the storage
     mode), masks float [B,T] x 3 -> pooled fp32 [B,3,D]."""

@@ -36,6 +36,8 @@ class RNNEncoder(nn.Module):
     def forward(self, input, *args):
         video_encoding, _, _ = self.rnn_cell(input)
         ln = self.video_layernorm
+        if TF.layer_norm_ok(video_encoding):
+            return TF.layer_norm(video_encoding, ln.weight, ln.bias, ln.eps)
         if video_encoding.dtype != ln.weight.dtype:
             return F.layer_norm(video_encoding, ln.normalized_shape, ln.weight.to(video_encoding.dtype), ln.bias.to(video_encoding.dtype), ln.eps)
         return ln(video_encoding)
@@ -90,6 +92,8 @@ class QueryAwareEncoder(nn.Module):
         x = video_feat
         for blk, q in zip(self.blocks, queries):
             x = blk(x, q)
+        if TF.layer_norm_ok(x):                              # one pass forward, one pass backward (csrc/layer_norm.hip); bf16 storage: bf16 in / out
+            return TF.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         if x.dtype != self.norm.weight.dtype:                # bf16 storage mode: bf16 in and out, fp32 statistics inside the kernel
             return F.layer_norm(x, self.norm.normalized_shape, self.norm.weight.to(x.dtype), self.norm.bias.to(x.dtype), self.norm.eps)
         return self.norm(x)
