@@ -58,6 +58,7 @@ struct WgradArgs {                                      // A / B0 / B1: fp32 (ts
   float* C1; long ldc1; long c1_gs;                     // optional second output for the columns k >= K0 (the B1 segment), else NULL: C1[g][n][k - K0]
   float* ws;                                            // ... or partials [splits][groups][N][K0+K1]
   long M; int N; int groups; int splits; int cps;       // cps = chunks (of 32 rows) per split
+  unsigned per_magic; int per_sh;                       // row / period = (row * per_magic) >> per_sh  (rows < 2^31; host: period_division)
 };
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // (rne(a), rne(b)) packed, a in the low half
@@ -74,12 +75,18 @@ __device__ __forceinline__ int xcd_major(int bid, int g) {               // posi
   const int x = bid & 7, s = bid >> 3;
   return x * (g >> 3) + min(x, g & 7) + s;
 }
-// source row of B's shifted segment exists?  32-bit arithmetic (M < 2^31, checked on the host)
-__device__ __forceinline__ bool row_ok(unsigned r, int shift, unsigned rows, unsigned period) {
-  if (period > 0) { const int t = (int)(r % period) - shift; return t >= 0 && t < (int)period; }
-  const long q = (long)r - shift;
-  return q >= 0 && q < (long)rows;
+// The shifted segment (B1): source row m - shift exists iff the position t = m % period of row m in its sequence has 0 <= t - shift <
+// period (the host passes period = M for "one sequence").  Until round 4 this was `cond ? load : zero` around a `%`: a divergent
+// branch in the chunk loop; behind it the selects of the landed rows were scheduled into the half that had just REQUESTED them
+// (each behind a s_waitcnt vmcnt(0)), and the LSTM layer's [2][2048 x 16384] x [16384 x 1536] took 777-825 us against 596 us with
+// shift = 0 (profiles/r4/wgrad_shift_ab_v1.txt).  Now: the chunk's first position by one multiply-high on the scalar unit, one add
+// and one unsigned compare per row, an UNCONDITIONAL load (of row m itself when row m - shift does not exist), a select on the
+// landed registers when they are split, and a scheduling fence behind the workgroup barrier: 632 us.
+__device__ __forceinline__ unsigned div_period(unsigned r, unsigned magic, int sh) {
+  return (unsigned)(((unsigned long long)r * magic) >> sh);
 }
+__device__ __forceinline__ float4 keep_if(bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); }
+__device__ __forceinline__ uint2 keep_if(bool ok, uint2 v) { return make_uint2(ok ? v.x : 0u, ok ? v.y : 0u); }
 
 // Geometry of one kernel variant: WN x WK waves, each a 64 x 64 output block.
 template <int WN, int WK>
@@ -142,12 +149,12 @@ struct Role {
   }
 };
 
-template <int WN, int WK, bool SHIFTED, typename ET>
+template <int WN, int WK, int SHIFTED, typename ET>     // SHIFTED: 0 no; 1 period % 32 == 0 (a chunk lies inside one sequence); 2 any period
 __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, int split, int g, int n0, int k0) {
   using G = Geo<WN, WK>;
   constexpr bool BF = storage_is_bf16<ET>::value;          // bf16 operands: one plane per operand, one MFMA per product
   typedef typename Raw4T<ET>::type Raw;
-  struct Staged { Raw a[G::RA]; Raw b[G::RB]; };          // one chunk's operand rows of a thread, in flight / waiting for the split
+  struct Staged { Raw a[G::RA]; Raw b[G::RB]; bool ok[G::RB]; };   // one chunk's operand rows of a thread, in flight / waiting for the split (ok: the B row exists)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int K = a.K0 + a.K1;
   const long chunks = a.M / BM;
@@ -162,8 +169,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
   const int shift = SHIFTED ? (int)(g ? -a.shift : a.shift) : 0;
   const unsigned brow0 = (unsigned)(c_begin * BM) + rb.row0();
   const ET* pa = static_cast<const ET*>(a.A) + g * a.a_gs + n0 + 4 * ra.c4 + (c_begin * BM + ra.row0()) * a.lda;
-  const ET* pb = (seg1 ? static_cast<const ET*>(a.B1) + g * a.b1_gs + (k0 - a.K0) : static_cast<const ET*>(a.B0) + k0) + 4 * rb.c4 +
-                 ((long)brow0 - shift) * ldb;
+  const ET* bcol = (seg1 ? static_cast<const ET*>(a.B1) + g * a.b1_gs + (k0 - a.K0) : static_cast<const ET*>(a.B0) + k0) + 4 * rb.c4;
+  const ET* pb = bcol + ((long)brow0 - shift) * ldb;
+  const unsigned per = (unsigned)a.period;
+  const long soff = (long)shift * ldb;
 
   auto request = [&](Staged& r, int c) {                   // chunk c of the range (clamped: the tail re-requests the last chunk)
     c = min(c, nc - 1);
@@ -171,10 +180,20 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
     const ET* qb = pb + (long)c * BM * ldb;
 #pragma unroll
     for (int i = 0; i < G::RA; ++i) r.a[i] = ldraw4(qa + i * a.lda);
+    unsigned tb = 0;
+    if (SHIFTED == 1) {                                     // position of the chunk's first row in its sequence: scalar unit
+      const unsigned m0 = __builtin_amdgcn_readfirstlane((unsigned)(c_begin + c) * BM);
+      tb = m0 - div_period(m0, a.per_magic, a.per_sh) * per;
+    }
 #pragma unroll
     for (int i = 0; i < G::RB; ++i) {
       if (SHIFTED) {
-        r.b[i] = row_ok(brow0 + (unsigned)c * BM + i, shift, (unsigned)a.M, (unsigned)a.period) ? ldraw4(qb + i * ldb) : zero_raw4(qb);
+        unsigned ts;                                        // position of the SOURCE row in the sequence; >= period (as unsigned) = outside
+        if (SHIFTED == 1) ts = tb + (unsigned)(rb.row0() + i - shift);          // (period % 32 == 0: a chunk lies inside one sequence)
+        else { const unsigned m = brow0 + (unsigned)c * BM + i; ts = m - div_period(m, a.per_magic, a.per_sh) * per - (unsigned)shift; }
+        const bool ok = ts < per;
+        r.b[i] = ldraw4(qb + i * ldb + (ok ? 0L : soff));   // a row that does not exist: read row m itself (always there)
+        r.ok[i] = ok;
       } else {
         r.b[i] = ldraw4(qb + i * ldb);
       }
@@ -184,7 +203,14 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
     unsigned* Ahi = lds + buf * G::kBuf; unsigned* Alo = Ahi + G::kPlaneA;
     unsigned* Bhi = Alo + G::kPlaneA;    unsigned* Blo = Bhi + G::kPlaneB;
     ra.write(r.a, Ahi, Alo);
-    rb.write(r.b, Bhi, Blo);
+    if (SHIFTED) {
+      Raw b[G::RB];
+#pragma unroll
+      for (int i = 0; i < G::RB; ++i) b[i] = keep_if(r.ok[i], r.b[i]);
+      rb.write(b, Bhi, Blo);
+    } else {
+      rb.write(r.b, Bhi, Blo);
+    }
   };
 
   f32x16 acc[2][2];
@@ -245,13 +271,13 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
     for (int i = 0; i < 6; ++i) {                                        // MFMAs 8-13: the requests two chunks ahead
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, SHIFTED ? 7 : 4, 0);     // (shifted rows: position, validity and address select per row)
     }
 #pragma unroll
     for (int i = 0; i < 10; ++i) {                                       // MFMAs 14-23: the next chunk's planes go to LDS
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, SHIFTED ? 5 : 4, 0);
     }
 #endif
   };
@@ -276,7 +302,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
 #define ABL_REQ(x) { if (!(TSG_WGRAD_ABL & 2)) { x; } }
 #define ABL_CMP(x) { if (!(TSG_WGRAD_ABL & 8)) { x; } }
 #define ABL_STG(x) { if (!(TSG_WGRAD_ABL & 4)) { x; } }
-#define ABL_BAR() { if (!(TSG_WGRAD_ABL & 1)) __syncthreads(); }
+// (sched_barrier behind the workgroup barrier: nothing of the next half may be scheduled into this one.  Without it the selects of the
+// shifted segment -- ready as soon as their load is ISSUED -- filled VALU slots of the half that requested them, each behind a
+// s_waitcnt vmcnt(0): a full memory round trip per chunk in the B1 tiles.)
+#define ABL_BAR() { if (!(TSG_WGRAD_ABL & 1)) __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
     for (int c = 0; c + 1 < nc; c += 2) {
       ABL_REQ(request(s0, c + 2)) TSG_TICK(0)
       ABL_CMP(compute(0)) TSG_TICK(1)
@@ -322,8 +351,12 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_split_kernel(const WgradAr
   const int v = xcd_major(blockIdx.x, gridDim.x);
   const int split = v / tps, rem = v % tps, g = rem / tpg, tile = rem % tpg;
   const int n0 = (tile / tiles_k) * G::TN, k0 = (tile % tiles_k) * G::TK;
-  if (k0 >= a.K0 && a.shift != 0) wgrad_tile<WN, WK, true, ET>(a, lds, split, g, n0, k0);      // workgroup-uniform
-  else wgrad_tile<WN, WK, false, ET>(a, lds, split, g, n0, k0);
+  if (k0 >= a.K0 && a.shift != 0) {                                                            // workgroup-uniform
+    if (a.period % BM == 0) wgrad_tile<WN, WK, 1, ET>(a, lds, split, g, n0, k0);
+    else wgrad_tile<WN, WK, 2, ET>(a, lds, split, g, n0, k0);
+  } else {
+    wgrad_tile<WN, WK, 0, ET>(a, lds, split, g, n0, k0);
+  }
 }
 
 // C[g][n][k] = sum_s ws[s][g][n][k], float4 per thread
@@ -433,7 +466,13 @@ static int wgrad_impl(const char* fn, bool bf, const void* A, long long lda, lon
   WgradArgs a;
   a.A = A; a.lda = lda; a.a_gs = a_group_stride;
   a.B0 = B0; a.ldb0 = ldb0; a.K0 = K0;
-  a.B1 = B1; a.ldb1 = ldb1; a.b1_gs = b1_group_stride; a.K1 = K1; a.shift = shift; a.period = period;
+  a.B1 = B1; a.ldb1 = ldb1; a.b1_gs = b1_group_stride; a.K1 = K1; a.shift = shift; a.period = period > 0 ? period : M;   // 0 = one sequence of M rows
+  {                                                       // floor(r / period) for r < 2^31: (r * ceil(2^(31+l) / period)) >> (31 + l), 2^l >= period
+    int l = 0;
+    while ((1LL << l) < a.period) ++l;
+    a.per_sh = 31 + l;
+    a.per_magic = (unsigned)((((unsigned __int128)1 << a.per_sh) + a.period - 1) / a.period);
+  }
   a.C = (float*)C; a.ldc = ldc; a.c_gs = c_group_stride; a.ws = (float*)ws;
   a.C1 = (float*)C1; a.ldc1 = ldc1; a.c1_gs = c1_group_stride;
   a.M = M; a.N = N; a.groups = groups; a.splits = p.splits; a.cps = (int)((chunks + p.splits - 1) / p.splits);
