@@ -24,6 +24,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-ffp-contract=fast", "-fno-math-errno"]
+# per-source additions.  wgrad_split: under plain -O3 the SLP vectoriser packs the split's subtractions into v_pk_add_f32, which is slow
+# beside MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs"): the LSTM layer's dW 626 -> 595 us without it
+# (profiles/r4/gemm_wgrad_flags_ab_v1.txt; tsg_gemm_f32s measured the same either way and keeps the default)
+EXTRA_FLAGS = {"wgrad_split.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():
@@ -36,7 +40,7 @@ def _deps_hash(src: str) -> str:
             [os.path.join(HERE, "..", "include", "tsg_hip.h")]:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(CXXFLAGS).encode())
+    h.update(" ".join(CXXFLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])).encode())
     return h.hexdigest()
 
 
@@ -47,7 +51,7 @@ def _compile(src: str, force: bool, verbose: bool) -> str:
     want = _deps_hash(src)
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
         return obj
-    cmd = [HIPCC, *CXXFLAGS, "-c", src, "-o", obj]
+    cmd = [HIPCC, *CXXFLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

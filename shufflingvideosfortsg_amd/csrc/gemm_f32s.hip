@@ -253,8 +253,18 @@ __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restri
   // Persistent workgroups: workgroup w walks the tiles w, w + grid, ...: the fp32 stores of a finished tile drain under the next
   // tile's chunks (a 256 x 256 tile is 256 KiB of output: 15-20 us of store tail per tile when nothing runs beside it).
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  const int bid = xcd_remap(tile, ntiles, tiles_n);                 // the N tiles of one M tile share an XCD (X rows stay in its L2)
-  const int m0 = (bid / tiles_n) * TM, n0 = (bid % tiles_n) * kTN;
+  // Placement: workgroup i runs on XCD i % 8, each XCD has its own L2.  An XCD's 32 concurrent tiles are 8 (M) x 4 (N) neighbours
+  // when the shape allows it: per chunk its L2 serves 8 X pieces to 4 readers each and 4 W pieces to 8 readers each.  (Until round 4:
+  // all N tiles of one M tile on an XCD = 2 x 16 at N = 4096, every XCD streaming all of W every round: 478-488 us vs 450 us at
+  // [16384 x 1024] x [4096 x 1024]^T, profiles/r4/gemm_wgrad_flags_ab_v1.txt.)
+  int m0, n0;
+  if (tiles_n % 4 == 0 && (ntiles / tiles_n) % 8 == 0 && ntiles % 256 == 0) {
+    const int b = xcd_remap(tile, ntiles, 32), gq = b >> 5, r = b & 31, gn = tiles_n >> 2;
+    m0 = ((gq / gn) * 8 + (r >> 2)) * TM; n0 = ((gq % gn) * 4 + (r & 3)) * kTN;
+  } else {
+    const int b = xcd_remap(tile, ntiles, tiles_n);                 // the N tiles of one M tile share an XCD (X rows stay in its L2)
+    m0 = (b / tiles_n) * TM; n0 = (b % tiles_n) * kTN;
+  }
 
   // staging role: 8 threads per row (8 float4 = one 128-byte row segment), 64 rows per pass
   const int sr = tid >> 3, sq = tid & 7;
@@ -332,6 +342,7 @@ __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restri
   auto chunk = [&](int ks, auto w_tag, auto r_tag) {
     constexpr bool WRITE = decltype(w_tag)::value, REQ = decltype(r_tag)::value;
     lds_barrier();                                                   // chunk ks is in LDS; nobody reads the other buffer any more
+    __builtin_amdgcn_sched_barrier(0);                               // nothing of this chunk is scheduled in front of the barrier (2-4 %)
     if (WRITE) write_planes((ks + 1) & 1);
     if (REQ) request((ks + 2) * kBK);
     const unsigned* xt = lds + (ks & 1) * kBuf;
