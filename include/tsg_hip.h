@@ -289,6 +289,11 @@ int tsg_moment_pool_fwd(const void* feat, const void* m_target, const void* m_fo
 int tsg_moment_pool_bwd(const void* dpooled, const void* m_target, const void* m_fore, const void* m_back, void* dfeat,
                         int B, int T, int D, int dtype, void* stream);
 
+/* ---- batched fp32 transpose: dst[b][c][r] = src[b][r][c]; src [batch][rows] rows of cols floats, ld floats apart; dst contiguous (ABI revision 5).  The weight operands of
+ * the input-gradient GEMMs (dX = dY W on tsg_gemm_f32s, which takes W^T) and W_hh^T of the LSTM backward (tsg_lstm_bwd_ws*).
+ * rows % 4 == 0, cols % 4 == 0, ld % 4 == 0, ld >= cols, 16-byte aligned.                                                         */
+int tsg_transpose_f32(const void* src, long long ld, void* dst, int batch, int rows, int cols, void* stream);
+
 /* ---- LayerNorm over the channel axis: the final nn.LayerNorm(d), eps 1e-5, of QueryAwareEncoder.forward (components/VideoEncoder.py:96,112)
  * on the [rows = 2B*T, d] encoder output (ABI revision 5).  y = (x - mean) * rstd * gamma + beta with the biased variance of the row, as
  * torch.nn.LayerNorm; mean / rstd [rows] are kept for the backward.  The backward reads x and dy ONCE: dx, and dgamma / dbeta through one

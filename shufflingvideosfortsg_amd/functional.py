@@ -240,6 +240,18 @@ def split_bf16x3_t(x: torch.Tensor, col0: int, cols: int, row_shift: int, right:
     return out
 
 
+def transposed(w: torch.Tensor) -> torch.Tensor:
+    """``w.transpose(-1, -2).contiguous()`` of an fp32 matrix (a column slice is read in place) or a contiguous batch of them on
+    tsg_transpose_f32 -- the weight operand of the input-gradient GEMMs and W_hh^T of the LSTM backward; torch's strided copy elsewhere."""
+    if (_OWN_TRANSPOSE and w.is_cuda and w.dtype == torch.float32 and w.dim() in (2, 3) and w.shape[-1] % 4 == 0 and w.shape[-2] % 4 == 0
+            and w.stride(-1) == 1 and w.stride(-2) % 4 == 0 and w.stride(-2) >= w.shape[-1] and w.data_ptr() % 16 == 0
+            and (w.dim() == 2 or w.shape[0] == 1 or w.stride(0) == w.shape[1] * w.stride(1))):
+        out = torch.empty(*w.shape[:-2], w.shape[-1], w.shape[-2], device=w.device, dtype=w.dtype)
+        _call("tsg_transpose_f32", w, ptr(w), w.stride(-2), ptr(out), w.shape[0] if w.dim() == 3 else 1, w.shape[-2], w.shape[-1])
+        return out
+    return w.transpose(-1, -2).contiguous()
+
+
 def wgrad_f32s_ok(M: int, N: int, K0: int, K1: int = 0) -> bool:
     """Shapes tsg_wgrad_f32s takes (include/tsg_hip.h)."""
     return M > 0 and M % 32 == 0 and N > 0 and N % 256 == 0 and K0 % 128 == 0 and K1 % 128 == 0 and K0 + K1 > 0
@@ -253,7 +265,8 @@ def _rows2d(t: torch.Tensor) -> torch.Tensor:
 
 
 def wgrad_f32s(A: torch.Tensor, B0: torch.Tensor, N: int = None, groups: int = 1, a_group_stride: int = 0,
-               B1: torch.Tensor = None, K1: int = 0, b1_group_stride: int = 0, shift: int = 0, period: int = 0) -> torch.Tensor:
+               B1: torch.Tensor = None, K1: int = 0, b1_group_stride: int = 0, shift: int = 0, period: int = 0,
+               out: torch.Tensor = None) -> torch.Tensor:
     """C[g] = A[:, g*a_group_stride : +N]^T @ [B0 | B1[rows shifted by -+shift, g*b1_group_stride : +K1]] -> [groups, N, K0+K1]:
     the weight-gradient product in split precision with the operands converted on load (tsg_wgrad_f32s, include/tsg_hip.h).
     A [M, >= N], B0 [M, K0], B1 [M, >= K1] are fp32 matrices with contiguous rows (column slices are fine)."""
@@ -265,14 +278,21 @@ def wgrad_f32s(A: torch.Tensor, B0: torch.Tensor, N: int = None, groups: int = 1
     if A.shape[0] != M or (B1 is not None and B1.shape[0] != M) or (B1 is None) != (K1 == 0):
         raise ValueError("wgrad_f32s: operand rows differ")
     K = K0 + K1
-    C = torch.empty(groups, N, K, device=A.device, dtype=torch.float32)
+    if out is not None:                        # written in place: [N, K] (one group) or [groups, N, K], rows ldc floats apart (a column slice is fine)
+        if (out.dtype != torch.float32 or out.shape[-2:] != (N, K) or out.stride(-1) != 1 or out.stride(-2) % 4 or out.data_ptr() % 16
+                or (out.dim() == 3) != (groups > 1) or (out.dim() == 3 and (out.shape[0] != groups or out.stride(0) % 4))):
+            raise ValueError("wgrad_f32s: out must be an fp32 [N,K] / [groups,N,K] view with contiguous, 16-byte aligned rows")
+        C, ldc, cgs = out, out.stride(-2), (out.stride(0) if out.dim() == 3 else 0)
+    else:
+        C = torch.empty(groups, N, K, device=A.device, dtype=torch.float32)
+        ldc, cgs = K, N * K
     nb = int(load().tsg_wgrad_f32s_ws_bytes(M, N, K0, K1, groups))
     if nb < 0:
         raise ValueError(f"wgrad_f32s: unsupported shape M={M} N={N} K0={K0} K1={K1} groups={groups}")
     ws = torch.empty(nb, device=A.device, dtype=torch.uint8) if nb else None
     _call("tsg_wgrad_f32s", A, ptr(A), A.stride(0), a_group_stride, ptr(B0), B0.stride(0), K0,
           ptr(B1) if B1 is not None else None, B1.stride(0) if B1 is not None else 0, b1_group_stride, K1, shift, period,
-          ptr(C), K, N * K, ptr(ws) if ws is not None else None, nb, M, N, groups)
+          ptr(C), ldc, cgs, ptr(ws) if ws is not None else None, nb, M, N, groups)
     return C
 
 
@@ -341,6 +361,7 @@ _OWN_GEMM = os.environ.get("TSG_GEMM", "1") != "0"          # A/B switch: 0 = op
 # profiles/r4/bench_lstm_own_gemm_ab_v1.txt) -- and it takes the operand-plane passes (1.59 -> 0.24 ms per step) and the library's bf16
 # GEMMs (4.92 -> 0.60 ms) out of the step: all matrix work of the path is hand-written now.  TSG_LSTM_GEMM=lib keeps the old path (A/B).
 _LSTM_OWN_GEMM = os.environ.get("TSG_LSTM_GEMM", "own") != "lib"
+_OWN_TRANSPOSE = os.environ.get("TSG_TRANSPOSE", "own") != "torch"     # A/B switch: "torch" = .t().contiguous()
 # Two copy eliminations of round 4, measured separately in the step (profiles/r4/bench_no_copies_ab_v1.txt; 14.167-14.191 ms with neither):
 #   out2: the LSTM layer's dW_ih / dW_hh as two parameter-shaped outputs of ONE weight-gradient launch (tsg_wgrad_f32s_out2) instead of
 #         a [2][4h][I+h] block the host slices and copies: 14.134-14.141 ms -- adopted;
@@ -414,7 +435,7 @@ def _mm(a: torch.Tensor, b: torch.Tensor, mode=_AUTO) -> torch.Tensor:
             if _NO_COPIES and b.stride(1) == 1 and b.stride(0) % 4 == 0 and b.data_ptr() % 16 == 0:   # [K,N] row-major (or a column slice):
                 return gemm_f32s_nn(a, b)                                                  # the contraction-major form of the kernel, no transposed copy
             if b.is_contiguous() and b.numel() <= (1 << 24):
-                return gemm_f32s(a, b.t().contiguous())
+                return gemm_f32s(a, transposed(b))
         return torch.mm(_split_operand(a, 1, False), _split_operand(b, 0, True), out_dtype=torch.float32)
     # bf16 operands, fp32 accumulate AND fp32 output straight from the GEMM (no bf16 round trip of the result, no cast kernel)
     return torch.mm(a.to(_BF), b.to(_BF), out_dtype=torch.float32)
@@ -784,7 +805,7 @@ class _LinearHip(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if N % 4 == 0:
-                wt = w.t().contiguous()                                  # [K, N]: dx = dy W = Linear(dy, W^T)
+                wt = transposed(w)                                       # [K, N]: dx = dy W = Linear(dy, W^T)
                 dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
                 _call("tsg_linear_fwd", dy2, ptr(dy2), ptr(wt), None, ptr(dx), M, K, N, TSG_F32)
             else:
@@ -850,16 +871,21 @@ def _dx_f32s(dy2: torch.Tensor, w_rows: torch.Tensor) -> torch.Tensor:
     if _NO_COPIES and gemm_f32s_ok(M, K, N) and w_rows.stride(1) == 1 and w_rows.stride(0) % 4 == 0 and w_rows.data_ptr() % 16 == 0:
         return gemm_f32s_nn(dy2, w_rows)                           # the weight (slice) as it is stored: contraction-major operand
     if gemm_f32s_ok(M, K, N):
-        return gemm_f32s(dy2, w_rows.t().contiguous())
+        return gemm_f32s(dy2, transposed(w_rows))
     return _mm(dy2, w_rows, "f32s")
 
 
-def _dw_f32s(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
-    """dW [N,K] = dY [M,N]^T @ X [M,K] in the f32s arithmetic (tsg_wgrad_f32s where its tiles fit, else fp32)."""
+def _dw_f32s(dy2: torch.Tensor, x2: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """dW [N,K] = dY [M,N]^T @ X [M,K] in the f32s arithmetic (tsg_wgrad_f32s where its tiles fit, else fp32); ``out``: an [N,K] view
+    (e.g. the video columns of a full-width parameter gradient) written in place."""
     M, N = dy2.shape
     K = x2.shape[1]
     if _WGRAD_KERNEL and wgrad_f32s_ok(M, N, K):
+        if out is not None:
+            return wgrad_f32s(dy2, x2, out=out)
         return wgrad_f32s(dy2, x2)[0]
+    if out is not None:
+        return out.copy_(dy2.t() @ x2)
     return dy2.t() @ x2
 
 
@@ -982,6 +1008,150 @@ class _BoundaryHeadGemm(torch.autograd.Function):
         return dx, dws, dwe, dcs, db1p.sum(0), dw2p.sum(0), db2p.sum(0), dgate, None
 
 
+class _MatchHeadFull(torch.autograd.Function):
+    """The matching head (K5) with the MODULE'S PARAMETERS as inputs: x [B,T,Dv], q [B,Dq], W1 [H, Dv+Dq], b1 [H], w2 [H], b2 [1] ->
+    logits [B,T] (reference DistributionAlign.py:83-118, `Linear(cat(v, q)) -> act -> Linear(H,1)`).  The query half + bias is a
+    per-item row (one small fp32 GEMM), the video half runs in tsg_match_head_gemm with W1[:, :Dv] read in place, and the backward
+    returns ONE full-width dW1: the video columns written in place by the weight-gradient kernel, the query columns by one small
+    GEMM -- no column-slice nodes in the graph (each cost a zero-filled [H, Dv+Dq] buffer, a copy and an accumulation per step)."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, x, q, W1, b1, w2, b2, act):
+        require_device(x, q, W1, b1, w2, b2)
+        x = _f32c(x)
+        B, T, Dv = x.shape
+        H = W1.shape[0]
+        W1, b1, q = _f32p(W1), _f32p(b1), _f32p(q)
+        ctx.shapes = (w2.shape, b2.shape)
+        w2, b2 = _f32p(w2).view(-1), _f32p(b2).view(-1)
+        cs = torch.addmm(b1, q, W1[:, Dv:].t())                        # [B,H]: query half + bias, plain fp32
+        M = B * T
+        need_y = any(ctx.needs_input_grad[:6])
+        y = torch.empty(B, T, H, device=x.device, dtype=torch.float32) if need_y else None
+        out = torch.empty(B, T, device=x.device, dtype=torch.float32)
+        nb = int(load().tsg_head_gemm_ws_bytes(M, H, 1))
+        ws = torch.empty(max(nb, 16), device=x.device, dtype=torch.uint8)
+        _call("tsg_match_head_gemm", x, ptr(x), Dv, ptr(W1), W1.stride(0), ptr(cs), ptr(w2), ptr(b2), ptr(y) if need_y else None, ptr(out),
+              ptr(ws), nb, M, T, H, Dv, int(act))
+        if need_y:
+            ctx.save_for_backward(x, q, W1, y, cs, w2)
+        ctx.act = int(act)
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dl):
+        x, q, W1, y, cs, w2 = ctx.saved_tensors
+        B, T, H = y.shape
+        Dv = x.shape[2]
+        dl = _f32p(dl)
+        dy = torch.empty_like(y)
+        dcs = torch.empty_like(cs); dw2 = torch.empty_like(w2); db2 = torch.empty(1, device=y.device, dtype=torch.float32)
+        _call("tsg_match_head_bwd", y, ptr(y), ptr(cs), ptr(w2), ptr(dl), ptr(dy), ptr(dcs), ptr(dw2), ptr(db2), B, T, H, ctx.act, TSG_F32)
+        dy2, x2 = dy.view(B * T, H), x.view(B * T, Dv)
+        dx = _dx_f32s(dy2, W1[:, :Dv]).view(B, T, Dv) if ctx.needs_input_grad[0] else None
+        dq = dcs @ W1[:, Dv:] if ctx.needs_input_grad[1] else None
+        dW1 = None
+        if ctx.needs_input_grad[2]:
+            dW1 = torch.empty_like(W1)
+            _dw_f32s(dy2, x2, out=dW1[:, :Dv])
+            dW1[:, Dv:] = dcs.t() @ q
+        db1 = dcs.sum(0) if ctx.needs_input_grad[3] else None
+        return dx, dq, dW1, db1, dw2.view(ctx.shapes[0]), db2.view(ctx.shapes[1]), None
+
+
+def match_head_params(x, q, W1, b1, w2, b2, activation="relu"):
+    """Matching head from its parameters (tsg_match_head_gemm; see _MatchHeadFull)."""
+    return _MatchHeadFull.apply(x, q, W1, b1, w2, b2, _ACTS[activation])
+
+
+class _BoundaryHeadFull(torch.autograd.Function):
+    """The boundary head (K3) with the MODULE'S PARAMETERS as inputs: x [B,T,Dv], sent [B,Ds], the start / end heads' first Linears
+    W [Hm, Dv+Ds], b [Hm] and second Linears w2 [1,Hm], b2 [1], gate [B,T] | None, mask [B,T] | None -> (p_start, p_end) [B,T]
+    (reference SpanPredictor.py:71-85 on VideoSentenceConcat's rows).  As _MatchHeadFull: the video columns of the two first Linears are
+    read in place by tsg_boundary_head_gemm, the small vectors are packed by one cat, and the backward returns full-width dW per head
+    (video columns from the weight-gradient kernel in place, sentence columns from one small GEMM)."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, x, sent, Ws, bs, We, be, w2s, b2s, w2e, b2e, gate, mask):
+        require_device(x, sent, Ws, bs, We, be, w2s, b2s, w2e, b2e, gate, mask)
+        x = _f32c(x)
+        B, T, Dv = x.shape
+        Hm, J = Ws.shape[0], 2 * Ws.shape[0]
+        Ws, We, sent = _f32p(Ws), _f32p(We), _f32p(sent)
+        if We.shape != Ws.shape or Ws.stride(0) != We.stride(0) or Ws.stride(0) % 4 or Ws.data_ptr() % 16 or We.data_ptr() % 16 or Dv % 4:
+            raise ValueError("boundary_head: the two first Linears must be [Hm, Dv+Ds] row-major parameters of one shape")
+        cs = torch.cat([sent @ Ws[:, Dv:].t(), sent @ We[:, Dv:].t()], 1)              # [B,2Hm]: sentence half (b1 is added in the kernel)
+        pack = torch.cat([t.reshape(-1).to(torch.float32) for t in (bs, be, w2s, w2e, b2s, b2e)])
+        b1, w2, b2 = pack[:J], pack[J:2 * J], pack[2 * J:2 * J + 2]
+        gate_c = _f32p(gate) if gate is not None else None
+        mask_c = mask.to(torch.int32).contiguous() if mask is not None else None
+        need_y = any(ctx.needs_input_grad[:11])
+        y = torch.empty(B, T, J, device=x.device, dtype=torch.float32) if need_y else None
+        ps = torch.empty(B, T, device=x.device, dtype=torch.float32)
+        pe = torch.empty_like(ps)
+        nb = int(load().tsg_head_gemm_ws_bytes(B * T, J, 2))
+        wsb = torch.empty(max(nb, 16), device=x.device, dtype=torch.uint8)
+        _call("tsg_boundary_head_gemm", x, ptr(x), Dv, ptr(Ws), ptr(We), Ws.stride(0), ptr(cs), ptr(b1), ptr(w2), ptr(b2),
+              ptr(gate_c) if gate_c is not None else None, ptr(mask_c) if mask_c is not None else None, ptr(y) if need_y else None,
+              ptr(ps), ptr(pe), ptr(wsb), nb, B, T, Hm, Dv)
+        if need_y:
+            ctx.save_for_backward(x, sent, Ws, We, y, cs, b1, w2, ps, pe, *([gate_c] if gate_c is not None else []),
+                                  *([mask_c] if mask_c is not None else []))
+        ctx.has_gate, ctx.has_mask = gate_c is not None, mask_c is not None
+        ctx.shapes = (w2s.shape, w2e.shape)
+        return ps, pe
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dps, dpe):
+        saved = list(ctx.saved_tensors)
+        x, sent, Ws, We, y, cs, b1, w2, ps, pe = saved[:10]
+        rest = saved[10:]
+        gate = rest.pop(0) if ctx.has_gate else None
+        mask = rest.pop(0) if ctx.has_mask else None
+        B, T, J = y.shape
+        Dv, Hm = x.shape[2], J // 2
+        dps = _f32p(dps) if dps is not None else torch.zeros_like(ps)
+        dpe = _f32p(dpe) if dpe is not None else torch.zeros_like(pe)
+        dy = torch.empty_like(y); dcs = torch.empty_like(cs)
+        db1p = torch.empty(B, J, device=y.device, dtype=torch.float32)
+        dw2p = torch.empty_like(db1p)
+        db2p = torch.empty(B, 2, device=y.device, dtype=torch.float32)
+        dgate = torch.empty(B, T, device=y.device, dtype=torch.float32) if gate is not None else None
+        wk, nb = _k3_workspace(y.device, B, T, Hm)
+        _call("tsg_boundary_score_bwd_ws", y, ptr(y), ptr(cs), ptr(b1), ptr(w2),
+              ptr(gate) if gate is not None else None, ptr(mask) if mask is not None else None,
+              ptr(ps), ptr(pe), ptr(dps), ptr(dpe), ptr(dy), ptr(dcs), ptr(db1p), ptr(dw2p), ptr(db2p),
+              ptr(dgate) if dgate is not None else None, ptr(wk), nb, B, T, Hm, TSG_F32)
+        dy2, x2 = dy.view(B * T, J), x.view(B * T, Dv)
+        ws_, we_ = Ws[:, :Dv], We[:, :Dv]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if _NO_COPIES and gemm_f32s_ok(B * T, Dv, J) and Hm % 32 == 0:
+                dx = gemm_f32s_nn(dy2, ws_, we_).view(B, T, Dv)         # [W_start ; W_end] as two row segments, read in place
+            else:
+                dx = _dx_f32s(dy2, torch.cat([ws_, we_], 0)).view(B, T, Dv)
+        dsent = torch.addmm(dcs[:, :Hm] @ Ws[:, Dv:], dcs[:, Hm:], We[:, Dv:]) if ctx.needs_input_grad[1] else None
+        dWs = dWe = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[4]:
+            dW = torch.empty(2, Hm, Ws.shape[1], device=y.device, dtype=torch.float32)       # [start ; end], full width
+            dW2 = dW.view(J, Ws.shape[1])
+            _dw_f32s(dy2, x2, out=dW2[:, :Dv])
+            dW2[:, Dv:] = dcs.t() @ sent
+            dWs, dWe = dW[0], dW[1]
+        db1, dw2, db2 = db1p.sum(0), dw2p.sum(0), db2p.sum(0)
+        s2s, s2e = ctx.shapes
+        return (dx, dsent, dWs, db1[:Hm], dWe, db1[Hm:], dw2[:Hm].view(s2s), db2[0:1], dw2[Hm:].view(s2e), db2[1:2], dgate, None)
+
+
+def boundary_head_params(x, sent, Ws, bs, We, be, w2s, b2s, w2e, b2e, gate=None, mask=None):
+    """Boundary head from its parameters (tsg_boundary_head_gemm; see _BoundaryHeadFull)."""
+    return _BoundaryHeadFull.apply(x, sent, Ws, bs, We, be, w2s, b2s, w2e, b2e, gate, mask)
+
+
 def boundary_head_gemm(x, w_start, w_end, cs, b1, w2, b2, gate=None, mask=None):
     """Boundary head fused into its first-Linear GEMM (include/tsg_hip.h: tsg_boundary_head_gemm)."""
     return _BoundaryHeadGemm.apply(x, w_start, w_end, cs, b1, w2, b2, gate, mask)
@@ -1031,7 +1201,7 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 
 class _MomentPool(torch.autograd.Function):
     """MomentPooling's three masked means in one pass (tsg_moment_pool_fwd / _bwd): feat [B,T,D] (fp32, or bf16 in the storage
-    mode), masks float [B,T] x 3 -> pooled fp32 [B,3,D]."""
+    mode), masks float [B,T] x 3 -> (target, fore, back) means, fp32 [B,D] each (views of one [B,3,D] buffer)."""
 
     @staticmethod
     def forward(ctx, feat, m_target, m_fore, m_back):
@@ -1047,12 +1217,15 @@ class _MomentPool(torch.autograd.Function):
         _call("tsg_moment_pool_fwd", feat, ptr(feat), ptr(ms[0]), ptr(ms[1]), ptr(ms[2]), ptr(pooled), B, T, D, ctx.dt)
         ctx.save_for_backward(*ms)
         ctx.shape = (B, T, D)
-        return pooled
+        return pooled[:, 0], pooled[:, 1], pooled[:, 2]      # three outputs: their gradients arrive as three [B,D] tensors (as one [B,3,D]
+                                                             # selected three times, autograd zero-filled and accumulated three [B,3,D] buffers)
 
     @staticmethod
-    def backward(ctx, dpooled):
+    def backward(ctx, dt, df, db):
         ms = ctx.saved_tensors
         B, T, D = ctx.shape
+        like = next(g for g in (dt, df, db) if g is not None)
+        dpooled = torch.stack([g if g is not None else torch.zeros_like(like) for g in (dt, df, db)], 1)
         dpooled = _f32p(dpooled)
         dfeat = torch.empty(B, T, D, device=dpooled.device, dtype=_BF if ctx.dt == TSG_BF16 else torch.float32)
         _call("tsg_moment_pool_bwd", dpooled, ptr(dpooled), ptr(ms[0]), ptr(ms[1]), ptr(ms[2]), ptr(dfeat), B, T, D, ctx.dt)
@@ -1060,7 +1233,7 @@ class _MomentPool(torch.autograd.Function):
 
 
 def moment_pool(feat, m_target, m_fore, m_back):
-    """-> [B,3,D]: masked means of feat over the target / fore / back ranges (include/tsg_hip.h: tsg_moment_pool_fwd)."""
+    """-> (target, fore, back) [B,D]: masked means of feat over the three ranges (include/tsg_hip.h: tsg_moment_pool_fwd)."""
     return _MomentPool.apply(feat, m_target, m_fore, m_back)
 
 
@@ -1274,7 +1447,7 @@ class _BiLSTMLayer(torch.autograd.Function):
         h = W_hh.shape[2]
         TB = T * B
         dOut = _f32c(dOut) if dOut is not None else torch.zeros_like(out)
-        WhhT = W_hh.transpose(1, 2).contiguous()
+        WhhT = transposed(W_hh)
         dG = torch.empty((B, T, 2, 4 * h) if bm else (T, B, 2, 4 * h), device=x.device, dtype=torch.float32)
         dC = torch.empty(2, B, h, device=x.device, dtype=torch.float32)
         nb = int(load().tsg_lstm_bwd_ws_bytes(B, T, h))                      # ring workspace of the persistent backward (0: none)
@@ -1299,7 +1472,7 @@ class _BiLSTMLayer(torch.autograd.Function):
             # launch for dG[d]^T [x | h_{t-+1}[d]] of both directions, the shifted h rows read straight from `out`, written as the two
             # parameter-shaped tensors (tsg_wgrad_f32s_out2)
             if ctx.needs_input_grad[0]:
-                dx = (gemm_f32s_nn(dGf, W_ih) if _NO_COPIES else gemm_f32s(dGf, W_ih.t().contiguous())).view(x.shape)
+                dx = (gemm_f32s_nn(dGf, W_ih) if _NO_COPIES else gemm_f32s(dGf, transposed(W_ih))).view(x.shape)
             if _OUT2:
                 dW_ih, dW_hh = wgrad_f32s_out2(dGf, x2, o2, N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h, shift=shift, period=period)
                 return dx, dW_ih.view(8 * h, I), dbias, dW_hh, None, None
@@ -1382,7 +1555,7 @@ class _BiLSTMLayerBf16(torch.autograd.Function):
         h = W_hh.shape[2]
         TB = T * B
         dOut = _bfc(dOut) if dOut is not None else torch.zeros_like(out)
-        WhhT = W_hh.transpose(1, 2).contiguous()
+        WhhT = transposed(W_hh)
         dG = torch.empty(B, T, 2, 4 * h, device=x.device, dtype=_BF)
         dC = torch.empty(2, B, h, device=x.device, dtype=torch.float32)
         nb = int(load().tsg_lstm_bwd_ws_bytes(B, T, h))

@@ -95,12 +95,12 @@ class VideoTextSemanticMatch(nn.Module):
         act_name = {nn.ReLU: "relu", nn.Tanh: "tanh", nn.Sigmoid: "sigmoid"}.get(type(act))
         H = lin1.weight.size(0)
         if video_feat.is_cuda and act_name is not None and H % 4 == 0 and H <= 1024 and lin2.weight.size(0) == 1:
-            cs = TF.linear(query_feat, lin1.weight[:, Dv:], lin1.bias)
             B, T = video_feat.shape[:2]
             if video_feat.dtype == torch.float32 and video_feat.dim() == 3 and TF.head_gemm_ok(B * T, H, Dv, T, H):
                 # K5 as the EPILOGUE of the video half's GEMM (tsg_match_head_gemm): the accumulator tile goes through add +
                 # activation + the 1-output Linear in registers; W1[:, :Dv] is read in place; y exists only for the backward
-                return TF.match_head_gemm(video_feat, lin1.weight[:, :Dv], cs, lin2.weight, lin2.bias, act_name), None
+                return TF.match_head_params(video_feat, query_feat, lin1.weight, lin1.bias, lin2.weight, lin2.bias, act_name), None
+            cs = TF.linear(query_feat, lin1.weight[:, Dv:], lin1.bias)
             # K5: add + activation + the 1-output Linear in one pass over the video half's GEMM output (and one pass back)
             y = TF.linear(video_feat, lin1.weight[:, :Dv])
             return TF.match_head(y, cs, lin2.weight, lin2.bias, act_name), None

@@ -23,5 +23,5 @@ class RNNEncoder(nn.Module):
         self.textual_dim = sent_seq_set['rnn_hidden_dim'] * 2
 
     def forward(self, input):
-        word_encoding, hn, _ = self.rnn_cell(self.word_embed(input))
-        return word_encoding, torch.cat((hn[-2], hn[-1]), -1)
+        word_encoding, final, _ = self.rnn_cell(self.word_embed(input), states="final")     # final = cat(hn[-2], hn[-1])
+        return word_encoding, final

@@ -76,13 +76,10 @@ class MLP_predictor(nn.Module):
         if (video_feat.is_cuda and video_feat.dtype == torch.float32 and video_feat.dim() == 3
                 and TF.head_gemm_ok(video_feat.size(0) * video_feat.size(1), 2 * Hm, Dv, video_feat.size(1), Hm)):
             # K3 as the EPILOGUE of the video half's GEMM (tsg_boundary_head_gemm): the two heads' first Linears are read in place
-            # (column slices of the parameters, no stacked copy); only the [B,T] probabilities leave the kernel
-            ws_, we_ = self.start_mlp_1.weight[:, :Dv], self.end_mlp_1.weight[:, :Dv]
-            cs = torch.cat([TF.linear(sent_feat, self.start_mlp_1.weight[:, Dv:]), TF.linear(sent_feat, self.end_mlp_1.weight[:, Dv:])], 1)
-            b1 = torch.cat([self.start_mlp_1.bias, self.end_mlp_1.bias])
-            w2 = torch.cat([self.start_mlp_2.weight.reshape(-1), self.end_mlp_2.weight.reshape(-1)])
-            b2 = torch.cat([self.start_mlp_2.bias, self.end_mlp_2.bias])
-            return TF.boundary_head_gemm(video_feat, ws_, we_, cs, b1, w2, b2, gate, v_mask)
+            # (no stacked copy, no column-slice nodes); only the [B,T] probabilities leave the kernel
+            return TF.boundary_head_params(video_feat, sent_feat, self.start_mlp_1.weight, self.start_mlp_1.bias, self.end_mlp_1.weight,
+                                    self.end_mlp_1.bias, self.start_mlp_2.weight, self.start_mlp_2.bias, self.end_mlp_2.weight,
+                                    self.end_mlp_2.bias, gate, v_mask)
         W1, b1, w2, b2 = self._stacked()
         y = TF.linear(video_feat, W1[:, :Dv])
         cs = TF.linear(sent_feat, W1[:, Dv:])

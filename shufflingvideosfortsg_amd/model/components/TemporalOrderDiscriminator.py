@@ -35,8 +35,7 @@ class MomentPooling(nn.Module):
 
     def forward(self, feat, target_mask, fore_mask, back_mask):
         if feat.is_cuda and feat.dim() == 3 and target_mask.dim() == 2 and feat.size(-1) % 4 == 0 and feat.dtype in (torch.float32, torch.bfloat16):
-            pooled = TF.moment_pool(feat, target_mask, fore_mask, back_mask)                    # [B,3,D] fp32, one pass over feat
-            tgt, fore_avg, back_avg = pooled[:, 0], pooled[:, 1], pooled[:, 2]
+            tgt, fore_avg, back_avg = TF.moment_pool(feat, target_mask, fore_mask, back_mask)   # [B,D] fp32 each, one pass over feat
         elif feat.dim() == 3 and target_mask.dim() == 2:
             pooled = self.average_masks(feat, (target_mask, fore_mask, back_mask)).float()      # [B,3,D]: the small MLPs stay fp32
             tgt, fore_avg, back_avg = pooled[:, 0], pooled[:, 1], pooled[:, 2]

@@ -34,7 +34,7 @@ class RNNEncoder(nn.Module):
         self.video_layernorm = nn.LayerNorm(hidden_dim * 2)
 
     def forward(self, input, *args):
-        video_encoding, _, _ = self.rnn_cell(input)
+        video_encoding, _, _ = self.rnn_cell(input, states=False)
         ln = self.video_layernorm
         if TF.layer_norm_ok(video_encoding):
             return TF.layer_norm(video_encoding, ln.weight, ln.bias, ln.eps)
@@ -53,7 +53,7 @@ class rnn_recalibration_layer(nn.Module):
         self.sent_linear = nn.Linear(sent_dim, self.visual_dim)
 
     def forward(self, video_feat, word_feat):
-        rnn_output, _, _ = self.rnn_cell(video_feat)
+        rnn_output, _, _ = self.rnn_cell(video_feat, states=False)
         att = self.attention
         if self.ca_activ in ['sigmoid'] and type(att) is SCDM_Attention and word_feat.size(-1) == self.sent_linear.in_features:
             # fused tail: sent_linear(P @ words) = P @ (words W_l^T) + b_l, so the Linear runs on the N word rows

@@ -32,6 +32,25 @@ class _Joined(torch.autograd.Function):
         return g[:ctx.n0], g[ctx.n0:], None, None
 
 
+class _FinalStates(torch.autograd.Function):
+    """out [B,L,2h] (batch-major) -> [B,2h] = (out[:, -1, :h] | out[:, 0, h:]): the last layer's final hidden states of the two
+    directions, i.e. cat(hn[-2], hn[-1]).  One cat forward; backward = one zero fill and two slice copies (as four selects of a
+    stacked h_n it was four zero-filled [B,L,2h] gradients, four copies and four accumulations per step)."""
+
+    @staticmethod
+    def forward(ctx, out, h):
+        ctx.shape, ctx.h = out.shape, h
+        return torch.cat((out[:, -1, :h], out[:, 0, h:]), -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        h = ctx.h
+        d = g.new_zeros(ctx.shape)
+        d[:, -1, :h] = g[:, :h]
+        d[:, 0, h:] = g[:, h:]
+        return d, None
+
+
 class BiLSTM(nn.Module):
     _PARTS = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
 
@@ -67,7 +86,7 @@ class BiLSTM(nn.Module):
             self._fused[(k, part)] = base
         return _Joined.apply(pf, pr, base, stack)
 
-    def _hip_forward(self, x):
+    def _hip_forward(self, x, states=True):
         L, p = self.lstm, self.lstm.dropout
         bm = os.environ.get("TSG_LSTM_LAYOUT", "bm") != "tm"   # default: batch-major throughout, the kernels index [B,T,..]
         inp, hn, cn = (x if bm else x.transpose(0, 1).contiguous()), [], []     # directly; "tm" = transposed copies (A/B timing)
@@ -77,17 +96,27 @@ class BiLSTM(nn.Module):
             W_hh = self._joined(k, "weight_hh", stack=True)                  # [2, 4h, h]
             out, Cs = TF.bilstm_layer(inp, W_ih, bias, W_hh, batch_major=bm)
             h = self.hidden_size
-            hn += [out[:, -1, :h], out[:, 0, h:]] if bm else [out[-1, :, :h], out[0, :, h:]]
-            cn += [Cs[-1, 0], Cs[0, 1]]
+            if states is True:
+                hn += [out[:, -1, :h], out[:, 0, h:]] if bm else [out[-1, :, :h], out[0, :, h:]]
+                cn += [Cs[-1, 0], Cs[0, 1]]
             inp = F.dropout(out, p, self.training) if (p > 0 and k + 1 < self.num_layers) else out
-        return (out if bm else out.transpose(0, 1).contiguous()), torch.stack(hn, 0), torch.stack(cn, 0)
+        out = out if bm else out.transpose(0, 1).contiguous()
+        if states is True:
+            return out, torch.stack(hn, 0), torch.stack(cn, 0)
+        if states == "final":                      # [B, 2h] = the last layer's (forward h_T | reverse h_1): all the sentence encoder uses
+            return out, _FinalStates.apply(out, self.hidden_size), None
+        return out, None, None                     # the video encoders discard h_n / c_n: no selects, no stacks, nothing to back-propagate
 
-    def forward(self, x, h0=None, c0=None):
+    def forward(self, x, h0=None, c0=None, states=True):
         """-> (out [B,L,2h], hn [2*layers,B,h], cn); zero initial state on x's device (the reference
-        allocates it with a hard ``.cuda()``)."""
+        allocates it with a hard ``.cuda()``).  ``states`` (an addition to the reference's signature, default = the reference's
+        result): False -> (out, None, None) for callers that discard the final states; "final" -> (out, [B,2h] = cat(hn[-2], hn[-1]),
+        None), the one combination SentenceEncoder.RNNEncoder uses."""
         if x.is_cuda and self.backend == "hip" and h0 is None and c0 is None:
-            return self._hip_forward(x)
+            return self._hip_forward(x, states)
         self.lstm.flatten_parameters()
         state = None if (h0 is None or c0 is None) else (h0, c0)
         out, (hn, cn) = self.lstm(x, state)
-        return out, hn, cn
+        if states == "final":
+            return out, torch.cat((hn[-2], hn[-1]), -1), None
+        return (out, hn, cn) if states is True else (out, None, None)

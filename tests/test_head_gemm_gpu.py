@@ -182,3 +182,64 @@ def test_gemm_f32s_ld_slices(f32s):
     assert torch.equal(Yw[:, :N], y) and float(Yw[:, N:].abs().max()) == 0.0
     # (split-precision product of N(0,1) operands: ~2^-16 relative per term; the equality above is the point of this test)
     torch.testing.assert_close(y, x.double().mm(w.double().t()).float() + bias, atol=1e-3, rtol=1e-3)
+
+
+def _heads_inputs(B, T, Dv, Ds, Hm, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.3).cuda()
+    return dict(x=r(B, T, Dv), sent=r(B, Ds), Ws=r(Hm, Dv + Ds) * 0.2, bs=r(Hm), We=r(Hm, Dv + Ds) * 0.2, be=r(Hm), w2s=r(1, Hm), b2s=r(1),
+                w2e=r(1, Hm), b2e=r(1), gate=torch.sigmoid(r(B, T)), W1=r(H, Dv + Ds) * 0.2, b1=r(H), w2=r(1, H), b2=r(1),
+                mask=(torch.rand(B, T, generator=g) > 0.1).cuda())
+
+
+@pytest.mark.parametrize("B,T,Dv,Ds,Hm", [(4, 128, 1024, 1024, 256), (8, 64, 512, 256, 256)])
+def test_boundary_head_params_equals_the_sliced_route(B, T, Dv, Ds, Hm, f32s):
+    """_BoundaryHeadFull (parameters in, full-width dW out) against the route it replaces -- column-slice views, torch Linears for the
+    sentence half, torch.cat of the small vectors -- which the oracle tests above pin: same probabilities (bit-equal: same kernel, same
+    cs up to the small GEMM's arithmetic) and the same gradients for every input and parameter."""
+    from shufflingvideosfortsg_amd import functional as TF
+    d = _heads_inputs(B, T, Dv, Ds, Hm, 1024, 5)
+    names = ("x", "sent", "Ws", "bs", "We", "be", "w2s", "b2s", "w2e", "b2e", "gate")
+    gs, ge = torch.randn(B, T, device="cuda"), torch.randn(B, T, device="cuda")
+
+    def run(new):
+        p = {k: d[k].clone().requires_grad_(True) for k in names}
+        if new:
+            ps, pe = TF.boundary_head_params(*(p[k] for k in names), d["mask"])
+        else:
+            cs = torch.cat([p["sent"] @ p["Ws"][:, Dv:].t(), p["sent"] @ p["We"][:, Dv:].t()], 1)
+            ps, pe = TF.boundary_head_gemm(p["x"], p["Ws"][:, :Dv], p["We"][:, :Dv], cs, torch.cat([p["bs"], p["be"]]),
+                                           torch.cat([p["w2s"].reshape(-1), p["w2e"].reshape(-1)]), torch.cat([p["b2s"], p["b2e"]]),
+                                           p["gate"], d["mask"])
+        ((ps * gs).sum() + (pe * ge).sum()).backward()
+        return ps.detach(), pe.detach(), {k: p[k].grad for k in names}
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in names:
+        scale = max(1e-6, float(b[2][k].abs().max()))
+        torch.testing.assert_close(a[2][k], b[2][k], atol=2e-5 * scale, rtol=1e-4, msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("B,T,Dv,Dq,H", [(8, 128, 1024, 1024, 1024), (16, 64, 512, 256, 512)])
+def test_match_head_params_equals_the_sliced_route(B, T, Dv, Dq, H, f32s):
+    from shufflingvideosfortsg_amd import functional as TF
+    d = _heads_inputs(B, T, Dv, Dq, 256, H, 6)
+    names = ("x", "sent", "W1", "b1", "w2", "b2")
+    gl = torch.randn(B, T, device="cuda")
+
+    def run(new):
+        p = {k: d[k].clone().requires_grad_(True) for k in names}
+        if new:
+            out = TF.match_head_params(*(p[k] for k in names), "relu")
+        else:
+            cs = torch.addmm(p["b1"], p["sent"], p["W1"][:, Dv:].t())
+            out = TF.match_head_gemm(p["x"], p["W1"][:, :Dv], cs, p["w2"], p["b2"], "relu")
+        (out * gl).sum().backward()
+        return out.detach(), {k: p[k].grad for k in names}
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0])
+    for k in names:
+        scale = max(1e-6, float(b[1][k].abs().max()))
+        torch.testing.assert_close(a[1][k], b[1][k], atol=2e-5 * scale, rtol=1e-4, msg=lambda m, k=k: f"{k}: {m}")

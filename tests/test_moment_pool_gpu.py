@@ -34,13 +34,19 @@ def test_moment_pool_kernel_vs_oracle(B, T, D):
     ref = torch.stack([avg(tgt), avg(fore), avg(back)], 1)
     ref.backward(gp)
     fd = feat.detach().cuda().requires_grad_(True)
-    out = TF.moment_pool(fd, tgt.cuda(), fore.cuda(), back.cuda())
+    out = torch.stack(TF.moment_pool(fd, tgt.cuda(), fore.cuda(), back.cuda()), 1)      # (target, fore, back) [B,D] each
     out.backward(gp.cuda())
     torch.cuda.synchronize()
     torch.testing.assert_close(out.detach().cpu(), ref.detach(), atol=1e-5, rtol=1e-5)
     torch.testing.assert_close(fd.grad.cpu(), feat.grad, atol=1e-6, rtol=1e-5)
-    out2 = TF.moment_pool(fd.detach(), tgt.cuda(), fore.cuda(), back.cuda())
+    out2 = torch.stack(TF.moment_pool(fd.detach(), tgt.cuda(), fore.cuda(), back.cuda()), 1)
     assert torch.equal(out2, out.detach())              # fixed-order sums
+    # a gradient for one output only (the others unused): the missing ones count as zero
+    fd2 = feat.detach().cuda().requires_grad_(True)
+    TF.moment_pool(fd2, tgt.cuda(), fore.cuda(), back.cuda())[1].backward(gp[:, 1].cuda())
+    feat.grad = None
+    avg(fore).backward(gp[:, 1])
+    torch.testing.assert_close(fd2.grad.cpu(), feat.grad, atol=1e-6, rtol=1e-5)
 
 
 def test_moment_pool_bf16_storage():
@@ -54,7 +60,7 @@ def test_moment_pool_bf16_storage():
     ref = torch.stack([avg(tgt), avg(fore), avg(back)], 1)
     ref.backward(gp)
     fd = feat.detach().to(torch.bfloat16).cuda().requires_grad_(True)
-    out = TF.moment_pool(fd, tgt.cuda(), fore.cuda(), back.cuda())
+    out = torch.stack(TF.moment_pool(fd, tgt.cuda(), fore.cuda(), back.cuda()), 1)
     assert out.dtype == torch.float32
     out.backward(gp.cuda())
     assert fd.grad.dtype == torch.bfloat16

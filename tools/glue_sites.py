@@ -29,7 +29,7 @@ for _ in range(3):
     step()
 torch.cuda.synchronize()
 STEPS = 3
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True, with_modules=True) as prof:
     for _ in range(STEPS):
         step()
     torch.cuda.synchronize()
@@ -48,12 +48,17 @@ for e in prof.events():
         if "/repo/" in fr and "tools/" not in fr:
             site = fr.split("/repo/")[-1]
             break
-    if site == "?" and e.stack:
-        site = "autograd: " + (e.stack[0][-60:] if e.stack else "")
+    if site == "?":                                       # no Python stack (backward thread): the enclosing autograd node / module
+        par, chain = e.cpu_parent, []
+        while par is not None and len(chain) < 3:
+            if par.name.startswith("autograd::engine::evaluate_function") or par.name.startswith("nn.Module") or "Backward" in par.name:
+                chain.append(par.name.replace("autograd::engine::evaluate_function: ", ""))
+            par = par.cpu_parent
+        site = " < ".join(chain) if chain else "?"
     k = (e.name, site, str(e.input_shapes)[:60])
     acc[k][0] += e.self_device_time_total if hasattr(e, "self_device_time_total") else dt
     acc[k][1] += 1
 rows = sorted(((v[0] / STEPS, v[1] / STEPS, k) for k, v in acc.items()), reverse=True)
 print(f"# {sum(r[1] for r in rows):.0f} small ops per step, {sum(r[0] for r in rows):.0f} us/step")
-for us, n, (op, site, shp) in rows[:70]:
+for us, n, (op, site, shp) in rows[:110]:
     print(f"{us:8.1f} us x{n:5.1f}  {op:28s} {site:70s} {shp}")
