@@ -1290,6 +1290,24 @@ def gmd_losses(ps, pe, om, pm, od, pd, fs, pfs, tl, ptl, vm, lam=(1.0, 1.0, 1.0)
 _WGRAD_KERNEL = os.environ.get("TSG_WGRAD", "1") != "0"      # A/B switch: 0 = library GEMMs for the weight gradients
 
 
+_ONES = {}
+
+
+def _colsum(t2: torch.Tensor) -> torch.Tensor:
+    """Column sums of an fp32 [M,N] matrix (a bias gradient): on the GPU as a one-row fp32 GEMM ones[1,M] @ t2 -- torch's dim-0 reduction
+    takes 20 us for [2560 x 1024] (one wave per column block), the GEMM 5."""
+    M = t2.shape[0]
+    if not (t2.is_cuda and t2.dtype == torch.float32 and M >= 256 and t2.dim() == 2):
+        return t2.sum(0)
+    key = (t2.device, M)
+    ones = _ONES.get(key)
+    if ones is None:
+        if torch.cuda.is_current_stream_capturing():
+            return t2.sum(0)
+        ones = _ONES[key] = torch.ones(1, M, device=t2.device, dtype=torch.float32)
+    return torch.mm(ones, t2).view(-1)
+
+
 class _LinearSplit(torch.autograd.Function):
     """y = x w^T (+ b) with the two large GEMMs (forward, input gradient) in the split-precision mode on the library's bf16
     kernels; the weight gradient dY^T x has a small output and a T*B-long contraction over the ROWS of both operands, a shape
@@ -1337,7 +1355,7 @@ class _LinearSplit(torch.autograd.Function):
                 dw = torch.mm(At, Bt.t(), out_dtype=torch.float32)
             else:
                 dw = dy2.t() @ x2
-        db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = _colsum(dy2) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 
@@ -1400,10 +1418,14 @@ class _BiLSTMLayer(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, x, W_ih, bias, W_hh, bm=False, mode=_AUTO):
-        require_device(x, W_ih, bias, W_hh)
+    def forward(ctx, x, W_ih, bias, W_hh, bm=False, mode=_AUTO, bias2=None):
+        require_device(x, W_ih, bias, W_hh, bias2)
         mode = ctx.mode = _GEMM_DTYPE if mode is _AUTO else mode      # kept for the backward (it used to read the global)
         x, W_ih, bias, W_hh = _f32c(x), _f32c(W_ih), _f32c(bias), _f32c(W_hh)
+        ctx.two_biases = bias2 is not None
+        own = mode == "f32s" and _LSTM_OWN_GEMM and x.is_cuda and bias2 is not None and bias2.numel() == bias.numel()
+        if bias2 is not None and not (own and gemm_f32s_ok(x.numel() // x.shape[-1], W_ih.shape[0], x.shape[-1])):
+            bias, bias2 = bias + _f32c(bias2), None                   # (elsewhere the two nn.LSTM biases are added up front, as before)
         (B, T, I) = x.shape if bm else (x.shape[1], x.shape[0], x.shape[2])
         h = W_hh.shape[2]
         if W_ih.shape != (8 * h, I) or W_hh.shape != (2, 4 * h, h) or bias.numel() != 8 * h:
@@ -1416,7 +1438,8 @@ class _BiLSTMLayer(torch.autograd.Function):
             # the LSTM's matrix work on the hand-written kernels, operands converted on load: no operand planes in HBM at all
             # (forward: tsg_gemm_f32s; backward: tsg_gemm_f32s for dX, tsg_wgrad_f32s for [dW_ih | dW_hh] of both directions)
             ctx.own = True
-            Gx, kbias = gemm_f32s(x.view(T * B, I), W_ih), bias
+            # two biases (nn.LSTM's b_ih, b_hh): one rides in the GEMM's epilogue, the other is added by the recurrence kernel -- no add kernel
+            Gx, kbias = gemm_f32s(x.view(T * B, I), W_ih, _f32c(bias2) if bias2 is not None else None), bias
         elif mode == "f32s" and (T * B) % 4 == 0 and I % 4 == 0 and h % 4 == 0:
             ctx.Ws = split_bf16x3(W_ih, 1, True)                              # [8h, 3I] (hi, lo, hi): kept for the backward's dX
             Gx, kbias = torch.mm(split_bf16x3(x.view(T * B, I), 1, False), ctx.Ws.t(), out_dtype=torch.float32), bias
@@ -1475,9 +1498,9 @@ class _BiLSTMLayer(torch.autograd.Function):
                 dx = (gemm_f32s_nn(dGf, W_ih) if _NO_COPIES else gemm_f32s(dGf, transposed(W_ih))).view(x.shape)
             if _OUT2:
                 dW_ih, dW_hh = wgrad_f32s_out2(dGf, x2, o2, N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h, shift=shift, period=period)
-                return dx, dW_ih.view(8 * h, I), dbias, dW_hh, None, None
+                return dx, dW_ih.view(8 * h, I), dbias, dW_hh, None, None, (dbias if ctx.two_biases else None)
             D = wgrad_f32s(dGf, x2, N=4 * h, groups=2, a_group_stride=4 * h, B1=o2, K1=h, b1_group_stride=h, shift=shift, period=period)
-            return dx, D[:, :, :I].contiguous().view(8 * h, I), dbias, D[:, :, I:].contiguous(), None, None
+            return dx, D[:, :, :I].contiguous().view(8 * h, I), dbias, D[:, :, I:].contiguous(), None, None, (dbias if ctx.two_biases else None)
         if T == 1:
             dW_ih = _mm(dGf.t(), x2, mode)
             dW_hh = torch.zeros_like(W_hh)
@@ -1513,7 +1536,7 @@ class _BiLSTMLayer(torch.autograd.Function):
                 gf, hf = dG[1:, :, 0].reshape((T - 1) * B, 4 * h), out[:-1, :, :h].reshape((T - 1) * B, h)
                 gr, hr = dG[:-1, :, 1].reshape((T - 1) * B, 4 * h), out[1:, :, h:].reshape((T - 1) * B, h)
             dW_hh = torch.stack([_mm(gf.t(), hf, mode), _mm(gr.t(), hr, mode)])
-        return dx, dW_ih, dbias, dW_hh, None, None
+        return dx, dW_ih, dbias, dW_hh, None, None, (dbias if ctx.two_biases else None)
 
 
 def lstm_bf16_ok(T: int, h: int) -> bool:
@@ -1584,15 +1607,18 @@ class _BiLSTMLayerBf16(torch.autograd.Function):
         return dx, dW_ih, dbias, dW_hh
 
 
-def bilstm_layer(x, W_ih, bias, W_hh, batch_major=False):
+def bilstm_layer(x, W_ih, bias, W_hh, batch_major=False, bias2=None):
     """x [T,B,I] (or [B,T,I] with batch_major) -> (out in the same layout, Cs [T,2,B,h] cell states, not differentiable).
+    ``bias2``: a second bias vector (nn.LSTM keeps b_ih and b_hh apart); the layer uses bias + bias2.
     bf16 storage mode: bf16 in and out through the TSG_BF16 recurrence kernels where they exist (T > 1, h in 128..512 step 128,
     batch-major); other shapes run the fp32-storage path on an fp32 copy and return bf16."""
     if bf16_storage() and x.is_cuda:
         T, h = (x.shape[1] if batch_major else x.shape[0]), W_hh.shape[2]
+        if bias2 is not None:
+            bias = bias + bias2
         if batch_major and lstm_bf16_ok(T, h):
             return _BiLSTMLayerBf16.apply(x, W_ih, bias, W_hh)
         # the fp32-storage layer in the f32s arithmetic: the mode is an ARGUMENT (saved in ctx for the backward), not a flip of the global
         out, Cs = _BiLSTMLayer.apply(x.float(), W_ih, bias, W_hh, batch_major, "f32s")
         return out.to(_BF), Cs
-    return _BiLSTMLayer.apply(x, W_ih, bias, W_hh, batch_major)
+    return _BiLSTMLayer.apply(x, W_ih, bias, W_hh, batch_major, _AUTO, bias2)

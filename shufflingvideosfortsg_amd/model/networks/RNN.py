@@ -92,9 +92,8 @@ class BiLSTM(nn.Module):
         inp, hn, cn = (x if bm else x.transpose(0, 1).contiguous()), [], []     # directly; "tm" = transposed copies (A/B timing)
         for k in range(self.num_layers):
             W_ih = self._joined(k, "weight_ih")                              # [8h, I]   (forward rows, then reverse)
-            bias = self._joined(k, "bias_ih") + self._joined(k, "bias_hh")    # [8h]
             W_hh = self._joined(k, "weight_hh", stack=True)                  # [2, 4h, h]
-            out, Cs = TF.bilstm_layer(inp, W_ih, bias, W_hh, batch_major=bm)
+            out, Cs = TF.bilstm_layer(inp, W_ih, self._joined(k, "bias_ih"), W_hh, batch_major=bm, bias2=self._joined(k, "bias_hh"))
             h = self.hidden_size
             if states is True:
                 hn += [out[:, -1, :h], out[:, 0, h:]] if bm else [out[-1, :, :h], out[0, :, h:]]

@@ -126,7 +126,5 @@ class SCDM_Attention(nn.Module):
         """(W_a v, W_s s + b): the bias of W_a rides on the N word rows instead of the T clip rows -- tanh(W_s s_n + W_a v_t + b)
         is the same sum, and the [B,T,H] bias pass (and its [B*T,H] -> [H] gradient reduction) becomes a [B,N,H] one."""
         a = TF.linear(video_feat, self.W_a.weight, None)
-        s = TF.linear(sent_feat, self.W_s.weight, None)
-        if self.W_a.bias is not None:
-            s = s + self.W_a.bias.to(s.dtype)               # (bf16 storage mode: stays bf16)
+        s = TF.linear(sent_feat, self.W_s.weight, self.W_a.bias)     # (the bias in the Linear: its GEMM's epilogue / one in-place add)
         return a, s
