@@ -315,7 +315,7 @@ int tsg_linear_fwd(const void* x, const void* w, const void* bias, void* y, int 
 /* The same product in the split-precision ("f32s") arithmetic with the operands converted ON LOAD (ABI revision 4): every element is
  * split into hi = rne_bf16(x), lo = rne_bf16(x - hi) in registers and hi*hi + hi*lo + lo*hi is accumulated in fp32 on the bf16
  * MFMA -- tsg_split_bf16x3 + a bf16 GEMM over the 3x longer contraction, without the operand planes in memory.  fp32 in / out,
- * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL).  M % 256 == 0, N % 256 == 0, K % 32 == 0 (TSG_E_SHAPE otherwise).  The input
+ * y[M,N] = x[M,K] w[N,K]^T (+ bias[N], may be NULL).  M % 64 == 0, N % 256 == 0, K % 32 == 0 (TSG_E_SHAPE otherwise).  The input
  * gradient dX = dY W of the same Linears is this call with the weight passed transposed ([K,N] contiguous).                       */
 int tsg_gemm_f32s(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, void* stream);
 /* The same with row strides (in elements, multiples of 4) for x, w and y: a column slice of a row-major matrix is an operand as it

@@ -404,12 +404,20 @@ int launch_gemm(const char* fn, const float* x, long long ldx, const float* w0, 
   return check_launch(fn);
 }
 
-// M tile for a head GEMM: the largest of 256 / 128 / 64 that divides M and still gives every CU a tile (or the smallest that divides M)
+// M tile: the one of 256 / 128 / 64 rows (dividing M) with the smallest estimated time = full-chip rounds x time of one tile.  A tile's
+// time per 1024 columns of K, measured at one tile per CU (tools/gemm_small_time.py): 73 / 46 / 31 us -- the W tile (256 x 32 per chunk)
+// is converted by every workgroup whatever its M, so small tiles pay off only while they save a round or fill idle CUs:
+// [2560 x 1024] x [1024 x 1024]^T 70 / 47 / 33 us, [8192 x 1024] x [1024 x 1024]^T 77 / 57 / 69 us, [1280 x 1024] x [4096 x 1024]^T 74 / 53 / 67 us.
 inline int pick_tm(int M, int N) {
   const int cus = device_cu_count(), tiles_n = N / kTN;
-  for (int tm : {256, 128, 64})
-    if (M % tm == 0 && ((M / tm) * tiles_n >= cus || tm == 64)) return tm;
-  return M % 128 == 0 ? 128 : (M % 64 == 0 ? 64 : 0);
+  int best = 0; float best_cost = 0.f;
+  for (int tm : {256, 128, 64}) {
+    if (M % tm) continue;
+    const int tiles = (M / tm) * tiles_n;
+    const float cost = (float)((tiles + cus - 1) / cus) * (17.f + 0.22f * tm);
+    if (!best || cost < best_cost) { best = tm; best_cost = cost; }
+  }
+  return best;
 }
 
 inline long long head_ws_bytes(int M, int N, int heads) {
@@ -449,11 +457,17 @@ extern "C" int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, lon
     if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
   }
   if (M <= 0 || N <= 0 || K <= 0) return set_error(TSG_E_SHAPE, "%s: non-positive dimension M=%d N=%d K=%d", fn, M, N, K);
-  if (M % 256 || N % kTN || K % kBK)
-    return set_error(TSG_E_SHAPE, "%s: M=%d, N=%d must be multiples of 256 and K=%d of 32", fn, M, N, K);
+  if (M % 64 || N % kTN || K % kBK)
+    return set_error(TSG_E_SHAPE, "%s: M=%d must be a multiple of 64, N=%d of 256 and K=%d of 32", fn, M, N, K);
   if (ldx < K || ldw < K || ldy < N || ldx % 4 || ldw % 4) return set_error(TSG_E_ALIGN, "%s: leading dimensions ldx=%lld ldw=%lld ldy=%lld", fn, ldx, ldw, ldy);
   const EpiStore epi{(const float*)bias, (float*)y, ldy};
-  return launch_gemm<256>(fn, (const float*)x, ldx, (const float*)w, (const float*)w, N, ldw, epi, M, N, K, static_cast<hipStream_t>(stream));
+  auto st = static_cast<hipStream_t>(stream);
+  // M tile: 256 rows when that still gives every CU a tile; with few rows (the sentence side: 2560 = 128 x 20) 128 or 64, as the heads
+  static const int force_tm = getenv("TSG_GEMM_TM") ? atoi(getenv("TSG_GEMM_TM")) : 0;       // developer override (A/B timing)
+  const int tm = force_tm && M % force_tm == 0 ? force_tm : pick_tm(M, N);
+  if (tm == 256) return launch_gemm<256>(fn, (const float*)x, ldx, (const float*)w, (const float*)w, N, ldw, epi, M, N, K, st);
+  if (tm == 128) return launch_gemm<128>(fn, (const float*)x, ldx, (const float*)w, (const float*)w, N, ldw, epi, M, N, K, st);
+  return launch_gemm<64>(fn, (const float*)x, ldx, (const float*)w, (const float*)w, N, ldw, epi, M, N, K, st);
 }
 
 // y[M,N] = x[M,K] w[K,N] (+ bias): the right operand contraction-major, optionally as two ROW segments (w0: rows < kseg, w1: the rest;

@@ -361,6 +361,7 @@ _OWN_GEMM = os.environ.get("TSG_GEMM", "1") != "0"          # A/B switch: 0 = op
 # profiles/r4/bench_lstm_own_gemm_ab_v1.txt) -- and it takes the operand-plane passes (1.59 -> 0.24 ms per step) and the library's bf16
 # GEMMs (4.92 -> 0.60 ms) out of the step: all matrix work of the path is hand-written now.  TSG_LSTM_GEMM=lib keeps the old path (A/B).
 _LSTM_OWN_GEMM = os.environ.get("TSG_LSTM_GEMM", "own") != "lib"
+_LSTM_SPLITK = os.environ.get("TSG_LSTM_SPLITK", "1") != "0"          # A/B switch: the sentence LSTM's dX as 8 K-chunks (bmm + sum)
 _OWN_TRANSPOSE = os.environ.get("TSG_TRANSPOSE", "own") != "torch"     # A/B switch: "torch" = .t().contiguous()
 # Two copy eliminations of round 4, measured separately in the step (profiles/r4/bench_no_copies_ab_v1.txt; 14.167-14.191 ms with neither):
 #   out2: the LSTM layer's dW_ih / dW_hh as two parameter-shaped outputs of ONE weight-gradient launch (tsg_wgrad_f32s_out2) instead of
@@ -375,11 +376,13 @@ _OUT2 = _NC in ("1", "out2")                                  # the two-output w
 
 
 def gemm_f32s_ok(M: int, N: int, K: int) -> bool:
-    """Shapes tsg_gemm_f32s takes AND is the faster path for (include/tsg_hip.h): whole 256 x 256 tiles, at least 100 of them
-    (with few tiles the library's smaller ones win: 63 vs 41 us at [2560 x 1024] x [1024 x 1024] = 40 tiles; 133 vs 171 us at 128 tiles).
-    The LSTM input GEMM ([T*B, I] x [8h, I]: 450 vs 436-454 us at 1024 tiles, and its W planes are needed by the backward anyway) stays
-    on the library path."""
-    return _OWN_GEMM and M % 256 == 0 and N % 256 == 0 and K % 32 == 0 and (M // 256) * (N // 256) >= 100
+    """Shapes tsg_gemm_f32s takes AND is the faster path for (include/tsg_hip.h): whole tiles of 64 / 128 / 256 rows x 256 columns (the
+    kernel picks the M tile).  Against the operand passes + the library's bf16 GEMM (tools/gemm_small_time.py, gemm_f32s_time.py):
+    [2560 x 1024] x [1024 x 1024]^T 33 vs 42 us, [8192 x 1024] x [1024 x 1024]^T 57 vs 69, [16384 x 1024] x [4096 x 1024]^T 450 vs 427-479;
+    with FEW tiles and a LONG contraction the library's split-K wins ([1280 x 4096] x [1024 x 4096]^T: 110 vs 80 us) and keeps the product."""
+    if not (_OWN_GEMM and M % 64 == 0 and N % 256 == 0 and K % 32 == 0):
+        return False
+    return K <= 2048 or ((M + 255) // 256) * (N // 256) >= 100
 
 
 def gemm_f32s(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
@@ -1519,7 +1522,13 @@ class _BiLSTMLayer(torch.autograd.Function):
                 # 24 MB permute of its split.  No second pass over dG (110 us per layer).
                 Ws = ctx.Ws if ctx.Ws is not None else split_bf16x3(W_ih, 1, True)
                 Wt = Ws.view(8 * h, 3, I).permute(2, 0, 1).reshape(I, 24 * h)
-                dx = torch.mm(At.view(24 * h, TB).t(), Wt.t(), out_dtype=torch.float32).view(x.shape)
+                if TB <= 4096 and h % 64 == 0 and 24 * h >= 6144 and _LSTM_SPLITK:
+                    # few rows, long contraction (the sentence encoder: 1280 x 12288 x I): the library runs it on 50 tiles at 0.3 PFLOP/s
+                    # (98 + 103 us per step).  The same product as 8 K-chunks in one batched GEMM + a sum of the 8 partial results.
+                    c, kc = 8, 3 * h
+                    dx = torch.bmm(At.view(c, kc, TB).transpose(1, 2), Wt.view(I, c, kc).permute(1, 2, 0), out_dtype=torch.float32).sum(0).view(x.shape)
+                else:
+                    dx = torch.mm(At.view(24 * h, TB).t(), Wt.t(), out_dtype=torch.float32).view(x.shape)
             split_bf16x3_t(x2, 0, I, 0, True, Bt, 0, dup_row0=I + h)         # x planes, in both directions' batches
             split_bf16x3_t(o2, 0, h, shift, True, Bt, I, period)             # h_{t-1}, forward direction
             split_bf16x3_t(o2, h, h, -shift, True, Bt, 2 * I + h, period)    # h_{t+1}, reverse direction

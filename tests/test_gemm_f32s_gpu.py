@@ -6,7 +6,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("M,N,K,bias", [(256, 256, 32, False), (512, 768, 96, True), (2048, 1024, 1024, True), (16384, 512, 2048, False)])
+@pytest.mark.parametrize("M,N,K,bias", [(256, 256, 32, False), (512, 768, 96, True), (2048, 1024, 1024, True), (16384, 512, 2048, False),
+                                        (64, 256, 64, True), (2560, 1024, 1024, True), (1280, 4096, 1024, False), (8192, 1024, 1024, False), (192, 512, 96, True)])
 def test_gemm_f32s_matches_fp64_and_the_planes_path(M, N, K, bias):
     from shufflingvideosfortsg_amd import functional as F
     g = torch.Generator().manual_seed(M + N + K)
@@ -31,6 +32,8 @@ def test_gemm_f32s_rejects_ragged_shapes():
     lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
     x = torch.zeros(256, 64, device="cuda"); w = torch.zeros(256, 64, device="cuda"); y = torch.zeros(256, 256, device="cuda")
     assert lib.tsg_gemm_f32s(ptr(x), ptr(w), None, ptr(y), 255, 256, 64, st) == -2
+    assert lib.tsg_gemm_f32s(ptr(x), ptr(w), None, ptr(y), 96, 256, 64, st) == -2             # rows: whole 64-row tiles
+    assert lib.tsg_gemm_f32s(ptr(x), ptr(w), None, ptr(y), 256, 128, 64, st) == -2
     assert lib.tsg_gemm_f32s(ptr(x), ptr(w), None, ptr(y), 256, 256, 48, st) == -2
     assert lib.tsg_gemm_f32s(None, ptr(w), None, ptr(y), 256, 256, 64, st) == -1
 
