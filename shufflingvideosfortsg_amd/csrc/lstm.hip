@@ -1272,8 +1272,7 @@ extern "C" int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const voi
     int rc = lstm_check(fn, B, T, h, dtype);
     if (rc) return rc;
     auto st = static_cast<hipStream_t>(stream);
-    hipError_t e = dbias ? zero_async(dbias, sizeof(float) * 8 * h, st) : hipSuccess;
-    if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+    hipError_t e = hipSuccess;                               // (dbias is zeroed together with the first chunk's sync words: one node)
     const bool split = dtype == TSG_F32S;
     const int rows = persist_chunk_rows(B, h / 32, bwd_persist_capacity());      // > 0 (tsg_lstm_bwd_ws_persistent)
     const size_t K8 = (size_t)8 * h, H2 = (size_t)2 * h;
@@ -1285,7 +1284,7 @@ extern "C" int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const voi
       for (int c0 = 0; c0 < B; c0 += rows) {
         const int Bc = B - c0 < rows ? B - c0 : rows;
         const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;
-        e = zero_async(ws, kSyncBytes, st);
+        e = zero3_async(ws, kSyncBytes, c0 == 0 ? dbias : nullptr, sizeof(float) * 8 * h, nullptr, 0, st);
         if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
         hipLaunchKernelGGL(pb, dim3(2 * (h / 32) * cdiv(Bc, 16)), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT,
                            (const lstm_bf16*)R + (size_t)c0 * h * 4, (const float*)Cs + (size_t)c0 * h, (const lstm_bf16*)dOut + seq * H2,
@@ -1303,7 +1302,7 @@ extern "C" int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const voi
     for (int c0 = 0; c0 < B; c0 += rows) {                   // row chunks as in the forward; the ring is reused, dbias accumulates
       const int Bc = B - c0 < rows ? B - c0 : rows;
       const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;
-      e = zero_async(ws, kSyncBytes, st);
+      e = zero3_async(ws, kSyncBytes, c0 == 0 ? dbias : nullptr, sizeof(float) * 8 * h, nullptr, 0, st);
       if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
       hipLaunchKernelGGL(pk, dim3(2 * (h / 32) * cdiv(Bc, 16)), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT,
                          (const float*)R + (size_t)c0 * h * 4, (const float*)Cs + (size_t)c0 * h, (const float*)dOut + seq * H2,

@@ -209,9 +209,7 @@ extern "C" int tsg_match_head_bwd(const void* y, const void* cs, const void* w2,
   int rc = mh_check(fn, B, T, H, activation, dtype);
   if (rc) return rc;
   auto st = static_cast<hipStream_t>(stream);
-  hipError_t e = zero_async(dcs, sizeof(float) * (size_t)B * H, st);
-  if (e == hipSuccess) e = zero_async(dw2, sizeof(float) * H, st);
-  if (e == hipSuccess) e = zero_async(db2, sizeof(float), st);
+  hipError_t e = zero3_async(dcs, sizeof(float) * (size_t)B * H, dw2, sizeof(float) * H, db2, sizeof(float), st);     // one node, not three
   if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
   const int grid = B * cdiv(T, kMhRows);
   if (dtype == TSG_BF16) {

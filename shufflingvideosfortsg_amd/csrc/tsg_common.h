@@ -165,5 +165,24 @@ inline hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {      // p 
   return hipGetLastError();
 }
 
+// Up to three small buffers zeroed by ONE kernel node (each launch costs ~4.5 us of device time plus the gap in front of it).
+static __global__ void zero_words3_kernel(unsigned* __restrict__ p0, size_t n0, unsigned* __restrict__ p1, size_t n1,
+                                          unsigned* __restrict__ p2, size_t n2) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1 + n2; i += stride) {
+    if (i < n0) p0[i] = 0u;
+    else if (i < n0 + n1) p1[i - n0] = 0u;
+    else p2[i - n0 - n1] = 0u;
+  }
+}
+inline hipError_t zero3_async(void* p0, size_t b0, void* p1, size_t b1, void* p2, size_t b2, hipStream_t st) {   // pointers 4-byte aligned,
+  const size_t n0 = p0 ? b0 / 4 : 0, n1 = p1 ? b1 / 4 : 0, n2 = p2 ? b2 / 4 : 0, words = n0 + n1 + n2;          // bytes multiples of 4
+  if (words == 0) return hipSuccess;
+  const int blocks = (int)((words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024);
+  hipLaunchKernelGGL(zero_words3_kernel, dim3(blocks), dim3(256), 0, st, static_cast<unsigned*>(p0), n0, static_cast<unsigned*>(p1), n1,
+                     static_cast<unsigned*>(p2), n2);
+  return hipGetLastError();
+}
+
 #endif  // __HIPCC__
 }  // namespace tsg
