@@ -91,7 +91,36 @@ def to_device(batch, device):
                     out[gt][k] = v.to(device)
             fs = out[gt]["framestps"]
             out[gt]["framestps"] = (fs if isinstance(fs, torch.Tensor) else torch.tensor(fs, dtype=torch.long)).to(device)
+    # The GMD step runs the original and the shuffled stream as ONE batch of 2B (model/SpanGroundMatchDisc.py): their tensors are
+    # placed back to back in one device allocation, so the model's batch concatenation is a view (`adjacent_cat`), not a 64 MB copy
+    # and four small ones per step.
+    if "pseudo_video" in out and isinstance(out.get("video"), torch.Tensor):
+        out["video"], out["pseudo_video"] = _adjacent(out["video"], out["pseudo_video"])
+    if "gt" in out and "pseudo_gt" in out:
+        for k in ("temporal_labels", "fore_masks", "back_masks"):
+            a, b = out["gt"].get(k), out["pseudo_gt"].get(k)
+            if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor):
+                out["gt"][k], out["pseudo_gt"][k] = _adjacent(a, b)
     return out
+
+
+def _adjacent(a, b):
+    """Two equally shaped tensors as the two halves of one allocation (views)."""
+    if a.shape != b.shape or a.dtype != b.dtype or a.device != b.device:
+        return a, b
+    both = torch.empty((2 * a.shape[0],) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+    both[:a.shape[0]].copy_(a); both[a.shape[0]:].copy_(b)
+    return both[:a.shape[0]], both[a.shape[0]:]
+
+
+def adjacent_cat(a, b):
+    """``torch.cat([a, b], 0)``; a VIEW when b starts where a ends in the same storage (see ``to_device``) and neither needs a gradient."""
+    if (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.shape == b.shape and a.dtype == b.dtype and a.device == b.device
+            and a.dim() >= 1 and a.is_contiguous() and b.is_contiguous() and not a.requires_grad and not b.requires_grad
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and b.storage_offset() == a.storage_offset() + a.numel()
+            and a.untyped_storage().nbytes() >= (b.storage_offset() + b.numel()) * a.element_size()):
+        return torch.as_strided(a, (2 * a.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+    return torch.cat([a, b], 0)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

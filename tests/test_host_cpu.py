@@ -121,3 +121,26 @@ def test_strong_scaling_shards_and_device_move():
     d = data.to_device(parts[1], "cpu")
     assert d["gt"]["framestps"].dtype == torch.long and d["gt"]["framestps"].tolist() == full["gt"]["framestps"][2:4]
     assert isinstance(parts[1]["gt"]["framestps"], list)                      # the host batch is not modified
+
+
+def test_pair_batch_halves_are_adjacent_and_cat_is_a_view():
+    """data.to_device places the original and the shuffled stream back to back; adjacent_cat then returns a view with torch.cat's
+    values, and falls back to a copy for anything else (other storages, a gap, a tensor that needs a gradient)."""
+    import torch
+    from shufflingvideosfortsg_amd import data
+    b = data.synthetic_batch(4, 16, 5, video_dim=32, pair=True)
+    d = data.to_device(b, "cpu")
+    v = data.adjacent_cat(d["video"], d["pseudo_video"])
+    assert v.data_ptr() == d["video"].data_ptr() and torch.equal(v, torch.cat([b["video"], b["pseudo_video"]], 0))
+    for k in ("temporal_labels", "fore_masks", "back_masks"):
+        m = data.adjacent_cat(d["gt"][k], d["pseudo_gt"][k])
+        assert m.data_ptr() == d["gt"][k].data_ptr() and torch.equal(m, torch.cat([b["gt"][k], b["pseudo_gt"][k]], 0))
+    x, y = torch.randn(3, 4), torch.randn(3, 4)
+    assert torch.equal(data.adjacent_cat(x, y), torch.cat([x, y], 0))
+    z = torch.randn(6, 4)
+    c = data.adjacent_cat(z[:2], z[3:5])                                    # same storage, a gap between them: a copy
+    assert c.data_ptr() != z.data_ptr() and torch.equal(c, torch.cat([z[:2], z[3:5]], 0))
+    g = torch.randn(4, 4, requires_grad=True)
+    c = data.adjacent_cat(g[:2], g[2:])                                     # needs a gradient: torch.cat (autograd splits it back)
+    c.sum().backward()
+    assert torch.equal(g.grad, torch.ones(4, 4))
