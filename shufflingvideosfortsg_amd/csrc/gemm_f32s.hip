@@ -284,8 +284,10 @@ __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restri
 #pragma unroll
       for (int p = 0; p < 4; ++p) rw[p] = *reinterpret_cast<const float4*>(wt + (size_t)p * ldw);
     } else {
+#if !(defined(TSG_GEMM_ABL) && (TSG_GEMM_ABL & 2))
 #pragma unroll
       for (int p = 0; p < 4; ++p) rw[p] = *reinterpret_cast<const float4*>(wsrc + p * passw + k0);
+#endif
     }
   };
   // split once, here, and write the bf16 planes: row r, 16-byte piece (sq >> 1) ^ ((r >> 2) & 3), 8-byte half sq & 1
@@ -311,9 +313,16 @@ __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restri
         *reinterpret_cast<uint2*>(base + 2 * kPlaneX + ot) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(base + 2 * kPlaneX + kPlaneW + ot) = make_uint2(l0, l1);
       } else {
+#if defined(TSG_GEMM_ABL) && (TSG_GEMM_ABL & 2)
+        // ablation: no W staging at all (stale planes)
+#elif defined(TSG_GEMM_ABL) && (TSG_GEMM_ABL & 1)
+        *reinterpret_cast<uint2*>(base + 2 * kPlaneX + o) = make_uint2(__float_as_uint(rw[p].x), __float_as_uint(rw[p].y));     // ablation: no conversion
+        *reinterpret_cast<uint2*>(base + 2 * kPlaneX + kPlaneW + o) = make_uint2(__float_as_uint(rw[p].z), __float_as_uint(rw[p].w));
+#else
         g_split_pair(rw[p].x, rw[p].y, h0, l0); g_split_pair(rw[p].z, rw[p].w, h1, l1);
         *reinterpret_cast<uint2*>(base + 2 * kPlaneX + o) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(base + 2 * kPlaneX + kPlaneW + o) = make_uint2(l0, l1);
+#endif
       }
     }
   };
