@@ -44,13 +44,15 @@ def test_wgrad_wide_dynamic_range_and_zero_rows():
     assert _rel(hi_only, ref) > 1e-4                    # a plain bf16 product is NOT good enough here
 
 
+@pytest.mark.parametrize("Bn,T", [(8, 16), (4, 64), (3, 96), (4, 40), (2, 256)])
 @pytest.mark.parametrize("bm", [True, False])
-def test_wgrad_lstm_operands(bm):
+def test_wgrad_lstm_operands(bm, Bn, T):
     """Two groups (directions), B = [x | h_{t-1}] / [x | h_{t+1}] read from `out` with a row shift: equals the explicitly
-    shifted construction, in the batch-major (period T, shift 1) and time-major (shift B) layouts."""
+    shifted construction, in the batch-major (period T, shift 1) and time-major (shift B) layouts.  Sequence lengths below a
+    chunk (16), whole chunks (64, 96, 256: the scalar-position path) and not a multiple of a chunk (40: chunks straddle sequences)."""
     from shufflingvideosfortsg_amd import functional as F
     g = torch.Generator().manual_seed(5)
-    Bn, T, I, h = 8, 16, 128, 128
+    I, h = 128, 128
     TB = Bn * T
     dG = torch.randn(TB, 8 * h, generator=g).cuda()
     x = torch.randn(TB, I, generator=g).cuda()
