@@ -190,7 +190,10 @@ class GraphedTrainStep:
         self._zero()
         # capture on the warm-up stream: autograd's AccumulateGrad nodes were created there, and a capture on another stream
         # would record cross-stream event nodes into the graph (a forked graph: hipGraphLaunch then enqueues node by node)
-        with torch.cuda.graph(self.graph_a, stream=side):
+        # capture_error_mode="thread_local": RCCL's watchdog thread polls the events of the eager exchanges (warm-up steps, dp.adopt below)
+        # with hipEventQuery; under the default "global" mode a poll that lands inside a capture aborts the process ("operation not
+        # permitted when stream is capturing": seen once in ~6 runs of the world-1 RCCL test).  Nothing of another thread is captured.
+        with torch.cuda.graph(self.graph_a, stream=side, capture_error_mode="thread_local"):
             self._zero()
             self.loss = step_fn(model, batch)
             self.loss.backward()
@@ -198,7 +201,8 @@ class GraphedTrainStep:
         self.grads = [p.grad for p in self.params]          # the graph's static gradient tensors (None: no gradient)
         if dp is not None and dp.active:
             dp.adopt(self.grads, self.guard)                # gather + exchange once: .grad now points into the flat buffer
-        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=side):
+            torch.cuda.synchronize()                        # the exchange has finished before the second capture begins
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=side, capture_error_mode="thread_local"):
             optimizer_step(opt, self.loss, dp=dp, guard=self.guard)   # reads the REDUCED flag (dp.guard: static memory of the flat buffer)
 
     def _zero(self):
