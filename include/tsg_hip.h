@@ -404,6 +404,11 @@ int tsg_wgrad_f32s_out2(const void* A, long long lda, long long a_group_stride, 
                         const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift, long long period,
                         void* C, long long ldc, long long c_group_stride, void* C1, long long ldc1, long long c1_group_stride,
                         void* ws, long long ws_bytes, long long M, int N, int groups, void* stream);
+/* The same for bf16 operands (the arithmetic of tsg_wgrad_bf16: one bf16 MFMA per product, fp32 outputs): the LSTM layers of the bf16 storage mode. */
+int tsg_wgrad_bf16_out2(const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
+                        const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift, long long period,
+                        void* C, long long ldc, long long c_group_stride, void* C1, long long ldc1, long long c1_group_stride,
+                        void* ws, long long ws_bytes, long long M, int N, int groups, void* stream);
 
 /* The same product with bf16 OPERANDS (the bf16 storage mode, ABI revision 3): A, B0, B1 are bf16 matrices (strides in elements,
  * multiples of 4; 16-byte aligned bases), C and ws fp32 as above (workspace size: tsg_wgrad_f32s_ws_bytes).  One bf16 MFMA per

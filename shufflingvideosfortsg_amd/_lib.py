@@ -33,6 +33,8 @@ _SIGNATURES = {
                        _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _I, _I, _P],
     "tsg_wgrad_f32s_out2": [_P, c_longlong, c_longlong, _P, c_longlong, _I, _P, c_longlong, c_longlong, _I, c_longlong, c_longlong,
                             _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _I, _I, _P],
+    "tsg_wgrad_bf16_out2": [_P, c_longlong, c_longlong, _P, c_longlong, _I, _P, c_longlong, c_longlong, _I, c_longlong, c_longlong,
+                            _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _I, _I, _P],
     "tsg_wgrad_bf16": [_P, c_longlong, c_longlong, _P, c_longlong, _I, _P, c_longlong, c_longlong, _I, c_longlong, c_longlong,
                        _P, c_longlong, c_longlong, _P, c_longlong, c_longlong, _I, _I, _P],
     "tsg_boundary_score_fwd": [_P] * 9 + [_I] * 4 + [_P],

@@ -518,3 +518,13 @@ extern "C" int tsg_wgrad_bf16(const void* A, long long lda, long long a_group_st
   return wgrad_impl("tsg_wgrad_bf16", true, A, lda, a_group_stride, B0, ldb0, K0, B1, ldb1, b1_group_stride, K1, shift, period, C, ldc,
                     c_group_stride, ws, ws_bytes, M, N, groups, stream);
 }
+
+// tsg_wgrad_f32s_out2 for bf16 operands (the bf16 storage mode's LSTM layers): dW_ih / dW_hh as two fp32 outputs from one launch.
+extern "C" int tsg_wgrad_bf16_out2(const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
+                                   const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift,
+                                   long long period, void* C, long long ldc, long long c_group_stride, void* C1, long long ldc1,
+                                   long long c1_group_stride, void* ws, long long ws_bytes, long long M, int N, int groups, void* stream) {
+  if (!C1) return set_error(TSG_E_NULL, "tsg_wgrad_bf16_out2: NULL second output");
+  return wgrad_impl("tsg_wgrad_bf16_out2", true, A, lda, a_group_stride, B0, ldb0, K0, B1, ldb1, b1_group_stride, K1, shift, period, C, ldc,
+                    c_group_stride, ws, ws_bytes, M, N, groups, stream, C1, ldc1, c1_group_stride);
+}

@@ -314,6 +314,23 @@ def wgrad_f32s_out2(A: torch.Tensor, B0: torch.Tensor, B1: torch.Tensor, N: int,
     return C0, C1
 
 
+def wgrad_bf16_out2(A: torch.Tensor, B0: torch.Tensor, B1: torch.Tensor, N: int, K1: int, a_group_stride: int, b1_group_stride: int,
+                    shift: int, period: int):
+    """``wgrad_f32s_out2`` for bf16 operands (tsg_wgrad_bf16_out2): -> (C0 [2, N, K0], C1 [2, N, K1]) fp32."""
+    require_device(A, B0, B1)
+    A, B0, B1 = _rows2d_bf(A), _rows2d_bf(B0), _rows2d_bf(B1)
+    M, K0 = B0.shape
+    C0 = torch.empty(2, N, K0, device=A.device, dtype=torch.float32)
+    C1 = torch.empty(2, N, K1, device=A.device, dtype=torch.float32)
+    nb = int(load().tsg_wgrad_f32s_ws_bytes(M, N, K0, K1, 2))
+    if nb < 0:
+        raise ValueError(f"wgrad_bf16_out2: unsupported shape M={M} N={N} K0={K0} K1={K1}")
+    ws = torch.empty(nb, device=A.device, dtype=torch.uint8) if nb else None
+    _call("tsg_wgrad_bf16_out2", A, ptr(A), A.stride(0), a_group_stride, ptr(B0), B0.stride(0), K0, ptr(B1), B1.stride(0), b1_group_stride, K1,
+          shift, period, ptr(C0), K0, N * K0, ptr(C1), K1, N * K1, ptr(ws) if ws is not None else None, nb, M, N, 2)
+    return C0, C1
+
+
 def _rows2d_bf(t: torch.Tensor) -> torch.Tensor:
     """bf16 2-D operand whose rows are contiguous (a column slice of a row-major matrix is taken as it is)."""
     if t.dtype != torch.bfloat16 or t.dim() != 2:
@@ -1300,14 +1317,16 @@ def _colsum(t2: torch.Tensor) -> torch.Tensor:
     """Column sums of an fp32 [M,N] matrix (a bias gradient): on the GPU as a one-row fp32 GEMM ones[1,M] @ t2 -- torch's dim-0 reduction
     takes 20 us for [2560 x 1024] (one wave per column block), the GEMM 5."""
     M = t2.shape[0]
-    if not (t2.is_cuda and t2.dtype == torch.float32 and M >= 256 and t2.dim() == 2):
-        return t2.sum(0)
-    key = (t2.device, M)
+    if not (t2.is_cuda and t2.dtype in (torch.float32, _BF) and M >= 256 and t2.dim() == 2):
+        return t2.sum(0, dtype=torch.float32)
+    key = (t2.device, M, t2.dtype)
     ones = _ONES.get(key)
     if ones is None:
         if torch.cuda.is_current_stream_capturing():
-            return t2.sum(0)
-        ones = _ONES[key] = torch.ones(1, M, device=t2.device, dtype=torch.float32)
+            return t2.sum(0, dtype=torch.float32)
+        ones = _ONES[key] = torch.ones(1, M, device=t2.device, dtype=t2.dtype)
+    if t2.dtype == _BF:
+        return torch.mm(ones, t2, out_dtype=torch.float32).view(-1)     # bf16 rows, fp32 sums (the bias gradient is never rounded to bf16)
     return torch.mm(ones, t2).view(-1)
 
 
@@ -1388,7 +1407,7 @@ class _LinearBf16(torch.autograd.Function):
                 dw = wgrad_bf16(dy2, x2)[0]                    # tsg_wgrad_bf16 (csrc/wgrad_split.hip): dY^T X on the hand-written kernel
             else:
                 dw = torch.mm(dy2.t(), x2, out_dtype=torch.float32)
-        db = torch.sum(dy2, 0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = _colsum(dy2) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 
@@ -1601,9 +1620,9 @@ class _BiLSTMLayerBf16(torch.autograd.Function):
         if _WGRAD_KERNEL and wgrad_f32s_ok(TB, 4 * h, I, h):
             # ONE launch per layer: D[d] = dG[d]^T [x | h_{t-+1}[d]] for both directions holds dW_ih[d] and dW_hh[d]; the shifted
             # h rows are read straight from `out` (row r -+ 1 of the same sequence, zero at its ends) -- no shifted copy, no fp32
-            D = wgrad_bf16(dGf, x.view(TB, I), N=4 * h, groups=2, a_group_stride=4 * h, B1=out.view(TB, 2 * h), K1=h, b1_group_stride=h,
-                           shift=1, period=T)
-            return dx, D[:, :, :I].contiguous().view(8 * h, I), dbias, D[:, :, I:].contiguous()
+            dW_ih, dW_hh = wgrad_bf16_out2(dGf, x.view(TB, I), out.view(TB, 2 * h), N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h,
+                                           shift=1, period=T)            # the two parameter-shaped tensors: no slicing copies
+            return dx, dW_ih.view(8 * h, I), dbias, dW_hh
         dW_ih = torch.mm(dGf.t(), x.view(TB, I), out_dtype=torch.float32)           # [8h, I], both directions
         # dW_hh[d] = sum_t dG_t[d]^T h_{t-1}[d] (h_{t+1} for the reverse direction): the partner rows as ONE shifted bf16 copy of
         # `out` (zero at the sequence ends), then a GEMM per direction on strided column views (no cat, no fp32 operands)

@@ -19,7 +19,7 @@ batch = data.synthetic_batch(B, T, N, seed=1234, pair=True, device=dev)
 def step():
     for p in model.parameters():
         p.grad = None
-    with engine.precision("f32s"):
+    with engine.precision(os.environ.get("MODE", "f32s")):
         loss, _, _ = engine.gmd_step(model, batch, params)
     loss.backward()
     engine.optimizer_step(opt, loss)
