@@ -420,6 +420,156 @@ Plan make_plan(long long M, int N, int K, int groups) {
   return p;
 }
 
+// ---- bf16 operands, round 4: LDS-DMA staging + transposed fragment reads ------------------------------------------------------
+// With bf16 operands (tsg_wgrad_bf16) the kernel above is bound by its operand path, not by the MFMAs (one product instead of three:
+// 8 MFMAs per wave and chunk; ablation at the LSTM layer's shape: 303 us, 208 without the loads, 252 without the MFMAs).  bf16 rows need
+// no conversion, so they can go global -> LDS by DMA (global_load_lds_dwordx4: no registers, no VALU, no ds_write) as they are stored --
+// [32 rows m][128 columns] images with 256-byte rows -- and the m-contiguous MFMA fragments come out of ds_read_b64_tr_b16 (gfx950's
+// transposing LDS read: per 16 lanes a 4-row x 16-column block, delivered column-major), two per fragment.
+// Image = cdna_hip_programming.md T10 (b): 16-byte chunk ch of row r at 256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))); the DMA writes
+// LDS lane-linearly, so the XOR is applied to the SOURCE chunk each lane fetches.  Tile 256 (n) x 128 (k) as above = three images per
+// chunk (A columns 0-127, A columns 128-255, B); ring of three chunk buffers, DMA two chunks ahead, one raw s_barrier per chunk behind a
+// counted s_waitcnt vmcnt (a wave waits for ITS three DMA instructions of the chunk, the barrier covers the others').
+// Rows of the shifted segment that do not exist are fetched from a page of zeros.  Requires period % 32 == 0 (else the kernel above).
+constexpr int kTrImg = 8192, kTrSub = 3 * kTrImg;                      // one 32-row sub-chunk: A columns 0-127 | A columns 128-255 | B
+__device__ const uint4 g_wgrad_zero_page[16] = {};                     // 256 bytes of zeros
+
+__device__ __forceinline__ int tr_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+// The DMA as inline asm: hipcc puts a s_waitcnt vmcnt(0) in front of every LDS read while a compiler-visible LDS-DMA is in flight (it
+// cannot tell the ring buffers apart), which would drain the two chunks of look-ahead in every iteration.  It does not see this one;
+// the kernel waits for it itself (counted s_waitcnt vmcnt + s_barrier).  The fragment reads stay compiler-visible (their lgkmcnt waits
+// are the compiler's).  lds_addr: wave-uniform LDS byte address; the hardware adds 16 bytes per lane.
+__device__ __forceinline__ void tr_dma16(const void* src, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lds_addr) : "memory", "m0");
+}
+typedef short tr_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 tr_read(const char* img, int off) {
+  const tr_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_s16x4*)(img + off));
+  return __builtin_bit_cast(uint2, v);
+}
+
+template <int SUB, int NB>                      // SUB = 32-row sub-chunks per barrier interval (1 or 2), NB = ring depth (DMA runs NB - 1 intervals ahead)
+__global__ __launch_bounds__(512) void wgrad_bf16_tr_kernel(const WgradArgs a) {
+  constexpr int kTrBuf = SUB * kTrSub, AHEAD = NB - 1;
+  extern __shared__ __align__(16) unsigned lds[];
+  char* ring = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = a.K0 + a.K1, tiles_k = K / 128, tpg = (a.N / 256) * tiles_k, tps = tpg * a.groups;
+  const int v = xcd_major(blockIdx.x, gridDim.x);
+  const int split = v / tps, rem = v % tps, g = rem / tpg, tile = rem % tpg;
+  const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 128;
+  const long chunks = a.M / BM;
+  const long c_begin = (long)split * a.cps;
+  const int nc = (int)(min(chunks, c_begin + a.cps) - c_begin);          // chunks of this row range (may be <= 0)
+  const bool seg1 = k0 >= a.K0;
+  const bool shifted = seg1 && a.shift != 0;
+  const long ldb = seg1 ? a.ldb1 : a.ldb0;
+  const int shift = shifted ? (int)(g ? -a.shift : a.shift) : 0;
+  const unsigned per = (unsigned)a.period;
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;     // LDS byte address of the ring
+  // DMA role: the wave moves rows 4 wv .. 4 wv + 3 of the three images (one 1 KiB instruction each); lane -> (row, 16-byte slot)
+  const int drow = 4 * wv + (lane >> 4), dch = (lane & 15) ^ tr_swz(drow);
+  const bf16_t* pa = static_cast<const bf16_t*>(a.A) + g * a.a_gs + n0 + 8 * dch + (c_begin * BM + drow) * a.lda;
+  const bf16_t* pb = (seg1 ? static_cast<const bf16_t*>(a.B1) + g * a.b1_gs + (k0 - a.K0) : static_cast<const bf16_t*>(a.B0) + k0) + 8 * dch +
+                     (c_begin * BM + drow - shift) * ldb;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_wgrad_zero_page) + 8 * (lane & 15);
+  auto dma = [&](int c, int buf) {                                     // interval c = sub-chunks SUB c .. SUB c + SUB - 1 of this row range
+#pragma unroll
+    for (int sc = 0; sc < SUB; ++sc) {
+      const int cc = SUB * c + sc;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * kTrBuf + sc * kTrSub + 4 * wv * 256));   // wave-uniform
+      const bf16_t* qa = pa + (long)cc * BM * a.lda;
+      const bf16_t* qb = pb + (long)cc * BM * ldb;
+      if (shifted) {                                                     // workgroup-uniform
+        const unsigned m0 = (unsigned)(c_begin + cc) * BM;
+        const unsigned tb = m0 - div_period(m0, a.per_magic, a.per_sh) * per;
+        const unsigned ts = tb + (unsigned)(drow - shift);               // position of the source row in its sequence; >= period: outside
+        qb = ts < per ? qb : zero;
+      }
+      const bool beyond = SUB > 1 && cc >= nc;                           // a sub-chunk past the range (odd count): zeros contribute nothing
+      tr_dma16(beyond ? zero : qa, dst);
+      tr_dma16(beyond ? zero : qa + 128, dst + kTrImg);
+      tr_dma16(beyond ? zero : qb, dst + 2 * kTrImg);
+    }
+  };
+
+  // fragment addresses: lane = (16-lane group: column half, k half; q = row of the 4 x 16 block; p = 8-byte piece of the row's 32 bytes)
+  const int wn = wv >> 1, wk = wv & 1;
+  const int g16 = lane >> 4, chalf = g16 & 1, kg = g16 >> 1, fq = (lane & 15) >> 2, fp = lane & 3;
+  int offA[2][2][2], offB[2][2][2];                                      // [tile][m step][half of the 8 rows]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int row = 16 * ms + 8 * kg + 4 * hf + fq, sw = tr_swz(row);
+        const int cA = 64 * wn + 32 * t, cB = 64 * wk + 32 * t;
+        offA[t][ms][hf] = (cA >> 7) * kTrImg + 256 * row + 16 * (((((cA & 127) + 16 * chalf) >> 3) + (fp >> 1)) ^ sw) + 8 * (fp & 1);
+        offB[t][ms][hf] = 2 * kTrImg + 256 * row + 16 * ((((cB + 16 * chalf) >> 3) + (fp >> 1)) ^ sw) + 8 * (fp & 1);
+      }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  const int ni = (nc + SUB - 1) / SUB;                                  // barrier intervals
+  if (ni > 0) {
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+      if (i < ni) dma(i, i);
+#pragma unroll 1
+    for (int c = 0; c < ni; ++c) {
+      // this wave's DMA instructions of interval c have landed: 3 SUB per interval, up to AHEAD - 1 later intervals stay in flight
+      const int later = min(ni - 1 - c, AHEAD - 1);
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * 3 * SUB) : "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * SUB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                      // ... and everybody else's; nobody reads buffer (c + AHEAD) % NB any more
+      if (c + AHEAD < ni) dma(c + AHEAD, (c + AHEAD) % NB);
+      const char* img = ring + (c % NB) * kTrBuf;
+#pragma unroll
+      for (int sc = 0; sc < SUB; ++sc)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+          u32x4 fa[2], fb[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const uint2 a0 = tr_read(img + sc * kTrSub, offA[t][ms][0]), a1 = tr_read(img + sc * kTrSub, offA[t][ms][1]);
+            const uint2 b0 = tr_read(img + sc * kTrSub, offB[t][ms][0]), b1 = tr_read(img + sc * kTrSub, offB[t][ms][1]);
+            fa[t] = (u32x4){a0.x, a0.y, a1.x, a1.y};
+            fb[t] = (u32x4){b0.x, b0.y, b1.x, b1.y};
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma(fa[i], fb[j], acc[i][j]);
+        }
+    }
+  }
+
+  // epilogue: as wgrad_tile
+  const int r = lane & 31, hh = lane >> 5;
+  const bool to1 = a.splits == 1 && a.C1 && k0 >= a.K0;
+  float* out = a.splits == 1 ? (to1 ? a.C1 + g * a.c1_gs - a.K0 : a.C + g * a.c_gs) : a.ws + ((size_t)split * a.groups + g) * (size_t)a.N * K;
+  const long ldo = a.splits == 1 ? (to1 ? a.ldc1 : a.ldc) : K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int n = n0 + 64 * wn + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * hh;
+        const int k = k0 + 64 * wk + 32 * j + r;
+        out[(size_t)n * ldo + k] = acc[i][j][q];
+      }
+}
+
 template <int WN, int WK, typename ET>
 int launch(const char* fn, const WgradArgs& a, int grid, hipStream_t st) {
   using G = Geo<WN, WK>;
@@ -476,7 +626,17 @@ static int wgrad_impl(const char* fn, bool bf, const void* A, long long lda, lon
   a.C = (float*)C; a.ldc = ldc; a.c_gs = c_group_stride; a.ws = (float*)ws;
   a.C1 = (float*)C1; a.ldc1 = ldc1; a.c1_gs = c1_group_stride;
   a.M = M; a.N = N; a.groups = groups; a.splits = p.splits; a.cps = (int)((chunks + p.splits - 1) / p.splits);
-  if (bf) rc = p.tn == 256 ? launch<4, 2, bf16_t>(fn, a, p.tiles * p.splits, st) : launch<2, 2, bf16_t>(fn, a, p.tiles * p.splits, st);
+  static const bool tr_ok = !(getenv("TSG_WGRAD_BF16_TR") && atoi(getenv("TSG_WGRAD_BF16_TR")) == 0);    // A/B switch: 0 = the register-staged kernel
+  if (bf && tr_ok && p.tn == 256 && (shift == 0 || K1 == 0 || a.period % BM == 0) && (lda & 7) == 0 && (ldb0 & 7) == 0 && (ldb1 & 7) == 0 &&
+      (a_group_stride & 7) == 0 && (b1_group_stride & 7) == 0) {
+    static const int cfg = getenv("TSG_WGRAD_TR_CFG") ? atoi(getenv("TSG_WGRAD_TR_CFG")) : 0;      // developer A/B: (sub-chunks, ring depth)
+#define TSG_TR_LAUNCH(SUBV, NBV) { auto kern = wgrad_bf16_tr_kernel<SUBV, NBV>; const size_t lb = (size_t)NBV * SUBV * kTrSub;          \
+      hipError_t e = allow_lds(kern, lb); if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e)); \
+      hipLaunchKernelGGL(kern, dim3(p.tiles * p.splits), dim3(512), lb, st, a); }
+    if (cfg == 1) TSG_TR_LAUNCH(1, 4) else if (cfg == 2) TSG_TR_LAUNCH(2, 3) else if (cfg == 3) TSG_TR_LAUNCH(2, 2) else TSG_TR_LAUNCH(1, 3)
+#undef TSG_TR_LAUNCH
+    rc = check_launch(fn);
+  } else if (bf) rc = p.tn == 256 ? launch<4, 2, bf16_t>(fn, a, p.tiles * p.splits, st) : launch<2, 2, bf16_t>(fn, a, p.tiles * p.splits, st);
   else rc = p.tn == 256 ? launch<4, 2, float>(fn, a, p.tiles * p.splits, st) : launch<2, 2, float>(fn, a, p.tiles * p.splits, st);
 #ifdef TSG_WGRAD_TIMING
   return rc;
