@@ -242,9 +242,25 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
         fl = 3 * 2.0 * M * Nn * Kk
         out[name].update(bound="mfma", mfma_flops=fl, achieved_TFLOPs=round(fl / out[name]["mean_us"] / 1e6, 1),
                          mfma_frac=round(fl / out[name]["mean_us"] / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4))
+    # the LSTM layer's weight gradient: both directions' dG[d]^T [x | h_(t-+1)[d]] in one launch, the shifted h rows read from the layer
+    # output, two parameter-shaped outputs (tsg_wgrad_f32s_out2): 4 launches per step, the largest share of the weight-gradient time
+    hh = d // 2
+    if (2 * B * T) % 32 == 0 and (4 * hh) % 256 == 0 and d % 128 == 0 and hh % 128 == 0:
+        M = 2 * B * T
+        dGw = torch.randn(M, 8 * hh, device=dev); xw = torch.randn(M, d, device=dev); ow = torch.randn(M, 2 * hh, device=dev)
+        C0 = torch.empty(2, 4 * hh, d, device=dev); C1 = torch.empty(2, 4 * hh, hh, device=dev)
+        nbw = int(lib.tsg_wgrad_f32s_ws_bytes(M, 4 * hh, d, hh, 2)); wsw = torch.empty(max(nbw, 16), device=dev, dtype=torch.uint8)
+        name = f"tsg_wgrad_f32s_out2[LSTM layer: 2 x {4 * hh}x{M} . {M}x({d}+{hh})]"
+        run(name, lambda: lib.tsg_wgrad_f32s_out2(ptr(dGw), 8 * hh, 4 * hh, ptr(xw), d, d, ptr(ow), 2 * hh, hh, hh, 1, T, ptr(C0), d, 4 * hh * d,
+                                                  ptr(C1), hh, 4 * hh * hh, ptr(wsw), nbw, M, 4 * hh, 2, st),
+            (M * (8 * hh + d + 2 * hh) + 2 * 4 * hh * (d + hh)) * e)
+        fl = 3 * 2.0 * M * 8 * hh * (d + hh)
+        out[name].update(bound="mfma", mfma_flops=fl, achieved_TFLOPs=round(fl / out[name]["mean_us"] / 1e6, 1),
+                         mfma_frac=round(fl / out[name]["mean_us"] / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4))
     # the hand-written split-on-load projection GEMM (csrc/gemm_f32s.hip) at the two shapes the step runs it on most (W_a forward /
     # input gradient; the heads' first Linear): same accounting
-    for (M, Nn, Kk) in ((2 * B * T, d, d), (2 * B * T, 512, 2 * d)):
+    # ... plus the two LSTM-layer products it carries since round 4 (input projection, dX), the largest launches of the step
+    for (M, Nn, Kk) in ((2 * B * T, d, d), (2 * B * T, 512, 2 * d), (2 * B * T, 4 * d, d), (2 * B * T, d, 4 * d)):
         if M % 256 or Nn % 256 or Kk % 32:
             continue
         Xg = torch.randn(M, Kk, device=dev); Wg = torch.randn(Nn, Kk, device=dev) / Kk ** 0.5; Yg = torch.empty(M, Nn, device=dev)
