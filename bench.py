@@ -378,9 +378,11 @@ def main():
     # the bf16 storage mode keeps the clip features resident in its storage dtype (inputs are resident in HBM before the timed region
     # in every mode; which dtype they are resident in is part of the mode)
     batch_bf16 = dict(batch)
-    for k in ("video", "pseudo_video"):
-        if k in batch:
-            batch_bf16[k] = batch[k].to(torch.bfloat16)
+    if "pseudo_video" in batch:                              # (the two streams stay back to back: the model's batch concatenation is a view)
+        vb = data.adjacent_cat(batch["video"], batch["pseudo_video"]).to(torch.bfloat16)
+        batch_bf16["video"], batch_bf16["pseudo_video"] = vb[:batch["video"].shape[0]], vb[batch["video"].shape[0]:]
+    else:
+        batch_bf16["video"] = batch["video"].to(torch.bfloat16)
     MODES = {"f32": None, "bf16": "bf16", "f32s": "f32s", "bf16g": torch.bfloat16}
     gdt = MODES[a.dtype]
 
