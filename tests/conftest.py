@@ -9,6 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The CPU oracle's recurrences are thousands of small ops; with torch's default of one thread per hardware thread (128 on the GPU box) every
+# one of them pays a 128-way fork / join: the 2-layer BiLSTM at [3, 512, 1024] takes 52.9 s with 128 threads, 1.2 s with 8
+# (tools/oracle_threads_probe.py).  The GPU suite spent 9 of its 15 minutes there.
+torch.set_num_threads(min(8, os.cpu_count() or 1))
 
 
 def pytest_configure(config):
