@@ -315,9 +315,10 @@ def cpu_baseline(kind, params, T, N, sample_B):
             out = O.baseline_forward(sd, b["video"], b["query"], b["video_mask"])
             loss = O.span_ground_loss(out["start"], out["end"], b["gt"]["framestps"])
         loss.backward()
-    # The oracle's LSTM is a Python loop of small GEMMs: beyond ~32 intra-op threads the fork/join overhead dominates
-    # (with all 256 host threads of the GPU box one step takes many minutes), so the thread count is capped and stated.
-    cores = min(os.cpu_count() or 1, 32)
+    # The oracle's LSTM is a Python loop of small GEMMs: beyond ~16 intra-op threads the fork / join overhead dominates, so the thread
+    # count is capped at the fastest setting and stated (tools/oracle_threads_probe.py on the GPU box's 256 host threads, a step of 16
+    # pairs: 8 threads 5.3 pairs/s, 16: 6.6, 32: 3.8, 64: 1.9; torch's default of 128: minutes per step).
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     sB = max(1, min(16, sample_B))                         # pairs per CPU step
     log(f"cpu baseline: oracle {kind} steps of {sB} pairs on {cores} of {os.cpu_count()} host threads")
