@@ -158,6 +158,66 @@ def test_wgrad_bf16_lstm_operands():
         assert _rel(D[d], ref) < 2e-6, d
 
 
+@pytest.mark.parametrize("Bn,T", [(8, 16), (4, 64), (3, 96), (4, 40), (2, 256), (16, 128)])
+@pytest.mark.parametrize("bm", [True, False])
+def test_wgrad_bf16_lstm_operands_layouts(bm, Bn, T):
+    """The bf16 weight gradient of an LSTM layer in both sequence layouts: sequence lengths that are whole 32-row chunks (64, 96, 128,
+    256 and every time-major case: the LDS-DMA + transposing-read kernel, shifted rows that do not exist served from the zero page)
+    and lengths that are not (16, 40 batch-major: the register-staged kernel) -- vs the explicitly shifted float64 product of the
+    bf16 values, and the two-output entry point bit-equal to slicing the single output."""
+    from shufflingvideosfortsg_amd import functional as F
+    g = torch.Generator().manual_seed(11)
+    I, h = 128, 128
+    TB = Bn * T
+    dG = torch.randn(TB, 8 * h, generator=g).bfloat16().cuda()
+    x = torch.randn(TB, I, generator=g).bfloat16().cuda()
+    out = torch.randn(TB, 2 * h, generator=g).bfloat16().cuda()
+    shift, period = (1, T) if bm else (Bn, 0)
+    D = F.wgrad_bf16(dG, x, N=4 * h, groups=2, a_group_stride=4 * h, B1=out, K1=h, b1_group_stride=h, shift=shift, period=period)
+    assert D.shape == (2, 4 * h, I + h) and D.dtype == torch.float32
+    o3 = out.view(Bn, T, 2 * h) if bm else out.view(T, Bn, 2 * h)
+    prev, nxt = torch.zeros_like(o3), torch.zeros_like(o3)
+    if bm:
+        prev[:, 1:] = o3[:, :-1]; nxt[:, :-1] = o3[:, 1:]
+    else:
+        prev[1:] = o3[:-1]; nxt[:-1] = o3[1:]
+    for d, hs in ((0, prev.reshape(TB, 2 * h)[:, :h]), (1, nxt.reshape(TB, 2 * h)[:, h:])):
+        ref = dG[:, d * 4 * h:(d + 1) * 4 * h].double().t() @ torch.cat([x, hs], 1).double()
+        assert _rel(D[d], ref) < 2e-6, d
+    C0, C1 = F.wgrad_bf16_out2(dG, x, out, N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h, shift=shift, period=period)
+    assert torch.equal(C0, D[:, :, :I]) and torch.equal(C1, D[:, :, I:])
+    assert torch.equal(D, F.wgrad_bf16(dG, x, N=4 * h, groups=2, a_group_stride=4 * h, B1=out, K1=h, b1_group_stride=h, shift=shift, period=period))
+
+
+@pytest.mark.parametrize("env", [{"TSG_WGRAD_TR_CFG": "1"}, {"TSG_WGRAD_TR_CFG": "2"}, {"TSG_WGRAD_TR_CFG": "3"}, {"TSG_WGRAD_BF16_TR": "0"}])
+def test_wgrad_bf16_kernel_variants(env):
+    """The other ring shapes of the LDS-DMA kernel (sub-chunks x depth: <1,4>, <2,3>, <2,2>) and the register-staged kernel it replaced
+    (TSG_WGRAD_BF16_TR=0) are read once per process: each checked in a child process on a plain product (ragged chunk count) and on an
+    LSTM layer's shifted operands."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from shufflingvideosfortsg_amd import functional as F\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "rel = lambda c, r: float((c.double() - r).abs().max() / r.abs().max())\n"
+        "for (M, N, K) in ((2560, 1024, 1024), (4128, 256, 384), (32, 256, 128)):\n"
+        "    A = torch.randn(M, N, generator=g).bfloat16().cuda(); B = torch.randn(M, K, generator=g).bfloat16().cuda()\n"
+        "    C = F.wgrad_bf16(A, B)[0]\n"
+        "    assert rel(C, A.double().t() @ B.double()) < 2e-6 and torch.equal(C, F.wgrad_bf16(A, B)[0])\n"
+        "Bn, T, I, h = 4, 64, 128, 128; TB = Bn * T\n"
+        "dG = torch.randn(TB, 8 * h, generator=g).bfloat16().cuda(); x = torch.randn(TB, I, generator=g).bfloat16().cuda()\n"
+        "out = torch.randn(Bn, T, 2 * h, generator=g).bfloat16().cuda()\n"
+        "D = F.wgrad_bf16(dG, x, N=4 * h, groups=2, a_group_stride=4 * h, B1=out.view(TB, 2 * h), K1=h, b1_group_stride=h, shift=1, period=T)\n"
+        "hp = torch.zeros_like(out); hp[:, 1:, :h] = out[:, :-1, :h]; hp[:, :-1, h:] = out[:, 1:, h:]; hp = hp.view(TB, 2 * h).double()\n"
+        "for d in range(2):\n"
+        "    gd = dG[:, d * 4 * h:(d + 1) * 4 * h].double()\n"
+        "    assert rel(D[d], torch.cat([gd.t() @ x.double(), gd.t() @ hp[:, d * h:(d + 1) * h]], 1)) < 2e-6\n"
+        "print('variant ok')\n") % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("bm", [True, False])
 def test_wgrad_two_outputs_equal_the_sliced_single_output(bm):
     """tsg_wgrad_f32s_out2 (round 4): the B0 / B1 column segments to two parameter-shaped outputs -- bit-equal to slicing the
