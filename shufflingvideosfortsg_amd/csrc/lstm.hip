@@ -429,13 +429,13 @@ __device__ __forceinline__ void raise_error(unsigned* sync, ErrSink esink) {
 }
 // start barrier of the persistent kernels: publish this workgroup's XCD in its group's mask, meet the grid once, and
 // report whether the whole group sits on one XCD.  false + error word set when the bounded wait expires.
-__device__ __forceinline__ bool grid_start(unsigned* sync, int group, int l2x, ErrSink esink) {
+__device__ __forceinline__ bool grid_start(unsigned* sync, int group, int l2x, ErrSink esink, unsigned nactive) {
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_or(sync + kSyncGroupWord + group, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" : : "v"(old) : "memory");       // the mask update has been performed before this workgroup counts as arrived
     __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int spins = 0;
-    while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+    while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nactive) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > kSpinLimit || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
         raise_error(sync, esink);
@@ -511,6 +511,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // NW = w
   const int uslices = h / UW, bslices = (B + 15) / 16;
   const int vidx = xcd_major_index(), group = vidx / uslices;     // exchange group = (direction, batch slice): its uslices
   const int us = vidx % uslices, d = group / bslices, bs = group % bslices;   // workgroups are neighbours in XCD-major order
+  const int nactive = 2 * uslices * bslices;              // a PADDED grid (persist_grid) puts whole groups on one XCD each; the
+  if (vidx >= nactive) return;                            // workgroups beyond the last group have no role (uniform exit, before any barrier)
   const int at = wv;                                      // 8 waves = 8 A-tiles (32 units) x ONE 16-row batch tile: the slab a
                                                           // workgroup fetches per step is 16 rows (32 KiB at h = 512), half of the
                                                           // 4 x 2 arrangement's, for the same MFMA work per wave
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // NW = w
     __syncthreads();
   }
   if ((flags & 2) && blockIdx.x == 0) return;                // TSG_LSTM_INJECT_TIMEOUT: workgroup 0 never arrives (test of the error path)
-  const bool local = grid_start(sync, group, flags & 1, esink);
+  const bool local = grid_start(sync, group, flags & 1, esink, (unsigned)nactive);
   if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
 
 #ifdef TSG_LSTM_TIMING
@@ -825,6 +827,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
   const int nus = h / 32, bslices = (B + 15) / 16;         // TW = h / 128 = 16-unit tiles per wave = float4 per thread
   const int vidx = xcd_major_index(), group = vidx / nus;   // exchange group = (direction, batch slice), see the forward kernel
   const int us = vidx % nus, d = group / bslices, bs = group % bslices;
+  const int nactive = 2 * nus * bslices;                    // padded grid (persist_grid): workgroups beyond the last group have no role
+  if (vidx >= nactive) return;
   const int b0 = bs * 16, K = 4 * h;
   const int jb = lane & 15, ku = lane >> 4;
   // A fragments: tile t of this wave = output units 16*(wv*TW + t) + jb; local k' = 16s + 4ku + m -> gate s/2, unit
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
     __syncthreads();
   }
   if ((flags & 2) && blockIdx.x == 0) return;                // TSG_LSTM_INJECT_TIMEOUT: workgroup 0 never arrives (test of the error path)
-  const bool local = grid_start(sync, group, flags & 1, esink);
+  const bool local = grid_start(sync, group, flags & 1, esink, (unsigned)nactive);
   if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
 
 #ifdef TSG_LSTM_TIMING
@@ -1111,6 +1115,21 @@ static int persist_chunk_rows(int B, int wgs_per_slice, int cap) {
   const int chunks = cdiv(slices, max_slices);
   return cdiv(slices, chunks) * 16;
 }
+// Grid of a persistent launch with `slices` 16-row batch slices: 2 * slices exchange groups of `wgs` workgroups each.  Workgroup i
+// runs on XCD i % 8 and the kernels order their roles XCD-major (xcd_major_index), so a group sits on ONE XCD -- and takes the
+// L2-local exchange -- when the group size divides the per-XCD share of the grid.  With fewer than 8 groups (at h = 512: up to 48
+// rows -- the 16-pair per-GPU shards of BASELINE configs 3 / 4) the natural grid's share is smaller than a group and EVERY group
+// straddles two XCDs; the grid is then PADDED to 8 * wgs: XCD x hosts group x, and the workgroups beyond the last group return at
+// once (they never reach the start barrier, which counts the active ones only).  Backward step 3.50 -> 3.13 us (f32s) / 2.97 -> 2.69
+// (bf16 storage) at [32, 512, 512], 3.31 -> 2.87 / 3.00 -> 2.48 at [40, 128, 512]; the forward does not change (profiles/r4/
+// lstm_padded_grid_ab_v1.txt).  Not for 8 .. 15 groups that do not divide evenly (96 rows: 12 groups, 8 of them local on the natural
+// grid): packing them two per XCD on six XCDs measured 4.68 -> 4.15 us in f32s but 3.53 -> 3.75 in bf16.
+// TSG_LSTM_PAD=0: natural grids (A/B).  Correctness never depends on the placement: the groups verify it (grid_start).
+static int persist_grid(int slices, int wgs, int cap) {
+  static const bool pad = !(getenv("TSG_LSTM_PAD") && atoi(getenv("TSG_LSTM_PAD")) == 0);
+  const int natural = 2 * slices * wgs, padded = 8 * wgs;
+  return (pad && 2 * slices < 8 && padded <= cap) ? padded : natural;
+}
 static int launch_flags() {       // bit 0: L2-local exchange allowed; bit 1: inject a start-barrier timeout (tests)
   const char* e = getenv("TSG_LSTM_INJECT_TIMEOUT");
   return (l2_exchange() ? 1 : 0) | ((e && atoi(e) != 0) ? 2 : 0);
@@ -1142,10 +1161,14 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
     return set_error(TSG_E_SHAPE, "%s: dtype TSG_BF16 needs the persistent kernel (sync_ws given, TSG_LSTM_PERSIST != 0, T > 1, h in "
                      "{128,256,384,512}); got T=%d h=%d", fn, T, h);
   if (sync_ws && (bf || persist_wanted(T)) && h % 32 == 0 && h <= kPersistMaxH && T > 1) {
-    static int nw_env = -1;                                 // TSG_LSTM_NW=4: 16-unit workgroups of 4 waves, two per CU (experiment)
-    if (nw_env < 0) { const char* e = getenv("TSG_LSTM_NW"); nw_env = (e && atoi(e) == 4) ? 4 : 8; }
+    // 16-unit workgroups of 4 waves (half the MFMA and gate work per workgroup and step, twice the workgroups): slower when they
+    // have to share CUs (two per CU at 128 rows: 5.15 vs 4.59 us per step), faster when the chip is mostly idle -- up to 32 rows
+    // (the 16-pair per-GPU shards of BASELINE configs 3 / 4): 3.01 -> 2.82 us per step at [32, 512, 512], 2.85 -> 2.68 at 16 rows,
+    // no difference at 40 / 48 rows (profiles/r4/lstm_fwd_nw4_small_batch_ab_v1.txt).  TSG_LSTM_NW=4 / 8 forces one of them.
+    static int nw_env = -1;
+    if (nw_env < 0) { const char* e = getenv("TSG_LSTM_NW"); nw_env = e ? (atoi(e) == 4 ? 4 : 8) : 0; }
     const bool split = dtype == TSG_F32S;                  // other hidden sizes: the fp32 arithmetic (more accurate, slower)
-    const int NW = (nw_env == 4 && h == 512 && split && !bf) ? 4 : 8;
+    const int NW = ((nw_env == 4 || (nw_env == 0 && B <= 32)) && h == 512 && split && !bf) ? 4 : 8;
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
     const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 33 + 4);
     static_assert(kSlabFloats >= 16 * (kPersistMaxH + 8), "slab region holds the fp32 slab too");
@@ -1161,7 +1184,7 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
         const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;
         hipError_t e = zero_async(sync_ws, kSyncBytes, st);
         if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-        hipLaunchKernelGGL(pb, dim3(2 * (h / 32) * cdiv(Bc, 16)), dim3(512), plds, st, (const lstm_bf16*)Gx + seq * K8, (const float*)bias,
+        hipLaunchKernelGGL(pb, dim3(persist_grid(cdiv(Bc, 16), h / 32, capb)), dim3(512), plds, st, (const lstm_bf16*)Gx + seq * K8, (const float*)bias,
                            (const float*)Whh, (lstm_bf16*)out + seq * H2, (lstm_bf16*)R + (size_t)c0 * h * 4, (float*)Cs + (size_t)c0 * h,
                            (unsigned*)sync_ws, Bc, B, T, h, HLS, launch_flags(), bm, error_sink());
       }
@@ -1184,7 +1207,7 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
         const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;              // first sequence row of the chunk
         hipError_t e = zero_async(sync_ws, kSyncBytes, st);
         if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-        hipLaunchKernelGGL(pk, dim3(2 * (h / (4 * NW)) * cdiv(Bc, 16)), dim3(64 * NW), plds, st, (const float*)Gx + seq * K8, (const float*)bias,
+        hipLaunchKernelGGL(pk, dim3(persist_grid(cdiv(Bc, 16), h / (4 * NW), cap)), dim3(64 * NW), plds, st, (const float*)Gx + seq * K8, (const float*)bias,
                            (const float*)Whh, (float*)out + seq * H2, (float*)R + (size_t)c0 * h * 4, (float*)Cs + (size_t)c0 * h,
                            (unsigned*)sync_ws, Bc, B, T, h, HLS, launch_flags(), bm, error_sink());
       }
@@ -1286,7 +1309,7 @@ extern "C" int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const voi
         const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;
         e = zero3_async(ws, kSyncBytes, c0 == 0 ? dbias : nullptr, sizeof(float) * 8 * h, nullptr, 0, st);
         if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-        hipLaunchKernelGGL(pb, dim3(2 * (h / 32) * cdiv(Bc, 16)), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT,
+        hipLaunchKernelGGL(pb, dim3(persist_grid(cdiv(Bc, 16), h / 32, bwd_persist_capacity())), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT,
                            (const lstm_bf16*)R + (size_t)c0 * h * 4, (const float*)Cs + (size_t)c0 * h, (const lstm_bf16*)dOut + seq * H2,
                            dHn ? (const float*)dHn + (size_t)c0 * h : nullptr, (lstm_bf16*)dG + seq * K8, (float*)((char*)ws + kSyncBytes),
                            (unsigned*)ws, (float*)dbias, Bc, B, T, h, launch_flags(), bm, error_sink());
@@ -1304,7 +1327,7 @@ extern "C" int tsg_lstm_bwd_ws_layout(const void* WhhT, const void* R, const voi
       const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;
       e = zero3_async(ws, kSyncBytes, c0 == 0 ? dbias : nullptr, sizeof(float) * 8 * h, nullptr, 0, st);
       if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-      hipLaunchKernelGGL(pk, dim3(2 * (h / 32) * cdiv(Bc, 16)), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT,
+      hipLaunchKernelGGL(pk, dim3(persist_grid(cdiv(Bc, 16), h / 32, bwd_persist_capacity())), dim3(kThreads), kBwd2Lds, st, (const float*)WhhT,
                          (const float*)R + (size_t)c0 * h * 4, (const float*)Cs + (size_t)c0 * h, (const float*)dOut + seq * H2,
                          dHn ? (const float*)dHn + (size_t)c0 * h : nullptr, (float*)dG + seq * K8, (float*)((char*)ws + kSyncBytes),
                          (unsigned*)ws, (float*)dbias, Bc, B, T, h, launch_flags(), bm, error_sink());
