@@ -268,7 +268,9 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
         run(name, lambda: lib.tsg_gemm_f32s(ptr(Xg), ptr(Wg), None, ptr(Yg), M, Nn, Kk, st), (M * Kk + Nn * Kk + M * Nn) * e)
         fl = 3 * 2.0 * M * Nn * Kk
         out[name].update(bound="mfma", mfma_flops=fl, achieved_TFLOPs=round(fl / out[name]["mean_us"] / 1e6, 1),
-                         mfma_frac=round(fl / out[name]["mean_us"] / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4))
+                         mfma_frac=round(fl / out[name]["mean_us"] / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4),
+                         per_cycle_note="mfma_frac is against the nominal 2.5 PFLOP/s (2.4 GHz); per GPU-active cycle the committed PMC pass of the step "
+                                        "(profiles/r4/mfma_utilisation_f32s_v1.txt, a profile citation) gives 55 % for this kernel and 56 % for the weight gradient")
     return out
 
 
