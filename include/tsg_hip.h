@@ -294,6 +294,15 @@ int tsg_moment_pool_bwd(const void* dpooled, const void* m_target, const void* m
  * rows % 4 == 0, cols % 4 == 0, ld % 4 == 0, ld >= cols, 16-byte aligned.                                                         */
 int tsg_transpose_f32(const void* src, long long ld, void* dst, int batch, int rows, int cols, void* stream);
 
+/* ---- dropout without a stored mask (ABI revision 5): y[i] = keep(i) ? x[i] / (1 - p) : 0 over n contiguous elements, keep(i) a counter-based
+ * hash of i and of the keys -- the dropout between the layers of the BiLSTMs (networks/RNN.py:27-31, nn.LSTM(dropout=...), training mode).
+ * The BACKWARD is the same call on the gradient with the same keys (the mask is regenerated, nothing is stored).  key_mode 0: keys from the
+ * host's (seed, offset); 1: keys derived in the kernel from the device-resident pair rng_dev ([0] = seed, [1] = offset, uint64 each) and
+ * written to keys_io (two uint32) -- for launches captured into a HIP graph whose replays advance the offset; 2: keys read from keys_io
+ * (the backward of a key_mode-1 launch).  0 <= p < 1; x, y 16-byte aligned; dtype TSG_F32 / TSG_F32S (float) or TSG_BF16.            */
+int tsg_dropout(const void* x, void* y, long long n, float p, uint64_t seed, uint64_t offset, const void* rng_dev, void* keys_io,
+                int key_mode, int dtype, void* stream);
+
 /* ---- LayerNorm over the channel axis: the final nn.LayerNorm(d), eps 1e-5, of QueryAwareEncoder.forward (components/VideoEncoder.py:96,112)
  * on the [rows = 2B*T, d] encoder output (ABI revision 5).  y = (x - mean) * rstd * gamma + beta with the biased variance of the row, as
  * torch.nn.LayerNorm; mean / rstd [rows] are kept for the backward.  The backward reads x and dy ONCE: dx, and dgamma / dbeta through one

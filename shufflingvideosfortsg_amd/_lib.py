@@ -67,6 +67,7 @@ _SIGNATURES = {
     "tsg_boundary_head_gemm": [_P, c_longlong, _P, _P, c_longlong] + [_P] * 10 + [c_longlong, _I, _I, _I, _I, _P],
     "tsg_boundary_softmax": [_P, _P, _I, _I, _P],
     "tsg_transpose_f32": [_P, c_longlong, _P, _I, _I, _I, _P],
+    "tsg_dropout": [_P, _P, c_longlong, c_float, c_uint64, c_uint64, _P, _P, _I, _I, _P],
     "tsg_layer_norm_fwd": [_P] * 6 + [c_longlong, _I, c_float, _I, _P],
     "tsg_layer_norm_bwd_ws_bytes": [c_longlong, _I],
     "tsg_layer_norm_bwd": [_P] * 9 + [c_longlong, c_longlong, _I, _I, _P],

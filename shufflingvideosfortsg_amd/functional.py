@@ -1219,6 +1219,66 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     return _LayerNorm.apply(x, gamma, beta, eps)
 
 
+_OWN_DROPOUT = os.environ.get("TSG_DROPOUT", "own") != "torch"          # A/B switch: "torch" = F.dropout (byte mask written and re-read)
+
+
+class _Dropout(torch.autograd.Function):
+    """Dropout without a stored mask (tsg_dropout): the backward is the same launch on the gradient, the mask regenerated from the keys."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, offset, rng):
+        require_device(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ctx.dt = TSG_BF16 if x.dtype == _BF else TSG_F32
+        ctx.p, ctx.seed, ctx.offset = p, seed, offset
+        if rng is not None:                                          # under graph capture: (seed, offset) in device memory, keys kept for the backward
+            keys = torch.empty(2, dtype=torch.int32, device=x.device)
+            _call("tsg_dropout", x, ptr(x), ptr(y), x.numel(), p, 0, 0, ptr(rng), ptr(keys), 1, ctx.dt)
+            ctx.save_for_backward(keys)
+        else:
+            _call("tsg_dropout", x, ptr(x), ptr(y), x.numel(), p, seed, offset, None, None, 0, ctx.dt)
+        ctx.has_keys = rng is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        if ctx.has_keys:
+            _call("tsg_dropout", dy, ptr(dy), ptr(dx), dy.numel(), ctx.p, 0, 0, None, ptr(ctx.saved_tensors[0]), 2, ctx.dt)
+        else:
+            _call("tsg_dropout", dy, ptr(dy), ptr(dx), dy.numel(), ctx.p, ctx.seed, ctx.offset, None, None, 0, ctx.dt)
+        return dx, None, None, None, None
+
+
+def dropout_ok(x) -> bool:
+    return _OWN_DROPOUT and x.is_cuda and x.dtype in (torch.float32, _BF) and x.numel() > 0
+
+
+def dropout(x, p, training=True):
+    """F.dropout(x, p, training) on the hand-written kernel: the keep decision of element i is a counter-based hash of i and of
+    (seed, offset) -- seed = torch.initial_seed(), offset drawn from torch's CPU generator per call, so ``torch.manual_seed`` makes it
+    reproducible and every call draws a fresh mask; under a HIP-graph capture the pair lives in device memory and the captured
+    increment of the offset makes every REPLAY draw a fresh mask (the state of ``mha_graph_rng``)."""
+    if not training or p <= 0.0:
+        return x
+    if p >= 1.0:
+        return x * 0.0
+    seed, offset, rng = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, None
+    if torch.distributed.is_available() and torch.distributed.is_initialized():      # ranks seeded alike still draw different masks
+        seed = (seed + 0x9E3779B97F4A7C15 * torch.distributed.get_rank()) & 0xFFFFFFFFFFFFFFFF
+    if torch.cuda.is_current_stream_capturing():
+        rng = _mha_rng_state.get(_cuda_device(x.device))
+        if rng is None:
+            raise RuntimeError("dropout under graph capture needs functional.mha_graph_rng(device) called before the capture "
+                               "(engine.GraphedTrainStep does)")
+        rng[1] += 1                                                  # captured: advances on every replay
+    else:
+        offset = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return _Dropout.apply(x, float(p), seed, offset, rng)
+
+
 class _MomentPool(torch.autograd.Function):
     """MomentPooling's three masked means in one pass (tsg_moment_pool_fwd / _bwd): feat [B,T,D] (fp32, or bf16 in the storage
     mode), masks float [B,T] x 3 -> (target, fore, back) means, fp32 [B,D] each (views of one [B,3,D] buffer)."""

@@ -98,7 +98,10 @@ class BiLSTM(nn.Module):
             if states is True:
                 hn += [out[:, -1, :h], out[:, 0, h:]] if bm else [out[-1, :, :h], out[0, :, h:]]
                 cn += [Cs[-1, 0], Cs[0, 1]]
-            inp = F.dropout(out, p, self.training) if (p > 0 and k + 1 < self.num_layers) else out
+            if p > 0 and k + 1 < self.num_layers:         # nn.LSTM's dropout between the layers: no stored mask (tsg_dropout)
+                inp = TF.dropout(out, p, self.training) if TF.dropout_ok(out) else F.dropout(out, p, self.training)
+            else:
+                inp = out
         out = out if bm else out.transpose(0, 1).contiguous()
         if states is True:
             return out, torch.stack(hn, 0), torch.stack(cn, 0)
