@@ -312,3 +312,53 @@ def test_bilstm_joined_parameters_are_zero_copy_and_survive_repointing():
     o1, _, _ = run(m)
     o2, _, _ = run(ref)
     assert torch.equal(o1, o2) and not torch.equal(o1, o0)
+
+
+_GRID_CHILD = r"""
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+from shufflingvideosfortsg_amd import _lib
+from shufflingvideosfortsg_amd._lib import ptr
+lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+for (B, T, h, dt) in ((32, 24, 512, 2), (40, 12, 512, 2), (16, 16, 512, 1), (32, 12, 256, 0), (8, 10, 128, 2)):
+    g = torch.Generator().manual_seed(B + T + h)
+    bf = dt == 1
+    Gx = (torch.randn(T, B, 2, 4 * h, generator=g) * 0.5).cuda(); W = (torch.randn(2, 4 * h, h, generator=g) / h ** 0.5).cuda()
+    dOut = torch.randn(T, B, 2 * h, generator=g).cuda(); WT = W.transpose(1, 2).contiguous()
+    if bf: Gx, dOut = Gx.bfloat16(), dOut.bfloat16()
+    sdt = torch.bfloat16 if bf else torch.float32
+    sync = torch.zeros(512, dtype=torch.int32, device="cuda")
+    out = torch.empty(T, B, 2 * h, device="cuda", dtype=sdt); R = torch.empty(T, 2, B, h, 4, device="cuda", dtype=sdt); Cs = torch.empty(T, 2, B, h, device="cuda")
+    assert lib.tsg_lstm_fwd(ptr(Gx), ptr(W), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, dt, st) == 0
+    nb = lib.tsg_lstm_bwd_ws_bytes(B, T, h)
+    dG = torch.empty(T, B, 2, 4 * h, device="cuda", dtype=sdt); dC = torch.zeros(2, B, h, device="cuda")
+    ws = torch.empty(nb // 4 + 4, device="cuda"); db = torch.empty(8 * h, device="cuda")
+    assert lib.tsg_lstm_bwd_ws(ptr(WT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC), ptr(ws), nb, ptr(db), B, T, h, dt, st) == 0
+    torch.cuda.synchronize()
+    assert int(sync[0]) == 0 and int(ws[:1].view(torch.int32)[0]) == 0
+    hs = lambda t: hashlib.sha256(t.contiguous().view(torch.uint8).cpu().numpy().tobytes()).hexdigest()[:16]
+    print("CASE", B, T, h, dt, int(sync[1]), int(sync[3]), int(ws[3:4].view(torch.int32)[0]), hs(out), hs(Cs), hs(dG))
+"""
+
+
+def test_padded_persistent_grids_are_placement_only():
+    """Round 4: with fewer than 8 exchange groups the persistent grids are padded to one group per XCD (persist_grid) so that the
+    groups take the L2-local exchange.  The padding changes WHERE workgroups run, not what they compute: forward outputs, cell
+    states and gate gradients are bit-identical to the natural grids' (TSG_LSTM_PAD=0), and the padded launches report every
+    active workgroup on the L2-local path where the natural ones report none.  (Forward workgroup width pinned with TSG_LSTM_NW=8:
+    the 16-unit forward of small batches has its own parity runs above.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for pad in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", _GRID_CHILD % root], env=dict(os.environ, TSG_LSTM_PAD=pad, TSG_LSTM_NW="8"),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        runs[pad] = [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("CASE")]
+        assert len(runs[pad]) == 5, r.stdout + r.stderr
+    for nat, padd in zip(runs["0"], runs["1"]):
+        assert nat[:4] == padd[:4]
+        assert nat[7:] == padd[7:], (nat, padd)                        # out, Cs, dG: same bits
+        arrived, fwd_local, bwd_local = (int(v) for v in padd[4:7])
+        assert fwd_local == arrived and bwd_local == arrived, padd    # every active workgroup of the padded grids on the L2-local path
+        assert int(nat[5]) == 0 and int(nat[6]) == 0, nat             # none on the natural grids of these batch sizes
