@@ -1469,6 +1469,128 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
     }
   };
 
+  const bool abl_nobar = TSG_SKIP(512), abl_swap = TSG_SKIP(1024) && wv >= kFusedWaves / 2;
+  // ---------------- column phase -----------------------------------------------------------------
+  // Generic in the columns per lane: the MFMA-row variant works on 64-column slices in its row phase (two MFMA tiles per wave), but
+  // its column phase is the VALU loop of the other variant and amortises its per-row overhead (exponential of the a row, de broadcast,
+  // da store, loop control) better over 2 columns per lane: the waves regroup as SP/2 slices of 128 columns x twice the row splits.
+  auto column_phase = [&](auto cpl_tag, const int SP, const int RS) {
+    constexpr int CPL = decltype(cpl_tag)::value, SW = kWave * CPL;
+    const int sw = wv % SP, rq = wv / SP;
+    const int col = (pt * SP + sw) * SW + lane * CPL;
+    const bool kok = col < H;
+    const size_t rowH = (size_t)b * T * H + (kok ? col : 0);
+    const int nrows = rq < T ? (T - rq + RS - 1) / RS : 0;          // this wave's rows: t = rq + RS*i
+    float es[NP][CPL], dsacc[NP][CPL], dwacc[CPL], w4[CPL];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { es[n][c] = 0.f; dsacc[n][c] = 0.f; }
+      if (n < N && kok) ld_cols<CPL>(s + ((size_t)b * N + n) * H + col, es[n]);
+      exp2_cols<CPL>(es[n]);
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { dwacc[c] = 0.f; w4[c] = (col + c < H) ? 4.f * w[col + c] : 0.f; }
+    float aring[kFusedPF][CPL];
+#pragma unroll
+    for (int u = 0; u < kFusedPF; ++u) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) aring[u][c] = 0.f;
+      if (u < nrows && kok) ld_cols<CPL>(a + rowH + (size_t)(rq + RS * u) * H, aring[u]);
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < nrows; i0 += kFusedPF) {
+#pragma unroll
+      for (int u = 0; u < kFusedPF; ++u) {
+        const int i = i0 + u, t = rq + RS * i;
+        if (i < nrows && !TSG_SKIP(32)) {                           // wave-uniform
+          float ea[CPL], dasum[CPL];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) { ea[c] = aring[u][c]; dasum[c] = 0.f; }
+          const int inx = i + kFusedPF;
+          if (inx < nrows && kok) ld_cols<CPL>(a + rowH + (size_t)(rq + RS * inx) * H, aring[u]);
+          exp2_cols<CPL>(ea);
+          const float* drow = De + t * NP;
+#pragma unroll
+          for (int n4 = 0; n4 < NP; n4 += 4) {
+            const float4 d4 = *reinterpret_cast<const float4*>(drow + n4);   // broadcast
+            const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) {
+                const float r = fast_rcp(fmaf(ea[c], es[n4 + j][c], 1.f));
+                const float q = fmaf(-r, r, r);
+                dsacc[n4 + j][c] = fmaf(dd[j], q, dsacc[n4 + j][c]);
+                dasum[c] = fmaf(dd[j], q, dasum[c]);
+                dwacc[c] = fmaf(dd[j], r, dwacc[c]);
+              }
+          }
+          if (kok) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) dasum[c] *= w4[c];
+            st_cols<CPL>(da + rowH + (size_t)t * H, dasum);
+          }
+        }
+      }
+    }
+    // T-sums of the column phase
+    if (!abl_nobar) __syncthreads();                               // De no longer read; `red` overlays `part` only, but keep order simple
+    for (int q = 1; q < RS; ++q) {
+      if (rq == q) {
+#pragma unroll
+        for (int n = 0; n < NP; ++n) st_cols<CPL>(red + (((size_t)(q - 1) * SP + sw) * NP + n) * SW + lane * CPL, dsacc[n]);
+      }
+    }
+    if (!abl_nobar) lds_barrier();
+    if (rq == 0) {
+      for (int q = 1; q < RS; ++q) {
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+          float o[CPL];
+          ld_cols<CPL>(red + (((size_t)(q - 1) * SP + sw) * NP + n) * SW + lane * CPL, o);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) dsacc[n][c] += o[c];
+        }
+      }
+      if (kok) {
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+          if (n < N) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) dsacc[n][c] *= w4[c];
+            st_cols<CPL>(ds + ((size_t)b * N + n) * H + col, dsacc[n]);
+          }
+        }
+      }
+    }
+    if (!abl_nobar) lds_barrier();
+    if (rq > 0) st_cols<CPL>(red + ((size_t)(rq - 1) * SP + sw) * SW + lane * CPL, dwacc);
+    if (!abl_nobar) lds_barrier();
+    if (rq == 0 && kok) {
+      for (int q = 1; q < RS; ++q) {
+        float o[CPL];
+        ld_cols<CPL>(red + ((size_t)(q - 1) * SP + sw) * SW + lane * CPL, o);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) dwacc[c] += o[c];
+      }
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+        if (col + c < H && !TSG_SKIP(256)) atomicAdd(dw + col + c, -2.f * dwacc[c]);
+    }
+  };
+  auto run_column = [&]() {
+    if constexpr (MROW && fused_cpl<NP>() == 2) {
+      if (SP % 2 == 0) column_phase(std::integral_constant<int, 2>{}, SP / 2, 2 * RS);
+      else column_phase(std::integral_constant<int, 1>{}, SP, RS);
+    } else {
+      column_phase(std::integral_constant<int, CPL>{}, SP, RS);
+    }
+  };
+  // Timing-only experiment (-DTSG_ABLATE builds, results are garbage): bit 512 drops every workgroup barrier inside the two phases and the
+  // partner exchange (the reference point), bit 1024 additionally lets waves 4..7 run their column phase BEFORE their row phase, so that
+  // each SIMD holds one wave in the memory-bound row phase and one in the VALU-bound column phase: the upper bound of what a
+  // tile-pipelined kernel (row phase of tile i + 1 under the column phase of tile i) could gain.
   // ---------------- row phase ------------------------------------------------------------------
   if constexpr (MROW) {
     // The row phase is three small GEMMs per 32-row tile and 32-column tile of the wave's slice -- G = P VW (K = N words),
@@ -1505,6 +1627,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
       gb[ct] = (GATE && colw + 32 * ct + jl < Ds) ? gbias[colw + 32 * ct + jl] : 0.f;
     }
     __syncthreads();                                               // Pl and the VW slices staged
+    if (abl_swap) run_column();
     for (int r0 = 0; r0 < TL; r0 += 32 * RS) {
       const int t0 = r0 + 32 * rq;                                 // this wave's row tile of the round
       if (t0 < TL && !TSG_SKIP(16)) {                              // wave-uniform
@@ -1596,7 +1719,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
           for (int v = 0; v < 16; ++v) myW[((v & 3) + 8 * (v >> 2) + 4 * kk) * (NP + 1) + jl] = dpacc[v];
         }
       }
-      lds_barrier();
+      if (!abl_nobar) lds_barrier();
       for (int idx = tid; idx < 32 * RS * NP; idx += kFusedThreads) {
         const int row = idx / NP, n = idx % NP, t = r0 + row;
         if (t < TL) {
@@ -1605,7 +1728,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
           De[t * NP + n] = sum;
         }
       }
-      lds_barrier();
+      if (!abl_nobar) lds_barrier();
     }
     publish_dp();
     // T-sums of the row phase.  The accumulator tiles hold dVW[n = rho(v, kk)][column jl]; row splits rq > 0 hand theirs to
@@ -1619,7 +1742,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
           for (int v = 0; v < 16; ++v) redm[((((size_t)(q - 1) * SP + sw) * CTW + ct) * 16 + v) * 64 + lane] = dvw[ct][v];
       }
     }
-    lds_barrier();
+    if (!abl_nobar) lds_barrier();
     if (rq == 0) {
 #pragma unroll
       for (int ct = 0; ct < CTW; ++ct) {
@@ -1641,7 +1764,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
         if (kk == 0 && col < Ds && !TSG_SKIP(256)) atomicAdd(dbias + col, gs);
       }
     }
-    lds_barrier();                                                 // redm is read; the column phase may overlay it
+    if (!abl_nobar) lds_barrier();                                                 // redm is read; the column phase may overlay it
   } else {
     float vreg[NP][CPL], dvacc[NP][CPL], gsum[CPL], gb[CPL];
 #pragma unroll
@@ -1664,7 +1787,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
     }
     const int q4 = lane >> 4, nq = ((q4 & 1) << 1) | (q4 >> 1);
     const int per_sub = kFusedSub / RS;                           // this wave's rows per folding round (RS divides 32)
-    __syncthreads();                                              // Pl staged
+    if (!abl_nobar) __syncthreads();                                              // Pl staged
     for (int sb0 = 0, i0 = 0; sb0 < T; sb0 += kFusedSub, i0 += per_sub) {
 #pragma unroll 1
       for (int ib = 0; ib < per_sub; ib += kFusedPF) {
@@ -1735,7 +1858,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
           }
         }
       }
-      lds_barrier();
+      if (!abl_nobar) lds_barrier();
       const int sbn = T - sb0 < kFusedSub ? T - sb0 : kFusedSub;
       for (int idx = tid; idx < sbn * NP; idx += kFusedThreads) {
         const int r = idx / NP, n = idx % NP;
@@ -1743,7 +1866,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
         for (int c = 0; c < SP; ++c) sum += part[(c * kFusedSub + r) * (NP + 1) + n];
         De[(sb0 + r) * NP + n] = sum;
       }
-      lds_barrier();
+      if (!abl_nobar) lds_barrier();
     }
     publish_dp();
     // T-sums of the row phase: dVW and the gate bias gradient.  Row splits rq > 0 hand theirs to rq = 0 through LDS.
@@ -1753,7 +1876,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
         for (int n = 0; n < NP; ++n) st_cols<CPL>(red + (((size_t)(q - 1) * SP + sw) * NP + n) * SW + lane * CPL, dvacc[n]);
       }
     }
-    lds_barrier();
+    if (!abl_nobar) lds_barrier();
     if (rq == 0) {
       for (int q = 1; q < RS; ++q) {
 #pragma unroll
@@ -1771,9 +1894,9 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
       }
     }
     if (GATE) {                                                    // dbias: fold the row splits with a second round
-      lds_barrier();
+      if (!abl_nobar) lds_barrier();
       if (rq > 0) st_cols<CPL>(red + ((size_t)(rq - 1) * SP + sw) * SW + lane * CPL, gsum);
-      lds_barrier();
+      if (!abl_nobar) lds_barrier();
       if (rq == 0 && jok) {
         for (int q = 1; q < RS; ++q) {
           float o[CPL];
@@ -1790,7 +1913,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
 
   // ---------------- exchange: dP over ALL columns, then de -------------------------------------
   // (partial rows stored right after the row loop: `publish_dp`; counted in here, behind the T-sum epilogue: `count_in`)
-  if (parts > 1) {
+  if (parts > 1 && !abl_nobar) {
     count_in();
     if (tid == 0) {
       unsigned spins = 0;
@@ -1815,7 +1938,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     }
-    __syncthreads();
+    if (!abl_nobar) __syncthreads();
     // every part's partial in part order (deterministic).  Plain loads: thread 0's agent-scope acquire followed by the
     // workgroup barrier orders them after the neighbours' published stores, and they can be issued back to back (atomic
     // loads are kept in program order by the compiler: one memory round trip each, ~40 in a row).
@@ -1827,9 +1950,9 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
       for (int p = 0; p < parts; ++p) v += xch[((size_t)b * parts + p) * T * NP + idx];
       De[idx] = v;
     }
-    __syncthreads();
+    if (!abl_nobar) __syncthreads();
   } else {
-    __syncthreads();
+    if (!abl_nobar) __syncthreads();
   }
   for (int r = tid; r < T; r += kFusedThreads) {
     float dp[NP], dot = 0.f;
@@ -1841,123 +1964,9 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
 #pragma unroll
     for (int n = 0; n < NP; ++n) De[r * NP + n] = Pl[r * NP + n] * (dp[n] - dot);      // 0 for padded words (P = 0)
   }
-  __syncthreads();
+  if (!abl_nobar) __syncthreads();
 
-  // ---------------- column phase -----------------------------------------------------------------
-  // Generic in the columns per lane: the MFMA-row variant works on 64-column slices in its row phase (two MFMA tiles per wave), but
-  // its column phase is the VALU loop of the other variant and amortises its per-row overhead (exponential of the a row, de broadcast,
-  // da store, loop control) better over 2 columns per lane: the waves regroup as SP/2 slices of 128 columns x twice the row splits.
-  auto column_phase = [&](auto cpl_tag, const int SP, const int RS) {
-    constexpr int CPL = decltype(cpl_tag)::value, SW = kWave * CPL;
-    const int sw = wv % SP, rq = wv / SP;
-    const int col = (pt * SP + sw) * SW + lane * CPL;
-    const bool kok = col < H;
-    const size_t rowH = (size_t)b * T * H + (kok ? col : 0);
-    const int nrows = rq < T ? (T - rq + RS - 1) / RS : 0;          // this wave's rows: t = rq + RS*i
-    float es[NP][CPL], dsacc[NP][CPL], dwacc[CPL], w4[CPL];
-#pragma unroll
-    for (int n = 0; n < NP; ++n) {
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) { es[n][c] = 0.f; dsacc[n][c] = 0.f; }
-      if (n < N && kok) ld_cols<CPL>(s + ((size_t)b * N + n) * H + col, es[n]);
-      exp2_cols<CPL>(es[n]);
-    }
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) { dwacc[c] = 0.f; w4[c] = (col + c < H) ? 4.f * w[col + c] : 0.f; }
-    float aring[kFusedPF][CPL];
-#pragma unroll
-    for (int u = 0; u < kFusedPF; ++u) {
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) aring[u][c] = 0.f;
-      if (u < nrows && kok) ld_cols<CPL>(a + rowH + (size_t)(rq + RS * u) * H, aring[u]);
-    }
-#pragma unroll 1
-    for (int i0 = 0; i0 < nrows; i0 += kFusedPF) {
-#pragma unroll
-      for (int u = 0; u < kFusedPF; ++u) {
-        const int i = i0 + u, t = rq + RS * i;
-        if (i < nrows && !TSG_SKIP(32)) {                           // wave-uniform
-          float ea[CPL], dasum[CPL];
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) { ea[c] = aring[u][c]; dasum[c] = 0.f; }
-          const int inx = i + kFusedPF;
-          if (inx < nrows && kok) ld_cols<CPL>(a + rowH + (size_t)(rq + RS * inx) * H, aring[u]);
-          exp2_cols<CPL>(ea);
-          const float* drow = De + t * NP;
-#pragma unroll
-          for (int n4 = 0; n4 < NP; n4 += 4) {
-            const float4 d4 = *reinterpret_cast<const float4*>(drow + n4);   // broadcast
-            const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) {
-                const float r = fast_rcp(fmaf(ea[c], es[n4 + j][c], 1.f));
-                const float q = fmaf(-r, r, r);
-                dsacc[n4 + j][c] = fmaf(dd[j], q, dsacc[n4 + j][c]);
-                dasum[c] = fmaf(dd[j], q, dasum[c]);
-                dwacc[c] = fmaf(dd[j], r, dwacc[c]);
-              }
-          }
-          if (kok) {
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) dasum[c] *= w4[c];
-            st_cols<CPL>(da + rowH + (size_t)t * H, dasum);
-          }
-        }
-      }
-    }
-    // T-sums of the column phase
-    __syncthreads();                                               // De no longer read; `red` overlays `part` only, but keep order simple
-    for (int q = 1; q < RS; ++q) {
-      if (rq == q) {
-#pragma unroll
-        for (int n = 0; n < NP; ++n) st_cols<CPL>(red + (((size_t)(q - 1) * SP + sw) * NP + n) * SW + lane * CPL, dsacc[n]);
-      }
-    }
-    lds_barrier();
-    if (rq == 0) {
-      for (int q = 1; q < RS; ++q) {
-#pragma unroll
-        for (int n = 0; n < NP; ++n) {
-          float o[CPL];
-          ld_cols<CPL>(red + (((size_t)(q - 1) * SP + sw) * NP + n) * SW + lane * CPL, o);
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) dsacc[n][c] += o[c];
-        }
-      }
-      if (kok) {
-#pragma unroll
-        for (int n = 0; n < NP; ++n) {
-          if (n < N) {
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) dsacc[n][c] *= w4[c];
-            st_cols<CPL>(ds + ((size_t)b * N + n) * H + col, dsacc[n]);
-          }
-        }
-      }
-    }
-    lds_barrier();
-    if (rq > 0) st_cols<CPL>(red + ((size_t)(rq - 1) * SP + sw) * SW + lane * CPL, dwacc);
-    lds_barrier();
-    if (rq == 0 && kok) {
-      for (int q = 1; q < RS; ++q) {
-        float o[CPL];
-        ld_cols<CPL>(red + ((size_t)(q - 1) * SP + sw) * SW + lane * CPL, o);
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) dwacc[c] += o[c];
-      }
-#pragma unroll
-      for (int c = 0; c < CPL; ++c)
-        if (col + c < H && !TSG_SKIP(256)) atomicAdd(dw + col + c, -2.f * dwacc[c]);
-    }
-  };
-  if constexpr (MROW && fused_cpl<NP>() == 2) {
-    if (SP % 2 == 0) column_phase(std::integral_constant<int, 2>{}, SP / 2, 2 * RS);
-    else column_phase(std::integral_constant<int, 1>{}, SP, RS);
-  } else {
-    column_phase(std::integral_constant<int, CPL>{}, SP, RS);
-  }
+  if (!abl_swap) run_column();
 }
 
 // zero up to three small accumulator blocks with ONE launch (dw, dbias, the exchange counters)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Timing-only ablation of the gate-fused K1 backward (needs tools/_ablate/k1abl.so = a -DTSG_ABLATE build of scdm_attn.hip):
-TSG_ABLATE_MASK bit 16 skips the row phase, 32 the column phase, 64 the wait on the partner workgroups, 256 the dw / dbias atomics.
+TSG_ABLATE_MASK bit 16 skips the row phase, 32 the column phase, 64 the wait on the partner workgroups, 256 the dw / dbias atomics,
+512 every workgroup barrier inside the phases + the exchange, 1024 (with 512) waves 4..7 run the column phase before the row phase
+(the overlap experiment); TSG_ABL_MASKS=0,512,1536 selects the masks.
 python tools/k1_bwd_ablate.py [B]"""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,6 +28,6 @@ for _ in range(100): fn()
 e1.record(); torch.cuda.synchronize()
 print("mask", os.environ.get("TSG_ABLATE_MASK", "0"), "%%.1f us" %% (e0.elapsed_time(e1) / 100 * 1e3), flush=True)
 ''' % root
-for mask in ("0", "16", "32", "48", "64", "112", "368", "0"):
+for mask in (os.environ.get("TSG_ABL_MASKS", "0,16,32,48,64,112,368,0").split(",")):
     env = dict(os.environ, TSG_HIP_LIB=os.path.join(root, "tools", "_ablate", "k1abl.so"), TSG_ABLATE_MASK=mask)
     subprocess.run([sys.executable, "-c", code, B], env=env)
