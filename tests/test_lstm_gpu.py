@@ -344,8 +344,8 @@ for (B, T, h, dt) in ((32, 24, 512, 2), (40, 12, 512, 2), (16, 16, 512, 1), (32,
 def test_padded_persistent_grids_are_placement_only():
     """Round 4: with fewer than 8 exchange groups the persistent grids are padded to one group per XCD (persist_grid) so that the
     groups take the L2-local exchange.  The padding changes WHERE workgroups run, not what they compute: forward outputs, cell
-    states and gate gradients are bit-identical to the natural grids' (TSG_LSTM_PAD=0), and the padded launches report every
-    active workgroup on the L2-local path where the natural ones report none.  (Forward workgroup width pinned with TSG_LSTM_NW=8:
+    states and gate gradients are bit-identical to the natural grids' (TSG_LSTM_PAD=0); the L2-local counts of both are printed (on this
+    pool: every active workgroup of the padded grids, none of the natural ones).  (Forward workgroup width pinned with TSG_LSTM_NW=8:
     the 16-unit forward of small batches has its own parity runs above.)"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
