@@ -1,5 +1,8 @@
 """K5 (csrc/match_head.hip): matching-head tail  logits = w2 . act(y + cs) + b2  vs the torch formulation
-(TwoLayerdMLP after VideoTextConcat, reference components/DistributionAlign.py:51-98), forward and backward."""
+(TwoLayerdMLP after VideoTextConcat, reference components/DistributionAlign.py:51-98), forward and backward.
+This file checks the kernel against the same formula written in torch ops; the check against the ORACLE (oracle.csmm, the
+restatement of the reference module) is tests/test_head_gemm_gpu.py (the head as the epilogue of its GEMM, what the models run)
+and tests/test_fullsize_gpu.py (the module at the benchmark shape)."""
 import pytest
 import torch
 
