@@ -793,8 +793,9 @@ static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
 // the A operand of  partial_dh[16 rows][ALL h units] = dG_own W_hh[own gate rows, :]  -- no operand has to be fetched.
 // What is exchanged is the reduction: every workgroup writes its partial tile as whole 128-byte write-through lines into
 // a ring slot (one 2 KiB block per consumer), and polls the h/32 blocks addressed to it -- 32 KiB per workgroup and
-// step, like the forward's h slab and a quarter of a dG slab.  Ring = 4 slots, slot = step % 4, and the
-// "written" mark is a generation tag instead of a sentinel: every partial value carries (step/4) % 2 in its lowest
+// step, like the forward's h slab and a quarter of a dG slab.  Ring = 2 slots, slot = step % 2 (round 4; four slots until then: 33.5 MB
+// at [128, ., 512], more than the chip's L2s hold, so the blocks were re-fetched from memory -- see launch_flags), and the
+// "written" mark is a generation tag instead of a sentinel: every partial value carries (step/2) % 2 in its lowest
 // mantissa bit (a perturbation of at most one ulp of a partial sum); a consumer accepts a float4 when all four tags
 // match the generation it expects, so a slot needs no re-marking between uses (re-marking with sentinel lines doubled
 // the write-through traffic: 14.1 us per step).  Consumers are never more than one step apart, so a slot's previous
@@ -857,6 +858,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
   float dc_carry = 0.f;
   float dbsum[4] = {0.f, 0.f, 0.f, 0.f};                    // this thread's sum over the time steps of its four gate gradients
   const int hq = h / 4;                                     // float4 per partial row
+  // ring depth: 2 slots (flags bit 3, the default: tag = (step / 2) % 2) or 4 (tag = (step / 4) % 2).  Two suffice: a workgroup stores step s + 2
+  // only after it has polled step s + 1 from every producer of its group, and those stored step s + 1 only after their loads of step s had
+  // returned (the poll loop ends on s_waitcnt vmcnt(0) with every tag checked) -- nobody can still be reading the slot that step s + 2 overwrites.
+  const int rmask = (flags & 8) ? 1 : 3, rsh = (flags & 8) ? 1 : 2;
   auto slot_base = [&](int slot) { return ring + ((size_t)(slot * 2 + d) * bslices + bs) * nus * nus * 512; };
   // producer side: float4 i of this thread = (row pr, units 4*pc .. +3) of the partial tile -> block of consumer pc/8
   auto prod_ptr = [&](int slot, int i) {
@@ -866,7 +871,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
 
   {  // all four slots start with the "odd generation" tag (low mantissa bit 1) on every element, then the grid meets once
     const u32x4 sent = {kSentinel | 1u, kSentinel | 1u, kSentinel | 1u, kSentinel | 1u};
-    for (int slot = 0; slot < 4; ++slot)
+    for (int slot = 0; slot <= rmask; ++slot)
       for (int i = 0; i < TW; ++i) store_sc1_u4(prod_ptr(slot, i), sent);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -904,12 +909,12 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
       // poll the nus blocks addressed to this workgroup in slot (step-1)%4: thread = (producer group pg, row pr, 4 units pc);
       // its loads i = producers pg + 4i (always four loads: the ones beyond TW repeat the first and are ignored)
       const int pg = tid >> 7, pr = (tid & 127) >> 3, pc = tid & 7;
-      const float* cbase = slot_base((step - 1) & 3) + (size_t)us * nus * 512;
+      const float* cbase = slot_base((step - 1) & rmask) + (size_t)us * nus * 512;
       const float* src[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) src[i] = cbase + ((size_t)(pg + 4 * (i < TW ? i : 0)) * 16 + pr) * 32 + 4 * pc;
       const unsigned pending = (1u << TW) - 1u;
-      const unsigned gen = ((unsigned)(step - 1) >> 2) & 1u;         // generation of slot (step-1)%4: every element carries it in its low bit
+      const unsigned gen = ((unsigned)(step - 1) >> rsh) & 1u;         // generation of slot (step-1)%4: every element carries it in its low bit
       u32x4 q[4];
       int spins = 0;
       while (true) {
@@ -1031,11 +1036,11 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
       if (step > 0) TSG_TICK(5)                              // (timing builds: MFMAs issued and their results written to LDS)
       lds_barrier();
       if (step > 0) TSG_TICK(2)                              // MFMA + gather
-      const unsigned gtag = ((unsigned)step >> 2) & 1u;      // generation of slot step%4, carried in the low mantissa bit
+      const unsigned gtag = ((unsigned)step >> rsh) & 1u;      // generation of slot step%4, carried in the low mantissa bit
       for (int i = 0; i < TW; ++i) {
         const int idx = tid + i * kThreads, pr = idx / hq, pc = idx % hq;
         const f32x4 v = *reinterpret_cast<const f32x4*>(Pl + pr * kPLS + 4 * pc);
-        store_x_u4(prod_ptr(step & 3, i), (u32x4){(__float_as_uint(v[0]) & ~1u) | gtag, (__float_as_uint(v[1]) & ~1u) | gtag,
+        store_x_u4(prod_ptr(step & rmask, i), (u32x4){(__float_as_uint(v[0]) & ~1u) | gtag, (__float_as_uint(v[1]) & ~1u) | gtag,
                                                  (__float_as_uint(v[2]) & ~1u) | gtag, (__float_as_uint(v[3]) & ~1u) | gtag}, local);
       }
       if (step > 0) TSG_TICK(3)                              // partial stores issued
@@ -1132,7 +1137,11 @@ static int persist_grid(int slices, int wgs, int cap) {
 }
 static int launch_flags() {       // bit 0: L2-local exchange allowed; bit 1: inject a start-barrier timeout (tests)
   const char* e = getenv("TSG_LSTM_INJECT_TIMEOUT");
-  return (l2_exchange() ? 1 : 0) | ((e && atoi(e) != 0) ? 2 : 0);
+  // bit 3: two-slot partial-dh ring in the backward (default; TSG_LSTM_RING=4 = the four slots of rounds 1-3, A/B).  Four slots of 8.4 MB are
+  // 33.5 MB -- more than the eight 4 MB L2s together -- so the ring fell out of the L2s it is exchanged through: 1.0 GB of re-fetches per
+  // launch at [128, 128, 512] (PMC: 1502 -> 454 MB read), 4.49 -> 3.88 us per step (f32s), 4.05 -> 3.27 (bf16 storage)
+  static const int ring2 = [] { const char* r = getenv("TSG_LSTM_RING"); return (r && atoi(r) == 4) ? 0 : 8; }();
+  return (l2_exchange() ? 1 : 0) | ((e && atoi(e) != 0) ? 2 : 0) | ring2;
 }
 static bool persist_wanted(int T) { const int m = persist_mode(); return m > 0 || (m < 0 && T >= 8); }
 

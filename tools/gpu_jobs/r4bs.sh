@@ -1,0 +1,12 @@
+#!/bin/bash
+# GPU job of round 4 (bs): memory-side traffic per kernel of the f32s step (PMC: FETCH_SIZE and WRITE_SIZE in separate passes)
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=$PWD/gpurun_out/r4bs; rm -rf $O; mkdir -p $O
+C="--steps 3 --warmup 2 --cpu-sample 0 --no-alt --no-micro --graph off"
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf -o p -- python3 bench.py $C > $O/pf.json 2> $O/pf.err
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pw -o p -- python3 bench.py $C > $O/pw.json 2> $O/pw.err
+A=$(find $O/pf -name "*counter_collection.csv" | head -1); B=$(find $O/pw -name "*counter_collection.csv" | head -1)
+python3 tools/pmc_traffic_by_kernel.py $A $B 20 > $O/step_traffic_by_kernel_f32s.txt 2>&1
+find $O -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
+cut -c1-170 $O/step_traffic_by_kernel_f32s.txt
