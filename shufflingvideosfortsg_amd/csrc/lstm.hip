@@ -485,6 +485,28 @@ constexpr int kSlabFloats = 2 * 16 * kHLB;       // LDS dwords of the slab regio
 // element (0x7FA5: never the rounding of h = o tanh(c)), the slab a workgroup polls per step is 16 KiB instead of 32.
 constexpr unsigned kSentinel16 = 0x7fa5u;
 typedef bf16_t lstm_bf16;
+// Streaming (use-once) operands of the persistent BACKWARD kernel -- R, Cs, dOut in, dG out -- carry the non-temporal hint: they pass through
+// the L2s the partial-dh ring lives in (2.1 MB of ring + 0.65 MB of these per XCD and step against 4 MB of L2), and as ordinary lines they pushed
+// dirty ring blocks out before the next generation could overwrite them in place: 1333 -> 728 MB written per launch at [128, 128, 512] (PMC),
+// 3.91 -> 3.56 us per step (f32s), 3.33 -> 3.04 (bf16 storage); profiles/r4/lstm_bwd_nontemporal_ab_v1.txt.  Not in the forward kernel: there
+// the hint on Gx / R / Cs measured 3.90 -> 4.10 us per step in f32s (its exchange is `out` itself, 0.26 MB per XCD and step -- nothing to protect).
+// -DTSG_LSTM_NO_NT: plain accesses (A/B).
+typedef unsigned u32x2nt __attribute__((ext_vector_type(2)));
+#ifndef TSG_LSTM_NO_NT
+__device__ __forceinline__ float4 ld4s(const float* p) { const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ float4 ld4s(const bf16_t* p) {
+  const u32x2nt u = __builtin_nontemporal_load(reinterpret_cast<const u32x2nt*>(p));
+  return make_float4(bf16_lo(u[0]), bf16_hi(u[0]), bf16_lo(u[1]), bf16_hi(u[1]));
+}
+__device__ __forceinline__ float ld1s(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float ld1s(const bf16_t* p) { return __uint_as_float((unsigned)__builtin_nontemporal_load(&p->bits) << 16); }
+__device__ __forceinline__ void st1s(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st1s(bf16_t* p, float v) { __builtin_nontemporal_store((unsigned short)(pack_bf16x2(v, 0.f) & 0xffffu), &p->bits); }
+#else
+template <typename T> __device__ __forceinline__ float4 ld4s(const T* p) { return ld4(p); }
+template <typename T> __device__ __forceinline__ float ld1s(const T* p) { return ld1(p); }
+template <typename T> __device__ __forceinline__ void st1s(T* p, float v) { st1(p, v); }
+#endif
 template <int MODE> struct SeqT { typedef float type; };
 template <> struct SeqT<2> { typedef lstm_bf16 type; };
 
@@ -898,10 +920,10 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
       // requesting them one step ahead, after the previous poll -- what the forward kernel does with its input gates --
       // measured 4.8-5.6 us in every variant tried)
       const size_t sidx = (((size_t)tt * 2 + d) * Bs + b) * h + u;
-      g4 = ld4(R + sidx * 4);
-      cc = Cs[sidx];
-      if (has_prev) cpv = Cs[(((size_t)tp * 2 + d) * Bs + b) * h + u];
-      dov = ld1(dOut + seq_row(tt, b, Bs, T, bm) * 2 * h + d * h + u);
+      g4 = ld4s(R + sidx * 4);
+      cc = ld1s(Cs + sidx);
+      if (has_prev) cpv = ld1s(Cs + (((size_t)tp * 2 + d) * Bs + b) * h + u);
+      dov = ld1s(dOut + seq_row(tt, b, Bs, T, bm) * 2 * h + d * h + u);
       if (step == 0 && dHn) dov += dHn[((size_t)d * Bs + b) * h + u];
     }
     float rec = 0.f;
@@ -954,7 +976,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
       if (live) {
         GT* g = dG + (seq_row(tt, b, Bs, T, bm) * 2 + d) * K + u;
 #pragma unroll
-        for (int gate = 0; gate < 4; ++gate) st1(g + gate * h, dg[gate]);
+        for (int gate = 0; gate < 4; ++gate) st1s(g + gate * h, dg[gate]);
       }
 #pragma unroll
       for (int gate = 0; gate < 4; ++gate) {
