@@ -361,10 +361,15 @@ def main():
     torch.manual_seed(0)
     log(f"building {a.model} (d={a.d}) on {torch.cuda.get_device_name(local)}")
     model = engine.build_model(a.model, params).to(dev).train()
-    # gradient exchange after the backward by default: a bucket all-reduce launched DURING the backward would share the CUs
-    # with the persistent LSTM kernels (which need every CU for the length of a layer: their start is delayed and their
-    # exchange groups may lose the one-XCD placement) for at most ~1 ms of hidden communication (186 MB per step)
-    dp = FlatGradAllReduce(model, overlap=os.environ.get("TSG_DP_OVERLAP", "0") == "1")
+    # gradient exchange: bucket all-reduces launched DURING the backward, but never beside a persistent LSTM kernel (those need every
+    # CU for the length of a layer): dp's gated mode launches the complete buckets right BEHIND each persistent launch of the backward --
+    # RCCL's stream picks them up when that kernel has finished and they run under the dX / weight-gradient GEMMs that follow -- and the
+    # hot path fences them in front of the next persistent launch (functional.set_persistent_gate).  TSG_DP_OVERLAP=0: one all-reduce of
+    # the whole buffer after the backward (rounds 1-4).  The graph-replay leg below always exchanges after the backward.
+    overlap = os.environ.get("TSG_DP_OVERLAP", "1") == "1"
+    dp = FlatGradAllReduce(model, overlap=overlap, gated=True, bucket_mb=float(os.environ.get("TSG_DP_BUCKET_MB", "24")))
+    if dp.gated:
+        functional.set_persistent_gate(dp)
     opt = engine.make_optimizer(model, params)
     # weak scaling: B pairs per rank.  strong scaling: B is the GLOBAL batch; every rank builds the same global batch (same seed)
     # and keeps its contiguous shard, as the reference's DataParallel scatters one batch over the GPUs (train.py:343)
@@ -436,6 +441,8 @@ def main():
 
     if a.graph_only:
         opt_g = engine.make_optimizer(model, params, capturable=True)
+        dp.set_overlap(False)
+        functional.set_persistent_gate(None)
         gstep = engine.GraphedTrainStep(model, opt_g, lambda m, b: forward(), batch, dp=dp)
         for _ in range(3):
             gstep()
@@ -526,6 +533,8 @@ def main():
         torch.cuda.synchronize()
         try:
             opt_g = engine.make_optimizer(model, params, capturable=True)
+            dp.set_overlap(False)                                 # graph replay: ONE exchange of the static gradients behind graph A
+            functional.set_persistent_gate(None)
             gstep = engine.GraphedTrainStep(model, opt_g, lambda m, b: forward(), batch, dp=dp)
         except Exception as e:                                    # noqa: BLE001
             err = f"{type(e).__name__}: {e}"[:300]

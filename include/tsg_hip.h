@@ -37,11 +37,12 @@
 extern "C" {
 #endif
 
-#define TSG_VERSION 5   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points
+#define TSG_VERSION 6   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points
                            3: tsg_error_word (device-side expiry report); dtype TSG_BF16 (bf16 storage) in K1 / K1g / K2 / K3 / LSTM
                            4: tsg_boundary_score_bwd_ws (K3 backward in one launch); tsg_gemm_f32s
                            5: tsg_scdm_bwd_mode / tsg_scdm_bwd_fused_ok (path selection as a call and a predicate instead of an
-                              environment variable and an error code); per-device error words */
+                              environment variable and an error code); per-device error words
+                           6: tsg_lstm_fwd_ws (the persistent LSTM forward's exchange ring in a caller-owned workspace) */
 #define TSG_F32 0
 #define TSG_BF16 1   /* bf16 storage of the activations, fp32 arithmetic (see Conventions)                               */
 #define TSG_F32S 2   /* fp32 storage; matrix products as split-precision bf16 MFMAs (x = hi + lo; hi*hi + hi*lo + lo*hi,
@@ -204,6 +205,15 @@ int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, 
  * activations (BiLSTM batch_first=True, RNN.py:27), no transposed copies around the recurrence; R and Cs stay time-major. */
 int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                       int B, int T, int h, int dtype, int batch_major, void* stream);
+/* Same, with a workspace that also holds the EXCHANGE RING of the persistent kernel (ABI revision 6): ws = tsg_lstm_fwd_ws_bytes(B,T,h)
+ * bytes (TSG_LSTM_SYNC_BYTES of sync words + [4 slots][2 ceil(B/16) groups][16 rows][h] dwords; 0 = no ring for this hidden size:
+ * h % 128 != 0 or h > 512), 16-byte aligned, caller-owned, contents irrelevant on entry.  With it the workgroups hand h_t over through
+ * the ring (which stays inside the L2s it is exchanged through; in the TSG_F32S arithmetic it carries h already split into bf16 hi / lo
+ * halves) instead of polling `out`; `out` is written with ordinary stores.  Results are bit-identical to tsg_lstm_fwd_bias.  A smaller
+ * workspace (>= TSG_LSTM_SYNC_BYTES) or TSG_LSTM_XR=0 in the environment selects the tsg_lstm_fwd_bias behaviour.                     */
+long long tsg_lstm_fwd_ws_bytes(int B, int T, int h);
+int tsg_lstm_fwd_ws(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* ws, long long ws_bytes,
+                    int B, int T, int h, int dtype, int batch_major, void* stream);
 
 /* Error sink of the persistent kernels: an int in memory the host can read without synchronising (pinned / host-mapped, or
  * device memory), set to 1 by any persistent launch whose bounded wait expired (its results are then invalid; word 0 of

@@ -53,6 +53,8 @@ _SIGNATURES = {
     "tsg_gmd_losses_fwd": [_P] * 13 + [_I, _I, c_float, c_float, c_float, _P],
     "tsg_gmd_losses_bwd": [_P] * 20 + [_I, _I, c_float, c_float, c_float, _P],
     "tsg_lstm_fwd_bias": [_P] * 7 + [_I] * 5 + [_P],
+    "tsg_lstm_fwd_ws": [_P] * 7 + [c_longlong] + [_I] * 5 + [_P],
+    "tsg_lstm_fwd_ws_bytes": [_I, _I, _I],
     "tsg_lstm_bwd": [_P] * 7 + [_I] * 4 + [_P],
     "tsg_lstm_bwd_ws": [_P] * 8 + [c_longlong, _P] + [_I] * 4 + [_P],
     "tsg_lstm_bwd_ws_layout": [_P] * 8 + [c_longlong, _P] + [_I] * 5 + [_P],
@@ -82,7 +84,7 @@ _SIGNATURES = {
     "tsg_span_pred": [_P] * 4 + [_I] * 3 + [_P],
     "tsg_mha_bwd": [_P] * 10 + [_I] * 6 + [c_float, _I, c_float, c_uint64, c_uint64, _I, _P],
 }
-_RESTYPE = {"tsg_last_error": c_char_p, "tsg_lstm_bwd_ws_bytes": c_longlong, "tsg_scdm_bwd_ws_bytes": c_longlong,
+_RESTYPE = {"tsg_last_error": c_char_p, "tsg_lstm_bwd_ws_bytes": c_longlong, "tsg_lstm_fwd_ws_bytes": c_longlong, "tsg_scdm_bwd_ws_bytes": c_longlong,
              "tsg_wgrad_f32s_ws_bytes": c_longlong, "tsg_boundary_score_bwd_ws_bytes": c_longlong, "tsg_head_gemm_ws_bytes": c_longlong, "tsg_layer_norm_bwd_ws_bytes": c_longlong}
 
 
@@ -108,8 +110,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)            # AttributeError here = header / library mismatch
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, c_int)
-    if lib.tsg_version() != 5:
-        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 5 expected by the Python host code")
+    if lib.tsg_version() != 6:
+        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 6 expected by the Python host code")
     _lib = lib
     return lib
 

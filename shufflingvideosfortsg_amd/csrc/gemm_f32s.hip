@@ -441,7 +441,7 @@ int check_head(const char* fn, std::initializer_list<const void*> ptrs, int M, i
     if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
   }
   if (M <= 0 || T <= 0 || N <= 0 || K <= 0 || M % T) return set_error(TSG_E_SHAPE, "%s: bad dimensions M=%d T=%d N=%d K=%d (M must be B*T)", fn, M, T, N, K);
-  if (M % 64 || N % kTN || K % kBK || Hm % kTN || M > (1 << 23))
+  if (M % 64 || N % kTN || K % kBK || Hm % kTN || M > (1 << 22))   // (1 << 22: the epilogue derives the batch item of a row as (row + 0.5) * (1 / T) in fp32, exact below 2^22)
     return set_error(TSG_E_SHAPE, "%s: M=%d must be a multiple of 64, N=%d and the head width %d of 256, K=%d of 32", fn, M, N, Hm, K);
   if (ldx < K || ldw < K || ldx % 4 || ldw % 4) return set_error(TSG_E_ALIGN, "%s: ldx=%lld / ldw=%lld must be >= K and multiples of 4", fn, ldx, ldw);
   return 0;
@@ -537,7 +537,7 @@ extern "C" int tsg_boundary_head_gemm(const void* x, long long ldx, const void* 
                                       const void* b1, const void* w2, const void* b2, const void* gate, const int32_t* mask, void* y,
                                       void* p_start, void* p_end, void* ws, long long ws_bytes, int B, int T, int Hm, int K, void* stream) {
   const char* fn = "tsg_boundary_head_gemm";
-  if (B <= 0 || T <= 0 || (long long)B * T > (1 << 23)) return set_error(TSG_E_SHAPE, "%s: bad B=%d T=%d", fn, B, T);
+  if (B <= 0 || T <= 0 || (long long)B * T > (1 << 22)) return set_error(TSG_E_SHAPE, "%s: bad B=%d T=%d", fn, B, T);
   const int M = B * T, N = 2 * Hm;
   int rc = check_head(fn, {x, w_start, w_end, cs, b1, w2, b2, (const void*)p_start, (const void*)p_end, (const void*)ws}, M, T, N, K, ldx, ldw, Hm);
   if (rc) return rc;

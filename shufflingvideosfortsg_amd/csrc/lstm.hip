@@ -368,6 +368,11 @@ __device__ __forceinline__ u32x4 load_sc1_u4(const float* p) {           // inte
   asm volatile("global_load_dwordx4 %0, %1, off " TSG_LD_BITS : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+__device__ __forceinline__ u32x4 load_sc1_u4_s(const unsigned* sbase, unsigned voff) {   // scalar base + 32-bit lane offset (bytes): one VGPR per address
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2 " TSG_LD_BITS : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  return v;
+}
 __device__ __forceinline__ void store_sc1_u4(float* p, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off " TSG_ST_BITS : : "v"(p), "v"(v) : "memory");
 }
@@ -510,12 +515,20 @@ template <typename T> __device__ __forceinline__ void st1s(T* p, float v) { st1(
 template <int MODE> struct SeqT { typedef float type; };
 template <> struct SeqT<2> { typedef lstm_bf16 type; };
 
-template <int HJ, int MODE, int NW>               // HJ = h / 16 when known at compile time (no branch between MFMAs), else 0;
-__global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // NW = waves = A-tiles per workgroup (8: 32 units, one workgroup
+// XR (round 5): the hand-off goes through a COMPACT exchange ring instead of `out` itself.  Polling `out` means polling lines that were marked
+// once, up front, for all T steps (64 KB per XCD and step: far more than an L2 holds over a launch), so a poll that arrives before the producer's
+// store misses the L2 and fetches the stale sentinel line from the memory side -- and `out` rows of one slab lie T * 2h elements apart in the
+// model's batch-major layout.  The ring [4 slots][group][16 rows][h] (32 KiB per group and slot, 256 KiB per XCD at [128, ., 512]) never leaves
+// the L2 it is exchanged through: every poll, early or late, is an L2 hit.  Slot = step % 4; the sentinel protocol is unchanged, a producer
+// re-marks its part of slot (s + 2) % 4 right after its poll of step s (everybody has finished reading that slot's previous contents by then:
+// see the loop), and `out` gets an ordinary store off the critical path.  In the split-precision mode the ring carries h already split into
+// bf16 (hi, lo) -- one 128-byte line per (row, producer): hi halves then lo halves -- so the consumers copy planes instead of splitting the slab.
+template <int HJ, int MODE, int NW, bool XR = false> // HJ = h / 16 when known at compile time (no branch between MFMAs), else 0;
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_kernel(    // NW = waves = A-tiles per workgroup (8: 32 units, one workgroup
                                                                         // per CU; 4: 16 units, two independent chains per CU)
     const typename SeqT<MODE>::type* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh,
     typename SeqT<MODE>::type* __restrict__ out, typename SeqT<MODE>::type* __restrict__ R, float* __restrict__ Cs,
-    unsigned* __restrict__ sync, int B, int Bs, int T, int h, int HLS, int flags, int bm, ErrSink esink) {
+    unsigned* __restrict__ sync, int B, int Bs, int T, int h, int HLS, int flags, int bm, ErrSink esink, unsigned* __restrict__ xr = nullptr) {
   constexpr bool SPLIT = MODE >= 1, BF = MODE == 2;
   typedef typename SeqT<MODE>::type GT;
   constexpr int NT = 64 * NW, UW = 4 * NW, HTS = UW + 1;  // threads, units per workgroup, h-tile row stride
@@ -570,11 +583,22 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // NW = w
     for (int k = 0; k < 4; ++k) bi[k] = bias[(size_t)d * 4 * h + k * h + u];
   }
 
+  // exchange ring (XR): dword address of this workgroup's chunk of (slot, row): [slot][group][row][producer][CH dwords]
+  constexpr int CH = BF ? UW / 2 : UW;                     // dwords per (row, producer) chunk: fp32 UW values | UW/2 hi + UW/2 lo pairs | UW/2 bf16 pairs
+  const int rowdw = uslices * CH;                          // dwords per ring row (= h, or h / 2 with bf16 storage)
+  const int ngroups = 2 * bslices;
+  auto xr_row = [&](int slot, int row) { return xr + ((size_t)(slot * ngroups + group) * 16 + row) * rowdw; };
+  auto xr_chunk = [&](int slot, int row) { return xr_row(slot, row) + us * CH; };
   {
     // Every lane marks the elements of `out` it will store (all T steps) with the sentinel -- the same lane, the same
     // address and the same write-through path as the later h store, so the two stay ordered -- and the grid meets once
     // (arrival counter sync[1]) so that no consumer can poll an element before its sentinel is in memory.
-    {
+    if constexpr (XR) {                                      // the four ring slots instead of all T steps of `out`
+      const int row = tid / UW, col = tid % UW;
+      if (!BF || (col & 1) == 0)
+        for (int slot = 0; slot < 4; ++slot)
+          store_sc1_u(reinterpret_cast<float*>(xr_chunk(slot, row) + (BF ? col >> 1 : col)), MODE == 0 ? kSentinel : (kSentinel16 | (kSentinel16 << 16)));
+    } else {
       const int row = tid / UW, col = tid % UW;              // the same whole-line pattern as the h stores of the step loop
       if (b0 + row < B && (!BF || (col & 1) == 0))           // bf16: the even columns mark (and later store) two elements per dword
         for (int t = 0; t < T; ++t)
@@ -599,6 +623,17 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // NW = w
     const GT* g = Gx + (seq_row(d == 0 ? 0 : T - 1, b, Bs, T, bm) * 2 + d) * 4 * h + u;
     gxn[0] = ld1(g); gxn[1] = ld1(g + h); gxn[2] = ld1(g + 2 * h); gxn[3] = ld1(g + 3 * h);
   }
+#ifdef TSG_LSTM_DEFER_RC
+  // R / Cs of a step (saved for the backward, nobody waits for them) leave AFTER the next step's poll: issued right behind the h stores they sat
+  // in front of the poll loads in this CU's memory queue, and the poll's s_waitcnt vmcnt(0) waited for their acknowledgements too
+  float4 rc_g = make_float4(0.f, 0.f, 0.f, 0.f); float rc_c = 0.f; size_t rc_s = 0; bool rc_have = false;
+  unsigned* o_ptr = nullptr; unsigned o_val = 0u; bool o_have = false;       // (XR) this thread's dword of `out`
+  auto store_rc = [&]() {
+    if (o_have) *o_ptr = o_val;
+    if (rc_have) { Cs[rc_s] = rc_c; st4(R + rc_s * 4, rc_g); }
+    rc_have = o_have = false;
+  };
+#endif
   for (int step = 0; step < T; ++step) {
 #ifdef TSG_LSTM_TIMING
     tm0 = __builtin_amdgcn_s_memtime();
@@ -630,20 +665,25 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // NW = w
         // poll the slab until no element of this thread's 16-byte pieces is the sentinel (loads unconditional, see above)
         unsigned pending = 0u;
         const float* src[SV];
+        unsigned xoff[SV];
 #pragma unroll
         for (int i = 0; i < SV; ++i) {
           const int idx = tid + i * NT, r = idx / nrowp, c4 = idx % nrowp;
           const bool ok = r < 16 && b0 + r < B;
           if (ok) pending |= 1u << i;
-          src[i] = reinterpret_cast<const float*>(out + seq_row(tp, ok ? b0 + r : b0, Bs, T, bm) * 2 * h + d * h + (ok ? c4 * (BF ? 8 : 4) : 0));
+          if constexpr (XR) { src[i] = nullptr; xoff[i] = ok ? 4u * (unsigned)(r * rowdw + c4 * 4) : 0u; }   // byte offset inside the group's slab: the same every step
+          else src[i] = reinterpret_cast<const float*>(out + seq_row(tp, ok ? b0 + r : b0, Bs, T, bm) * 2 * h + d * h + (ok ? c4 * (BF ? 8 : 4) : 0));
         }
+        const unsigned* xbase = XR ? xr_row((step - 1) & 3, 0) : nullptr;     // (XR) wave-uniform slab base of the slot polled now
         // (measured and dropped: two or three staggered copies of the poll in flight -- the extra slab traffic costs more
         // than the shorter retry saves, 13.7 vs 11.5 us per step)
         static_assert(SV == 2 || SV == 4 || SV == 8, "the wait below lists 2, 4 or 8 loads");
         int spins = 0;
         while (true) {
 #pragma unroll
-          for (int i = 0; i < SV; ++i) q[i] = load_sc1_u4(src[i]);
+          for (int i = 0; i < SV; ++i) {
+            if constexpr (XR) q[i] = load_sc1_u4_s(xbase, xoff[i]); else q[i] = load_sc1_u4(src[i]);
+          }
           if constexpr (SV == 2)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]) : : "memory");
           else if constexpr (SV == 4)
@@ -657,7 +697,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // NW = w
             bool pend = false;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-              if constexpr (BF) pend = pend || (q[i][m] & 0xffffu) == kSentinel16 || (q[i][m] >> 16) == kSentinel16;
+              if constexpr (BF || (XR && SPLIT)) pend = pend || (q[i][m] & 0xffffu) == kSentinel16 || (q[i][m] >> 16) == kSentinel16;
               else pend = pend || q[i][m] == kSentinel;
             }
             if (pend) raw |= 1u << i;
@@ -684,10 +724,28 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // NW = w
       }
       TSG_TICK(0)                                            // poll: slab complete in registers
       prefetch_gx();
+#ifdef TSG_LSTM_DEFER_RC
+      store_rc();                                            // the step before's R / Cs: behind the poll, not in front of it
+#endif
+      if constexpr (XR) {
+        // re-mark this workgroup's part of slot (step + 2) % 4 (it held step - 2): this poll has seen step - 1 from every producer of the
+        // group, each of which stored it only after ITS poll of step - 1 -- the last reader of step - 2 -- had returned.  The mark is
+        // acknowledged before this workgroup's stores of step + 1 are issued (the next poll ends on vmcnt(0)), the data of step + 2 follows
+        // it from the same lane to the same address
+        const int row = tid / UW, col = tid % UW;
+        if (step + 2 < T && (!BF || (col & 1) == 0))
+          store_x(reinterpret_cast<float*>(xr_chunk((step + 2) & 3, row) + (BF ? col >> 1 : col)),
+                  __uint_as_float(MODE == 0 ? kSentinel : (kSentinel16 | (kSentinel16 << 16))), local);
+      }
 #pragma unroll
       for (int i = 0; i < SV; ++i) {
         const int idx = tid + i * NT, r = idx / nrowp, c4 = idx % nrowp;
-        if constexpr (BF) {
+        if constexpr (XR && SPLIT && !BF) {
+          // ring chunk = [hi pairs of the producer's UW units | lo pairs]: piece -> (producer, plane, 8 units) -> the LDS planes as they are
+          constexpr int PPC = UW / 4, PPH = PPC / 2;          // 16-byte pieces per chunk / per plane half
+          const int pp = c4 / PPC, qq = c4 % PPC;
+          if (r < 16) *reinterpret_cast<u32x4*>((qq >= PPH ? Hlo : Hhi) + r * kHLB + pp * (UW / 2) + 4 * (qq % PPH)) = q[i];
+        } else if constexpr (BF) {
           if (r < 16) *reinterpret_cast<u32x4*>(Hhi + r * kHLB + c4 * 4) = q[i];      // the bf16 row as it is: the one operand plane
         } else if constexpr (SPLIT) {
           uint2 hi2, lo2;
@@ -772,7 +830,33 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // NW = w
       Ht[jb * HTS + at * 4 + ku] = go * tanh_f(c);
     }
     lds_barrier();                                        // tile complete; the slab in LDS is free again
-    {
+    if constexpr (XR) {
+      // ring first (the hand-off); `out` -- which nobody polls any more -- is an ordinary store (deferred behind the next poll with R / Cs
+      // under TSG_LSTM_DEFER_RC).  Rows beyond B are neither stored nor polled.
+      const int row = tid / UW, col = tid % UW;
+      const bool rl = b0 + row < B;
+      unsigned ov = 0u, rv = 0u;                             // dword for `out`, dword for the ring
+      bool oact = rl, ract = rl && step + 1 < T;
+      if constexpr (BF) {
+        oact = oact && (col & 1) == 0; ract = ract && (col & 1) == 0;
+        ov = rv = pack_bf16x2(Ht[row * HTS + (col & ~1)], Ht[row * HTS + (col | 1)]);
+      } else if constexpr (SPLIT) {
+        const int pc = col % (UW / 2);                       // dword `col` of the chunk: hi pair pc (col < UW / 2) or lo pair pc
+        unsigned hi, lo;
+        split_pair(Ht[row * HTS + 2 * pc], Ht[row * HTS + 2 * pc + 1], hi, lo);
+        rv = col < UW / 2 ? hi : lo;
+        ov = __float_as_uint(Ht[row * HTS + col]);
+      } else {
+        ov = rv = __float_as_uint(Ht[row * HTS + col]);
+      }
+      if (ract) store_x(reinterpret_cast<float*>(xr_chunk(step & 3, row) + (BF ? col >> 1 : col)), __uint_as_float(rv), local);
+      unsigned* op = reinterpret_cast<unsigned*>(out + seq_row(tt, rl ? b0 + row : b0, Bs, T, bm) * 2 * h + d * h + us * UW + (BF ? (col & ~1) : col));
+#ifdef TSG_LSTM_DEFER_RC
+      o_ptr = op; o_val = ov; o_have = oact;
+#else
+      if (oact) *op = ov;
+#endif
+    } else {
       const int row = tid / UW, col = tid % UW;
       if constexpr (BF) {
         if (b0 + row < B && (col & 1) == 0)
@@ -782,6 +866,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // NW = w
         if (b0 + row < B) store_x(out + seq_row(tt, b0 + row, Bs, T, bm) * 2 * h + d * h + us * UW + col, Ht[row * HTS + col], local);
       }
     }
+#ifdef TSG_LSTM_DEFER_RC
+    rc_g = make_float4(gi, gf, gg, go); rc_c = c; rc_s = (((size_t)tt * 2 + d) * Bs + b) * h + u; rc_have = live;
+    if (step + 1 == T) store_rc();
+#else
     if (live) {
       const size_t s = (((size_t)tt * 2 + d) * Bs + b) * h + u;
       // (R / Cs as non-temporal stores: 3.70 -> 3.31 us per step stand-alone in the bf16 storage mode at [128, 128, 512], nothing in the train
@@ -789,6 +877,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_persist_kernel(    // NW = w
       Cs[s] = c;
       st4(R + s * 4, make_float4(gi, gf, gg, go));
     }
+#endif
 #ifdef TSG_LSTM_TIMING
     if (step > 0) TSG_TICK(3)                                // gates, stores issued, workgroup met
 #endif
@@ -907,6 +996,40 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
 #ifdef TSG_LSTM_TIMING
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tm0 = 0, tm1 = 0;
 #endif
+#ifdef TSG_LSTM_BWD_DEFER_DG
+  GT* dg_ptr = dG; float dg_val[4] = {0.f, 0.f, 0.f, 0.f}; bool dg_have = false;
+  auto store_dg = [&]() {
+    if (dg_have) {
+#pragma unroll
+      for (int gate = 0; gate < 4; ++gate) st1s(dg_ptr + gate * h, dg_val[gate]);
+    }
+    dg_have = false;
+  };
+#endif
+#ifdef TSG_LSTM_BWD_TOUCH
+  // The step's streamed operands (R, Cs, dOut of this workgroup's 16 x 32 tile: 6 lines per row with fp32 storage) come from memory, are requested in
+  // front of the poll and the poll's vmcnt(0) waits for them.  One dword of each of their lines is requested a step AHEAD, right behind the poll
+  // before (result unused): by the time the real loads are issued the lines sit in the L2.
+  unsigned touch_sink = 0u;
+  auto touch_next = [&](int stepn) {
+    if (stepn >= T) return;
+    const int fsn = T - 1 - stepn, ttn = d == 0 ? fsn : T - 1 - fsn;
+    const int tpn = d == 0 ? ttn - 1 : ttn + 1;
+    constexpr int LR = BF ? 2 : 4, LP = LR + 3;             // lines of R per row; lines per row in all (R, Cs of the step, Cs of its c_{t-1}, dOut)
+    if (tid < 16 * LP) {
+      const int r = tid / LP, k = tid % LP;
+      if (b0 + r < B && !(k == LR + 1 && (tpn < 0 || tpn >= T))) {
+        const size_t sidx = (((size_t)ttn * 2 + d) * Bs + b0 + r) * h + us * 32;
+        const char* p = k < LR ? reinterpret_cast<const char*>(R + sidx * 4) + 128 * k
+                      : k == LR ? reinterpret_cast<const char*>(Cs + sidx)
+                      : k == LR + 1 ? reinterpret_cast<const char*>(Cs + (((size_t)tpn * 2 + d) * Bs + b0 + r) * h + us * 32)
+                                : reinterpret_cast<const char*>(dOut + seq_row(ttn, b0 + r, Bs, T, bm) * 2 * h + d * h + us * 32);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink) : "v"(p) : "memory");
+      }
+    }
+  };
+  touch_next(1);
+#endif
   for (int step = 0; step < T; ++step) {
 #ifdef TSG_LSTM_TIMING
     tm0 = __builtin_amdgcn_s_memtime();
@@ -958,6 +1081,12 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
         }
       }
       TSG_TICK(0)                                            // poll: all partial blocks landed
+#ifdef TSG_LSTM_BWD_TOUCH
+      touch_next(step + 1);
+#endif
+#ifdef TSG_LSTM_BWD_DEFER_DG
+      store_dg();                                            // the step before's dG: behind the poll, not in front of it
+#endif
       f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -975,11 +1104,19 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
       const float dc = fmaf(dh * go, 1.f - tc * tc, dc_carry);
       dc_carry = dc * gf;
       const float dg[4] = {dc * gg * gi * (1.f - gi), dc * cpv * gf * (1.f - gf), dc * gi * (1.f - gg * gg), dh * tc * go * (1.f - go)};
+#ifdef TSG_LSTM_BWD_DEFER_DG
+      dg_ptr = dG + (seq_row(tt, live ? b : b0, Bs, T, bm) * 2 + d) * K + u;
+#pragma unroll
+      for (int gate = 0; gate < 4; ++gate) dg_val[gate] = dg[gate];
+      dg_have = live;
+      if (step + 1 == T || step == 0) store_dg();           // (step 0 has no poll behind it in step 1's sense: keep the first one simple)
+#else
       if (live) {
         GT* g = dG + (seq_row(tt, b, Bs, T, bm) * 2 + d) * K + u;
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) st1s(g + gate * h, dg[gate]);
       }
+#endif
 #pragma unroll
       for (int gate = 0; gate < 4; ++gate) {
         const float dgv = live ? dg[gate] : 0.f;
@@ -1169,13 +1306,49 @@ static int launch_flags() {       // bit 0: L2-local exchange allowed; bit 1: in
 }
 static bool persist_wanted(int T) { const int m = persist_mode(); return m > 0 || (m < 0 && T >= 8); }
 
+static int lstm_fwd_impl(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* sync_ws, long long ws_bytes,
+                         int B, int T, int h, int dtype, int batch_major, void* stream);
+
 extern "C" int tsg_lstm_fwd(const void* Gx, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                             int B, int T, int h, int dtype, void* stream) {
-  return tsg_lstm_fwd_bias(Gx, nullptr, Whh, out, R, Cs, sync_ws, B, T, h, dtype, 0, stream);
+  return lstm_fwd_impl(Gx, nullptr, Whh, out, R, Cs, sync_ws, sync_ws ? kSyncBytes : 0, B, T, h, dtype, 0, stream);
 }
 
 extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* sync_ws,
                                  int B, int T, int h, int dtype, int batch_major, void* stream) {
+  return lstm_fwd_impl(Gx, bias, Whh, out, R, Cs, sync_ws, sync_ws ? kSyncBytes : 0, B, T, h, dtype, batch_major, stream);
+}
+
+// workspace of tsg_lstm_fwd_ws: the sync words + the exchange ring [4 slots][2 * ceil(B/16) groups][16 rows][h] dwords (0: no ring for this h)
+extern "C" long long tsg_lstm_fwd_ws_bytes(int B, int T, int h) {
+  (void)T;
+  if (B <= 0 || h <= 0 || h % 128 || h > kPersistMaxH) return 0;
+  return kSyncBytes + 4LL * 2 * cdiv(B, 16) * 16 * h * (long long)sizeof(float);
+}
+
+extern "C" int tsg_lstm_fwd_ws(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* ws, long long ws_bytes,
+                               int B, int T, int h, int dtype, int batch_major, void* stream) {
+  if (ws && ws_bytes < kSyncBytes) return set_error(TSG_E_SHAPE, "tsg_lstm_fwd_ws: workspace of %lld bytes is smaller than TSG_LSTM_SYNC_BYTES", ws_bytes);
+  return lstm_fwd_impl(Gx, bias, Whh, out, R, Cs, ws, ws ? ws_bytes : 0, B, T, h, dtype, batch_major, stream);
+}
+
+static bool xr_wanted() {          // TSG_LSTM_XR=0: poll `out` itself even when the caller passed a ring (A/B)
+  static const bool on = !(getenv("TSG_LSTM_XR") && atoi(getenv("TSG_LSTM_XR")) == 0);
+  return on;
+}
+
+template <int HJ, int MODE, int NW, bool XR>
+static void launch_fwd_persist(int grid, size_t lds, hipStream_t st, const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs,
+                               void* ws, int Bc, int B, int T, int h, int HLS, int bm, size_t seq, int c0) {
+  typedef typename SeqT<MODE>::type GT;
+  const size_t K8 = (size_t)8 * h, H2 = (size_t)2 * h;
+  hipLaunchKernelGGL((lstm_fwd_persist_kernel<HJ, MODE, NW, XR>), dim3(grid), dim3(64 * NW), lds, st, (const GT*)Gx + seq * K8, (const float*)bias,
+                     (const float*)Whh, (GT*)out + seq * H2, (GT*)R + (size_t)c0 * h * 4, (float*)Cs + (size_t)c0 * h, (unsigned*)ws, Bc, B, T, h,
+                     HLS, launch_flags(), bm, error_sink(), XR ? (unsigned*)((char*)ws + kSyncBytes) : nullptr);
+}
+
+static int lstm_fwd_impl(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* sync_ws, long long ws_bytes,
+                         int B, int T, int h, int dtype, int batch_major, void* stream) {
   const int bm = batch_major != 0;
   const char* fn = "tsg_lstm_fwd";
   if (bias && !aligned16(bias)) return set_error(TSG_E_ALIGN, "%s: bias %p is not 16-byte aligned", fn, bias);
@@ -1183,6 +1356,7 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
     if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
   }
+  if (sync_ws && !aligned16(sync_ws)) return set_error(TSG_E_ALIGN, "%s: workspace %p is not 16-byte aligned", fn, sync_ws);
   int rc = lstm_check(fn, B, T, h, dtype);
   if (rc) return rc;
   auto st = static_cast<hipStream_t>(stream);
@@ -1201,48 +1375,47 @@ extern "C" int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* W
     static int nw_env = -1;
     if (nw_env < 0) { const char* e = getenv("TSG_LSTM_NW"); nw_env = e ? (atoi(e) == 4 ? 4 : 8) : 0; }
     const bool split = dtype == TSG_F32S;                  // other hidden sizes: the fp32 arithmetic (more accurate, slower)
-    const int NW = ((nw_env == 4 || (nw_env == 0 && B <= 32)) && h == 512 && split && !bf) ? 4 : 8;
+    // the exchange ring (XR kernels): the caller's workspace holds it, hidden sizes 128 / 256 / 384 / 512
+    const long long need = tsg_lstm_fwd_ws_bytes(B, T, h);
+    const bool xr = need > 0 && ws_bytes >= need && xr_wanted();
+    const int NW = ((nw_env == 4 || (nw_env == 0 && B <= 32)) && h == 512 && (split || (bf && xr))) ? 4 : 8;
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
     const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 33 + 4);
     static_assert(kSlabFloats >= 16 * (kPersistMaxH + 8), "slab region holds the fp32 slab too");
-    if (bf) {
-      auto pb = h == 512 ? lstm_fwd_persist_kernel<32, 2, 8> : h == 384 ? lstm_fwd_persist_kernel<24, 2, 8>
-              : h == 256 ? lstm_fwd_persist_kernel<16, 2, 8> : lstm_fwd_persist_kernel<8, 2, 8>;
-      const int capb = persist_capacity(3, pb, 64 * 8, plds, 1);
-      const int rowsb = persist_chunk_rows(B, h / 32, capb);
-      if (rowsb <= 0) return set_error(TSG_E_SHAPE, "%s: the persistent kernel cannot be co-resident on this device (TSG_BF16)", fn);
-      const size_t K8 = (size_t)8 * h, H2 = (size_t)2 * h;
-      for (int c0 = 0; c0 < B; c0 += rowsb) {
-        const int Bc = B - c0 < rowsb ? B - c0 : rowsb;
-        const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;
-        hipError_t e = zero_async(sync_ws, kSyncBytes, st);
-        if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-        hipLaunchKernelGGL(pb, dim3(persist_grid(cdiv(Bc, 16), h / 32, capb)), dim3(512), plds, st, (const lstm_bf16*)Gx + seq * K8, (const float*)bias,
-                           (const float*)Whh, (lstm_bf16*)out + seq * H2, (lstm_bf16*)R + (size_t)c0 * h * 4, (float*)Cs + (size_t)c0 * h,
-                           (unsigned*)sync_ws, Bc, B, T, h, HLS, launch_flags(), bm, error_sink());
-      }
-      return check_launch(fn);
+    typedef void (*Launch)(int, size_t, hipStream_t, const void*, const void*, const void*, void*, void*, void*, void*, int, int, int, int, int, int, size_t, int);
+    Launch go = nullptr;
+    int cap = 0;
+#define TSG_FWD_PICK(HJ_, MODE_, NW_, XR_, SLOT_)                                                                          \
+    { go = launch_fwd_persist<HJ_, MODE_, NW_, XR_>;                                                                        \
+      cap = persist_capacity(SLOT_, lstm_fwd_persist_kernel<HJ_, MODE_, NW_, XR_>, 64 * NW_, plds, NW_ == 4 ? 2 : 1); }
+#define TSG_FWD_PICK_H(MODE_, XR_, SLOT_)                                                                                  \
+    { if (h == 512) TSG_FWD_PICK(32, MODE_, 8, XR_, SLOT_) else if (h == 384) TSG_FWD_PICK(24, MODE_, 8, XR_, SLOT_)        \
+      else if (h == 256) TSG_FWD_PICK(16, MODE_, 8, XR_, SLOT_) else if (h == 128) TSG_FWD_PICK(8, MODE_, 8, XR_, SLOT_) }
+    if (NW == 4) {
+      if (bf) TSG_FWD_PICK(32, 2, 4, true, 1)
+      else if (xr) TSG_FWD_PICK(32, 1, 4, true, 1)
+      else TSG_FWD_PICK(32, 1, 4, false, 1)
+    } else if (bf) {
+      if (xr) TSG_FWD_PICK_H(2, true, 3) else TSG_FWD_PICK_H(2, false, 3)
+    } else if (split) {
+      if (xr) TSG_FWD_PICK_H(1, true, 0) else TSG_FWD_PICK_H(1, false, 0)
+    } else {
+      if (xr) TSG_FWD_PICK_H(0, true, 0) else TSG_FWD_PICK_H(0, false, 0)
     }
-    auto pk = NW == 4 ? lstm_fwd_persist_kernel<32, 1, 4>
-            : h == 512 ? (split ? lstm_fwd_persist_kernel<32, 1, 8> : lstm_fwd_persist_kernel<32, 0, 8>)
-            : h == 256 ? (split ? lstm_fwd_persist_kernel<16, 1, 8> : lstm_fwd_persist_kernel<16, 0, 8>)
-            : h == 384 ? (split ? lstm_fwd_persist_kernel<24, 1, 8> : lstm_fwd_persist_kernel<24, 0, 8>)
-            : h == 128 ? (split ? lstm_fwd_persist_kernel<8, 1, 8> : lstm_fwd_persist_kernel<8, 0, 8>)
-            : lstm_fwd_persist_kernel<0, 0, 8>;
-    const int cap = persist_capacity(NW == 4 ? 1 : 0, pk, 64 * NW, plds, NW == 4 ? 2 : 1);
+    if (!go) TSG_FWD_PICK(0, 0, 8, false, 0)               // other hidden sizes (multiples of 32): the generic fp32 kernel, polling `out`
+#undef TSG_FWD_PICK_H
+#undef TSG_FWD_PICK
     // more rows than co-resident workgroups allow (B = 256 at h = 512: grid 512 on 256 CUs): the rows are independent, so the
     // layer runs as consecutive launches over balanced row chunks (pointer offsets; Bs = B keeps the tensors' strides)
     const int rows = persist_chunk_rows(B, h / (4 * NW), cap);
+    if (bf && rows <= 0) return set_error(TSG_E_SHAPE, "%s: the persistent kernel cannot be co-resident on this device (TSG_BF16)", fn);
     if (rows > 0) {
-      const size_t K8 = (size_t)8 * h, H2 = (size_t)2 * h;
       for (int c0 = 0; c0 < B; c0 += rows) {
         const int Bc = B - c0 < rows ? B - c0 : rows;
         const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;              // first sequence row of the chunk
         hipError_t e = zero_async(sync_ws, kSyncBytes, st);
         if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
-        hipLaunchKernelGGL(pk, dim3(persist_grid(cdiv(Bc, 16), h / (4 * NW), cap)), dim3(64 * NW), plds, st, (const float*)Gx + seq * K8, (const float*)bias,
-                           (const float*)Whh, (float*)out + seq * H2, (float*)R + (size_t)c0 * h * 4, (float*)Cs + (size_t)c0 * h,
-                           (unsigned*)sync_ws, Bc, B, T, h, HLS, launch_flags(), bm, error_sink());
+        go(persist_grid(cdiv(Bc, 16), h / (4 * NW), cap), plds, st, Gx, bias, Whh, out, R, Cs, sync_ws, Bc, B, T, h, HLS, bm, seq, c0);
       }
       return check_launch(fn);
     }

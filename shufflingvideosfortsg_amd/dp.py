@@ -27,10 +27,23 @@ class FlatGradAllReduce:
 
     bucket_mb: target bucket size.  xGMI is point-to-point (7 links/GPU), so few large ring
     reductions beat many small ones; 32 MiB buckets give ~6 buckets for the 186 MB d=1024 model.
+
+    Launch order: the buckets are launched in INDEX order on every rank -- bucket b leaves from a hook only when buckets
+    0..b-1 have left, ``finish()`` flushes the rest in index order -- so the ranks issue the same sequence of collectives whatever
+    subset of parameters received a gradient on each of them (a bucket that completes early on one rank simply waits for the slower
+    ranks inside the collective; launching "whichever bucket completed first" mis-paired the all-reduces of ranks with unequal
+    gradient presence and hung).
+
+    gated=True (round 5, the GPU default of ``bench.py --gpus N``): the persistent LSTM kernels need every CU for the length of a layer
+    (one 512-thread workgroup per CU, all co-resident), so a bucket's all-reduce must never run BESIDE one.  The hot path calls
+    ``before_persistent()`` in front of every persistent launch of the backward (all outstanding collectives are waited for ON THE
+    STREAM, no host block) and ``after_persistent()`` behind it (every bucket that is complete, in index order, is gathered and
+    launched): RCCL's stream picks the collective up when the persistent kernel has finished, and it runs under the dX / weight-gradient
+    GEMMs that follow -- ordinary grids that share the CUs -- until the next persistent launch fences it.  Hooks only count.
     """
 
     def __init__(self, module: torch.nn.Module, process_group: Optional[dist.ProcessGroup] = None,
-                 bucket_mb: float = 32.0, overlap: bool = True, broadcast: bool = True):
+                 bucket_mb: float = 32.0, overlap: bool = True, broadcast: bool = True, gated: bool = False):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -68,14 +81,20 @@ class FlatGradAllReduce:
             self.buckets.append((start, off, cur))
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._next = 0             # next bucket to launch: the launch order is the index order on every rank
         self._handles = []
+        self._fenced = 0           # handles[:_fenced] have been waited for on the stream
         self.overlap = overlap and self.active
+        self._gated_wanted = bool(gated)
+        self.gated = self._gated_wanted and self.overlap
+        self._hooked = False
         # RCCL averages inside the reduction (no extra pass over the buffer); gloo has no AVG: sum, then one division
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         if self.overlap:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
+            self._hooked = True
         if broadcast and self.world > 1:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0, group=self.group)
@@ -86,7 +105,9 @@ class FlatGradAllReduce:
             p.grad = None
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._next = 0
         self._handles = []
+        self._fenced = 0
 
     def _gather(self, b):
         """Bucket b's gradients -> its slice of the flat buffer (one multi-tensor copy; parameters without a gradient
@@ -107,11 +128,42 @@ class FlatGradAllReduce:
         self._launched[b] = True
         self._handles.append(dist.all_reduce(self.flat[s:e], op=self._op, group=self.group, async_op=True))
 
+    def _advance(self, flush: bool = False):
+        """Launch, in index order, every bucket whose gradients are all there (``flush``: every remaining bucket; parameters
+        without a gradient contribute zeros)."""
+        while self._next < len(self.buckets) and (flush or self._ready[self._next] >= len(self.buckets[self._next][2])):
+            self._launch(self._next)
+            self._next += 1
+
     def _hook(self, p):
-        b = self._bucket_of[id(p)]
-        self._ready[b] += 1
-        if self._ready[b] == len(self.buckets[b][2]) and not self._launched[b]:
-            self._launch(b)
+        if not self.overlap:
+            return
+        self._ready[self._bucket_of[id(p)]] += 1
+        if not self.gated:
+            self._advance()
+
+    def set_overlap(self, on: bool, gated: Optional[bool] = None):
+        """Switch between the bucket-by-bucket exchange during the backward and ONE exchange after it (the graph-replay protocol needs
+        the latter).  The hooks are registered on first use and stay; they are inert while the overlap is off."""
+        on = bool(on) and self.active
+        if on and not self._hooked:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._hook)
+            self._hooked = True
+        self.overlap = on
+        self.gated = on and (self._gated_wanted if gated is None else bool(gated))
+
+    # -- gating against the persistent kernels (called by functional around every persistent launch of the backward) ------------
+    def before_persistent(self):
+        """Every collective launched so far must have finished before the kernel enqueued next starts: stream-level waits."""
+        for h in self._handles[self._fenced:]:
+            h.wait()
+        self._fenced = len(self._handles)
+
+    def after_persistent(self):
+        """A persistent kernel has just been enqueued: collectives launched now start when it has finished."""
+        if self.gated:
+            self._advance()
 
     def _set_guard(self, guard):
         slot = self.flat[self._numel:]
@@ -133,9 +185,7 @@ class FlatGradAllReduce:
             return
         self._set_guard(guard)
         if self.overlap:
-            for b in range(len(self.buckets)):             # buckets with parameters that received no gradient
-                if not self._launched[b]:
-                    self._launch(b)
+            self._advance(flush=True)                      # what the hooks / gates have not launched yet, in index order
             # the buckets are already in flight: the guard slot goes in a collective of its own (4 bytes)
             self._handles.append(dist.all_reduce(self.flat[self._numel:], op=self._op, group=self.group, async_op=True))
         else:

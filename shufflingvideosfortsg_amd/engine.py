@@ -144,11 +144,8 @@ def optimizer_step(opt, loss, dp=None, guard=None):
             opt.step()
         finally:
             opt.found_inf = None
-    elif dp is not None and getattr(dp, "active", False):
-        if float(bad.item()) == 0.0:                       # host-side optimizers (the gloo CPU tests): same rule, read on the host
-            opt.step()
-    else:
-        opt.step()
+    elif float(bad.item()) == 0.0:                         # host-side optimizers (CPU tests, non-fused GPU optimizers), with or without a
+        opt.step()                                         # gradient exchange: the same rule, the flag read on the host (one sync)
 
 
 class GraphedTrainStep:

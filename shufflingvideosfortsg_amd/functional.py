@@ -94,6 +94,27 @@ def check_kernel_errors() -> None:
                                 "TSG_LSTM_PERSIST=0 selects the launch-per-step LSTM kernels, TSG_K1_BWD=split the two-kernel K1 backward.")
 
 
+_persistent_gate = None      # dp.FlatGradAllReduce (gated mode): fences its collectives against the persistent / partner-exchange kernels
+
+
+def set_persistent_gate(gate) -> None:
+    """Register the object whose ``before_persistent()`` / ``after_persistent()`` are called around every backward launch that needs
+    the whole chip to itself (the persistent LSTM kernels: one workgroup per CU, all co-resident; the K1 backward's partner exchange:
+    ``before`` only).  ``None`` removes it.  See ``dp.FlatGradAllReduce`` (gated=True)."""
+    global _persistent_gate
+    _persistent_gate = gate
+
+
+def _gate_before():
+    if _persistent_gate is not None:
+        _persistent_gate.before_persistent()
+
+
+def _gate_after():
+    if _persistent_gate is not None:
+        _persistent_gate.after_persistent()
+
+
 def check_lstm_errors() -> None:
     """``check_kernel_errors`` preceded, once per process, by the persistent-LSTM self-test (before the first LSTM launch)."""
     global _selftest_done
@@ -389,6 +410,11 @@ _OWN_TRANSPOSE = os.environ.get("TSG_TRANSPOSE", "own") != "torch"     # A/B swi
 # TSG_NO_COPIES = out2 (default) / nn / 1 (both) / 0 (neither).
 _NC = os.environ.get("TSG_NO_COPIES", "out2")
 _NO_COPIES = _NC in ("1", "nn")                               # the contraction-major GEMM operand
+
+
+def _nn_ok(M: int) -> bool:
+    """tsg_gemm_f32s_nn (TSG_NO_COPIES=nn / 1) launches 256-row tiles only (M % 64 alone let a backward with 64 k rows raise)."""
+    return _NO_COPIES and M % 256 == 0
 _OUT2 = _NC in ("1", "out2")                                  # the two-output weight gradient
 
 
@@ -452,7 +478,7 @@ def _mm(a: torch.Tensor, b: torch.Tensor, mode=_AUTO) -> torch.Tensor:
         if a.is_cuda and a.is_contiguous() and gemm_f32s_ok(a.shape[0], b.shape[1], a.shape[1]):
             if b.t().is_contiguous():
                 return gemm_f32s(a, b.t())
-            if _NO_COPIES and b.stride(1) == 1 and b.stride(0) % 4 == 0 and b.data_ptr() % 16 == 0:   # [K,N] row-major (or a column slice):
+            if _nn_ok(a.shape[0]) and b.stride(1) == 1 and b.stride(0) % 4 == 0 and b.data_ptr() % 16 == 0:   # [K,N] row-major (or a column slice):
                 return gemm_f32s_nn(a, b)                                                  # the contraction-major form of the kernel, no transposed copy
             if b.is_contiguous() and b.numel() <= (1 << 24):
                 return gemm_f32s(a, transposed(b))
@@ -529,6 +555,7 @@ class _ScdmAttn(torch.autograd.Function):
         nb = int(load().tsg_scdm_bwd_ws_bytes(B, T, N, H, Ds, 0))
         ws = torch.empty(nb // 4 + 4, device=a.device, dtype=torch.float32)
         if ctx.dt != TSG_BF16 or scdm_bwd_fused_ok(B, T, N, H, Ds):
+            _gate_before()                          # the partner exchange of the one-launch backward wants its workgroup pairs co-resident
             _call("tsg_scdm_attn_bwd", a, ptr(a), ptr(s), ptr(w), ptr(sent), ptr(P), ptr(dC), ptr(da), ptr(ds),
                                            ptr(dw), ptr(dsent), ptr(ws), nb, B, T, N, H, Ds, ctx.dt)
         else:
@@ -581,6 +608,7 @@ class _ScdmGate(torch.autograd.Function):
         nb = int(load().tsg_scdm_bwd_ws_bytes(B, T, N, H, Ds, 1))
         ws = torch.empty(nb // 4 + 4, device=a.device, dtype=torch.float32)
         if ctx.dt != TSG_BF16 or scdm_bwd_fused_ok(B, T, N, H, Ds):
+            _gate_before()                          # the partner exchange of the one-launch backward wants its workgroup pairs co-resident
             _call("tsg_scdm_gate_bwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(r), ptr(P), ptr(dout),
                   ptr(da), ptr(ds), ptr(dw), ptr(dVW), ptr(dgb), ptr(dr), ptr(ws), nb, B, T, N, H, Ds, ctx.dt)
         else:
@@ -880,7 +908,7 @@ def head_gemm_ok(M: int, N: int, K: int, T: int, head_width: int) -> bool:
     """Shapes the fused head GEMMs (tsg_match_head_gemm / tsg_boundary_head_gemm, include/tsg_hip.h) take; the modules use them in the
     "f32s" mode (their arithmetic) and keep GEMM + K3 / K5 otherwise."""
     return (_GEMM_DTYPE == "f32s" and _OWN_GEMM and M > 0 and M % 64 == 0 and N % 256 == 0 and head_width % 256 == 0 and K % 32 == 0
-            and 0 < T <= 8192 and M % T == 0 and M <= (1 << 23))
+            and 0 < T <= 8192 and M % T == 0 and M <= (1 << 22))
 
 
 def _dx_f32s(dy2: torch.Tensor, w_rows: torch.Tensor) -> torch.Tensor:
@@ -888,7 +916,7 @@ def _dx_f32s(dy2: torch.Tensor, w_rows: torch.Tensor) -> torch.Tensor:
     constraints hold, else the generic split-precision product."""
     M, N = dy2.shape
     K = w_rows.shape[1]
-    if _NO_COPIES and gemm_f32s_ok(M, K, N) and w_rows.stride(1) == 1 and w_rows.stride(0) % 4 == 0 and w_rows.data_ptr() % 16 == 0:
+    if _nn_ok(M) and gemm_f32s_ok(M, K, N) and w_rows.stride(1) == 1 and w_rows.stride(0) % 4 == 0 and w_rows.data_ptr() % 16 == 0:
         return gemm_f32s_nn(dy2, w_rows)                           # the weight (slice) as it is stored: contraction-major operand
     if gemm_f32s_ok(M, K, N):
         return gemm_f32s(dy2, transposed(w_rows))
@@ -1017,7 +1045,7 @@ class _BoundaryHeadGemm(torch.autograd.Function):
         dy2, x2 = dy.view(B * T, J), x.view(B * T, K)
         dx = None
         if ctx.needs_input_grad[0]:
-            if _NO_COPIES and gemm_f32s_ok(B * T, K, J) and Hm % 32 == 0:
+            if _nn_ok(B * T) and gemm_f32s_ok(B * T, K, J) and Hm % 32 == 0:
                 dx = gemm_f32s_nn(dy2, ws_, we_).view(B, T, K)          # [W_start ; W_end] as two row segments, read in place
             else:
                 dx = _dx_f32s(dy2, torch.cat([ws_, we_], 0)).view(B, T, K)
@@ -1150,7 +1178,7 @@ class _BoundaryHeadFull(torch.autograd.Function):
         ws_, we_ = Ws[:, :Dv], We[:, :Dv]
         dx = None
         if ctx.needs_input_grad[0]:
-            if _NO_COPIES and gemm_f32s_ok(B * T, Dv, J) and Hm % 32 == 0:
+            if _nn_ok(B * T) and gemm_f32s_ok(B * T, Dv, J) and Hm % 32 == 0:
                 dx = gemm_f32s_nn(dy2, ws_, we_).view(B, T, Dv)         # [W_start ; W_end] as two row segments, read in place
             else:
                 dx = _dx_f32s(dy2, torch.cat([ws_, we_], 0)).view(B, T, Dv)
@@ -1211,7 +1239,8 @@ class _LayerNorm(torch.autograd.Function):
 
 
 def layer_norm_ok(x: torch.Tensor) -> bool:
-    return x.is_cuda and x.dtype in (torch.float32, _BF) and x.shape[-1] % 4 == 0 and x.shape[-1] <= 2048 and os.environ.get("TSG_LN", "1") != "0"
+    # (not under torch.autocast: F.layer_norm autocasts to fp32 in and out there, and this Function is not a custom_fwd one -- ADVICE r4)
+    return not torch.is_autocast_enabled() and x.is_cuda and x.dtype in (torch.float32, _BF) and x.shape[-1] % 4 == 0 and x.shape[-1] <= 2048 and os.environ.get("TSG_LN", "1") != "0"
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):
@@ -1253,7 +1282,7 @@ class _Dropout(torch.autograd.Function):
 
 
 def dropout_ok(x) -> bool:
-    return _OWN_DROPOUT and x.is_cuda and x.dtype in (torch.float32, _BF) and x.numel() > 0
+    return not torch.is_autocast_enabled() and _OWN_DROPOUT and x.is_cuda and x.dtype in (torch.float32, _BF) and x.numel() > 0
 
 
 def dropout(x, p, training=True):
@@ -1491,6 +1520,14 @@ def linear_hip(x, w, b=None):
     return _LinearHip.apply(x, w, b)
 
 
+def _lstm_fwd_ws(B, T, h, device):
+    """Workspace of ``tsg_lstm_fwd_ws`` (int32 tensor, byte count): TSG_LSTM_SYNC_BYTES of sync words, followed -- for the hidden sizes
+    the persistent kernel takes -- by its exchange ring.  A fresh allocation per call (the caching allocator returns the same block in a
+    steady-state step; inside a graph capture it belongs to the graph's pool), never shared between launches that may overlap."""
+    nb = max(int(load().tsg_lstm_fwd_ws_bytes(B, T, h)), 2048)
+    return torch.empty(nb // 4, device=device, dtype=torch.int32), nb
+
+
 class _BiLSTMLayer(torch.autograd.Function):
     """One bidirectional LSTM layer from zero state.  x [T,B,I] (time-major) or, with ``bm``, [B,T,I] (batch-major, the
     model's layout: the kernels index the sequence tensors either way, so no transposed copies surround the recurrence);
@@ -1530,12 +1567,12 @@ class _BiLSTMLayer(torch.autograd.Function):
         out = torch.empty((B, T, 2 * h) if bm else (T, B, 2 * h), device=x.device, dtype=torch.float32)
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=torch.float32)
         Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
-        sync = torch.empty(512, device=x.device, dtype=torch.int32)         # TSG_LSTM_SYNC_BYTES: persistent-kernel sync words
+        sync, nws = _lstm_fwd_ws(B, T, h, x.device)                        # sync words + the persistent kernel's exchange ring
         # outside the strict-fp32 mode the recurrence's W_hh products are split-precision bf16 MFMAs as well (TSG_F32S)
         ctx.rec_dtype = TSG_F32 if mode is None else TSG_F32S
         check_lstm_errors()
-        _call("tsg_lstm_fwd_bias", x, ptr(Gx), ptr(kbias) if kbias is not None else None, ptr(W_hh), ptr(out), ptr(R), ptr(Cs),
-              ptr(sync), B, T, h, ctx.rec_dtype, int(bm))
+        _call("tsg_lstm_fwd_ws", x, ptr(Gx), ptr(kbias) if kbias is not None else None, ptr(W_hh), ptr(out), ptr(R), ptr(Cs),
+              ptr(sync), nws, B, T, h, ctx.rec_dtype, int(bm))
         ctx.lstm_sync = sync
         ctx.bm = bool(bm)
         ctx.save_for_backward(x, W_ih, W_hh, out, R, Cs)
@@ -1560,8 +1597,10 @@ class _BiLSTMLayer(torch.autograd.Function):
         fused_db = ws is not None and bool(load().tsg_lstm_bwd_ws_persistent(B, T, h, nb))   # persistent path also sums dG -> dbias
         dbias = torch.empty(8 * h, device=x.device, dtype=torch.float32) if fused_db else None
         check_lstm_errors()
+        _gate_before()
         _call("tsg_lstm_bwd_ws_layout", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC),
               ptr(ws) if ws is not None else None, nb, ptr(dbias) if fused_db else None, B, T, h, ctx.rec_dtype, int(bm))
+        _gate_after()
         dGf = dG.view(TB, 8 * h)
         mode = ctx.mode
         fast = mode == "f32s" and T > 1 and TB % 16 == 0 and h % 4 == 0 and I % 4 == 0
@@ -1577,7 +1616,7 @@ class _BiLSTMLayer(torch.autograd.Function):
             # launch for dG[d]^T [x | h_{t-+1}[d]] of both directions, the shifted h rows read straight from `out`, written as the two
             # parameter-shaped tensors (tsg_wgrad_f32s_out2)
             if ctx.needs_input_grad[0]:
-                dx = (gemm_f32s_nn(dGf, W_ih) if _NO_COPIES else gemm_f32s(dGf, transposed(W_ih))).view(x.shape)
+                dx = (gemm_f32s_nn(dGf, W_ih) if _nn_ok(TB) else gemm_f32s(dGf, transposed(W_ih))).view(x.shape)
             if _OUT2:
                 dW_ih, dW_hh = wgrad_f32s_out2(dGf, x2, o2, N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h, shift=shift, period=period)
                 return dx, dW_ih.view(8 * h, I), dbias, dW_hh, None, None, (dbias if ctx.two_biases else None)
@@ -1650,9 +1689,9 @@ class _BiLSTMLayerBf16(torch.autograd.Function):
         out = torch.empty(B, T, 2 * h, device=x.device, dtype=_BF)
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=_BF)
         Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
-        sync = torch.empty(512, device=x.device, dtype=torch.int32)
+        sync, nws = _lstm_fwd_ws(B, T, h, x.device)
         check_lstm_errors()
-        _call("tsg_lstm_fwd_bias", x, ptr(Gx), ptr(bias), ptr(W_hh), ptr(out), ptr(R), ptr(Cs), ptr(sync), B, T, h, TSG_BF16, 1)
+        _call("tsg_lstm_fwd_ws", x, ptr(Gx), ptr(bias), ptr(W_hh), ptr(out), ptr(R), ptr(Cs), ptr(sync), nws, B, T, h, TSG_BF16, 1)
         ctx.lstm_sync = sync
         ctx.save_for_backward(x, Wb, W_hh, out, R, Cs)
         ctx.mark_non_differentiable(Cs)
@@ -1673,8 +1712,10 @@ class _BiLSTMLayerBf16(torch.autograd.Function):
         ws = torch.empty(nb // 4 + 4, device=x.device, dtype=torch.float32)
         dbias = torch.empty(8 * h, device=x.device, dtype=torch.float32)
         check_lstm_errors()
+        _gate_before()
         _call("tsg_lstm_bwd_ws_layout", x, ptr(WhhT), ptr(R), ptr(Cs), ptr(dOut), None, ptr(dG), ptr(dC), ptr(ws), nb, ptr(dbias),
               B, T, h, TSG_BF16, 1)
+        _gate_after()
         dGf = dG.view(TB, 8 * h)
         dx = torch.mm(dGf, Wb).view(x.shape) if ctx.needs_input_grad[0] else None
         if _WGRAD_KERNEL and wgrad_f32s_ok(TB, 4 * h, I, h):

@@ -34,7 +34,8 @@ class MomentPooling(nn.Module):
         return torch.bmm(M, feat) / (M.sum(2, keepdim=True) + 1e-6)               # [B,K,D]
 
     def forward(self, feat, target_mask, fore_mask, back_mask):
-        if feat.is_cuda and feat.dim() == 3 and target_mask.dim() == 2 and feat.size(-1) % 4 == 0 and feat.dtype in (torch.float32, torch.bfloat16):
+        if (feat.is_cuda and feat.dim() == 3 and target_mask.dim() == 2 and feat.size(-1) % 4 == 0 and feat.dtype in (torch.float32, torch.bfloat16)
+                and not torch.is_autocast_enabled()):
             tgt, fore_avg, back_avg = TF.moment_pool(feat, target_mask, fore_mask, back_mask)   # [B,D] fp32 each, one pass over feat
         elif feat.dim() == 3 and target_mask.dim() == 2:
             pooled = self.average_masks(feat, (target_mask, fore_mask, back_mask)).float()      # [B,3,D]: the small MLPs stay fp32

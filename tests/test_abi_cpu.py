@@ -29,7 +29,7 @@ def test_exports_match_header(lib):
     assert want == _lib.exported_symbols(), "ctypes signature table and header disagree"
     for name in want:
         assert hasattr(lib, name), f"{name} declared in tsg_hip.h but not exported by libtsg_hip.so"
-    assert lib.tsg_version() == 5
+    assert lib.tsg_version() == 6
 
 
 def test_argument_errors_without_gpu(lib):

@@ -108,21 +108,43 @@ class Branchy(nn.Module):
         self.only0 = nn.Linear(4, 4)
         self.never = nn.Linear(2, 2)
 
+    gate = None
+
     def forward(self, x, use_branch):
         y = torch.tanh(self.shared(x))
+        if self.gate is not None:
+            y = self.gate(y)
         if use_branch:
             y = y + self.only0(y)
+        elif self.gate is not None:
+            y = self.gate(y)
         return y.pow(2).mean()
 
 
-def _worker4(rank, world, port, protocol, poison_rank, out):
+def _worker4(rank, world, port, protocol, poison_rank, out, bucket_mb=0.0001):
     import copy
     from shufflingvideosfortsg_amd import engine
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
     torch.manual_seed(7)
     model = Branchy()
-    dp = FlatGradAllReduce(model, bucket_mb=0.0001, overlap=(protocol == "overlap"))
+    dp = FlatGradAllReduce(model, bucket_mb=bucket_mb, overlap=protocol in ("overlap", "gated"), gated=(protocol == "gated"))
+    if protocol == "gated":
+        # what functional does around a persistent launch of the backward: a fence in front, the complete buckets launched behind it.
+        # Here the "persistent launch" sits in the middle of the backward (a hook on the hidden activation) and only on ranks 1..3 a second
+        # time -- the ranks reach their gates with different sets of complete buckets
+        calls = []
+
+        class Gate(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, y):
+                return y.view_as(y)
+
+            @staticmethod
+            def backward(ctx, g):
+                dp.before_persistent(); calls.append("gate"); dp.after_persistent()
+                return g
+        model.gate = Gate.apply
     opt = torch.optim.Adam(model.parameters(), lr=0.1)          # host optimizer: engine.optimizer_step reads the reduced flag on the host
     before = copy.deepcopy(model.state_dict())
     g = torch.Generator().manual_seed(11)
@@ -146,15 +168,18 @@ def _worker4(rank, world, port, protocol, poison_rank, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("protocol", ["after", "overlap", "static"])
+@pytest.mark.parametrize("protocol,bucket_mb", [("after", 0.0001), ("overlap", 0.0001), ("static", 0.0001),
+                                                # one bucket PER PARAMETER: rank 0 completes `only0.*` by hooks, the others never do --
+                                                # with "launch whichever bucket completed" the ranks issued their all-reduces in different orders and hung
+                                                ("overlap", 1e-6), ("gated", 1e-6), ("gated", 0.0001)])
 @pytest.mark.parametrize("poison_rank", [None, 2])
-def test_world4_unequal_gradient_presence_and_reduced_guard(protocol, poison_rank):
+def test_world4_unequal_gradient_presence_and_reduced_guard(protocol, bucket_mb, poison_rank):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     world = 4
-    procs = [ctx.Process(target=_worker4, args=(r, world, port, protocol, poison_rank, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, protocol, poison_rank, q, bucket_mb)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted((q.get() for _ in range(world)), key=lambda t: t[0])

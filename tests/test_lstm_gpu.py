@@ -240,6 +240,44 @@ def test_bilstm_batch_major_layout(shape, dt):
         torch.testing.assert_close(a, b, atol=0, rtol=0)
 
 
+@pytest.mark.parametrize("shape", [(128, 24, 512), (33, 12, 128), (64, 20, 512), (40, 9, 256), (16, 10, 384), (96, 8, 512), (256, 8, 512)])
+@pytest.mark.parametrize("dt", [0, 2, 1])
+@pytest.mark.parametrize("bm", [0, 1])
+def test_exchange_ring_forward_equals_out_polling(shape, dt, bm):
+    """tsg_lstm_fwd_ws (round 5: the hand-off through the compact exchange ring in the caller's workspace; in the f32s arithmetic the
+    ring carries h already split into bf16 halves) gives bit-identical out / R / Cs to tsg_lstm_fwd_bias (consumers poll the
+    sentinel-marked `out` itself) -- strict fp32, f32s and bf16 storage, both layouts, B % 16 != 0, the chunked 256-row case, all four
+    hidden sizes -- on a workspace full of stale non-sentinel data, twice in a row on the same buffers."""
+    from shufflingvideosfortsg_amd import _lib
+    from shufflingvideosfortsg_amd._lib import ptr
+    B, T, h = shape
+    lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(B * T + h + dt)
+    bf = dt == 1
+    seq = torch.bfloat16 if bf else torch.float32
+    Gx = (torch.randn(*((B, T) if bm else (T, B)), 2, 4 * h, generator=g) * 0.5).cuda().to(seq)
+    W = (torch.randn(2, 4 * h, h, generator=g) / h ** 0.5).cuda(); bias = (torch.randn(8 * h, generator=g) * 0.1).cuda()
+    nws = lib.tsg_lstm_fwd_ws_bytes(B, T, h)
+    assert nws > 2048
+    res = []
+    for ring in (False, True, True):
+        ws = torch.full((nws // 4,), 0x3f800000, dtype=torch.int32, device="cuda")      # stale "data" (1.0f), not sentinels
+        out = torch.full((B, T, 2 * h) if bm else (T, B, 2 * h), 9.0, device="cuda", dtype=seq)
+        R = torch.empty(T, 2, B, h, 4, device="cuda", dtype=seq); Cs = torch.empty(T, 2, B, h, device="cuda")
+        if ring:
+            rc = lib.tsg_lstm_fwd_ws(ptr(Gx), ptr(bias), ptr(W), ptr(out), ptr(R), ptr(Cs), ptr(ws), nws, B, T, h, dt, bm, st)
+        else:
+            rc = lib.tsg_lstm_fwd_bias(ptr(Gx), ptr(bias), ptr(W), ptr(out), ptr(R), ptr(Cs), ptr(ws), B, T, h, dt, bm, st)
+        assert rc == 0, lib.tsg_last_error()
+        torch.cuda.synchronize()
+        assert int(ws[0]) == 0, "bounded wait expired"
+        assert torch.isfinite(out.float()).all()
+        res.append((out, R, Cs))
+    for k in (1, 2):
+        for a, b in zip(res[0], res[k]):
+            assert torch.equal(a, b)
+
+
 def test_persistent_lstm_timeout_is_reported():
     """A persistent launch whose start barrier cannot complete (TSG_LSTM_INJECT_TIMEOUT: workgroup 0 never arrives) must not
     hang, must set the launch's error word, and must surface as LstmWaitExpired on the next LSTM call (pinned error sink,
