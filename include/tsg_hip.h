@@ -210,8 +210,12 @@ int tsg_lstm_fwd_bias(const void* Gx, const void* bias, const void* Whh, void* o
  * h % 128 != 0 or h > 512), 16-byte aligned, caller-owned, contents irrelevant on entry.  With it the workgroups hand h_t over through
  * the ring (which stays inside the L2s it is exchanged through; in the TSG_F32S arithmetic it carries h already split into bf16 hi / lo
  * halves) instead of polling `out`; `out` is written with ordinary stores.  Results are bit-identical to tsg_lstm_fwd_bias.  A smaller
- * workspace (>= TSG_LSTM_SYNC_BYTES) or TSG_LSTM_XR=0 in the environment selects the tsg_lstm_fwd_bias behaviour.                     */
+ * workspace (>= TSG_LSTM_SYNC_BYTES), or a shape at which the ring is not the faster path (tsg_lstm_set_ring), selects the
+ * tsg_lstm_fwd_bias behaviour.                                                                                                         */
 long long tsg_lstm_fwd_ws_bytes(int B, int T, int h);
+/* When tsg_lstm_fwd_ws takes the ring: -1 = automatic (default: where it measured faster -- B >= 96 rows, or TSG_BF16 at B <= 32; TSG_LSTM_XR=0/1
+ * in the environment overrides the default), 0 = never, 1 = whenever the workspace holds one.  Process-wide, like tsg_lstm_set_persist. */
+int tsg_lstm_set_ring(int mode);
 int tsg_lstm_fwd_ws(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* ws, long long ws_bytes,
                     int B, int T, int h, int dtype, int batch_major, void* stream);
 
@@ -349,6 +353,16 @@ int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, long long ldw,
 int tsg_gemm_f32s_nn(const void* x, long long ldx, const void* w0, const void* w1, int kseg, long long ldw, const void* bias,
                      void* y, long long ldy, int M, int N, int K, void* stream);
 
+/* ---- The same projections in the bf16 STORAGE mode (ABI revision 6; csrc/gemm_bf16.hip): y [M,N] = x [M,K] . w [N,K]^T (+ bias [N], fp32 or
+ * NULL); x and w are bf16 matrices (row strides ldx / ldw in elements, multiples of 8; w as an nn.Linear stores its weight), fp32 accumulation,
+ * y bf16 (out_dtype TSG_BF16) or fp32 (TSG_F32), row stride ldy elements (even).  Operands go global -> LDS by DMA and are read as MFMA
+ * fragments without passing a register; replaces torch.mm -> hipBLASLt for W_s / W_a / sent_linear (networks/attention.py:104-113,
+ * components/VideoEncoder.py:59), the heads' first Linear (SpanPredictor.py:71-85, DistributionAlign.py:83-118) and nn.LSTM's input
+ * projection and input gradient (networks/RNN.py:31,42: dX = dG W^T^T takes a transposed bf16 copy of the weight).
+ * M % 128 == 0, N % 256 == 0, K % 32 == 0; 16-byte aligned pointers.                                                                       */
+int tsg_gemm_bf16(const void* x, long long ldx, const void* w, long long ldw, const void* bias, void* y, long long ldy,
+                  int M, int N, int K, int out_dtype, void* stream);
+
 /* ---- the heads as the EPILOGUE of their own first-Linear GEMM (ABI revision 5; round-3 review: SURVEY 8f #2 "split-W Linear + ReLU
  * + dot epilogue").  Same f32s arithmetic and tiling as tsg_gemm_f32s (row tiles of 256 / 128 / 64 so that a narrow head still
  * covers the chip); the accumulator tile goes through the head's tail in registers and only [rows]-sized logits leave the kernel.
@@ -412,6 +426,12 @@ int tsg_split_bf16x3_t(const void* x, long long ld_in, long long row_shift, long
  * ws: scratch of tsg_wgrad_f32s_ws_bytes(...) bytes (0: may be NULL) -- partial tiles of the row ranges the contraction is cut
  * into, added in a fixed order by a second launch: results are run-to-run identical.                                        */
 long long tsg_wgrad_f32s_ws_bytes(long long M, int N, int K0, int K1, int groups);
+/* How row ranges of a tile are combined (ABI revision 6).  Where the tile count does not fill the chip evenly but is at least half of it, the
+ * kernels can cut the flattened (tile, chunk) space into one equal piece per CU ("stream-K": a tile's last-arriving contributor adds the partial
+ * tiles in a fixed order -- no reduce launch, run-to-run identical) instead of `splits` whole row ranges per tile + a reduce kernel.  mode -1 =
+ * automatic (default: stream-K for bf16 operands, where it measured 5 % faster; the row-range scheme for fp32 operands, where it did not),
+ * 0 = never, 1 = always; TSG_WGRAD_SK=0/1 in the environment sets the initial mode.  tsg_wgrad_f32s_ws_bytes covers either scheme.          */
+int tsg_wgrad_set_stream_k(int mode);
 int tsg_wgrad_f32s(const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
                    const void* B1, long long ldb1, long long b1_group_stride, int K1, long long shift, long long period,
                    void* C, long long ldc, long long c_group_stride, void* ws, long long ws_bytes,

@@ -48,6 +48,9 @@ _SIGNATURES = {
     "tsg_lstm_error_sink": [_P],
     "tsg_lstm_set_l2_exchange": [_I],
     "tsg_lstm_set_persist": [_I],
+    "tsg_lstm_set_ring": [_I],
+    "tsg_wgrad_set_stream_k": [_I],
+    "tsg_gemm_bf16": [_P, c_longlong, _P, c_longlong, _P, _P, c_longlong, _I, _I, _I, _I, _P],
     "tsg_match_head_fwd": [_P] * 5 + [_I] * 5 + [_P],
     "tsg_match_head_bwd": [_P] * 8 + [_I] * 5 + [_P],
     "tsg_gmd_losses_fwd": [_P] * 13 + [_I, _I, c_float, c_float, c_float, _P],

@@ -1332,10 +1332,20 @@ extern "C" int tsg_lstm_fwd_ws(const void* Gx, const void* bias, const void* Whh
   return lstm_fwd_impl(Gx, bias, Whh, out, R, Cs, ws, ws ? ws_bytes : 0, B, T, h, dtype, batch_major, stream);
 }
 
-static bool xr_wanted() {          // TSG_LSTM_XR=0: poll `out` itself even when the caller passed a ring (A/B)
-  static const bool on = !(getenv("TSG_LSTM_XR") && atoi(getenv("TSG_LSTM_XR")) == 0);
-  return on;
+// Where the ring pays (profiles/r5/lstm_fwd_ring_*_v1.txt, one MI355X, us per step out-polling -> ring): at the full-chip grids -- [128, 128, 512]
+// f32s 3.85-3.91 -> 3.81-3.83 batch-major, 3.76 -> 3.60 time-major; bf16 storage 3.75-3.77 -> 3.69-3.70 -- and, with bf16 storage, at the
+// 16-pair shards of BASELINE configs 3 / 4 (<= 32 rows), where it makes the 4-wave workgroups possible (one A-tile per wave needs no second
+// register set: 146 VGPRs): 3.26 -> 2.87 at [32, 512, 512], 3.16 -> 2.67 at [16, 128, 512].  It LOSES at half-chip grids ([64, ., 512]: 3.32 ->
+// 3.49 f32s: one group per XCD, nothing contends for the L2 and the extra re-mark / `out` stores are pure cost) and in f32s at <= 32 rows (the
+// 4-wave f32s ring kernel spills: 2.91 -> 3.32).  TSG_LSTM_XR=1 / 0: always / never (A/B).
+static std::atomic<int> g_xr{-2};     // -2: not decided yet (TSG_LSTM_XR); -1 auto, 0 never, 1 always; tsg_lstm_set_ring overrides
+static bool xr_wanted(int B, bool bf) {
+  int v = g_xr.load(std::memory_order_relaxed);
+  if (v == -2) { const char* e = getenv("TSG_LSTM_XR"); v = e ? (atoi(e) != 0) : -1; g_xr.store(v, std::memory_order_relaxed); }
+  if (v >= 0) return v != 0;
+  return B >= 96 || (bf && B <= 32);
 }
+extern "C" int tsg_lstm_set_ring(int mode) { g_xr.store(mode < 0 ? -1 : (mode != 0), std::memory_order_relaxed); return 0; }
 
 template <int HJ, int MODE, int NW, bool XR>
 static void launch_fwd_persist(int grid, size_t lds, hipStream_t st, const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs,
@@ -1377,7 +1387,7 @@ static int lstm_fwd_impl(const void* Gx, const void* bias, const void* Whh, void
     const bool split = dtype == TSG_F32S;                  // other hidden sizes: the fp32 arithmetic (more accurate, slower)
     // the exchange ring (XR kernels): the caller's workspace holds it, hidden sizes 128 / 256 / 384 / 512
     const long long need = tsg_lstm_fwd_ws_bytes(B, T, h);
-    const bool xr = need > 0 && ws_bytes >= need && xr_wanted();
+    const bool xr = need > 0 && ws_bytes >= need && xr_wanted(B, bf);
     const int NW = ((nw_env == 4 || (nw_env == 0 && B <= 32)) && h == 512 && (split || (bf && xr))) ? 4 : 8;
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
     const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 33 + 4);

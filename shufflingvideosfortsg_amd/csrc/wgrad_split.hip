@@ -36,6 +36,7 @@
 // 121-124 us, the step 14.60-14.65 vs 14.36-14.43 ms (profiles/r4/wgrad_tile256_ab_v1.txt): fewer, larger tiles need twice the row
 // ranges (partial-tile traffic) and lose the sched_group_barrier interleave below, which is worth more than the geometry.)
 #include "tsg_common.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace tsg {
@@ -50,6 +51,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 32;                                  // rows of the contraction per chunk
 constexpr int P = 20;                                   // LDS pitch of one column in dwords: 16 (32 bf16 rows) + 4
 
+constexpr int kMaxContrib = 3;                          // stream-K: workgroups that may contribute to one output tile
 struct WgradArgs {                                      // A / B0 / B1: fp32 (tsg_wgrad_f32s) or bf16 (tsg_wgrad_bf16) elements; strides in elements
   const void* A; long lda; long a_gs;
   const void* B0; long ldb0; int K0;
@@ -59,7 +61,18 @@ struct WgradArgs {                                      // A / B0 / B1: fp32 (ts
   float* ws;                                            // ... or partials [splits][groups][N][K0+K1]
   long M; int N; int groups; int splits; int cps;       // cps = chunks (of 32 rows) per split
   unsigned per_magic; int per_sh;                       // row / period = (row * per_magic) >> per_sh  (rows < 2^31; host: period_division)
+  // stream-K (round 5; ipw > 0): the grid's workgroups cut the flattened (tile, chunk) space into equal pieces of ipw chunks -- a workgroup
+  // covers the tail of one tile and the head of the next -- instead of `splits` whole row ranges per tile.  A tile that several workgroups
+  // contribute to (at most kMaxContrib) is finished by its LAST arriver: see finish_tile.
+  long ipw;                                             // chunks per workgroup (0 = the split / reduce-kernel scheme above)
+  unsigned* tickets;                                    // [tiles] arrival counters, zero at launch, zero again at exit
+  float* part;                                          // [tiles][kMaxContrib][TN * TK] partial accumulators in register order
 };
+
+typedef float w_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_agent_x4(float* p, w_f32x4 v) {       // write-through (agent scope): visible to an sc1 load on another XCD
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // (rne(a), rne(b)) packed, a in the low half
   return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
@@ -149,17 +162,90 @@ struct Role {
   }
 };
 
+// Epilogue shared by the kernels of this file: the wave's 2 x 2 accumulator blocks (row = n, column = k on the lanes) go
+//   * straight to C / C1 (the workgroup computed the whole contraction of the tile),
+//   * to this row range's partial tile in the workspace (the split scheme; wgrad_reduce_kernel adds them), or
+//   * stream-K: to the tile's partial slot `me` of `ncontrib` (write-through stores in register order, s_waitcnt vmcnt(0), barrier, one relaxed
+//     agent-scope ticket -- the K3 / K1 backward's publication recipe, under the ISA gate of tests/test_isa_cpu.py); the LAST arriver reads the
+//     other slots with device-coherent loads, adds the contributions in slot order -- its own from registers -- and writes C.  The sum order
+//     is fixed by the slot index, so the result does not depend on who arrives last; no float atomics, no second kernel, and a tile's partial
+//     data (128 KiB per slot) is written and read once instead of `splits` times through a reduce launch.
+// a tile lies inside one column segment (K0 % 128 == 0); with a second output the B1 segment's tiles go to C1, columns from 0.
+__device__ __forceinline__ void store_tile(const WgradArgs& a, const f32x16 (&acc)[2][2], float* out, long ldo, int n0, int k0, int wn, int wk, int lane) {
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int n = n0 + 64 * wn + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * hh;
+        const int k = k0 + 64 * wk + 32 * j + r;
+        out[(size_t)n * ldo + k] = acc[i][j][q];
+      }
+}
+template <int NT, int TNK>                              // NT threads, TNK = TN * TK elements per tile
+__device__ __forceinline__ void finish_tile(const WgradArgs& a, f32x16 (&acc)[2][2], int tile, int g, int n0, int k0, int wn, int wk,
+                                            int me, int ncontrib, unsigned* flag) {
+  const int tid = threadIdx.x, lane = tid & 63, K = a.K0 + a.K1;
+  const bool to1 = a.C1 && k0 >= a.K0;
+  float* out = to1 ? a.C1 + g * a.c1_gs - a.K0 : a.C + g * a.c_gs;
+  const long ldo = to1 ? a.ldc1 : a.ldc;
+  (void)K;
+  if (ncontrib == 1) { store_tile(a, acc, out, ldo, n0, k0, wn, wk, lane); return; }
+  // slot layout: [block ij (4)][float4 q4 (4)][thread][4] -> a wave instruction writes / reads 1 KiB contiguous; blocks q4 are NT * 16 bytes apart
+  float* slot0 = a.part + (size_t)tile * kMaxContrib * TNK;
+  float* mine = slot0 + (size_t)me * TNK + (size_t)tid * 4;
+#pragma unroll
+  for (int ij = 0; ij < 4; ++ij)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const f32x16& c = acc[ij >> 1][ij & 1];
+      st_agent_x4(mine + (size_t)(ij * 4 + q4) * NT * 4, (w_f32x4){c[4 * q4], c[4 * q4 + 1], c[4 * q4 + 2], c[4 * q4 + 3]});
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // the partial tile is acknowledged before the ticket moves
+  __syncthreads();
+  if (tid == 0) *flag = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ncontrib - 1);
+  __syncthreads();
+  const bool last = *flag != 0u;
+  __syncthreads();                                                             // (flag may be rewritten by the workgroup's next segment)
+  if (!last) return;
+#pragma unroll
+  for (int ij = 0; ij < 4; ++ij) {
+    f32x16& c = acc[ij >> 1][ij & 1];
+    w_f32x4 sum[4];
+    bool have = false;
+    for (int j = 0; j < ncontrib; ++j) {                                       // slot order; slot `me` from the registers
+      w_f32x4 v[4];
+      if (j == me) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) v[q4] = (w_f32x4){c[4 * q4], c[4 * q4 + 1], c[4 * q4 + 2], c[4 * q4 + 3]};
+      } else {
+        const float* src = slot0 + (size_t)j * TNK + (size_t)tid * 4 + (size_t)(ij * 4) * NT * 4;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)                                         // four device-coherent loads in flight, one wait
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[q4]) : "v"(src + (size_t)q4 * NT * 4) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
+      }
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) sum[q4] = have ? sum[q4] + v[q4] : v[q4];
+      have = true;
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) { c[4 * q4] = sum[q4][0]; c[4 * q4 + 1] = sum[q4][1]; c[4 * q4 + 2] = sum[q4][2]; c[4 * q4 + 3] = sum[q4][3]; }
+  }
+  store_tile(a, acc, out, ldo, n0, k0, wn, wk, lane);
+  if (tid == 0) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the workspace leaves as it came: zero tickets
+}
+
 template <int WN, int WK, int SHIFTED, typename ET>     // SHIFTED: 0 no; 1 period % 32 == 0 (a chunk lies inside one sequence); 2 any period
-__device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, int split, int g, int n0, int k0) {
+__device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, long c_begin, int nc, int g, int n0, int k0, f32x16 (&acc)[2][2]) {
   using G = Geo<WN, WK>;
   constexpr bool BF = storage_is_bf16<ET>::value;          // bf16 operands: one plane per operand, one MFMA per product
   typedef typename Raw4T<ET>::type Raw;
   struct Staged { Raw a[G::RA]; Raw b[G::RB]; bool ok[G::RB]; };   // one chunk's operand rows of a thread, in flight / waiting for the split (ok: the B row exists)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int K = a.K0 + a.K1;
-  const long chunks = a.M / BM;
-  const long c_begin = (long)split * a.cps;
-  const int nc = (int)(min(chunks, c_begin + a.cps) - c_begin);          // chunks of this row range (may be <= 0)
+  // chunks [c_begin, c_begin + nc) of the contraction (nc may be <= 0)
 
   // load roles (see Role)
   const Role<G::RA, G::TN> ra(tid);
@@ -213,7 +299,6 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
     }
   };
 
-  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -321,21 +406,6 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
     if (nc & 1) compute(0);
   }
 
-  // epilogue: accumulator (row = n, column = k on the lanes) -> C or this split's partial tile
-  // (a tile lies inside one column segment: K0 % 128 == 0; with a second output the B1 segment's tiles go to C1, columns from 0)
-  const bool to1 = a.splits == 1 && a.C1 && k0 >= a.K0;
-  float* out = a.splits == 1 ? (to1 ? a.C1 + g * a.c1_gs - a.K0 : a.C + g * a.c_gs) : a.ws + ((size_t)split * a.groups + g) * (size_t)a.N * K;
-  const long ldo = a.splits == 1 ? (to1 ? a.ldc1 : a.ldc) : K;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int n = n0 + 64 * wn + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * hh;
-        const int k = k0 + 64 * wk + 32 * j + r;
-        out[(size_t)n * ldo + k] = acc[i][j][q];
-      }
 #ifdef TSG_WGRAD_TIMING
   __syncthreads();
   if (blockIdx.x == 0 && lane == 0)                        // cycles per chunk and phase: request, compute, stage, barrier
@@ -344,18 +414,55 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, unsigned* lds, in
 }
 
 template <int WN, int WK, typename ET>
+__device__ __forceinline__ void wgrad_segment(const WgradArgs& a, unsigned* lds, long c_begin, int nc, int g, int n0, int k0, f32x16 (&acc)[2][2]) {
+  if (k0 >= a.K0 && a.shift != 0) {                                                            // workgroup-uniform
+    if (a.period % BM == 0) wgrad_tile<WN, WK, 1, ET>(a, lds, c_begin, nc, g, n0, k0, acc);
+    else wgrad_tile<WN, WK, 2, ET>(a, lds, c_begin, nc, g, n0, k0, acc);
+  } else {
+    wgrad_tile<WN, WK, 0, ET>(a, lds, c_begin, nc, g, n0, k0, acc);
+  }
+}
+
+template <int WN, int WK, typename ET>
 __global__ __launch_bounds__(64 * WN * WK) void wgrad_split_kernel(const WgradArgs a) {
   extern __shared__ __align__(16) unsigned lds[];
+  __shared__ unsigned s_flag;
   using G = Geo<WN, WK>;
   const int K = a.K0 + a.K1, tiles_k = K / G::TK, tpg = (a.N / G::TN) * tiles_k, tps = tpg * a.groups;
   const int v = xcd_major(blockIdx.x, gridDim.x);
-  const int split = v / tps, rem = v % tps, g = rem / tpg, tile = rem % tpg;
-  const int n0 = (tile / tiles_k) * G::TN, k0 = (tile % tiles_k) * G::TK;
-  if (k0 >= a.K0 && a.shift != 0) {                                                            // workgroup-uniform
-    if (a.period % BM == 0) wgrad_tile<WN, WK, 1, ET>(a, lds, split, g, n0, k0);
-    else wgrad_tile<WN, WK, 2, ET>(a, lds, split, g, n0, k0);
+  const long chunks = a.M / BM;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wn = wv / WK, wk = wv % WK;
+  f32x16 acc[2][2];
+  // The workgroup's piece of the flattened (tile, chunk) space.  stream-K: [v * ipw, (v + 1) * ipw) = at most kMaxContrib - 1 tile segments;
+  // split scheme: ONE segment, row range `split` of tile v % tps (possibly empty: its partial tile is still written, as zeros).
+  long cur, end;
+  bool once = a.ipw == 0;
+  if (a.ipw > 0) {
+    cur = (long)v * a.ipw;
+    end = min((long)tps * chunks, cur + a.ipw);
   } else {
-    wgrad_tile<WN, WK, 0, ET>(a, lds, split, g, n0, k0);
+    const int split = v / tps;
+    cur = (long)(v % tps) * chunks + min(chunks, (long)split * a.cps);
+    end = (long)(v % tps) * chunks + min(chunks, (long)(split + 1) * a.cps);
+  }
+  while (cur < end || once) {                                                                  // workgroup-uniform
+    once = false;
+    const int tl = a.ipw > 0 ? (int)(cur / chunks) : v % tps;                                   // (split scheme: the tile is fixed, also for an empty row range)
+    const long c0 = cur - (long)tl * chunks;
+    const int nc = (int)max(0L, min(chunks - c0, end - cur));
+    const int g = tl / tpg, tile = tl % tpg;
+    const int n0 = (tile / tiles_k) * G::TN, k0 = (tile % tiles_k) * G::TK;
+    wgrad_segment<WN, WK, ET>(a, lds, c0, nc, g, n0, k0, acc);
+    if (a.ipw > 0) {
+      const int first = (int)(((long)tl * chunks) / a.ipw), lastw = (int)(((long)(tl + 1) * chunks - 1) / a.ipw);
+      __syncthreads();                                                                         // every wave has left the operand buffers (and s_flag)
+      finish_tile<G::NT, G::TN * G::TK>(a, acc, tl, g, n0, k0, wn, wk, v - first, lastw - first + 1, &s_flag);
+    } else {
+      const bool to1 = a.splits == 1 && a.C1 && k0 >= a.K0;
+      float* out = a.splits == 1 ? (to1 ? a.C1 + g * a.c1_gs - a.K0 : a.C + g * a.c_gs) : a.ws + ((size_t)(v / tps) * a.groups + g) * (size_t)a.N * K;
+      store_tile(a, acc, out, a.splits == 1 ? (to1 ? a.ldc1 : a.ldc) : K, n0, k0, wn, wk, lane);
+    }
+    cur += max(nc, 1);
   }
 }
 
@@ -386,7 +493,13 @@ int variant() {
   if (v < 0) { const char* e = getenv("TSG_WGRAD_CFG"); v = e ? atoi(e) : 0; if (v < 0 || v > 1) v = 0; }
   return v;
 }
-struct Plan { int tn, tk, slots, tiles, splits; long long ws; };
+struct Plan { int tn, tk, slots, tiles, splits; long long ws; long ipw; int grid; long long ticket_bytes; };
+std::atomic<int> g_stream_k{-2};           // -2: not decided yet (TSG_WGRAD_SK); -1 auto, 0 never, 1 always; tsg_wgrad_set_stream_k overrides
+int stream_k_mode() {
+  int v = g_stream_k.load(std::memory_order_relaxed);
+  if (v == -2) { const char* e = getenv("TSG_WGRAD_SK"); v = e ? (atoi(e) != 0) : -1; g_stream_k.store(v, std::memory_order_relaxed); }
+  return v;
+}
 
 // number of row ranges: the smallest power of two (<= 16, >= 4 chunks per range) that minimises the number of full-chip rounds
 // per unit of work
@@ -410,13 +523,32 @@ int check_args(const char* fn, long long M, int N, int K0, int K1, int groups) {
   return 0;
 }
 
-Plan make_plan(long long M, int N, int K, int groups) {
+Plan make_plan(long long M, int N, int K, int groups, bool bf) {
   Plan p;
   const int v = variant();
   p.tn = v == 0 ? 256 : 128; p.tk = 128; p.slots = v == 0 ? 256 : 512;
   p.tiles = groups * (N / p.tn) * (K / p.tk);
   p.splits = choose_splits(M / BM, p.tiles, p.slots);
   p.ws = p.splits == 1 ? 0 : (long long)sizeof(float) * p.splits * groups * N * K;
+  p.ipw = 0; p.grid = p.tiles * p.splits; p.ticket_bytes = 0;
+  // stream-K (round 5) where the tile count does not fill the chip evenly but is at least half of it (then a tile has at most kMaxContrib
+  // contributors): the LSTM layer's [2][2048 x 16384] x [16384 x 1536] = 192 tiles ran as 4 row ranges = 768 workgroups in 3 rounds with 100 MB
+  // of partial tiles out and back through a reduce launch; as ONE round of 256 workgroups of 384 chunks each it writes / reads the 128 KiB
+  // slots of the ~190 tile boundaries once.  TSG_WGRAD_SK=0: the split scheme (A/B).
+  // Measured (profiles/r5/wgrad_stream_k_ab_v1.txt, one MI355X, alternating processes): bf16 operands 302-311 -> 288-296 us at the LSTM layer's
+  // shape (the 3-round split scheme's fixed costs are 5 % of a 300 us kernel); fp32 operands (f32s) 707-719 -> 716-727 us -- there the reduce
+  // pass was never the bottleneck (the 3-product chunk loop is), and the two-segment workgroups' second prologue costs what the saved traffic
+  // gains.  Default: stream-K for bf16 operands only.  TSG_WGRAD_SK=1 / 0 or tsg_wgrad_set_stream_k: always / never (A/B, tests).
+  const int sk_mode = stream_k_mode();
+  const bool sk_on = sk_mode >= 0 ? sk_mode != 0 : bf;
+  const long chunks = (long)(M / BM);
+  if (sk_on && p.tn == 256 && p.tiles % p.slots != 0 && 2 * p.tiles >= p.slots && chunks >= 16) {
+    p.grid = p.slots;
+    p.ipw = ((long)p.tiles * chunks + p.grid - 1) / p.grid;
+    p.splits = 1;
+    p.ticket_bytes = roundup((long long)p.tiles * 4, 256);
+    p.ws = p.ticket_bytes + (long long)sizeof(float) * p.tiles * kMaxContrib * p.tn * p.tk;
+  }
   return p;
 }
 
@@ -449,18 +581,10 @@ __device__ __forceinline__ uint2 tr_read(const char* img, int off) {
 }
 
 template <int SUB, int NB>                      // SUB = 32-row sub-chunks per barrier interval (1 or 2), NB = ring depth (DMA runs NB - 1 intervals ahead)
-__global__ __launch_bounds__(512) void wgrad_bf16_tr_kernel(const WgradArgs a) {
+__device__ __forceinline__ void tr_segment(const WgradArgs& a, char* ring, long c_begin, int nc, int g, int n0, int k0, f32x16 (&acc)[2][2]) {
   constexpr int kTrBuf = SUB * kTrSub, AHEAD = NB - 1;
-  extern __shared__ __align__(16) unsigned lds[];
-  char* ring = reinterpret_cast<char*>(lds);
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int K = a.K0 + a.K1, tiles_k = K / 128, tpg = (a.N / 256) * tiles_k, tps = tpg * a.groups;
-  const int v = xcd_major(blockIdx.x, gridDim.x);
-  const int split = v / tps, rem = v % tps, g = rem / tpg, tile = rem % tpg;
-  const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 128;
-  const long chunks = a.M / BM;
-  const long c_begin = (long)split * a.cps;
-  const int nc = (int)(min(chunks, c_begin + a.cps) - c_begin);          // chunks of this row range (may be <= 0)
+  // chunks [c_begin, c_begin + nc) of the contraction (nc may be <= 0)
   const bool seg1 = k0 >= a.K0;
   const bool shifted = seg1 && a.shift != 0;
   const long ldb = seg1 ? a.ldb1 : a.ldb0;
@@ -510,7 +634,6 @@ __global__ __launch_bounds__(512) void wgrad_bf16_tr_kernel(const WgradArgs a) {
         offB[t][ms][hf] = 2 * kTrImg + 256 * row + 16 * ((((cB + 16 * chalf) >> 3) + (fp >> 1)) ^ sw) + 8 * (fp & 1);
       }
 
-  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -553,21 +676,47 @@ __global__ __launch_bounds__(512) void wgrad_bf16_tr_kernel(const WgradArgs a) {
     }
   }
 
-  // epilogue: as wgrad_tile
-  const int r = lane & 31, hh = lane >> 5;
-  const bool to1 = a.splits == 1 && a.C1 && k0 >= a.K0;
-  float* out = a.splits == 1 ? (to1 ? a.C1 + g * a.c1_gs - a.K0 : a.C + g * a.c_gs) : a.ws + ((size_t)split * a.groups + g) * (size_t)a.N * K;
-  const long ldo = a.splits == 1 ? (to1 ? a.ldc1 : a.ldc) : K;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int n = n0 + 64 * wn + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * hh;
-        const int k = k0 + 64 * wk + 32 * j + r;
-        out[(size_t)n * ldo + k] = acc[i][j][q];
-      }
+}
+
+template <int SUB, int NB>
+__global__ __launch_bounds__(512) void wgrad_bf16_tr_kernel(const WgradArgs a) {
+  extern __shared__ __align__(16) unsigned lds[];
+  __shared__ unsigned s_flag;
+  char* ring = reinterpret_cast<char*>(lds);
+  const int K = a.K0 + a.K1, tiles_k = K / 128, tpg = (a.N / 256) * tiles_k, tps = tpg * a.groups;
+  const int v = xcd_major(blockIdx.x, gridDim.x);
+  const long chunks = a.M / BM;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wn = wv >> 1, wk = wv & 1;
+  f32x16 acc[2][2];
+  long cur, end;                                                           // the workgroup's piece of the (tile, chunk) space: see wgrad_split_kernel
+  bool once = a.ipw == 0;
+  if (a.ipw > 0) {
+    cur = (long)v * a.ipw;
+    end = min((long)tps * chunks, cur + a.ipw);
+  } else {
+    const int split = v / tps;
+    cur = (long)(v % tps) * chunks + min(chunks, (long)split * a.cps);
+    end = (long)(v % tps) * chunks + min(chunks, (long)(split + 1) * a.cps);
+  }
+  while (cur < end || once) {
+    once = false;
+    const int tl = a.ipw > 0 ? (int)(cur / chunks) : v % tps;
+    const long c0 = cur - (long)tl * chunks;
+    const int nc = (int)max(0L, min(chunks - c0, end - cur));
+    const int g = tl / tpg, tile = tl % tpg;
+    const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 128;
+    tr_segment<SUB, NB>(a, ring, c0, nc, g, n0, k0, acc);
+    if (a.ipw > 0) {
+      const int first = (int)(((long)tl * chunks) / a.ipw), lastw = (int)(((long)(tl + 1) * chunks - 1) / a.ipw);
+      __syncthreads();                                                     // every wave has left the ring before the next segment's DMA
+      finish_tile<512, 256 * 128>(a, acc, tl, g, n0, k0, wn, wk, v - first, lastw - first + 1, &s_flag);
+    } else {
+      const bool to1 = a.splits == 1 && a.C1 && k0 >= a.K0;
+      float* out = a.splits == 1 ? (to1 ? a.C1 + g * a.c1_gs - a.K0 : a.C + g * a.c_gs) : a.ws + ((size_t)(v / tps) * a.groups + g) * (size_t)a.N * K;
+      store_tile(a, acc, out, a.splits == 1 ? (to1 ? a.ldc1 : a.ldc) : K, n0, k0, wn, wk, lane);
+    }
+    cur += max(nc, 1);
+  }
 }
 
 template <int WN, int WK, typename ET>
@@ -584,9 +733,12 @@ int launch(const char* fn, const WgradArgs& a, int grid, hipStream_t st) {
 
 using namespace tsg;
 
+extern "C" int tsg_wgrad_set_stream_k(int mode) { g_stream_k.store(mode < 0 ? -1 : (mode != 0), std::memory_order_relaxed); return 0; }
+
 extern "C" long long tsg_wgrad_f32s_ws_bytes(long long M, int N, int K0, int K1, int groups) {
   if (check_args("tsg_wgrad_f32s_ws_bytes", M, N, K0, K1, groups)) return -1;
-  return make_plan(M, N, K0 + K1, groups).ws;
+  const long long a = make_plan(M, N, K0 + K1, groups, false).ws, b = make_plan(M, N, K0 + K1, groups, true).ws;   // either operand type
+  return a > b ? a : b;
 }
 
 static int wgrad_impl(const char* fn, bool bf, const void* A, long long lda, long long a_group_stride, const void* B0, long long ldb0, int K0,
@@ -608,7 +760,7 @@ static int wgrad_impl(const char* fn, bool bf, const void* A, long long lda, lon
     return set_error(TSG_E_SHAPE, "%s: M, shift and period must fit 31 bits", fn);
   if (!aligned16(A) || !aligned16(C) || (B0 && !aligned16(B0)) || (B1 && !aligned16(B1)))
     return set_error(TSG_E_ALIGN, "%s: operands must be 16-byte aligned", fn);
-  const Plan p = make_plan(M, N, K, groups);
+  const Plan p = make_plan(M, N, K, groups, bf);
   if (p.ws > 0 && (!ws || ws_bytes < p.ws || !aligned16(ws)))
     return set_error(TSG_E_SHAPE, "%s: workspace of %lld bytes (16-byte aligned) required, got %lld", fn, p.ws, ws_bytes);
   auto st = static_cast<hipStream_t>(stream);
@@ -626,18 +778,23 @@ static int wgrad_impl(const char* fn, bool bf, const void* A, long long lda, lon
   a.C = (float*)C; a.ldc = ldc; a.c_gs = c_group_stride; a.ws = (float*)ws;
   a.C1 = (float*)C1; a.ldc1 = ldc1; a.c1_gs = c1_group_stride;
   a.M = M; a.N = N; a.groups = groups; a.splits = p.splits; a.cps = (int)((chunks + p.splits - 1) / p.splits);
+  a.ipw = p.ipw; a.tickets = (unsigned*)ws; a.part = p.ipw > 0 ? (float*)((char*)ws + p.ticket_bytes) : nullptr;
+  if (p.ipw > 0) {                                          // the tickets start at zero (the kernel leaves them at zero, but the caller's buffer is fresh)
+    hipError_t e = zero_async(ws, (size_t)p.ticket_bytes, st);
+    if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+  }
   static const bool tr_ok = !(getenv("TSG_WGRAD_BF16_TR") && atoi(getenv("TSG_WGRAD_BF16_TR")) == 0);    // A/B switch: 0 = the register-staged kernel
   if (bf && tr_ok && p.tn == 256 && (shift == 0 || K1 == 0 || a.period % BM == 0) && (lda & 7) == 0 && (ldb0 & 7) == 0 && (ldb1 & 7) == 0 &&
       (a_group_stride & 7) == 0 && (b1_group_stride & 7) == 0) {
     static const int cfg = getenv("TSG_WGRAD_TR_CFG") ? atoi(getenv("TSG_WGRAD_TR_CFG")) : 0;      // developer A/B: (sub-chunks, ring depth)
 #define TSG_TR_LAUNCH(SUBV, NBV) { auto kern = wgrad_bf16_tr_kernel<SUBV, NBV>; const size_t lb = (size_t)NBV * SUBV * kTrSub;          \
       hipError_t e = allow_lds(kern, lb); if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e)); \
-      hipLaunchKernelGGL(kern, dim3(p.tiles * p.splits), dim3(512), lb, st, a); }
+      hipLaunchKernelGGL(kern, dim3(p.grid), dim3(512), lb, st, a); }
     if (cfg == 1) TSG_TR_LAUNCH(1, 4) else if (cfg == 2) TSG_TR_LAUNCH(2, 3) else if (cfg == 3) TSG_TR_LAUNCH(2, 2) else TSG_TR_LAUNCH(1, 3)
 #undef TSG_TR_LAUNCH
     rc = check_launch(fn);
-  } else if (bf) rc = p.tn == 256 ? launch<4, 2, bf16_t>(fn, a, p.tiles * p.splits, st) : launch<2, 2, bf16_t>(fn, a, p.tiles * p.splits, st);
-  else rc = p.tn == 256 ? launch<4, 2, float>(fn, a, p.tiles * p.splits, st) : launch<2, 2, float>(fn, a, p.tiles * p.splits, st);
+  } else if (bf) rc = p.tn == 256 ? launch<4, 2, bf16_t>(fn, a, p.grid, st) : launch<2, 2, bf16_t>(fn, a, p.grid, st);
+  else rc = p.tn == 256 ? launch<4, 2, float>(fn, a, p.grid, st) : launch<2, 2, float>(fn, a, p.grid, st);
 #ifdef TSG_WGRAD_TIMING
   return rc;
 #endif

@@ -88,6 +88,7 @@ def check_kernel_errors() -> None:
         _err_sink[0] = 0
         for wd in _err_words.values():
             wd.zero_()
+        _k3_ws.clear()       # a launch that gave up may have left the cached K3 workspaces' tickets non-zero: the next call gets fresh, zeroed ones
         raise KernelWaitExpired("a kernel's bounded wait on other workgroups expired (persistent LSTM hand-off or the K1 backward's "
                                 "partner exchange: workgroups not co-resident, e.g. the GPU is shared with another process?): the "
                                 "outputs of that launch are invalid and the optimizer update of that step was skipped.  "
@@ -648,6 +649,17 @@ def _k3_workspace(device, B: int, T: int, Hm: int):
     return ws, nb
 
 
+def _k3_call(name: str, like: torch.Tensor, *args) -> None:
+    """``_call`` for the entry points that take a cached K3 workspace: when the call does not return 0 the cache is dropped, so that no
+    later call trusts tickets a failed call may have touched (round-4 review: "left zeroed by every call" only holds for calls that
+    ran to their end)."""
+    try:
+        _call(name, like, *args)
+    except Exception:
+        _k3_ws.clear()
+        raise
+
+
 class _BoundaryScore(torch.autograd.Function):
     """K3: (y=[B,T,2Hm], cs=[B,2Hm], b1=[2Hm], w2=[2Hm], b2=[2], gate=[B,T]|None, mask=[B,T] int|None)
     -> (p_start, p_end) [B,T]."""
@@ -691,7 +703,7 @@ class _BoundaryScore(torch.autograd.Function):
         db2p = torch.empty(B, 2, device=y.device, dtype=torch.float32)
         dgate = torch.empty(B, T, device=y.device, dtype=torch.float32) if gate is not None else None
         ws, nb = _k3_workspace(y.device, B, T, J // 2)
-        _call("tsg_boundary_score_bwd_ws", y, ptr(y), ptr(cs), ptr(b1), ptr(w2),
+        _k3_call("tsg_boundary_score_bwd_ws", y, ptr(y), ptr(cs), ptr(b1), ptr(w2),
                                                ptr(gate) if gate is not None else None,
                                                ptr(mask) if mask is not None else None,
                                                ptr(ps), ptr(pe), ptr(dps), ptr(dpe), ptr(dy), ptr(dcs), ptr(db1p),
@@ -1038,7 +1050,7 @@ class _BoundaryHeadGemm(torch.autograd.Function):
         db2p = torch.empty(B, 2, device=y.device, dtype=torch.float32)
         dgate = torch.empty(B, T, device=y.device, dtype=torch.float32) if gate is not None else None
         wk, nb = _k3_workspace(y.device, B, T, Hm)
-        _call("tsg_boundary_score_bwd_ws", y, ptr(y), ptr(cs), ptr(b1), ptr(w2),
+        _k3_call("tsg_boundary_score_bwd_ws", y, ptr(y), ptr(cs), ptr(b1), ptr(w2),
               ptr(gate) if gate is not None else None, ptr(mask) if mask is not None else None,
               ptr(ps), ptr(pe), ptr(dps), ptr(dpe), ptr(dy), ptr(dcs), ptr(db1p), ptr(dw2p), ptr(db2p),
               ptr(dgate) if dgate is not None else None, ptr(wk), nb, B, T, Hm, TSG_F32)
@@ -1170,7 +1182,7 @@ class _BoundaryHeadFull(torch.autograd.Function):
         db2p = torch.empty(B, 2, device=y.device, dtype=torch.float32)
         dgate = torch.empty(B, T, device=y.device, dtype=torch.float32) if gate is not None else None
         wk, nb = _k3_workspace(y.device, B, T, Hm)
-        _call("tsg_boundary_score_bwd_ws", y, ptr(y), ptr(cs), ptr(b1), ptr(w2),
+        _k3_call("tsg_boundary_score_bwd_ws", y, ptr(y), ptr(cs), ptr(b1), ptr(w2),
               ptr(gate) if gate is not None else None, ptr(mask) if mask is not None else None,
               ptr(ps), ptr(pe), ptr(dps), ptr(dpe), ptr(dy), ptr(dcs), ptr(db1p), ptr(dw2p), ptr(db2p),
               ptr(dgate) if dgate is not None else None, ptr(wk), nb, B, T, Hm, TSG_F32)
@@ -1470,6 +1482,44 @@ class _LinearSplit(torch.autograd.Function):
         return dx, dw, db
 
 
+_OWN_GEMM_BF16 = os.environ.get("TSG_OWN_GEMM_BF16", "1") != "0"     # 0: torch.mm -> hipBLASLt for the bf16 mode's projections (A/B)
+
+
+def gemm_bf16_ok(M: int, N: int, K: int) -> bool:
+    """Shapes tsg_gemm_bf16 takes (include/tsg_hip.h): whole 128 / 256-row x 256-column tiles, 32-deep K chunks."""
+    return _OWN_GEMM_BF16 and M > 0 and M % 128 == 0 and N % 256 == 0 and K % 32 == 0
+
+
+def gemm_bf16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None, out_dtype=None) -> torch.Tensor:
+    """y [M,N] = x [M,K] @ w [N,K]^T (+ bias) on the hand-written bf16 GEMM (csrc/gemm_bf16.hip: operands by LDS-DMA, fp32 accumulate);
+    x, w bf16 with contiguous rows (column slices of wider matrices go in as they are), bias fp32, y bf16 (default) or fp32."""
+    require_device(x, w, bias)
+    out_dtype = _BF if out_dtype is None else out_dtype
+    M, K = x.shape
+    N = w.shape[0]
+    if x.dtype != _BF or w.dtype != _BF or x.stride(1) != 1 or w.stride(1) != 1 or w.shape[1] != K:
+        raise ValueError(f"gemm_bf16: needs bf16 operands with contiguous rows, x{tuple(x.shape)} w{tuple(w.shape)}")
+    y = torch.empty(M, N, device=x.device, dtype=out_dtype)
+    _call("tsg_gemm_bf16", x, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(_f32c(bias)) if bias is not None else None, ptr(y), N, M, N, K,
+          TSG_BF16 if out_dtype == _BF else TSG_F32)
+    return y
+
+
+def _mm_bf16_nt(x2: torch.Tensor, wb: torch.Tensor, bias=None) -> torch.Tensor:
+    """x2 [M,K] bf16 @ wb [N,K]^T (+ bias) -> bf16: the own kernel where its tiling applies, else the library."""
+    if x2.is_cuda and gemm_bf16_ok(x2.shape[0], wb.shape[0], x2.shape[1]) and x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0:
+        return gemm_bf16(x2, wb, bias)
+    return torch.mm(x2, wb.t()) if bias is None else torch.addmm(bias.detach().to(_BF), x2, wb.t())
+
+
+def _mm_bf16_nn(dy2: torch.Tensor, wb: torch.Tensor) -> torch.Tensor:
+    """dy2 [M,N] bf16 @ wb [N,K] -> bf16 (the input gradient of a Linear): the own kernel on a transposed bf16 copy of the weight (8 MB for an
+    LSTM layer's W_ih: one small pass against a 100-us-class product), else the library's NN form."""
+    if dy2.is_cuda and gemm_bf16_ok(dy2.shape[0], wb.shape[1], dy2.shape[1]) and dy2.stride(1) == 1 and dy2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0:
+        return gemm_bf16(dy2, wb.t().contiguous())
+    return torch.mm(dy2, wb)
+
+
 class _LinearBf16(torch.autograd.Function):
     """y = x w^T (+ b) in the bf16 storage mode: bf16 activations in and out, the fp32 parameter rounded to bf16 once per use
     (kept for the backward), plain bf16 MFMA GEMMs with fp32 accumulation; the weight / bias gradients come out of their GEMM /
@@ -1479,7 +1529,7 @@ class _LinearBf16(torch.autograd.Function):
     def forward(ctx, x, w, b):
         x2 = _bfc(x).view(-1, x.shape[-1])
         wb = w.detach().to(_BF)
-        y = torch.mm(x2, wb.t()) if b is None else torch.addmm(b.detach().to(_BF), x2, wb.t())
+        y = _mm_bf16_nt(x2, wb, b)
         ctx.save_for_backward(x2, wb)
         ctx.has_bias, ctx.xshape = b is not None, x.shape
         return y.view(*x.shape[:-1], w.shape[0])
@@ -1488,7 +1538,7 @@ class _LinearBf16(torch.autograd.Function):
     def backward(ctx, dy):
         x2, wb = ctx.saved_tensors
         dy2 = _bfc(dy).view(-1, wb.shape[0])
-        dx = torch.mm(dy2, wb).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = _mm_bf16_nn(dy2, wb).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             M, (N, K) = x2.shape[0], wb.shape
@@ -1685,7 +1735,7 @@ class _BiLSTMLayerBf16(torch.autograd.Function):
         if W_ih.shape != (8 * h, I) or W_hh.shape != (2, 4 * h, h) or bias.numel() != 8 * h:
             raise ValueError(f"bilstm: shape mismatch x{tuple(x.shape)} W_ih{tuple(W_ih.shape)} W_hh{tuple(W_hh.shape)}")
         Wb = W_ih.detach().to(_BF)                                        # [8h, I]
-        Gx = torch.mm(x.view(B * T, I), Wb.t())                           # bf16 [B*T, 8h]; the bias is added inside the kernel
+        Gx = _mm_bf16_nt(x.view(B * T, I), Wb)                            # bf16 [B*T, 8h]; the bias is added inside the kernel
         out = torch.empty(B, T, 2 * h, device=x.device, dtype=_BF)
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=_BF)
         Cs = torch.empty(T, 2, B, h, device=x.device, dtype=torch.float32)
@@ -1717,7 +1767,7 @@ class _BiLSTMLayerBf16(torch.autograd.Function):
               B, T, h, TSG_BF16, 1)
         _gate_after()
         dGf = dG.view(TB, 8 * h)
-        dx = torch.mm(dGf, Wb).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = _mm_bf16_nn(dGf, Wb).view(x.shape) if ctx.needs_input_grad[0] else None
         if _WGRAD_KERNEL and wgrad_f32s_ok(TB, 4 * h, I, h):
             # ONE launch per layer: D[d] = dG[d]^T [x | h_{t-+1}[d]] for both directions holds dW_ih[d] and dW_hh[d]; the shifted
             # h rows are read straight from `out` (row r -+ 1 of the same sequence, zero at its ends) -- no shifted copy, no fp32

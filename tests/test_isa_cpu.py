@@ -21,7 +21,9 @@ LIB = os.path.join(ROOT, "shufflingvideosfortsg_amd", "libtsg_hip.so")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 # kernels whose cross-workgroup protocol is "agent-scope stores, workgroup barrier, one integer atomic on a counter"
-PUBLISHERS = ("scdm_bwd_fused_kernel", "boundary_bwd_one_kernel", "gemm_nt_f32s_kernel")
+PUBLISHERS = ("scdm_bwd_fused_kernel", "boundary_bwd_one_kernel", "gemm_nt_f32s_kernel",
+              # round 5: the stream-K weight gradient's tile tickets, the persistent LSTM kernels' start barrier, K4's last-arrival finalisation
+              "wgrad_split_kernel", "wgrad_bf16_tr_kernel", "lstm_fwd_persist_kernel", "lstm_bwd_persist2_kernel", "gmd_losses_fwd_kernel")
 
 
 def _disassemble(tmp_path):
@@ -123,6 +125,70 @@ def test_head_gemm_ticket_waits_for_its_partial_rows(kernels):
     assert len(names) >= 12, names                        # 3 row-tile sizes x (3 activations of K5 + K3)
     for k in names:
         assert _check_kernel(k, kernels[k]) >= 1, k
+
+
+def test_stream_k_weight_gradient_ticket_waits_for_its_partial_tile(kernels):
+    """csrc/wgrad_split.hip (round 5, stream-K): a workgroup that holds a SEGMENT of a tile's contraction publishes its partial accumulators
+    (sc1 stores), waits for them (vmcnt(0)), meets at a barrier and takes the tile's ticket; the last arriver reads the other slots with sc1
+    loads.  The weight gradients of the path's Linears and of nn.LSTM (networks/RNN.py:31,42) go through it."""
+    names = [k for k in kernels if "wgrad_split_kernel" in k or "wgrad_bf16_tr_kernel" in k]
+    assert len(names) >= 8, names                         # 4 register-staged variants + 4 LDS-DMA ring shapes
+    for k in names:
+        ins = kernels[k]
+        assert _check_kernel(k, ins) >= 1, k
+        a = _counter_atomics(ins)[0]
+        after = ins[a:]
+        assert any(re.match(r"global_load_dwordx4 .*\bsc1\b", t) for t in after), f"{k}: the last arriver's slot loads are not device-coherent"
+
+
+def test_persistent_lstm_hand_offs_keep_their_scope_bits(kernels):
+    """csrc/lstm.hip (BiLSTM, networks/RNN.py:26-48): the persistent kernels exchange h_t / partial dh between workgroups with the data as
+    the flag.  What the protocol needs from the ISA (round-4 review: asserted by comment only):
+      * the start barrier counts a workgroup as arrived only after its sentinel / tag marks are acknowledged (sc1 stores -> vmcnt(0) ->
+        barrier -> arrival atomic): the publication gate of this file;
+      * every poll load is an agent-scope (sc1) 16-byte load, and each poll round ends on s_waitcnt vmcnt(0) before its data is looked at;
+      * the exchange stores exist in the write-through (sc1) form (taken whenever a group is not verified to sit on one XCD);
+      * a give-up reaches the host: a system-scope (sc0 sc1) store to the error sink, and the launch's error word is polled with an
+        sc1 load that is waited for at once."""
+    names = [k for k in kernels if "lstm_fwd_persist_kernel" in k or "lstm_bwd_persist2_kernel" in k]
+    assert len(names) >= 30, len(names)                   # forward: 3 arithmetic modes x 4 hidden sizes x {out-polling, ring} + 4-wave kernels; backward: 12
+    for k in names:
+        ins = kernels[k]
+        # the ARRIVAL atomic is the first global_atomic_add (the XCD-mask `or` sits in front of it; a later add only counts the workgroups
+        # on the L2-local path -- a statistic behind the error-raising stores, not a publication)
+        arrive = next(i for i, t in enumerate(ins) if re.match(r"global_atomic_add(_u32)?\s", t))
+        marks = [i for i in range(arrive) if re.match(r"global_store_dword(x4)? ", ins[i]) and re.search(r"\bsc1\b", ins[i]) and not re.search(r"\bsc0\b", ins[i])]
+        assert marks, f"{k}: no sentinel / tag marks in front of the arrival atomic"
+        barrier = next((i for i in range(marks[-1], arrive) if ins[i].startswith("s_barrier")), None)
+        assert barrier is not None, f"{k}: no workgroup barrier between the marks and the arrival"
+        assert any(ins[i].startswith("s_waitcnt") and "vmcnt(0)" in ins[i] for i in range(marks[-1] + 1, barrier)), \
+            f"{k}: the marks are not waited for (vmcnt(0)) before the barrier in front of the arrival atomic"
+        polls = [i for i, t in enumerate(ins) if re.match(r"global_load_dwordx4 ", t) and re.search(r"\bsc1\b", t)]
+        assert len(polls) >= 2, f"{k}: {len(polls)} agent-scope poll loads"
+        last = polls[-1]
+        assert any(t.startswith("s_waitcnt") and "vmcnt(0)" in t for t in ins[last + 1:last + 4]), f"{k}: poll round does not end on vmcnt(0)"
+        wt = [t for t in ins if re.match(r"global_store_dword(x4)? ", t) and re.search(r"\bsc1\b", t) and not re.search(r"\bsc0\b", t)]
+        assert len(wt) >= 2, f"{k}: write-through exchange stores missing"
+        assert any(t.startswith("global_store_dword ") and re.search(r"\bsc0 sc1\b", t) for t in ins), f"{k}: no system-scope store to the error sink"
+        ew = [i for i, t in enumerate(ins) if re.match(r"global_load_dword v\d+, v\[\d+:\d+\], off sc1$", t) and "vmcnt(0)" in ins[i + 1]]
+        assert ew, f"{k}: no error-word poll of the form `load sc1 ; s_waitcnt vmcnt(0)` inside the poll loops"
+
+
+def test_k4_last_arrival_finalisation_is_a_release(kernels):
+    """csrc/losses.hip (grounding/loss.py:6-51 as train.py:142-165 combines them): every workgroup adds its loss terms with float atomics,
+    then `__threadfence()` and a ticket; the last arriver reads the sums.  On gfx950 the fence must be the full release -- buffer_wbl2 +
+    s_waitcnt vmcnt(0) -- in front of the ticket's atomic, and an invalidate behind it."""
+    names = [k for k in kernels if "gmd_losses_fwd_kernel" in k]
+    assert names
+    for k in names:
+        ins = kernels[k]
+        a = _counter_atomics(ins)
+        assert a, k
+        a = a[0]
+        window = ins[max(0, a - 16):a]
+        assert any(t.startswith("buffer_wbl2") for t in window) and any(t.startswith("s_waitcnt") and "vmcnt(0)" in t for t in window), \
+            f"{k}: no release (buffer_wbl2 + vmcnt(0)) in front of the ticket:\n  " + "\n  ".join(window)
+        assert any(t.startswith("buffer_inv") for t in ins[a:a + 24]), f"{k}: no invalidate behind the ticket"
 
 
 def test_gate_detects_the_round3_sequence():

@@ -240,10 +240,10 @@ def test_bilstm_batch_major_layout(shape, dt):
         torch.testing.assert_close(a, b, atol=0, rtol=0)
 
 
-@pytest.mark.parametrize("shape", [(128, 24, 512), (33, 12, 128), (64, 20, 512), (40, 9, 256), (16, 10, 384), (96, 8, 512), (256, 8, 512)])
+@pytest.mark.parametrize("shape", [(128, 24, 512), (33, 12, 128), (64, 20, 512), (40, 9, 256), (16, 10, 384), (96, 8, 512), (256, 8, 512), (24, 12, 512)])
 @pytest.mark.parametrize("dt", [0, 2, 1])
 @pytest.mark.parametrize("bm", [0, 1])
-def test_exchange_ring_forward_equals_out_polling(shape, dt, bm):
+def test_exchange_ring_forward_equals_out_polling(shape, dt, bm, request):
     """tsg_lstm_fwd_ws (round 5: the hand-off through the compact exchange ring in the caller's workspace; in the f32s arithmetic the
     ring carries h already split into bf16 halves) gives bit-identical out / R / Cs to tsg_lstm_fwd_bias (consumers poll the
     sentinel-marked `out` itself) -- strict fp32, f32s and bf16 storage, both layouts, B % 16 != 0, the chunked 256-row case, all four
@@ -260,6 +260,8 @@ def test_exchange_ring_forward_equals_out_polling(shape, dt, bm):
     nws = lib.tsg_lstm_fwd_ws_bytes(B, T, h)
     assert nws > 2048
     res = []
+    lib.tsg_lstm_set_ring(1)                                   # at every shape, not only where the ring is the default
+    request.addfinalizer(lambda: lib.tsg_lstm_set_ring(-1))
     for ring in (False, True, True):
         ws = torch.full((nws // 4,), 0x3f800000, dtype=torch.int32, device="cuda")      # stale "data" (1.0f), not sentinels
         out = torch.full((B, T, 2 * h) if bm else (T, B, 2 * h), 9.0, device="cuda", dtype=seq)

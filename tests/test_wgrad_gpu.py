@@ -232,3 +232,99 @@ def test_wgrad_two_outputs_equal_the_sliced_single_output(bm):
         C0, C1 = F.wgrad_f32s_out2(dG, x, out, N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h, shift=shift, period=period)
         assert C0.shape == (2, 4 * h, I) and C1.shape == (2, 4 * h, h)
         assert torch.equal(C0, D[:, :, :I]) and torch.equal(C1, D[:, :, I:])
+
+
+
+# ---- stream-K (round 5): tile counts that do not fill the chip evenly are cut into equal (tile, chunk) pieces, one per CU; a tile with
+# several contributors is finished by its last arriver in slot order (csrc/wgrad_split.hip: finish_tile) -------------------------------------
+@pytest.mark.parametrize("M,N,K", [
+    (2048, 2048, 2304),        # 144 tiles x 64 chunks on 256 workgroups: 36 chunks each, two or three contributors per tile
+    (1056, 1536, 3072),        # 144 tiles x 33 chunks: ragged pieces (19 chunks, the last workgroups shorter / empty)
+    (512, 2048, 2048),         # 128 tiles x 16 chunks: exactly two contributors per tile
+    (16384, 2048, 1280),       # a long contraction: 80 tiles -> NOT stream-K (fewer than half the CUs): the split scheme still runs
+])
+def test_wgrad_stream_k_matches_float64_and_is_deterministic(M, N, K, request):
+    from shufflingvideosfortsg_amd import _lib, functional as F
+    _lib.load().tsg_wgrad_set_stream_k(1)               # also for fp32 operands (default: bf16 operands only)
+    request.addfinalizer(lambda: _lib.load().tsg_wgrad_set_stream_k(-1))
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, N, generator=g).cuda()
+    B = torch.randn(M, K, generator=g).cuda()
+    C = F.wgrad_f32s(A, B)
+    ref = A.double().t() @ B.double()
+    assert _rel(C[0], ref) < 1e-5
+    for _ in range(3):                                  # who arrives last differs from launch to launch; the sum order does not
+        assert torch.equal(C, F.wgrad_f32s(A, B))
+    Ab, Bb = A.bfloat16(), B.bfloat16()
+    Cb = F.wgrad_bf16(Ab, Bb)
+    assert _rel(Cb[0], Ab.double().t() @ Bb.double()) < 2e-6
+    assert torch.equal(Cb, F.wgrad_bf16(Ab, Bb))
+
+
+@pytest.mark.parametrize("bm", [True, False])
+@pytest.mark.parametrize("Bn,T,I,h", [(8, 64, 512, 512), (128, 128, 1024, 512), (4, 40, 512, 512)])
+def test_wgrad_stream_k_lstm_operands(bm, Bn, T, I, h, request):
+    """The LSTM layer's [dW_ih | dW_hh] at stream-K tile counts (h = 512: 2 x 8 x (I + h) / 128 = 128 / 192 tiles), shifted second segment,
+    both layouts, incl. the headline shape [2][2048 x 16384] x [16384 x 1536] and a period that is not a multiple of a chunk: vs the
+    explicitly shifted float64 construction; the two-output form equals the sliced single output bit for bit; run-to-run identical."""
+    from shufflingvideosfortsg_amd import _lib, functional as F
+    _lib.load().tsg_wgrad_set_stream_k(1)
+    request.addfinalizer(lambda: _lib.load().tsg_wgrad_set_stream_k(-1))
+    g = torch.Generator().manual_seed(Bn + T)
+    TB = Bn * T
+    dG = torch.randn(TB, 8 * h, generator=g).cuda(); x = torch.randn(TB, I, generator=g).cuda(); out = torch.randn(TB, 2 * h, generator=g).cuda()
+    shift, period = (1, T) if bm else (Bn, 0)
+    D = F.wgrad_f32s(dG, x, N=4 * h, groups=2, a_group_stride=4 * h, B1=out, K1=h, b1_group_stride=h, shift=shift, period=period)
+    o3 = out.view(Bn, T, 2 * h) if bm else out.view(T, Bn, 2 * h)
+    prev, nxt = torch.zeros_like(o3), torch.zeros_like(o3)
+    if bm:
+        prev[:, 1:] = o3[:, :-1]; nxt[:, :-1] = o3[:, 1:]
+    else:
+        prev[1:] = o3[:-1]; nxt[:-1] = o3[1:]
+    for d, hs in ((0, prev.reshape(TB, 2 * h)[:, :h]), (1, nxt.reshape(TB, 2 * h)[:, h:])):
+        ref = dG[:, d * 4 * h:(d + 1) * 4 * h].double().t() @ torch.cat([x, hs], 1).double()
+        assert _rel(D[d], ref) < 1e-5, d
+    C0, C1 = F.wgrad_f32s_out2(dG, x, out, N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h, shift=shift, period=period)
+    assert torch.equal(C0, D[:, :, :I]) and torch.equal(C1, D[:, :, I:])
+    assert torch.equal(D, F.wgrad_f32s(dG, x, N=4 * h, groups=2, a_group_stride=4 * h, B1=out, K1=h, b1_group_stride=h, shift=shift, period=period))
+    if T % 32 == 0:                                     # the bf16 LDS-DMA kernel wants whole chunks per sequence; same decomposition
+        dGb, xb, ob = dG.bfloat16(), x.bfloat16(), out.bfloat16()
+        Db = F.wgrad_bf16(dGb, xb, N=4 * h, groups=2, a_group_stride=4 * h, B1=ob, K1=h, b1_group_stride=h, shift=shift, period=period)
+        o3b = ob.view(Bn, T, 2 * h) if bm else ob.view(T, Bn, 2 * h)
+        pb, nb_ = torch.zeros_like(o3b), torch.zeros_like(o3b)
+        if bm:
+            pb[:, 1:] = o3b[:, :-1]; nb_[:, :-1] = o3b[:, 1:]
+        else:
+            pb[1:] = o3b[:-1]; nb_[:-1] = o3b[1:]
+        for d, hs in ((0, pb.reshape(TB, 2 * h)[:, :h]), (1, nb_.reshape(TB, 2 * h)[:, h:])):
+            ref = dGb[:, d * 4 * h:(d + 1) * 4 * h].double().t() @ torch.cat([xb, hs], 1).double()
+            assert _rel(Db[d], ref) < 2e-6, d
+        assert torch.equal(Db, F.wgrad_bf16(dGb, xb, N=4 * h, groups=2, a_group_stride=4 * h, B1=ob, K1=h, b1_group_stride=h, shift=shift, period=period))
+
+
+def test_wgrad_stream_k_equals_the_split_scheme_to_rounding(tmp_path):
+    """TSG_WGRAD_SK=1 / 0 (read once per process: stream-K always / never; the default is stream-K for bf16 operands only) give the same
+    products in a different but equally fixed sum order: both within the float64 bound, and within rounding of each other."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from shufflingvideosfortsg_amd import functional as F\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "A = torch.randn(2048, 2048, generator=g).cuda(); B = torch.randn(2048, 2304, generator=g).cuda()\n"
+        "C = F.wgrad_f32s(A, B)[0]; Cb = F.wgrad_bf16(A.bfloat16(), B.bfloat16())[0]\n"
+        "assert torch.equal(C, F.wgrad_f32s(A, B)[0])\n"
+        "torch.save((C.cpu(), Cb.cpu()), sys.argv[1])\n") % root
+    outs = []
+    for sk in ("1", "0"):
+        f = str(tmp_path / f"c{sk}.pt")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, TSG_WGRAD_SK=sk), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(torch.load(f))
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(2048, 2048, generator=g); B = torch.randn(2048, 2304, generator=g)
+    ref = A.double().t() @ B.double()
+    for (C, Cb) in outs:
+        assert _rel(C, ref) < 1e-5
+    assert not torch.equal(outs[0][0], outs[1][0])          # (different decompositions really ran)
+    assert _rel(outs[0][0], outs[1][0].double()) < 2e-6 and _rel(outs[0][1], outs[1][1].double()) < 2e-6
