@@ -363,6 +363,19 @@ int tsg_gemm_f32s_nn(const void* x, long long ldx, const void* w0, const void* w
 int tsg_gemm_bf16(const void* x, long long ldx, const void* w, long long ldw, const void* bias, void* y, long long ldy,
                   int M, int N, int K, int out_dtype, void* stream);
 
+/* ---- The optimizer update of the whole model in one launch per 64 tensors (ABI revision 6; csrc/adam.hip): Adam as the reference builds it
+ * (grounding/train.py:367-371: torch.optim.Adam(lr, weight_decay = L2 added to the gradient, eps)), torch's single-tensor formulae in fp32:
+ *   g' = g * grad_scale + weight_decay * p;  m += (1 - beta1) (g' - m);  v = beta2 v + (1 - beta2) g'^2;
+ *   p -= (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),   t = updates so far + 1.
+ * params / grads / exp_avg / exp_avg_sq: HOST arrays of n device pointers (fp32, contiguous; any 4-byte alignment, 16 bytes is faster), numel: host
+ * array of element counts (< 2^31).  state: caller-owned DEVICE buffer of two words {float update count, unsigned ticket}, zeroed once by the
+ * caller, advanced by the kernel (no "step += 1" launch; replayable from a HIP graph).  skip: device float or NULL -- non-zero leaves the
+ * parameters, the moments and the count untouched (the guard of a step whose loss was not finite or whose bounded wait expired).
+ * grad_scale: 1, or 1 / world after a SUM all-reduce.  The hyper-parameters are doubles: 1 - beta and log beta are formed in double, as torch does.                                                                                     */
+int tsg_adam_step(int n, const void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                  const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
+                  void* state, const void* skip, void* stream);
+
 /* ---- the heads as the EPILOGUE of their own first-Linear GEMM (ABI revision 5; round-3 review: SURVEY 8f #2 "split-W Linear + ReLU
  * + dot epilogue").  Same f32s arithmetic and tiling as tsg_gemm_f32s (row tiles of 256 / 128 / 64 so that a narrow head still
  * covers the chip); the accumulator tile goes through the head's tail in registers and only [rows]-sized logits leave the kernel.

@@ -1,0 +1,123 @@
+// Adam(lr, L2 weight decay, eps) over ALL parameters of the model in ONE launch -- the optimizer the reference builds (grounding/train.py:367-371:
+// torch.optim.Adam(lr=1e-3, weight_decay=1e-4 (L2, added to the gradient -- not AdamW), eps=1e-6)), torch's single-tensor formulation in fp32:
+//     g' = g * grad_scale + wd * p ;  m = m + (1 - b1) (g' - m) ;  v = b2 v + (1 - b2) g'^2
+//     p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)          t = the step count AFTER this update (1, 2, ...)
+// Round-4 review, item 7: torch's fused Adam was the last foreign kernel family of size in the step (6 launches of multi_tensor_apply, 0.34 ms:
+// its pointer tables are chunked over several launches).  Here the tables of up to 64 tensors per launch (two launches for GMD's 80) travel in the kernel
+// arguments, a workgroup finds its tensor by a binary search over the chunk prefix, and every element is read / written once with 16-byte
+// accesses: 7 x 4 bytes per parameter = HBM-bound, 1.3 GB per step at d = 1024.
+//   * `skip` (device float, may be NULL): non-zero = leave parameters, moments and the step count untouched (the guard of
+//     engine.optimizer_step: a non-finite loss or an expired bounded wait anywhere in the step, reduced over the ranks);
+//   * `step` (device float): the count of updates so far; read by every workgroup at its start, advanced by the LAST workgroup to finish (a
+//     ticket: everybody has read it by then) unless the update is skipped -- no separate "step += 1" launch, graph-replay safe;
+//   * grad_scale folds the 1 / world of a SUM all-reduce into the update (1 when RCCL already averaged).
+#include "tsg_common.h"
+#include <cmath>
+
+namespace tsg {
+namespace {
+
+constexpr int kAdamMaxTensors = 64;               // per launch: the tables travel in the kernel arguments (2.6 KB)
+constexpr int kAdamChunk = 8192;                  // elements per workgroup (256 threads x 8 float4)
+struct AdamTable {
+  float* p[kAdamMaxTensors]; const float* g[kAdamMaxTensors]; float* m[kAdamMaxTensors]; float* v[kAdamMaxTensors];
+  unsigned first_chunk[kAdamMaxTensors + 1];      // prefix of chunks per tensor
+  unsigned numel[kAdamMaxTensors];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTable tb, float lr, float b2, float omb1, float omb2, float logb1, float logb2,
+                                                   float eps, float wd, float grad_scale,
+                                                   float* __restrict__ step, const float* __restrict__ skip, unsigned* __restrict__ ticket, int advance) {
+  const bool skipped = skip && *skip != 0.f;
+  if (!skipped) {
+    // the workgroup's tensor: the last t with first_chunk[t] <= blockIdx.x
+    int lo = 0, hi = tb.n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tb.first_chunk[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const unsigned base = (blockIdx.x - tb.first_chunk[lo]) * (unsigned)kAdamChunk, n = tb.numel[lo];
+    float* __restrict__ p = tb.p[lo]; const float* __restrict__ g = tb.g[lo]; float* __restrict__ m = tb.m[lo]; float* __restrict__ v = tb.v[lo];
+    const float t = *step + 1.f;
+    // 1 - b^t = -expm1(t log b): formed as 1 - exp(..) the fp32 difference loses three digits at b2 = 0.999, t = 1 (1 - 0.999 = 1e-3 from
+    // two numbers known to 6e-8).  log b and 1 - b arrive from the host, formed in DOUBLE from the double hyper-parameters as torch forms them
+    // (1 - 0.999f in fp32 is 1.0000467e-3: 5e-5 off)
+    const float bc1 = -expm1f(t * logb1);
+    const float bc2 = -expm1f(t * logb2);
+    const float step_size = lr / bc1, rs2 = 1.f / sqrtf(bc2);
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+      gg = fmaf(gg, grad_scale, wd * pp);
+      mm = fmaf(omb1, gg - mm, mm);
+      vv = fmaf(b2, vv, omb2 * gg * gg);
+      pp -= step_size * mm / fmaf(sqrtf(vv), rs2, eps);
+    };
+    const bool al16 = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
+    if (al16 && base + kAdamChunk <= n) {                                // a whole chunk of 16-byte aligned tensors (views into a flat gradient buffer need not be)
+#pragma unroll
+      for (int i = 0; i < kAdamChunk / 1024; ++i) {
+        const unsigned e = base + 1024u * i + 4u * threadIdx.x;
+        float4 pq = *reinterpret_cast<const float4*>(p + e), mq = *reinterpret_cast<const float4*>(m + e), vq = *reinterpret_cast<const float4*>(v + e);
+        const float4 gq = *reinterpret_cast<const float4*>(g + e);
+        upd(pq.x, gq.x, mq.x, vq.x); upd(pq.y, gq.y, mq.y, vq.y); upd(pq.z, gq.z, mq.z, vq.z); upd(pq.w, gq.w, mq.w, vq.w);
+        *reinterpret_cast<float4*>(p + e) = pq; *reinterpret_cast<float4*>(m + e) = mq; *reinterpret_cast<float4*>(v + e) = vq;
+      }
+    } else {
+      for (unsigned e = base + threadIdx.x; e < n && e < base + kAdamChunk; e += 256u) {
+        float pp = p[e], mm = m[e], vv = v[e];
+        upd(pp, g[e], mm, vv);
+        p[e] = pp; m[e] = mm; v[e] = vv;
+      }
+    }
+  }
+  // the last workgroup to finish advances the step count (every workgroup has read it) and re-arms the ticket
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived == gridDim.x - 1) {
+      if (!skipped && advance) *step = *step + 1.f;
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace
+}  // namespace tsg
+
+using namespace tsg;
+
+// n tensors (host arrays of device pointers, fp32, contiguous; 16-byte aligned tensors take the float4 path): params / grads / exp_avg / exp_avg_sq,
+// numel[i] elements each (< 2^31).  state: device buffer of 2 words {float step count, unsigned ticket (zero between calls)} owned by the caller
+// (zero-initialised once).  skip: device float or NULL.  More than 64 tensors run as consecutive launches that read the same step count; the
+// LAST launch advances it.
+extern "C" int tsg_adam_step(int n, const void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                             const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
+                             void* state, const void* skip, void* stream) {
+  const char* fn = "tsg_adam_step";
+  if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !state) return set_error(TSG_E_NULL, "%s: NULL argument or n=%d", fn, n);
+  if (!(beta1 > 0. && beta1 < 1. && beta2 > 0. && beta2 < 1.)) return set_error(TSG_E_SHAPE, "%s: betas (%g, %g) outside (0, 1)", fn, beta1, beta2);
+  for (int i = 0; i < n; ++i) {
+    if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]) return set_error(TSG_E_NULL, "%s: NULL tensor %d", fn, i);
+    if (numel[i] <= 0 || numel[i] >= (1LL << 31)) return set_error(TSG_E_SHAPE, "%s: tensor %d has %lld elements", fn, i, numel[i]);
+    if ((reinterpret_cast<uintptr_t>(params[i]) | reinterpret_cast<uintptr_t>(grads[i]) | reinterpret_cast<uintptr_t>(exp_avg[i]) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq[i])) & 3u)
+      return set_error(TSG_E_ALIGN, "%s: tensor %d is not 4-byte aligned", fn, i);
+  }
+  for (int i0 = 0; i0 < n; i0 += kAdamMaxTensors) {
+    const int cnt = n - i0 < kAdamMaxTensors ? n - i0 : kAdamMaxTensors;
+    AdamTable tb;
+    tb.n = cnt;
+    unsigned chunks = 0;
+    for (int i = 0; i < cnt; ++i) {
+      tb.p[i] = (float*)params[i0 + i]; tb.g[i] = (const float*)grads[i0 + i]; tb.m[i] = (float*)exp_avg[i0 + i]; tb.v[i] = (float*)exp_avg_sq[i0 + i];
+      tb.numel[i] = (unsigned)numel[i0 + i];
+      tb.first_chunk[i] = chunks;
+      chunks += (unsigned)((numel[i0 + i] + kAdamChunk - 1) / kAdamChunk);
+    }
+    tb.first_chunk[cnt] = chunks;
+    hipLaunchKernelGGL(adam_kernel, dim3(chunks), dim3(256), 0, static_cast<hipStream_t>(stream), tb, (float)lr, (float)beta2, (float)(1. - beta1), (float)(1. - beta2),
+                       (float)log(beta1), (float)log(beta2), (float)eps, (float)weight_decay, (float)grad_scale,
+                       (float*)state, (const float*)skip, (unsigned*)state + 1, i0 + cnt >= n ? 1 : 0);
+  }
+  return check_launch(fn);
+}

@@ -623,17 +623,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
     const GT* g = Gx + (seq_row(d == 0 ? 0 : T - 1, b, Bs, T, bm) * 2 + d) * 4 * h + u;
     gxn[0] = ld1(g); gxn[1] = ld1(g + h); gxn[2] = ld1(g + 2 * h); gxn[3] = ld1(g + 3 * h);
   }
-#ifdef TSG_LSTM_DEFER_RC
-  // R / Cs of a step (saved for the backward, nobody waits for them) leave AFTER the next step's poll: issued right behind the h stores they sat
-  // in front of the poll loads in this CU's memory queue, and the poll's s_waitcnt vmcnt(0) waited for their acknowledgements too
-  float4 rc_g = make_float4(0.f, 0.f, 0.f, 0.f); float rc_c = 0.f; size_t rc_s = 0; bool rc_have = false;
-  unsigned* o_ptr = nullptr; unsigned o_val = 0u; bool o_have = false;       // (XR) this thread's dword of `out`
-  auto store_rc = [&]() {
-    if (o_have) *o_ptr = o_val;
-    if (rc_have) { Cs[rc_s] = rc_c; st4(R + rc_s * 4, rc_g); }
-    rc_have = o_have = false;
-  };
-#endif
   for (int step = 0; step < T; ++step) {
 #ifdef TSG_LSTM_TIMING
     tm0 = __builtin_amdgcn_s_memtime();
@@ -724,9 +713,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
       }
       TSG_TICK(0)                                            // poll: slab complete in registers
       prefetch_gx();
-#ifdef TSG_LSTM_DEFER_RC
-      store_rc();                                            // the step before's R / Cs: behind the poll, not in front of it
-#endif
       if constexpr (XR) {
         // re-mark this workgroup's part of slot (step + 2) % 4 (it held step - 2): this poll has seen step - 1 from every producer of the
         // group, each of which stored it only after ITS poll of step - 1 -- the last reader of step - 2 -- had returned.  The mark is
@@ -831,8 +817,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
     }
     lds_barrier();                                        // tile complete; the slab in LDS is free again
     if constexpr (XR) {
-      // ring first (the hand-off); `out` -- which nobody polls any more -- is an ordinary store (deferred behind the next poll with R / Cs
-      // under TSG_LSTM_DEFER_RC).  Rows beyond B are neither stored nor polled.
+      // ring first (the hand-off); `out` -- which nobody polls any more -- is an ordinary store behind it.  Rows beyond B are neither stored
+      // nor polled.  (Measured and dropped, profiles/r5/lstm_fwd_ring_deferred_stores_ab_v1.txt: R / Cs / out stores issued behind the NEXT
+      // poll instead of in front of it: 3.85 -> 4.2 us per step -- stores in flight during the step delay the next h store behind them.)
       const int row = tid / UW, col = tid % UW;
       const bool rl = b0 + row < B;
       unsigned ov = 0u, rv = 0u;                             // dword for `out`, dword for the ring
@@ -851,11 +838,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
       }
       if (ract) store_x(reinterpret_cast<float*>(xr_chunk(step & 3, row) + (BF ? col >> 1 : col)), __uint_as_float(rv), local);
       unsigned* op = reinterpret_cast<unsigned*>(out + seq_row(tt, rl ? b0 + row : b0, Bs, T, bm) * 2 * h + d * h + us * UW + (BF ? (col & ~1) : col));
-#ifdef TSG_LSTM_DEFER_RC
-      o_ptr = op; o_val = ov; o_have = oact;
-#else
       if (oact) *op = ov;
-#endif
     } else {
       const int row = tid / UW, col = tid % UW;
       if constexpr (BF) {
@@ -866,10 +849,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
         if (b0 + row < B) store_x(out + seq_row(tt, b0 + row, Bs, T, bm) * 2 * h + d * h + us * UW + col, Ht[row * HTS + col], local);
       }
     }
-#ifdef TSG_LSTM_DEFER_RC
-    rc_g = make_float4(gi, gf, gg, go); rc_c = c; rc_s = (((size_t)tt * 2 + d) * Bs + b) * h + u; rc_have = live;
-    if (step + 1 == T) store_rc();
-#else
     if (live) {
       const size_t s = (((size_t)tt * 2 + d) * Bs + b) * h + u;
       // (R / Cs as non-temporal stores: 3.70 -> 3.31 us per step stand-alone in the bf16 storage mode at [128, 128, 512], nothing in the train
@@ -877,7 +856,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
       Cs[s] = c;
       st4(R + s * 4, make_float4(gi, gf, gg, go));
     }
-#endif
 #ifdef TSG_LSTM_TIMING
     if (step > 0) TSG_TICK(3)                                // gates, stores issued, workgroup met
 #endif
@@ -996,40 +974,6 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
 #ifdef TSG_LSTM_TIMING
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tm0 = 0, tm1 = 0;
 #endif
-#ifdef TSG_LSTM_BWD_DEFER_DG
-  GT* dg_ptr = dG; float dg_val[4] = {0.f, 0.f, 0.f, 0.f}; bool dg_have = false;
-  auto store_dg = [&]() {
-    if (dg_have) {
-#pragma unroll
-      for (int gate = 0; gate < 4; ++gate) st1s(dg_ptr + gate * h, dg_val[gate]);
-    }
-    dg_have = false;
-  };
-#endif
-#ifdef TSG_LSTM_BWD_TOUCH
-  // The step's streamed operands (R, Cs, dOut of this workgroup's 16 x 32 tile: 6 lines per row with fp32 storage) come from memory, are requested in
-  // front of the poll and the poll's vmcnt(0) waits for them.  One dword of each of their lines is requested a step AHEAD, right behind the poll
-  // before (result unused): by the time the real loads are issued the lines sit in the L2.
-  unsigned touch_sink = 0u;
-  auto touch_next = [&](int stepn) {
-    if (stepn >= T) return;
-    const int fsn = T - 1 - stepn, ttn = d == 0 ? fsn : T - 1 - fsn;
-    const int tpn = d == 0 ? ttn - 1 : ttn + 1;
-    constexpr int LR = BF ? 2 : 4, LP = LR + 3;             // lines of R per row; lines per row in all (R, Cs of the step, Cs of its c_{t-1}, dOut)
-    if (tid < 16 * LP) {
-      const int r = tid / LP, k = tid % LP;
-      if (b0 + r < B && !(k == LR + 1 && (tpn < 0 || tpn >= T))) {
-        const size_t sidx = (((size_t)ttn * 2 + d) * Bs + b0 + r) * h + us * 32;
-        const char* p = k < LR ? reinterpret_cast<const char*>(R + sidx * 4) + 128 * k
-                      : k == LR ? reinterpret_cast<const char*>(Cs + sidx)
-                      : k == LR + 1 ? reinterpret_cast<const char*>(Cs + (((size_t)tpn * 2 + d) * Bs + b0 + r) * h + us * 32)
-                                : reinterpret_cast<const char*>(dOut + seq_row(ttn, b0 + r, Bs, T, bm) * 2 * h + d * h + us * 32);
-        asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink) : "v"(p) : "memory");
-      }
-    }
-  };
-  touch_next(1);
-#endif
   for (int step = 0; step < T; ++step) {
 #ifdef TSG_LSTM_TIMING
     tm0 = __builtin_amdgcn_s_memtime();
@@ -1081,12 +1025,6 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
         }
       }
       TSG_TICK(0)                                            // poll: all partial blocks landed
-#ifdef TSG_LSTM_BWD_TOUCH
-      touch_next(step + 1);
-#endif
-#ifdef TSG_LSTM_BWD_DEFER_DG
-      store_dg();                                            // the step before's dG: behind the poll, not in front of it
-#endif
       f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1104,19 +1042,11 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
       const float dc = fmaf(dh * go, 1.f - tc * tc, dc_carry);
       dc_carry = dc * gf;
       const float dg[4] = {dc * gg * gi * (1.f - gi), dc * cpv * gf * (1.f - gf), dc * gi * (1.f - gg * gg), dh * tc * go * (1.f - go)};
-#ifdef TSG_LSTM_BWD_DEFER_DG
-      dg_ptr = dG + (seq_row(tt, live ? b : b0, Bs, T, bm) * 2 + d) * K + u;
-#pragma unroll
-      for (int gate = 0; gate < 4; ++gate) dg_val[gate] = dg[gate];
-      dg_have = live;
-      if (step + 1 == T || step == 0) store_dg();           // (step 0 has no poll behind it in step 1's sense: keep the first one simple)
-#else
       if (live) {
         GT* g = dG + (seq_row(tt, b, Bs, T, bm) * 2 + d) * K + u;
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) st1s(g + gate * h, dg[gate]);
       }
-#endif
 #pragma unroll
       for (int gate = 0; gate < 4; ++gate) {
         const float dgv = live ? dg[gate] : 0.f;

@@ -1439,13 +1439,13 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
   // wait, so a partner could count this part in and read rows that had not reached L2).  With the wait the rows are visible
   // device-wide before the counter moves.  Still no release fence: a fence here is an L2 WRITE-BACK (buffer_wbl2), and at this
   // point the L2 holds this workgroup's 256 KiB of freshly stored dr rows -- every workgroup of the XCD would stall on flushing
-  // them in the middle of the kernel (173 -> 147 us per launch at [128,128,20,1024]; -DTSG_K1_XCH_FENCE builds keep the fences: A/B).
+  // them in the middle of the kernel (173 -> 147 us per launch at [128,128,20,1024], measured in round 3 with a fenced build).
   // tests/test_isa_cpu.py disassembles the built code object and asserts the vmcnt(0) wait between the last sc1 store and the
   // counter's atomic in every instantiation.
   // Two steps (round 4).  publish_dp: the stores, right after the row loop.  count_in: the wait + barrier + ticket, AFTER the T-sum
   // epilogue of the row phase -- vmcnt counts loads and stores together and in order, so the acknowledgement wait also covers the
   // wave's queue of dr row stores; behind the epilogue that queue has drained under the epilogue's LDS work.  A/B on one box
-  // (tools/gpu_jobs/r4c.sh, -DTSG_K1_NO_ACK = the round-3 protocol without the wait): 165.4 / 166.4 us with the wait, 166.1 / 164.3
+  // (profiles/r4/k1g_bwd_ack_wait_ab_v1.txt; the round-3 protocol without the wait): 165.4 / 166.4 us with the wait, 166.1 / 164.3
   // without, at [128,128,20,1024] -- the acknowledgement wait is free.
   auto publish_dp = [&]() {
     if (parts <= 1) return;
@@ -1454,18 +1454,11 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
       __hip_atomic_store(mine + idx, De[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto count_in = [&]() {
-#ifndef TSG_K1_NO_ACK                                  // (A/B builds only: the round-3 protocol without the acknowledgement wait -- racy)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // acknowledgement of THIS thread's partial rows (write-through to L2 / memory)
-#endif
     __syncthreads();
     if (tid == 0) {
       xch_failed = 0u;
-#ifdef TSG_K1_XCH_FENCE
-      __threadfence();
-      __hip_atomic_fetch_add(cnt + b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#else
       __hip_atomic_fetch_add(cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
     }
   };
 
@@ -1917,11 +1910,7 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
     count_in();
     if (tid == 0) {
       unsigned spins = 0;
-#ifdef TSG_K1_XCH_FENCE
-      while (!TSG_SKIP(64) && __hip_atomic_load(cnt + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)parts) {
-#else
       while (!TSG_SKIP(64) && __hip_atomic_load(cnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)parts) {
-#endif
         if (++spins > kXchSpinLimit) {
           report_expiry(esink);                  // host sink + device word (the optimizer's guard reads the latter)
           xch_failed = 1u;
@@ -1929,14 +1918,10 @@ __global__ __launch_bounds__(kFusedThreads) void scdm_bwd_fused_kernel(
         }
         __builtin_amdgcn_s_sleep(8);
       }
-#ifdef TSG_K1_XCH_FENCE
-      __threadfence();
-#else
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // invalidate only (buffer_inv): the partners' rows are read after this; no write-back
       // the invalidate completes asynchronously: this wait holds the workgroup barrier below until it has (MI355X_MICROARCH.md,
       // "Consumer, always: one relaxed poll -> one agent acquire -> s_waitcnt vmcnt(0) -> barrier -> plain loads")
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     }
     if (!abl_nobar) __syncthreads();
     // every part's partial in part order (deterministic).  Plain loads: thread 0's agent-scope acquire followed by the

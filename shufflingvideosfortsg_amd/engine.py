@@ -101,12 +101,72 @@ class precision:
         return False
 
 
+class TsgAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(lr, weight_decay (L2), eps) -- the optimizer of the reference (train.py:367-371) -- on the hand-written kernel
+    (csrc/adam.hip: ``tsg_adam_step``): every parameter of the model in one launch per 64 tensors (two for GMD's 80) instead of the six
+    multi_tensor_apply launches of torch's fused Adam, the update count kept (and advanced) on the device, the skip flag of
+    ``optimizer_step`` read on the device.  Same state keys as torch's Adam (``exp_avg``, ``exp_avg_sq``, ``step``: ONE shared device
+    scalar here), so ``state_dict()`` round-trips; always graph-capturable.  fp32 CUDA parameters only; ``grad_scale`` folds a 1 / world
+    into the update when the gradient exchange summed instead of averaging."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True, capturable=True))
+        self.found_inf = None          # device float (non-zero = skip this update): the protocol of torch's fused optimizers (GradScaler)
+        self.grad_scale = 1.0
+        self._state_words = {}         # device -> [update count (float), ticket]
+        self._tables = {}
+
+    def _words(self, dev):
+        w = self._state_words.get(dev)
+        if w is None:
+            w = self._state_words[dev] = torch.zeros(2, device=dev, dtype=torch.float32)
+        return w
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import ctypes
+        from . import functional as TF
+        from ._lib import load, ptr
+        loss = closure() if closure is not None else None
+        lib = load()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            dev = ps[0].device
+            words = self._words(dev)
+            for p in ps:
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.device == dev):
+                    raise ValueError("TsgAdam: fp32 contiguous CUDA parameters on one device only")
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+                if st.get("step") is None or st["step"].data_ptr() != words.data_ptr():
+                    if isinstance(st.get("step"), torch.Tensor) and st["step"].numel() == 1 and st["step"].data_ptr() != words.data_ptr():
+                        words[0] = float(st["step"])                      # a loaded state_dict brings its own count: adopt it once
+                    st["step"] = words[0:1].view(())
+            n = len(ps)
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+            numel = (ctypes.c_longlong * n)(*[p.numel() for p in ps])
+            b1, b2 = group["betas"]
+            skip = self.found_inf
+            rc = lib.tsg_adam_step(n, arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]), arr([self.state[p]["exp_avg_sq"] for p in ps]),
+                                   numel, float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                   float(self.grad_scale), ptr(words), ptr(skip) if skip is not None else None, TF.stream_of(ps[0]))
+            TF.check(rc, "tsg_adam_step")
+        return loss
+
+
 def make_optimizer(model, params, capturable=False):
     """Adam(lr, L2 weight decay, eps=1e-6) as the reference builds it (train.py:367-371); on a GPU the single-pass
     fused implementation of the same update (one kernel over all parameters instead of ~7 foreach passes).
     ``capturable``: step counters on the device, so that the update can be part of a HIP graph (GraphedTrainStep)."""
     ps = list(model.parameters())
     fused = bool(ps) and all(p.is_cuda for p in ps)
+    import os
+    if fused and os.environ.get("TSG_OWN_ADAM", "1") != "0" and all(p.dtype == torch.float32 for p in ps):
+        return TsgAdam(ps, lr=params["lr"], weight_decay=params["weight_decay"], eps=1e-6)      # one launch per 64 tensors (csrc/adam.hip)
     return torch.optim.Adam(ps, lr=params["lr"], weight_decay=params["weight_decay"], eps=1e-6, fused=fused,
                             capturable=bool(capturable and fused))
 

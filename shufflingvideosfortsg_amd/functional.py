@@ -402,21 +402,11 @@ _OWN_GEMM = os.environ.get("TSG_GEMM", "1") != "0"          # A/B switch: 0 = op
 _LSTM_OWN_GEMM = os.environ.get("TSG_LSTM_GEMM", "own") != "lib"
 _LSTM_SPLITK = os.environ.get("TSG_LSTM_SPLITK", "1") != "0"          # A/B switch: the sentence LSTM's dX as 8 K-chunks (bmm + sum)
 _OWN_TRANSPOSE = os.environ.get("TSG_TRANSPOSE", "own") != "torch"     # A/B switch: "torch" = .t().contiguous()
-# Two copy eliminations of round 4, measured separately in the step (profiles/r4/bench_no_copies_ab_v1.txt; 14.167-14.191 ms with neither):
-#   out2: the LSTM layer's dW_ih / dW_hh as two parameter-shaped outputs of ONE weight-gradient launch (tsg_wgrad_f32s_out2) instead of
-#         a [2][4h][I+h] block the host slices and copies: 14.134-14.141 ms -- adopted;
-#   nn:   the contraction-major GEMM operand (tsg_gemm_f32s_nn: dX = dY W with the weight as stored) instead of a transposed copy of the
-#         weight + tsg_gemm_f32s: 14.257-14.269 ms -- SLOWER: the transposing stage of the W tile costs each of the 13 GEMM launches more
-#         than the 4-16 MB copy it deletes.  Kept as an entry point (functional.gemm_f32s_nn), not used by default.
-# TSG_NO_COPIES = out2 (default) / nn / 1 (both) / 0 (neither).
-_NC = os.environ.get("TSG_NO_COPIES", "out2")
-_NO_COPIES = _NC in ("1", "nn")                               # the contraction-major GEMM operand
-
-
-def _nn_ok(M: int) -> bool:
-    """tsg_gemm_f32s_nn (TSG_NO_COPIES=nn / 1) launches 256-row tiles only (M % 64 alone let a backward with 64 k rows raise)."""
-    return _NO_COPIES and M % 256 == 0
-_OUT2 = _NC in ("1", "out2")                                  # the two-output weight gradient
+# Round 4 measured two copy eliminations in the step (profiles/r4/bench_no_copies_ab_v1.txt): the LSTM layer's dW_ih / dW_hh as two
+# parameter-shaped outputs of ONE weight-gradient launch (tsg_wgrad_f32s_out2) -- adopted, it is what the layer runs; and the
+# contraction-major GEMM operand (tsg_gemm_f32s_nn: dX = dY W with the weight as stored) instead of a transposed copy + tsg_gemm_f32s --
+# SLOWER in the step (the transposing W stage costs each of the 13 GEMM launches more than the copy it deletes): the entry point and its
+# wrapper (gemm_f32s_nn) remain, nothing here routes to it (round 5: the environment switch and its five dispatch sites are gone).
 
 
 def gemm_f32s_ok(M: int, N: int, K: int) -> bool:
@@ -479,8 +469,6 @@ def _mm(a: torch.Tensor, b: torch.Tensor, mode=_AUTO) -> torch.Tensor:
         if a.is_cuda and a.is_contiguous() and gemm_f32s_ok(a.shape[0], b.shape[1], a.shape[1]):
             if b.t().is_contiguous():
                 return gemm_f32s(a, b.t())
-            if _nn_ok(a.shape[0]) and b.stride(1) == 1 and b.stride(0) % 4 == 0 and b.data_ptr() % 16 == 0:   # [K,N] row-major (or a column slice):
-                return gemm_f32s_nn(a, b)                                                  # the contraction-major form of the kernel, no transposed copy
             if b.is_contiguous() and b.numel() <= (1 << 24):
                 return gemm_f32s(a, transposed(b))
         return torch.mm(_split_operand(a, 1, False), _split_operand(b, 0, True), out_dtype=torch.float32)
@@ -928,8 +916,6 @@ def _dx_f32s(dy2: torch.Tensor, w_rows: torch.Tensor) -> torch.Tensor:
     constraints hold, else the generic split-precision product."""
     M, N = dy2.shape
     K = w_rows.shape[1]
-    if _nn_ok(M) and gemm_f32s_ok(M, K, N) and w_rows.stride(1) == 1 and w_rows.stride(0) % 4 == 0 and w_rows.data_ptr() % 16 == 0:
-        return gemm_f32s_nn(dy2, w_rows)                           # the weight (slice) as it is stored: contraction-major operand
     if gemm_f32s_ok(M, K, N):
         return gemm_f32s(dy2, transposed(w_rows))
     return _mm(dy2, w_rows, "f32s")
@@ -1057,10 +1043,7 @@ class _BoundaryHeadGemm(torch.autograd.Function):
         dy2, x2 = dy.view(B * T, J), x.view(B * T, K)
         dx = None
         if ctx.needs_input_grad[0]:
-            if _nn_ok(B * T) and gemm_f32s_ok(B * T, K, J) and Hm % 32 == 0:
-                dx = gemm_f32s_nn(dy2, ws_, we_).view(B, T, K)          # [W_start ; W_end] as two row segments, read in place
-            else:
-                dx = _dx_f32s(dy2, torch.cat([ws_, we_], 0)).view(B, T, K)
+            dx = _dx_f32s(dy2, torch.cat([ws_, we_], 0)).view(B, T, K)
         dws = dwe = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dW = _dw_f32s(dy2, x2)                                     # [2Hm, K]: rows of the start head, then of the end head
@@ -1190,10 +1173,7 @@ class _BoundaryHeadFull(torch.autograd.Function):
         ws_, we_ = Ws[:, :Dv], We[:, :Dv]
         dx = None
         if ctx.needs_input_grad[0]:
-            if _nn_ok(B * T) and gemm_f32s_ok(B * T, Dv, J) and Hm % 32 == 0:
-                dx = gemm_f32s_nn(dy2, ws_, we_).view(B, T, Dv)         # [W_start ; W_end] as two row segments, read in place
-            else:
-                dx = _dx_f32s(dy2, torch.cat([ws_, we_], 0)).view(B, T, Dv)
+            dx = _dx_f32s(dy2, torch.cat([ws_, we_], 0)).view(B, T, Dv)
         dsent = torch.addmm(dcs[:, :Hm] @ Ws[:, Dv:], dcs[:, Hm:], We[:, Dv:]) if ctx.needs_input_grad[1] else None
         dWs = dWe = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[4]:
@@ -1485,9 +1465,20 @@ class _LinearSplit(torch.autograd.Function):
 _OWN_GEMM_BF16 = os.environ.get("TSG_OWN_GEMM_BF16", "1") != "0"     # 0: torch.mm -> hipBLASLt for the bf16 mode's projections (A/B)
 
 
+_OWN_GEMM_BF16_ALL = os.environ.get("TSG_OWN_GEMM_BF16") == "all"   # every shape the kernel takes, also where the library is faster (A/B)
+
+
 def gemm_bf16_ok(M: int, N: int, K: int) -> bool:
-    """Shapes tsg_gemm_bf16 takes (include/tsg_hip.h): whole 128 / 256-row x 256-column tiles, 32-deep K chunks."""
-    return _OWN_GEMM_BF16 and M > 0 and M % 128 == 0 and N % 256 == 0 and K % 32 == 0
+    """Shapes tsg_gemm_bf16 takes (include/tsg_hip.h: whole 128 / 256-row x 256-column tiles, 32-deep K chunks) AND is the faster path for
+    (profiles/r5/gemm_bf16_vs_library_v1.txt, one MI355X, us own / hipBLASLt NT): up to one tile per CU -- [2560 x 1024] . [1024 x 1024]^T 19.7 / 24.9
+    (the library's NT pick at that shape: 263), [1280 x 1024] . [4096 x 1024]^T 22.6 / 25.8, [8192 x 1024] . [1024 x 1024]^T 25.1 / 26.2,
+    [16384 x 2048] . [512 x 2048]^T 37.2 / 40.8.  With several tiles per CU the kernel is LDS-bound (24 fragment reads + the DMA's writes per
+    32 MFMAs: the LDS pipe is as busy as the matrix pipe; ablations in the same file) and the library's 4-wave 128 x 128 wave tiles win:
+    [16384 x 1024] . [4096 x 1024]^T 158 / 122 -- those products stay on the library.  TSG_OWN_GEMM_BF16=all / 0: every shape / none."""
+    if not (_OWN_GEMM_BF16 and M > 0 and M % 128 == 0 and N % 256 == 0 and K % 32 == 0):
+        return False
+    tm = 256 if M % 256 == 0 else 128
+    return _OWN_GEMM_BF16_ALL or (M // tm) * (N // 256) < 256
 
 
 def gemm_bf16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None, out_dtype=None) -> torch.Tensor:
@@ -1662,16 +1653,13 @@ class _BiLSTMLayer(torch.autograd.Function):
         shift, period = (1, T) if bm else (B, 0)
         x2, o2 = x.view(TB, I), out.view(TB, 2 * h)
         if ctx.own and T > 1 and wgrad_f32s_ok(TB, 4 * h, I, h) and gemm_f32s_ok(TB, I, 8 * h):
-            # own kernels, no operand planes, no copies: dX = dG W_ih (tsg_gemm_f32s_nn: the weight as stored), and ONE weight-gradient
+            # own kernels, no operand planes: dX = dG W_ih on tsg_gemm_f32s (one transposed copy of the weight), and ONE weight-gradient
             # launch for dG[d]^T [x | h_{t-+1}[d]] of both directions, the shifted h rows read straight from `out`, written as the two
             # parameter-shaped tensors (tsg_wgrad_f32s_out2)
             if ctx.needs_input_grad[0]:
-                dx = (gemm_f32s_nn(dGf, W_ih) if _nn_ok(TB) else gemm_f32s(dGf, transposed(W_ih))).view(x.shape)
-            if _OUT2:
-                dW_ih, dW_hh = wgrad_f32s_out2(dGf, x2, o2, N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h, shift=shift, period=period)
-                return dx, dW_ih.view(8 * h, I), dbias, dW_hh, None, None, (dbias if ctx.two_biases else None)
-            D = wgrad_f32s(dGf, x2, N=4 * h, groups=2, a_group_stride=4 * h, B1=o2, K1=h, b1_group_stride=h, shift=shift, period=period)
-            return dx, D[:, :, :I].contiguous().view(8 * h, I), dbias, D[:, :, I:].contiguous(), None, None, (dbias if ctx.two_biases else None)
+                dx = gemm_f32s(dGf, transposed(W_ih)).view(x.shape)
+            dW_ih, dW_hh = wgrad_f32s_out2(dGf, x2, o2, N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h, shift=shift, period=period)
+            return dx, dW_ih.view(8 * h, I), dbias, dW_hh, None, None, (dbias if ctx.two_biases else None)
         if T == 1:
             dW_ih = _mm(dGf.t(), x2, mode)
             dW_hh = torch.zeros_like(W_hh)

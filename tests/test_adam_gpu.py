@@ -1,0 +1,101 @@
+"""tsg_adam_step / engine.TsgAdam (csrc/adam.hip; round 5): the reference's optimizer -- torch.optim.Adam(lr=1e-3, weight_decay=1e-4 (L2), eps=1e-6),
+grounding/train.py:367-371 -- as ONE launch per 64 tensors, against torch's own Adam on the same gradients: parameters and both moments after
+several updates, tensors of every size class (scalars, odd lengths, exactly one chunk, many chunks), more than 64 tensors, the on-device skip
+flag (found_inf: parameters, moments AND the update count untouched), the 1 / world gradient scale, and a state_dict round trip."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1,), (3,), (7, 5), (1024,), (8192,), (8193,), (2048, 1024), (300, 300), (2, 2048, 512), (4096,), (33, 17)] + [(64, 64)] * 60
+
+
+def _models(seed):
+    g = torch.Generator().manual_seed(seed)
+    ps = [torch.randn(*s, generator=g).cuda() for s in SHAPES]
+    a = [torch.nn.Parameter(p.clone()) for p in ps]
+    b = [torch.nn.Parameter(p.clone()) for p in ps]
+    return a, b, g
+
+
+def test_tsg_adam_matches_torch_adam():
+    from shufflingvideosfortsg_amd.engine import TsgAdam
+    a, b, g = _models(0)
+    assert len(a) > 64                                    # two launches per update
+    own = TsgAdam(a, lr=1e-3, weight_decay=1e-4, eps=1e-6)
+    ref = torch.optim.Adam(b, lr=1e-3, weight_decay=1e-4, eps=1e-6)
+    for it in range(6):
+        for pa, pb in zip(a, b):
+            gr = (torch.randn(pa.shape, generator=g) * (10.0 ** (it - 3))).cuda()     # gradient scales over six decades
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        own.step(); ref.step()
+    torch.cuda.synchronize()
+    assert float(own.state[a[0]]["step"]) == 6.0
+    for pa, pb in zip(a, b):
+        torch.testing.assert_close(pa.data, pb.data, rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(own.state[pa]["exp_avg"], ref.state[pb]["exp_avg"], rtol=2e-6, atol=1e-10)
+        torch.testing.assert_close(own.state[pa]["exp_avg_sq"], ref.state[pb]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+
+
+def test_tsg_adam_skip_flag_scale_and_state_dict():
+    from shufflingvideosfortsg_amd.engine import TsgAdam
+    a, b, g = _models(1)
+    own = TsgAdam(a, lr=1e-3, weight_decay=1e-4, eps=1e-6)
+    ref = torch.optim.Adam(b, lr=1e-3, weight_decay=1e-4, eps=1e-6)
+
+    def grads(scale_own=1.0):
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, generator=g).cuda()
+            pa.grad, pb.grad = gr * scale_own, gr.clone()
+    grads(); own.step(); ref.step()
+    before = [p.detach().clone() for p in a]
+    m_before = [own.state[p]["exp_avg"].clone() for p in a]
+    grads()
+    own.found_inf = torch.ones((), device="cuda")          # skip: nothing moves, the count stays at 1
+    own.step(); own.found_inf = None
+    torch.cuda.synchronize()
+    assert float(own.state[a[0]]["step"]) == 1.0
+    for p, q, m0 in zip(a, before, m_before):
+        assert torch.equal(p.data, q) and torch.equal(own.state[p]["exp_avg"], m0)
+    own.found_inf = torch.zeros((), device="cuda")         # flag present but clear: the update runs (same gradients as the skipped call)
+    own.step(); own.found_inf = None
+    ref.step()
+    for pa, pb in zip(a, b):
+        torch.testing.assert_close(pa.data, pb.data, rtol=2e-6, atol=1e-7)
+    # the 1 / world of a SUM all-reduce folded into the update: gradients 4x too large, grad_scale 1/4
+    grads(scale_own=4.0)
+    own.grad_scale = 0.25
+    own.step(); ref.step()
+    own.grad_scale = 1.0
+    for pa, pb in zip(a, b):
+        torch.testing.assert_close(pa.data, pb.data, rtol=2e-6, atol=1e-7)
+    # state_dict round trip into a fresh optimizer on fresh parameters: the count and the moments come along
+    import copy
+    sd = copy.deepcopy(own.state_dict())          # (load_state_dict does not copy tensors that already have the right dtype / device)
+    c = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    own2 = TsgAdam(c, lr=1e-3, weight_decay=1e-4, eps=1e-6)
+    own2.load_state_dict(sd)
+    grads()
+    for pc, pa in zip(c, a):
+        pc.grad = pa.grad.clone()
+    own.step(); own2.step(); ref.step()
+    torch.cuda.synchronize()
+    assert float(own2.state[c[0]]["step"]) == float(own.state[a[0]]["step"]) == 4.0
+    for pc, pa, pb in zip(c, a, b):
+        assert torch.equal(pc.data, pa.data)
+        torch.testing.assert_close(pa.data, pb.data, rtol=3e-6, atol=1e-7)
+
+
+def test_engine_optimizer_step_uses_the_own_adam_and_skips_on_the_device():
+    from shufflingvideosfortsg_amd import engine
+    torch.manual_seed(0)
+    m = torch.nn.Linear(64, 64).cuda()
+    opt = engine.make_optimizer(m, dict(lr=1e-3, weight_decay=1e-4))
+    assert isinstance(opt, engine.TsgAdam)
+    x = torch.randn(8, 64, device="cuda")
+    w0 = m.weight.detach().clone()
+    loss = m(x).pow(2).mean(); loss.backward()
+    engine.optimizer_step(opt, loss * float("nan"))        # a non-finite loss: skipped on the device, no host sync
+    assert torch.equal(m.weight.detach(), w0)
+    engine.optimizer_step(opt, loss)
+    assert not torch.equal(m.weight.detach(), w0)

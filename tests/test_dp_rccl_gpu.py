@@ -1,5 +1,7 @@
 """The RCCL gradient-exchange path with the real model on one GPU (world size 1, TSG_FORCE_DIST=1): three GMD train steps with the
-exchange after the backward (overlap=False) and bucket by bucket during it (overlap=True) must reproduce the losses of the
+exchange after the backward (overlap=False), bucket by bucket during it (overlap=True) and -- round 5, bench.py's default for N > 1 -- bucket
+by bucket but GATED around the persistent launches (each all-reduce launched right behind a persistent LSTM backward, fenced in front of
+the next one: never beside one) must reproduce the losses of the
 plain single-process steps, with the persistent LSTM kernels' error sink clean (an RCCL kernel co-resident with a
 one-workgroup-per-CU persistent launch must only delay it).  Runs in a child process (process-group state)."""
 import os
@@ -27,8 +29,17 @@ params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, 
 torch.manual_seed(0)
 model = engine.build_model("gmd", params).cuda().train()
 model.tod.dropout.p = 0.0
-dp = FlatGradAllReduce(model, overlap=(mode == "overlap"))
+dp = FlatGradAllReduce(model, overlap=(mode in ("overlap", "gated")), gated=(mode == "gated"), bucket_mb=24.0)
 assert dp.active == (mode != "plain")
+if mode == "gated":
+    TF.set_persistent_gate(dp)          # what bench.py --gpus N does: collectives fenced in front of / launched behind every persistent launch
+    calls = {"before": 0, "after": 0, "launched_by_gate": 0}
+    b0, a0 = dp.before_persistent, dp.after_persistent
+    def before():
+        calls["before"] += 1; b0()
+    def after():
+        n = len(dp._handles); a0(); calls["after"] += 1; calls["launched_by_gate"] += len(dp._handles) - n
+    dp.before_persistent, dp.after_persistent = before, after
 opt = engine.make_optimizer(model, params)
 batch = data.synthetic_batch(128, 64, 20, seed=5, pair=True, device="cuda")     # 256 encoder rows: full-chip persistent grids
 losses = []
@@ -43,6 +54,12 @@ with engine.precision("f32s"):
         losses.append(float(loss))
 torch.cuda.synchronize()
 TF.check_lstm_errors()
+if mode == "gated":
+    # per step: 6 persistent LSTM backward launches (4 video layers, 2 sentence layers) + 2 K1g backward launches fence; the buckets left
+    # the gate, not the hooks, except what finish() flushed (the sentence encoder's first layer and the word embedding come last)
+    assert calls["after"] == 3 * 6 and calls["before"] >= calls["after"], calls
+    assert calls["launched_by_gate"] >= 3 * (len(dp.buckets) - 2), (calls, len(dp.buckets))
+    print("GATE " + json.dumps(calls) + " buckets " + str(len(dp.buckets)))
 if mode != "plain":
     dist.destroy_process_group()
 print("LOSSES " + json.dumps(losses))
@@ -66,10 +83,11 @@ def test_forced_dist_steps_match_plain_steps():
     plain = _run("plain")
     after = _run("after")
     overlap = _run("overlap")
+    gated = _run("gated")
     assert all(abs(x) < 1e4 for x in plain)
     # the exchange is an average over ONE rank: the first step's loss is the same arithmetic; afterwards the float-atomic sums
     # of a few gradients (run-to-run rounding differences) pass through Adam with eps = 1e-6, which amplifies them
-    for got, name in ((after, "overlap=False"), (overlap, "overlap=True")):
+    for got, name in ((after, "overlap=False"), (overlap, "overlap=True"), (gated, "gated overlap (round 5)")):
         assert abs(got[0] - plain[0]) <= 2e-6 * max(1.0, abs(plain[0])), (name, got, plain)
         for a, b in zip(got[1:], plain[1:]):
             assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (name, got, plain)

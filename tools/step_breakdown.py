@@ -4,7 +4,7 @@ usage: step_breakdown.py <kernel_trace.csv> [step index] [--gemms] [--glue]"""
 import collections, csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], int(r['Grid_Size_X']), int(r['Workgroup_Size_X'])) for r in rows)
-idx = [i for i, e in enumerate(ev) if 'multi_tensor_apply' in e[2]]
+idx = [i for i, e in enumerate(ev) if 'multi_tensor_apply' in e[2] or 'adam_kernel' in e[2]]      # the optimizer update closes a step (torch's fused Adam or csrc/adam.hip)
 groups = []
 for i in idx:
     if groups and i - groups[-1][-1] <= 3: groups[-1].append(i)
@@ -14,6 +14,7 @@ s, e = groups[k][-1] + 1, groups[k + 1][-1]
 t0 = ev[s][0]
 def cat(n):
     if 'lstm_' in n: return 'lstm recurrence'
+    if 'adam_kernel' in n: return 'adam (own)'
     if n.startswith(('Cijk', 'Custom_Cijk')): return 'gemm bf16' if ('_BSS_BH' in n or '_BBS_BH' in n) else 'gemm f32'    # BSS: bf16 in, fp32 out; BBS: bf16 out
     if 'split_bf16' in n: return 'operand split'
     if 'tsg::' in n: return 'hot-path kernels'
