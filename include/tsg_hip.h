@@ -216,6 +216,10 @@ long long tsg_lstm_fwd_ws_bytes(int B, int T, int h);
 /* When tsg_lstm_fwd_ws takes the ring: -1 = automatic (default: where it measured faster -- B >= 96 rows, or TSG_BF16 at B <= 32; TSG_LSTM_XR=0/1
  * in the environment overrides the default), 0 = never, 1 = whenever the workspace holds one.  Process-wide, like tsg_lstm_set_persist. */
 int tsg_lstm_set_ring(int mode);
+/* With TSG_BF16 at h = 512 and a ring workspace, tsg_lstm_fwd_ws can run 64-UNIT workgroups (two A-tiles of W_hh per wave, 8 workgroups per
+ * exchange group) on half the CUs: half the slab readers per L2 for twice the MFMA work per wave.  -1 = automatic (default: B >= 96 rows;
+ * TSG_LSTM_W64=0/1 in the environment sets the initial mode), 0 = never, 1 = whenever the shape allows.  Same results bit for bit.           */
+int tsg_lstm_set_wide(int mode);
 int tsg_lstm_fwd_ws(const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs, void* ws, long long ws_bytes,
                     int B, int T, int h, int dtype, int batch_major, void* stream);
 

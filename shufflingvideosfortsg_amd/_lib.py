@@ -49,6 +49,7 @@ _SIGNATURES = {
     "tsg_lstm_set_l2_exchange": [_I],
     "tsg_lstm_set_persist": [_I],
     "tsg_lstm_set_ring": [_I],
+    "tsg_lstm_set_wide": [_I],
     "tsg_wgrad_set_stream_k": [_I],
     "tsg_adam_step": [_I, _P, _P, _P, _P, _P] + [ctypes.c_double] * 6 + [_P, _P, _P],
     "tsg_gemm_bf16": [_P, c_longlong, _P, c_longlong, _P, _P, c_longlong, _I, _I, _I, _I, _P],

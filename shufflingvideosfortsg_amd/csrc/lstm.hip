@@ -618,6 +618,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
 #else
 #define TSG_TICK(i) {}
 #endif
+#ifdef TSG_LSTM_DOUBLE_WORK
+  float dw_c = 0.f;
+#endif
   float gxn[4] = {0.f, 0.f, 0.f, 0.f};                     // input gates of the NEXT step (see the loop head)
   if (live) {
     const GT* g = Gx + (seq_row(d == 0 ? 0 : T - 1, b, Bs, T, bm) * 2 + d) * 4 * h + u;
@@ -646,6 +649,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
     };
     if (step == 0) prefetch_gx();
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#ifdef TSG_LSTM_DOUBLE_WORK
+    f32x4 dw_acc = {0.f, 0.f, 0.f, 0.f};
+#endif
     if (step > 0) {
       f32x4 v[SV];
       u32x4 q[SV];
@@ -755,6 +761,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
         constexpr int PFB = NJB < 3 ? NJB : 3;
         u32x4 bh[PFB], bl[PFB];
         f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+#ifdef TSG_LSTM_DOUBLE_WORK
+        f32x4 dw_acc2 = {0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
         for (int j = 0; j < PFB; ++j) {
           bh[j] = *reinterpret_cast<const u32x4*>(hr + 16 * j);
@@ -769,6 +778,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
           }
           if constexpr (BF) {                              // one product per k block, two accumulator chains
             if (j & 1) acc2 = mfma_bf16(ahi[j], vh, acc2); else acc = mfma_bf16(ahi[j], vh, acc);
+#ifdef TSG_LSTM_DOUBLE_WORK                                // timing-only emulation of TWO A-tiles per wave (64-unit workgroups): the MFMAs and the gates twice
+            if (j & 1) dw_acc2 = mfma_bf16(ahi[j], vh, dw_acc2); else dw_acc = mfma_bf16(ahi[j], vh, dw_acc);
+#endif
           } else {
             acc = mfma_bf16(ahi[j], vh, acc);
             acc2 = mfma_bf16(ahi[j], vl, acc2);
@@ -776,6 +788,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
           }
         }
         acc += acc2 + acc3;
+#ifdef TSG_LSTM_DOUBLE_WORK
+        dw_acc += dw_acc2;
+#endif
       } else {
       // B operand: one ds_read_b128 per 16 columns (row stride = 8 mod 64: conflict-free 16-lane groups), requested PFD
       // reads ahead of the MFMAs that consume it -- issued one at a time, each read's latency (~100+ cycles) sat in
@@ -814,6 +829,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
       c = fmaf(gf, cprev, gi * gg);
       cprev = c;
       Ht[jb * HTS + at * 4 + ku] = go * tanh_f(c);
+#ifdef TSG_LSTM_DOUBLE_WORK
+      {
+        const float gi2 = sigmoid_f(dw_acc[0] + gx[1]), gf2 = sigmoid_f(dw_acc[1] + gx[2]), gg2 = tanh_f(dw_acc[2] + gx[3]), go2 = sigmoid_f(dw_acc[3] + gx[0]);
+        dw_c = fmaf(gf2, dw_c, gi2 * gg2);
+        const float h2 = go2 * tanh_f(dw_c);
+        asm volatile("" :: "v"(h2));
+      }
+#endif
     }
     lds_barrier();                                        // tile complete; the slab in LDS is free again
     if constexpr (XR) {
@@ -864,6 +887,193 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
   if (blockIdx.x == 0 && tid == 0)
     for (int i = 0; i < 4; ++i) sync[8 + i] = (unsigned)(tph[i] / (unsigned long long)(T - 1));
 #endif
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// forward, persistent, bf16 storage, 64-UNIT workgroups on HALF the CUs (round 5; h = 512, >= 96 rows).
+// What paces the forward step at the full chip is not the work between its barriers but the all-gather of the 16-row h slab through
+// one XCD's L2 -- every workgroup of a group polls the whole slab, two groups share an L2 -- and the clock of a fully busy chip
+// ("Round 5": only the poll phase differs between 64 and 128 rows; with bf16 storage the MFMA phase halves and the
+// waiting grows by the same amount).  With bf16 storage W_hh is one plane: a wave can hold TWO A-tiles (8 units x 4 gates x h = 128 VGPRs), a
+// workgroup 64 units, a group 8 workgroups -- half the slab readers per L2 and half the CUs idle -- for twice the MFMA and gate work per
+// wave, which the waiting absorbs: a timing-only emulation (the 64-row grid with every wave's MFMAs and gates doubled:
+// profiles/r5/lstm_fwd_half_chip_emulation_v1.txt) ran 3.18 us per step against 3.66 for the 32-unit kernel at 128 rows.
+// Same protocol as lstm_fwd_persist_kernel<.., MODE = 2, NW = 8, XR = true>: data-as-flag through the 4-slot exchange ring (one 128-byte
+// line per (row, producer)), sentinels, re-mark of slot (s + 2) % 4 behind the poll of step s, the group's XCD check, bounded waits.
+// ---------------------------------------------------------------------------------------------
+template <int HJ>
+__global__ __launch_bounds__(512) void lstm_fwd_persist_w64_kernel(
+    const lstm_bf16* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh, lstm_bf16* __restrict__ out,
+    lstm_bf16* __restrict__ R, float* __restrict__ Cs, unsigned* __restrict__ sync, int B, int Bs, int T, int h, int flags, int bm,
+    ErrSink esink, unsigned* __restrict__ xr) {
+  constexpr int NT = 512, AT = 2, UW = 64, HTS = UW + 1, NJB = HJ / 2, CH = UW / 2;      // CH: dwords of a (row, producer) ring chunk
+  constexpr int SV = 2;                                    // 16-byte pieces of the 16-row bf16 slab per thread (16 x h x 2 bytes / 512 threads at h = 512)
+  extern __shared__ __align__(16) float Hl[];
+  unsigned* Hhi = reinterpret_cast<unsigned*>(Hl);         // [16][kHLB] dwords: the slab as it arrives (one bf16 plane)
+  float* Ht = Hl + kSlabFloats;                            // [16][HTS] this step's h tile (16 rows x 64 units), gathered for whole-line stores
+  __shared__ unsigned s_fail;
+  if (threadIdx.x == 0) s_fail = 0u;
+  const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+  const int uslices = h / UW, bslices = (B + 15) / 16;
+  const int vidx = xcd_major_index(), group = vidx / uslices;
+  const int us = vidx % uslices, d = group / bslices, bs = group % bslices;
+  const int nactive = 2 * uslices * bslices;
+  if (vidx >= nactive) return;
+  const int jb = lane & 15, ku = lane >> 4, b0 = bs * 16;
+  const int ngroups = 2 * bslices, rowdw = uslices * CH;   // (= h / 2 dwords per ring row)
+  auto xr_row = [&](int slot, int row) { return xr + ((size_t)(slot * ngroups + group) * 16 + row) * rowdw; };
+  auto xr_chunk = [&](int slot, int row) { return xr_row(slot, row) + us * CH; };
+
+  // A fragments of the wave's two tiles: tile ta = 2 wv + a holds units us * 64 + 4 ta .. + 3; row i = jb -> (unit + (jb >> 2), gate jb & 3);
+  // lane quad ku holds k = 32 j + 8 ku .. + 7 of k block j, rounded to bf16 once (the storage mode's one plane)
+  u32x4 ahi[AT][NJB];
+  int u0[AT];
+  float bi[AT][4];
+#pragma unroll
+  for (int a = 0; a < AT; ++a) {
+    u0[a] = us * UW + 4 * (AT * wv + a);
+    const float* wrow = Whh + (size_t)d * 4 * h * h + (size_t)((jb & 3) * h + u0[a] + (jb >> 2)) * h + 8 * ku;
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) {
+      u32x4 lo;
+      split8(*reinterpret_cast<const f32x4*>(wrow + 32 * j), *reinterpret_cast<const f32x4*>(wrow + 32 * j + 4), ahi[a][j], lo);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bi[a][k] = bias ? bias[(size_t)d * 4 * h + k * h + u0[a] + ku] : 0.f;
+  }
+  const int b = b0 + jb;
+  const bool live = b < B;
+  float cprev[AT] = {0.f, 0.f};
+  // thread -> (row, unit pair) of the 16 x 64 tile: marks, re-marks and h stores use the same lane for the same address
+  const int srow = tid >> 5, spair = tid & 31;
+  const unsigned sent2 = kSentinel16 | (kSentinel16 << 16);
+  for (int slot = 0; slot < 4; ++slot) store_sc1_u(reinterpret_cast<float*>(xr_chunk(slot, srow) + spair), sent2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if ((flags & 2) && blockIdx.x == 0) return;              // TSG_LSTM_INJECT_TIMEOUT: workgroup 0 never arrives (test of the error path)
+  const bool local = grid_start(sync, group, flags & 1, esink, (unsigned)nactive);
+  if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+
+  // poll pieces: the same every step (byte offsets inside the group's slab)
+  const int nrowp = h / 8;                                 // 16-byte pieces per slab row
+  unsigned xoff[SV], pending = 0u;
+#pragma unroll
+  for (int i = 0; i < SV; ++i) {
+    const int idx = tid + i * NT, r = idx / nrowp, c4 = idx % nrowp;
+    const bool ok = r < 16 && b0 + r < B;
+    if (ok) pending |= 1u << i;
+    xoff[i] = ok ? 4u * (unsigned)(r * rowdw + c4 * 4) : 0u;
+  }
+  float gxn[AT][4];
+#pragma unroll
+  for (int a = 0; a < AT; ++a)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gxn[a][k] = 0.f;
+  // (32-bit element offsets from the scalar tensor bases: one VGPR per address instead of a 64-bit pair -- the host checks that the
+  //  tensors stay below 2^31 elements; with 64-bit lane pointers hoisted out of the loop the kernel spilled 35 registers)
+  auto srow32 = [&](int t, int bb) { return bm ? (unsigned)bb * (unsigned)T + (unsigned)t : (unsigned)t * (unsigned)Bs + (unsigned)bb; };
+#ifndef TSG_W64_ABL
+#define TSG_W64_ABL 0            // timing-only ablations: 1 no R / Cs stores, 2 no Gx loads, 4 no `out` store
+#endif
+  auto load_gx = [&](int t) {
+    if (!live || (TSG_W64_ABL & 2)) return;
+    const unsigned g0 = (srow32(t, b) * 2u + (unsigned)d) * 4u * (unsigned)h + (unsigned)ku;
+#pragma unroll
+    for (int a = 0; a < AT; ++a)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gxn[a][k] = ld1(Gx + (g0 + (unsigned)(u0[a] + k * h)));
+  };
+  load_gx(d == 0 ? 0 : T - 1);
+  for (int step = 0; step < T; ++step) {
+    const int tt = d == 0 ? step : T - 1 - step;
+    float gx[AT][4];
+    auto take_gx = [&]() {                                 // the gates requested a step ago; request the next step's (behind the poll: see the 32-unit kernel)
+#pragma unroll
+      for (int a = 0; a < AT; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gx[a][k] = gxn[a][k] + bi[a][k];
+      if (step + 1 < T) load_gx(d == 0 ? step + 1 : T - 2 - step);
+    };
+    f32x4 acc[AT][2];
+#pragma unroll
+    for (int a = 0; a < AT; ++a) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = acc[a][0]; }
+    if (step == 0) take_gx();
+    if (step > 0) {
+      u32x4 q[SV];
+      const unsigned* xbase = xr_row((step - 1) & 3, 0);
+      int spins = 0;
+      while (true) {
+#pragma unroll
+        for (int i = 0; i < SV; ++i) q[i] = load_sc1_u4_s(xbase, xoff[i]);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]) : : "memory");
+        unsigned raw = 0u;
+#pragma unroll
+        for (int i = 0; i < SV; ++i) {
+          bool pend = false;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) pend = pend || (q[i][m] & 0xffffu) == kSentinel16 || (q[i][m] >> 16) == kSentinel16;
+          if (pend) raw |= 1u << i;
+        }
+        raw &= pending;
+        if (!raw) break;
+        if ((++spins & 31) == 0 && (spins > (kSpinLimit >> 6) || err_word(sync) != 0u)) {
+          raise_error(sync, esink);
+          __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          break;
+        }
+      }
+      take_gx();
+      // re-mark this workgroup's part of slot (step + 2) % 4 (it held step - 2: everybody has read it -- see the 32-unit kernel)
+      if (step + 2 < T) store_x(reinterpret_cast<float*>(xr_chunk((step + 2) & 3, srow) + spair), __uint_as_float(sent2), local);
+#pragma unroll
+      for (int i = 0; i < SV; ++i) {
+        const int idx = tid + i * NT, r = idx / nrowp, c4 = idx % nrowp;
+        if (!(pending & (1u << i))) q[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (r < 16) *reinterpret_cast<u32x4*>(Hhi + r * kHLB + c4 * 4) = q[i];
+      }
+      lds_barrier();
+      if (__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+      // one B fragment (ds_read_b128, three blocks ahead) feeds both tiles' MFMAs; two accumulator chains per tile
+      const unsigned* hr = Hhi + jb * kHLB + 4 * ku;
+      constexpr int PFB = NJB < 3 ? NJB : 3;
+      u32x4 bh[PFB];
+#pragma unroll
+      for (int j = 0; j < PFB; ++j) bh[j] = *reinterpret_cast<const u32x4*>(hr + 16 * j);
+#pragma unroll
+      for (int j = 0; j < NJB; ++j) {
+        const u32x4 vh = bh[j % PFB];
+        if (j + PFB < NJB) bh[j % PFB] = *reinterpret_cast<const u32x4*>(hr + 16 * (j + PFB));
+#pragma unroll
+        for (int a = 0; a < AT; ++a) acc[a][j & 1] = mfma_bf16(ahi[a][j], vh, acc[a][j & 1]);
+      }
+    }
+    float gate[AT][4], cc[AT];
+#pragma unroll
+    for (int a = 0; a < AT; ++a) {
+      const f32x4 z = acc[a][0] + acc[a][1];
+      gate[a][0] = sigmoid_f(z[0] + gx[a][0]); gate[a][1] = sigmoid_f(z[1] + gx[a][1]);
+      gate[a][2] = tanh_f(z[2] + gx[a][2]); gate[a][3] = sigmoid_f(z[3] + gx[a][3]);
+      cc[a] = fmaf(gate[a][1], cprev[a], gate[a][0] * gate[a][2]);
+      cprev[a] = cc[a];
+      if (live) Ht[jb * HTS + 4 * (AT * wv + a) + ku] = gate[a][3] * tanh_f(cc[a]);
+    }
+    lds_barrier();                                         // tile complete; the slab in LDS is free again
+    {
+      const bool rl = b0 + srow < B;
+      const unsigned pk = pack_bf16x2(Ht[srow * HTS + 2 * spair], Ht[srow * HTS + 2 * spair + 1]);
+      if (rl && step + 1 < T) store_x(reinterpret_cast<float*>(xr_chunk(step & 3, srow) + spair), __uint_as_float(pk), local);
+      if (rl && !(TSG_W64_ABL & 4)) *reinterpret_cast<unsigned*>(out + (srow32(tt, b0 + srow) * 2u * (unsigned)h + (unsigned)(d * h + us * UW + 2 * spair))) = pk;
+    }
+    if (live && !(TSG_W64_ABL & 1)) {
+#pragma unroll
+      for (int a = 0; a < AT; ++a) {
+        const unsigned sidx = (((unsigned)tt * 2u + (unsigned)d) * (unsigned)Bs + (unsigned)b) * (unsigned)h + (unsigned)(u0[a] + ku);
+        Cs[sidx] = cc[a];
+        st4(R + sidx * 4u, make_float4(gate[a][0], gate[a][1], gate[a][2], gate[a][3]));
+      }
+    }
+  }
 }
 
 
@@ -1276,6 +1486,14 @@ static bool xr_wanted(int B, bool bf) {
   return B >= 96 || (bf && B <= 32);
 }
 extern "C" int tsg_lstm_set_ring(int mode) { g_xr.store(mode < 0 ? -1 : (mode != 0), std::memory_order_relaxed); return 0; }
+// 64-unit workgroups on half the CUs (lstm_fwd_persist_w64_kernel: bf16 storage, h = 512, ring workspace): -1 automatic (>= 96 rows), 0 never, 1 whenever possible
+static std::atomic<int> g_w64{-2};
+static bool w64_wanted(int B) {
+  int v = g_w64.load(std::memory_order_relaxed);
+  if (v == -2) { const char* e = getenv("TSG_LSTM_W64"); v = e ? (atoi(e) != 0) : -1; g_w64.store(v, std::memory_order_relaxed); }
+  return v >= 0 ? v != 0 : B >= 96;
+}
+extern "C" int tsg_lstm_set_wide(int mode) { g_w64.store(mode < 0 ? -1 : (mode != 0), std::memory_order_relaxed); return 0; }
 
 template <int HJ, int MODE, int NW, bool XR>
 static void launch_fwd_persist(int grid, size_t lds, hipStream_t st, const void* Gx, const void* bias, const void* Whh, void* out, void* R, void* Cs,
@@ -1317,6 +1535,26 @@ static int lstm_fwd_impl(const void* Gx, const void* bias, const void* Whh, void
     const bool split = dtype == TSG_F32S;                  // other hidden sizes: the fp32 arithmetic (more accurate, slower)
     // the exchange ring (XR kernels): the caller's workspace holds it, hidden sizes 128 / 256 / 384 / 512
     const long long need = tsg_lstm_fwd_ws_bytes(B, T, h);
+    if (bf && h == 512 && need > 0 && ws_bytes >= need && w64_wanted(B) && (long long)T * B * 8 * h < (1LL << 31)) {
+      // bf16 storage at the full-chip sizes: 64-unit workgroups, 8 per exchange group, on half the CUs (see the kernel)
+      auto kw = lstm_fwd_persist_w64_kernel<32>;
+      const size_t wlds = sizeof(float) * ((size_t)kSlabFloats + 16 * 65 + 4);
+      const int capw = persist_capacity(3, kw, 512, wlds, 1);
+      const int rowsw = persist_chunk_rows(B, h / 64, capw);
+      if (rowsw > 0) {
+        const size_t K8 = (size_t)8 * h, H2 = (size_t)2 * h;
+        for (int c0 = 0; c0 < B; c0 += rowsw) {
+          const int Bc = B - c0 < rowsw ? B - c0 : rowsw;
+          const size_t seq = bm ? (size_t)c0 * T : (size_t)c0;
+          hipError_t e = zero_async(sync_ws, kSyncBytes, st);
+          if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+          hipLaunchKernelGGL(kw, dim3(persist_grid(cdiv(Bc, 16), h / 64, capw)), dim3(512), wlds, st, (const lstm_bf16*)Gx + seq * K8, (const float*)bias,
+                             (const float*)Whh, (lstm_bf16*)out + seq * H2, (lstm_bf16*)R + (size_t)c0 * h * 4, (float*)Cs + (size_t)c0 * h,
+                             (unsigned*)sync_ws, Bc, B, T, h, launch_flags(), bm, error_sink(), (unsigned*)((char*)sync_ws + kSyncBytes));
+        }
+        return check_launch(fn);
+      }
+    }
     const bool xr = need > 0 && ws_bytes >= need && xr_wanted(B, bf);
     const int NW = ((nw_env == 4 || (nw_env == 0 && B <= 32)) && h == 512 && (split || (bf && xr))) ? 4 : 8;
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH

@@ -23,7 +23,8 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 # kernels whose cross-workgroup protocol is "agent-scope stores, workgroup barrier, one integer atomic on a counter"
 PUBLISHERS = ("scdm_bwd_fused_kernel", "boundary_bwd_one_kernel", "gemm_nt_f32s_kernel",
               # round 5: the stream-K weight gradient's tile tickets, the persistent LSTM kernels' start barrier, K4's last-arrival finalisation
-              "wgrad_split_kernel", "wgrad_bf16_tr_kernel", "lstm_fwd_persist_kernel", "lstm_bwd_persist2_kernel", "gmd_losses_fwd_kernel")
+              "wgrad_split_kernel", "wgrad_bf16_tr_kernel", "lstm_fwd_persist_kernel", "lstm_fwd_persist_w64_kernel", "lstm_bwd_persist2_kernel",
+              "gmd_losses_fwd_kernel")
 
 
 def _disassemble(tmp_path):
@@ -150,7 +151,8 @@ def test_persistent_lstm_hand_offs_keep_their_scope_bits(kernels):
       * the exchange stores exist in the write-through (sc1) form (taken whenever a group is not verified to sit on one XCD);
       * a give-up reaches the host: a system-scope (sc0 sc1) store to the error sink, and the launch's error word is polled with an
         sc1 load that is waited for at once."""
-    names = [k for k in kernels if "lstm_fwd_persist_kernel" in k or "lstm_bwd_persist2_kernel" in k]
+    names = [k for k in kernels if "lstm_fwd_persist_kernel" in k or "lstm_fwd_persist_w64_kernel" in k or "lstm_bwd_persist2_kernel" in k]
+    assert any("w64" in k for k in names)
     assert len(names) >= 30, len(names)                   # forward: 3 arithmetic modes x 4 hidden sizes x {out-polling, ring} + 4-wave kernels; backward: 12
     for k in names:
         ins = kernels[k]

@@ -280,6 +280,40 @@ def test_exchange_ring_forward_equals_out_polling(shape, dt, bm, request):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,T", [(128, 24), (96, 16), (100, 12), (256, 8), (300, 6)])
+@pytest.mark.parametrize("bm", [0, 1])
+def test_wide_workgroup_forward_equals_the_32_unit_kernel(B, T, bm, request):
+    """lstm_fwd_persist_w64_kernel (round 5: bf16 storage, h = 512, 64-unit workgroups -- two A-tiles of W_hh per wave, 8 workgroups per exchange
+    group -- on half the CUs) gives bit-identical out / R / Cs to the 32-unit ring kernel: full chip in 32-unit terms (128 rows), 12 groups,
+    ragged rows, 256 rows in ONE launch (the 32-unit kernel needs two), 300 rows (chunked), both layouts, bias added in the kernel."""
+    from shufflingvideosfortsg_amd import _lib
+    from shufflingvideosfortsg_amd._lib import ptr, TSG_BF16
+    h = 512
+    lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(B * T + bm)
+    Gx = (torch.randn(*((B, T) if bm else (T, B)), 2, 4 * h, generator=g) * 0.5).cuda().bfloat16()
+    W = (torch.randn(2, 4 * h, h, generator=g) / h ** 0.5).cuda(); bias = (torch.randn(8 * h, generator=g) * 0.1).cuda()
+    nws = lib.tsg_lstm_fwd_ws_bytes(B, T, h)
+    request.addfinalizer(lambda: (lib.tsg_lstm_set_wide(-1), lib.tsg_lstm_set_ring(-1)))
+    lib.tsg_lstm_set_ring(1)
+    res = []
+    for wide in (0, 1, 1):
+        lib.tsg_lstm_set_wide(wide)
+        ws = torch.full((nws // 4,), 0x3f803f80, dtype=torch.int32, device="cuda")       # stale bf16 "data" (1.0, 1.0), not sentinels
+        out = torch.full((B, T, 2 * h) if bm else (T, B, 2 * h), 9.0, device="cuda", dtype=torch.bfloat16)
+        R = torch.empty(T, 2, B, h, 4, device="cuda", dtype=torch.bfloat16); Cs = torch.empty(T, 2, B, h, device="cuda")
+        rc = lib.tsg_lstm_fwd_ws(ptr(Gx), ptr(bias), ptr(W), ptr(out), ptr(R), ptr(Cs), ptr(ws), nws, B, T, h, TSG_BF16, bm, st)
+        assert rc == 0, lib.tsg_last_error()
+        torch.cuda.synchronize()
+        assert int(ws[0]) == 0, "bounded wait expired"
+        # arrival counter: 2 directions x slices x (8 or 16) workgroups of the LAST chunk -> tells which kernel ran
+        res.append((out, R, Cs, int(ws[1])))
+    assert res[1][3] * 2 == res[0][3] or B > 128, (res[0][3], res[1][3])       # half the workgroups (single-launch sizes)
+    for k in (1, 2):
+        for a, b in zip(res[0][:3], res[k][:3]):
+            assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+
+
 def test_persistent_lstm_timeout_is_reported():
     """A persistent launch whose start barrier cannot complete (TSG_LSTM_INJECT_TIMEOUT: workgroup 0 never arrives) must not
     hang, must set the launch's error word, and must surface as LstmWaitExpired on the next LSTM call (pinned error sink,

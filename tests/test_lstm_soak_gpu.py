@@ -78,7 +78,7 @@ def test_persistent_lstm_poisoned_exchange_buffers(l2x):
     lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
     TF.check_lstm_errors()
     lib.tsg_lstm_set_l2_exchange(l2x)
-    lib.tsg_lstm_set_ring(1)
+    lib.tsg_lstm_set_ring(1)                                 # (bf16 storage at >= 96 rows then runs the 64-unit kernel: its default)
     patterns = (0x7fc00000, 0x7fc00001, 0x7fa5c3e1, None)
     try:
         for (B, T, h, dt, bm) in POISON_SHAPES:
