@@ -368,6 +368,12 @@ __device__ __forceinline__ u32x4 load_sc1_u4(const float* p) {           // inte
   asm volatile("global_load_dwordx4 %0, %1, off " TSG_LD_BITS : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+// a wave-uniform pointer the compiler may hold in VGPRs (its divergence analysis is conservative): forced into an SGPR pair
+__device__ __forceinline__ const unsigned* uniform_ptr(const unsigned* p) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return reinterpret_cast<const unsigned*>(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ u32x4 load_sc1_u4_s(const unsigned* sbase, unsigned voff) {   // scalar base + 32-bit lane offset (bytes): one VGPR per address
   u32x4 v;
   asm volatile("global_load_dwordx4 %0, %1, %2 " TSG_LD_BITS : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
@@ -669,7 +675,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
           if constexpr (XR) { src[i] = nullptr; xoff[i] = ok ? 4u * (unsigned)(r * rowdw + c4 * 4) : 0u; }   // byte offset inside the group's slab: the same every step
           else src[i] = reinterpret_cast<const float*>(out + seq_row(tp, ok ? b0 + r : b0, Bs, T, bm) * 2 * h + d * h + (ok ? c4 * (BF ? 8 : 4) : 0));
         }
-        const unsigned* xbase = XR ? xr_row((step - 1) & 3, 0) : nullptr;     // (XR) wave-uniform slab base of the slot polled now
+        const unsigned* xbase = XR ? uniform_ptr(xr_row((step - 1) & 3, 0)) : nullptr;     // (XR) wave-uniform slab base of the slot polled now
         // (measured and dropped: two or three staggered copies of the poll in flight -- the extra slab traffic costs more
         // than the shorter retry saves, 13.7 vs 11.5 us per step)
         static_assert(SV == 2 || SV == 4 || SV == 8, "the wait below lists 2, 4 or 8 loads");
@@ -902,6 +908,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
 // Same protocol as lstm_fwd_persist_kernel<.., MODE = 2, NW = 8, XR = true>: data-as-flag through the 4-slot exchange ring (one 128-byte
 // line per (row, producer)), sentinels, re-mark of slot (s + 2) % 4 behind the poll of step s, the group's XCD check, bounded waits.
 // ---------------------------------------------------------------------------------------------
+#ifndef TSG_W64_ABL
+#define TSG_W64_ABL 0            // timing-only ablations: 1 no R / Cs stores, 2 no Gx loads, 4 no `out` store
+#endif
 template <int HJ>
 __global__ __launch_bounds__(512) void lstm_fwd_persist_w64_kernel(
     const lstm_bf16* __restrict__ Gx, const float* __restrict__ bias, const float* __restrict__ Whh, lstm_bf16* __restrict__ out,
@@ -912,6 +921,17 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_w64_kernel(
   extern __shared__ __align__(16) float Hl[];
   unsigned* Hhi = reinterpret_cast<unsigned*>(Hl);         // [16][kHLB] dwords: the slab as it arrives (one bf16 plane)
   float* Ht = Hl + kSlabFloats;                            // [16][HTS] this step's h tile (16 rows x 64 units), gathered for whole-line stores
+  // The streamed tensors go through LDS as well, so that every global access is a 16-byte piece of a full line.  (As per-lane accesses in the
+  // MFMA lane layout -- 8 two-byte Gx loads and 4 scattered R / Cs stores per lane and step -- they cost 2.8 of the step's 4.9 us:
+  // profiles/r5/lstm_fwd_w64_streaming_ablation_v1.txt.)
+  // Row strides = 4 / 8 / 4 mod 64 dwords: the gate phase touches these tiles in the MFMA lane layout (16 rows x 4 units per wave) -- on the
+  // natural strides (128 / 128 / 64 dwords) all 16 rows of a wave instruction fall on ONE bank (a 16-way conflict on 20 LDS accesses per lane
+  // and step: measured +1.3 us per step)
+  constexpr int GTS = 4 * 32 + 4, RTS = 64 * 2 + 8, CTS = 64 + 4;
+  unsigned* Gt = reinterpret_cast<unsigned*>(Ht + 16 * HTS);       // [16 rows][GTS]: 4 gates x 32 dwords -- the step's input gates, bf16 pairs as stored
+  unsigned* Rt = Gt + 16 * GTS;                                     // [16 rows][RTS]: 64 units x 2 dwords -- activated gates (i,f | g,o) as bf16 pairs
+  float* Ct = reinterpret_cast<float*>(Rt + 16 * RTS);              // [16 rows][CTS]: 64 units -- cell states
+  static_assert((kSlabFloats + 16 * HTS) % 4 == 0, "Gt is 16-byte aligned");
   __shared__ unsigned s_fail;
   if (threadIdx.x == 0) s_fail = 0u;
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
@@ -924,29 +944,30 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_w64_kernel(
   const int ngroups = 2 * bslices, rowdw = uslices * CH;   // (= h / 2 dwords per ring row)
   auto xr_row = [&](int slot, int row) { return xr + ((size_t)(slot * ngroups + group) * 16 + row) * rowdw; };
   auto xr_chunk = [&](int slot, int row) { return xr_row(slot, row) + us * CH; };
+  // (32-bit element offsets from the scalar tensor bases: one VGPR per address; the host checks that the tensors stay below 2^31 elements)
+  auto srow32 = [&](int t, int bb) { return bm ? (unsigned)bb * (unsigned)T + (unsigned)t : (unsigned)t * (unsigned)Bs + (unsigned)bb; };
 
   // A fragments of the wave's two tiles: tile ta = 2 wv + a holds units us * 64 + 4 ta .. + 3; row i = jb -> (unit + (jb >> 2), gate jb & 3);
   // lane quad ku holds k = 32 j + 8 ku .. + 7 of k block j, rounded to bf16 once (the storage mode's one plane)
   u32x4 ahi[AT][NJB];
-  int u0[AT];
   float bi[AT][4];
 #pragma unroll
   for (int a = 0; a < AT; ++a) {
-    u0[a] = us * UW + 4 * (AT * wv + a);
-    const float* wrow = Whh + (size_t)d * 4 * h * h + (size_t)((jb & 3) * h + u0[a] + (jb >> 2)) * h + 8 * ku;
+    const int u0 = us * UW + 4 * (AT * wv + a);
+    const float* wrow = Whh + (size_t)d * 4 * h * h + (size_t)((jb & 3) * h + u0 + (jb >> 2)) * h + 8 * ku;
 #pragma unroll
     for (int j = 0; j < NJB; ++j) {
       u32x4 lo;
       split8(*reinterpret_cast<const f32x4*>(wrow + 32 * j), *reinterpret_cast<const f32x4*>(wrow + 32 * j + 4), ahi[a][j], lo);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bi[a][k] = bias ? bias[(size_t)d * 4 * h + k * h + u0[a] + ku] : 0.f;
+    for (int k = 0; k < 4; ++k) bi[a][k] = bias ? bias[(size_t)d * 4 * h + k * h + u0 + ku] : 0.f;
   }
-  const int b = b0 + jb;
-  const bool live = b < B;
+  const bool live = b0 + jb < B;
   float cprev[AT] = {0.f, 0.f};
   // thread -> (row, unit pair) of the 16 x 64 tile: marks, re-marks and h stores use the same lane for the same address
   const int srow = tid >> 5, spair = tid & 31;
+  const bool rl = b0 + srow < B;
   const unsigned sent2 = kSentinel16 | (kSentinel16 << 16);
   for (int slot = 0; slot < 4; ++slot) store_sc1_u(reinterpret_cast<float*>(xr_chunk(slot, srow) + spair), sent2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -965,43 +986,29 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_w64_kernel(
     if (ok) pending |= 1u << i;
     xoff[i] = ok ? 4u * (unsigned)(r * rowdw + c4 * 4) : 0u;
   }
-  float gxn[AT][4];
-#pragma unroll
-  for (int a = 0; a < AT; ++a)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gxn[a][k] = 0.f;
-  // (32-bit element offsets from the scalar tensor bases: one VGPR per address instead of a 64-bit pair -- the host checks that the
-  //  tensors stay below 2^31 elements; with 64-bit lane pointers hoisted out of the loop the kernel spilled 35 registers)
-  auto srow32 = [&](int t, int bb) { return bm ? (unsigned)bb * (unsigned)T + (unsigned)t : (unsigned)t * (unsigned)Bs + (unsigned)bb; };
-#ifndef TSG_W64_ABL
-#define TSG_W64_ABL 0            // timing-only ablations: 1 no R / Cs stores, 2 no Gx loads, 4 no `out` store
-#endif
+  // thread -> 16-byte piece of the step's 16 x 4 x 64 bf16 tile of Gx (row srow, gate, 8 units): 512 pieces = one per thread, requested a step ahead
+  const int ggate = (tid >> 3) & 3, gpart = tid & 7;
+  u32x4 gq = {0u, 0u, 0u, 0u};
   auto load_gx = [&](int t) {
-    if (!live || (TSG_W64_ABL & 2)) return;
-    const unsigned g0 = (srow32(t, b) * 2u + (unsigned)d) * 4u * (unsigned)h + (unsigned)ku;
-#pragma unroll
-    for (int a = 0; a < AT; ++a)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) gxn[a][k] = ld1(Gx + (g0 + (unsigned)(u0[a] + k * h)));
+    if (!rl || (TSG_W64_ABL & 2)) return;
+    const unsigned g0 = (srow32(t, b0 + srow) * 2u + (unsigned)d) * 4u * (unsigned)h + (unsigned)(ggate * h + us * UW + 8 * gpart);
+    gq = *reinterpret_cast<const u32x4*>(Gx + g0);
   };
   load_gx(d == 0 ? 0 : T - 1);
   for (int step = 0; step < T; ++step) {
     const int tt = d == 0 ? step : T - 1 - step;
-    float gx[AT][4];
-    auto take_gx = [&]() {                                 // the gates requested a step ago; request the next step's (behind the poll: see the 32-unit kernel)
-#pragma unroll
-      for (int a = 0; a < AT; ++a)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gx[a][k] = gxn[a][k] + bi[a][k];
+    // the piece requested a step ago goes to LDS (its wait: the poll's vmcnt(0), or -- step 0 -- the compiler's), the next step's is requested behind it
+    auto take_gx = [&]() {
+      *reinterpret_cast<u32x4*>(Gt + srow * GTS + ggate * 32 + 4 * gpart) = gq;
       if (step + 1 < T) load_gx(d == 0 ? step + 1 : T - 2 - step);
     };
     f32x4 acc[AT][2];
 #pragma unroll
     for (int a = 0; a < AT; ++a) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = acc[a][0]; }
-    if (step == 0) take_gx();
+    if (step == 0) { take_gx(); lds_barrier(); }
     if (step > 0) {
       u32x4 q[SV];
-      const unsigned* xbase = xr_row((step - 1) & 3, 0);
+      const unsigned* xbase = uniform_ptr(xr_row((step - 1) & 3, 0));
       int spins = 0;
       while (true) {
 #pragma unroll
@@ -1048,29 +1055,35 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_w64_kernel(
         for (int a = 0; a < AT; ++a) acc[a][j & 1] = mfma_bf16(ahi[a][j], vh, acc[a][j & 1]);
       }
     }
-    float gate[AT][4], cc[AT];
 #pragma unroll
     for (int a = 0; a < AT; ++a) {
-      const f32x4 z = acc[a][0] + acc[a][1];
-      gate[a][0] = sigmoid_f(z[0] + gx[a][0]); gate[a][1] = sigmoid_f(z[1] + gx[a][1]);
-      gate[a][2] = tanh_f(z[2] + gx[a][2]); gate[a][3] = sigmoid_f(z[3] + gx[a][3]);
-      cc[a] = fmaf(gate[a][1], cprev[a], gate[a][0] * gate[a][2]);
-      cprev[a] = cc[a];
-      if (live) Ht[jb * HTS + 4 * (AT * wv + a) + ku] = gate[a][3] * tanh_f(cc[a]);
-    }
-    lds_barrier();                                         // tile complete; the slab in LDS is free again
-    {
-      const bool rl = b0 + srow < B;
-      const unsigned pk = pack_bf16x2(Ht[srow * HTS + 2 * spair], Ht[srow * HTS + 2 * spair + 1]);
-      if (rl && step + 1 < T) store_x(reinterpret_cast<float*>(xr_chunk(step & 3, srow) + spair), __uint_as_float(pk), local);
-      if (rl && !(TSG_W64_ABL & 4)) *reinterpret_cast<unsigned*>(out + (srow32(tt, b0 + srow) * 2u * (unsigned)h + (unsigned)(d * h + us * UW + 2 * spair))) = pk;
-    }
-    if (live && !(TSG_W64_ABL & 1)) {
+      const int ul = 4 * (AT * wv + a) + ku;               // unit of this lane inside the workgroup's 64
+      float gx[4];
 #pragma unroll
-      for (int a = 0; a < AT; ++a) {
-        const unsigned sidx = (((unsigned)tt * 2u + (unsigned)d) * (unsigned)Bs + (unsigned)b) * (unsigned)h + (unsigned)(u0[a] + ku);
-        Cs[sidx] = cc[a];
-        st4(R + sidx * 4u, make_float4(gate[a][0], gate[a][1], gate[a][2], gate[a][3]));
+      for (int k = 0; k < 4; ++k) {
+        const unsigned w2 = Gt[jb * GTS + k * 32 + (ul >> 1)];
+        gx[k] = ((ul & 1) ? bf16_hi(w2) : bf16_lo(w2)) + bi[a][k];
+      }
+      const f32x4 z = acc[a][0] + acc[a][1];
+      const float gi = sigmoid_f(z[0] + gx[0]), gf = sigmoid_f(z[1] + gx[1]), gg = tanh_f(z[2] + gx[2]), go = sigmoid_f(z[3] + gx[3]);
+      const float c = fmaf(gf, cprev[a], gi * gg);
+      cprev[a] = c;
+      if (live) {
+        Ht[jb * HTS + ul] = go * tanh_f(c);
+        *reinterpret_cast<uint2*>(Rt + jb * RTS + ul * 2) = make_uint2(pack_bf16x2(gi, gf), pack_bf16x2(gg, go));
+        Ct[jb * CTS + ul] = c;
+      }
+    }
+    lds_barrier();                                         // tiles complete; the slab and Gt are free again
+    if (rl) {
+      // h first (the hand-off): ring, then `out`; then R (16 rows x 64 units x 8 bytes = 512 pieces of 16 bytes) and Cs (256 pieces)
+      const unsigned pk = pack_bf16x2(Ht[srow * HTS + 2 * spair], Ht[srow * HTS + 2 * spair + 1]);
+      if (step + 1 < T) store_x(reinterpret_cast<float*>(xr_chunk(step & 3, srow) + spair), __uint_as_float(pk), local);
+      if (!(TSG_W64_ABL & 4)) *reinterpret_cast<unsigned*>(out + (srow32(tt, b0 + srow) * 2u * (unsigned)h + (unsigned)(d * h + us * UW + 2 * spair))) = pk;
+      if (!(TSG_W64_ABL & 1)) {
+        const unsigned sidx = (((unsigned)tt * 2u + (unsigned)d) * (unsigned)Bs + (unsigned)(b0 + srow)) * (unsigned)h + (unsigned)(us * UW);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned*>(R) + ((size_t)sidx * 2 + 4 * spair)) = *reinterpret_cast<const u32x4*>(Rt + srow * RTS + 4 * spair);
+        if (spair < 16) *reinterpret_cast<f32x4*>(Cs + (sidx + 4u * spair)) = *reinterpret_cast<const f32x4*>(Ct + srow * CTS + 4 * spair);
       }
     }
   }
@@ -1538,7 +1551,7 @@ static int lstm_fwd_impl(const void* Gx, const void* bias, const void* Whh, void
     if (bf && h == 512 && need > 0 && ws_bytes >= need && w64_wanted(B) && (long long)T * B * 8 * h < (1LL << 31)) {
       // bf16 storage at the full-chip sizes: 64-unit workgroups, 8 per exchange group, on half the CUs (see the kernel)
       auto kw = lstm_fwd_persist_w64_kernel<32>;
-      const size_t wlds = sizeof(float) * ((size_t)kSlabFloats + 16 * 65 + 4);
+      const size_t wlds = sizeof(float) * ((size_t)kSlabFloats + 16 * 65 + 16 * (4 * 32 + 4) + 16 * (64 * 2 + 8) + 16 * (64 + 4) + 4);
       const int capw = persist_capacity(3, kw, 512, wlds, 1);
       const int rowsw = persist_chunk_rows(B, h / 64, capw);
       if (rowsw > 0) {
