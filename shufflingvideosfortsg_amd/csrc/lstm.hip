@@ -543,6 +543,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
   float* Ht = Hl + kSlabFloats;                          // [16][kHLB] dwords), then Ht [16][33] = this step's h tile (16 rows x
   unsigned* Hhi = reinterpret_cast<unsigned*>(Hl);       // 32 units), gathered for whole-line stores
   unsigned* Hlo = Hhi + 16 * kHLB;
+  // The streamed tensors -- Gx in, R / Cs out -- go through LDS too (round 5), so that every global access is a 16-byte piece of a full line:
+  // as per-lane accesses in the MFMA lane layout (four strided loads and two scattered stores per lane and step) they cost the step ~1 us
+  // (profiles/r5/lstm_fwd_w64_streaming_ablation_v1.txt, lstm_fwd_staged_streams_ab_v1.txt).  Row strides = 4 / 8 / 4 mod 64 dwords: the gate phase
+  // touches the tiles with 16 rows x 4 units per wave instruction, which on the natural strides is a 16-way bank conflict.
+  constexpr int EW = BF ? 2 : 1;                           // elements per dword of the sequence tensors
+  constexpr int GTS = 4 * UW / EW + 4, RTS = 4 * UW / EW + 8, CTS = UW + 4;
+  unsigned* Gt = reinterpret_cast<unsigned*>(Ht + 16 * 36 + (16 * HTS > 16 * 36 ? 16 * HTS - 16 * 36 : 0));   // [16][GTS] input gates of the step, as stored
+  unsigned* Rt = Gt + 16 * GTS;                            // [16][RTS] activated gates (i,f,g,o per unit), as stored
+  float* Ct = reinterpret_cast<float*>(Rt + 16 * RTS);     // [16][CTS] cell states
   // raised by a wave whose bounded wait expired.  A static __shared__ variable: through a pointer derived from the dynamic
   // LDS block the compiler lost the address space and read the flag with a FLAT load, whose vmcnt(0) wait behind the barrier
   // also waited for the loads requested for the next step.
@@ -624,14 +633,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
 #else
 #define TSG_TICK(i) {}
 #endif
-#ifdef TSG_LSTM_DOUBLE_WORK
-  float dw_c = 0.f;
+  // thread -> 16-byte piece of the step's 16 x 4 x UW tile of Gx (row, gate, 16 / sizeof(GT) units), requested one step AHEAD
+  constexpr int PPG = UW / (4 * EW);                       // pieces per (row, gate)
+  const int grow = tid / (4 * PPG), ggate = (tid / PPG) % 4, gpart = tid % PPG;
+  const bool gact = tid < 64 * PPG && b0 + grow < B;
+  u32x4 gq = {0u, 0u, 0u, 0u};
+#ifndef TSG_FWD_ABL
+#define TSG_FWD_ABL 0            // timing-only ablations of the streams: 1 no R / Cs stores, 2 no Gx loads, 4 no `out` store
 #endif
-  float gxn[4] = {0.f, 0.f, 0.f, 0.f};                     // input gates of the NEXT step (see the loop head)
-  if (live) {
-    const GT* g = Gx + (seq_row(d == 0 ? 0 : T - 1, b, Bs, T, bm) * 2 + d) * 4 * h + u;
-    gxn[0] = ld1(g); gxn[1] = ld1(g + h); gxn[2] = ld1(g + 2 * h); gxn[3] = ld1(g + 3 * h);
-  }
+  auto load_gx = [&](int t) {
+    if (gact && !(TSG_FWD_ABL & 2)) gq = *reinterpret_cast<const u32x4*>(Gx + (seq_row(t, b0 + grow, Bs, T, bm) * 2 + d) * 4 * h + ggate * h + us * UW + gpart * 4 * EW);
+  };
+  load_gx(d == 0 ? 0 : T - 1);
   for (int step = 0; step < T; ++step) {
 #ifdef TSG_LSTM_TIMING
     tm0 = __builtin_amdgcn_s_memtime();
@@ -641,23 +654,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
     // The input gates of a step are requested one step AHEAD (right after the previous step's poll): the poll's
     // s_waitcnt vmcnt(0) waits for everything this wave has in flight, and a Gx load issued in front of it put an HBM
     // round trip (~1.5 us) into every hand-off that itself takes 0.24 us (tools/ubench/l2_pingpong.hip).
-    // They are taken over right AFTER the poll (whose wait has covered them), never at the loop head, where the wait for
-    // them would also wait for the stores of the step before.
-    float gx[4];
+    // The piece is taken over (to LDS) right AFTER the poll (whose wait has covered it), never at the loop head, where the wait for
+    // it would also wait for the stores of the step before.
     auto prefetch_gx = [&]() {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) gx[k] = gxn[k] + bi[k];
-      if (live && step + 1 < T) {
-        const int tn = d == 0 ? step + 1 : T - 2 - step;
-        const GT* g = Gx + (seq_row(tn, b, Bs, T, bm) * 2 + d) * 4 * h + u;
-        gxn[0] = ld1(g); gxn[1] = ld1(g + h); gxn[2] = ld1(g + 2 * h); gxn[3] = ld1(g + 3 * h);
-      }
+      if (tid < 64 * PPG) *reinterpret_cast<u32x4*>(Gt + grow * GTS + ggate * (UW / EW) + 4 * gpart) = gq;
+      if (step + 1 < T) load_gx(d == 0 ? step + 1 : T - 2 - step);
     };
-    if (step == 0) prefetch_gx();
+    if (step == 0) { prefetch_gx(); lds_barrier(); }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#ifdef TSG_LSTM_DOUBLE_WORK
-    f32x4 dw_acc = {0.f, 0.f, 0.f, 0.f};
-#endif
     if (step > 0) {
       f32x4 v[SV];
       u32x4 q[SV];
@@ -767,9 +771,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
         constexpr int PFB = NJB < 3 ? NJB : 3;
         u32x4 bh[PFB], bl[PFB];
         f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
-#ifdef TSG_LSTM_DOUBLE_WORK
-        f32x4 dw_acc2 = {0.f, 0.f, 0.f, 0.f};
-#endif
 #pragma unroll
         for (int j = 0; j < PFB; ++j) {
           bh[j] = *reinterpret_cast<const u32x4*>(hr + 16 * j);
@@ -784,9 +785,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
           }
           if constexpr (BF) {                              // one product per k block, two accumulator chains
             if (j & 1) acc2 = mfma_bf16(ahi[j], vh, acc2); else acc = mfma_bf16(ahi[j], vh, acc);
-#ifdef TSG_LSTM_DOUBLE_WORK                                // timing-only emulation of TWO A-tiles per wave (64-unit workgroups): the MFMAs and the gates twice
-            if (j & 1) dw_acc2 = mfma_bf16(ahi[j], vh, dw_acc2); else dw_acc = mfma_bf16(ahi[j], vh, dw_acc);
-#endif
           } else {
             acc = mfma_bf16(ahi[j], vh, acc);
             acc2 = mfma_bf16(ahi[j], vl, acc2);
@@ -794,9 +792,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
           }
         }
         acc += acc2 + acc3;
-#ifdef TSG_LSTM_DOUBLE_WORK
-        dw_acc += dw_acc2;
-#endif
       } else {
       // B operand: one ds_read_b128 per 16 columns (row stride = 8 mod 64: conflict-free 16-lane groups), requested PFD
       // reads ahead of the MFMAs that consume it -- issued one at a time, each read's latency (~100+ cycles) sat in
@@ -828,21 +823,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
     // h_t goes out first and as WHOLE 128-byte lines: the workgroup's 16 x 32 tile is gathered in LDS and every wave
     // writes two complete rows per store instruction (write-through); the per-lane 4-byte stores of the first version
     // put eight partial writes from eight waves on every line.  R / Cs (not on the critical path) follow.
-    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c = 0.f;
     if (live) {
-      gi = sigmoid_f(acc[0] + gx[0]); gf = sigmoid_f(acc[1] + gx[1]);
-      gg = tanh_f(acc[2] + gx[2]); go = sigmoid_f(acc[3] + gx[3]);
-      c = fmaf(gf, cprev, gi * gg);
-      cprev = c;
-      Ht[jb * HTS + at * 4 + ku] = go * tanh_f(c);
-#ifdef TSG_LSTM_DOUBLE_WORK
-      {
-        const float gi2 = sigmoid_f(dw_acc[0] + gx[1]), gf2 = sigmoid_f(dw_acc[1] + gx[2]), gg2 = tanh_f(dw_acc[2] + gx[3]), go2 = sigmoid_f(dw_acc[3] + gx[0]);
-        dw_c = fmaf(gf2, dw_c, gi2 * gg2);
-        const float h2 = go2 * tanh_f(dw_c);
-        asm volatile("" :: "v"(h2));
+      const int ul = at * 4 + ku;                          // this lane's unit inside the workgroup's UW
+      float gx[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if constexpr (BF) { const unsigned w2 = Gt[jb * GTS + k * (UW / 2) + (ul >> 1)]; gx[k] = ((ul & 1) ? bf16_hi(w2) : bf16_lo(w2)) + bi[k]; }
+        else gx[k] = __uint_as_float(Gt[jb * GTS + k * UW + ul]) + bi[k];
       }
-#endif
+      const float gi = sigmoid_f(acc[0] + gx[0]), gf = sigmoid_f(acc[1] + gx[1]);
+      const float gg = tanh_f(acc[2] + gx[2]), go = sigmoid_f(acc[3] + gx[3]);
+      const float c = fmaf(gf, cprev, gi * gg);
+      cprev = c;
+      Ht[jb * HTS + ul] = go * tanh_f(c);
+      if constexpr (BF) *reinterpret_cast<uint2*>(Rt + jb * RTS + ul * 2) = make_uint2(pack_bf16x2(gi, gf), pack_bf16x2(gg, go));
+      else *reinterpret_cast<f32x4*>(Rt + jb * RTS + ul * 4) = (f32x4){gi, gf, gg, go};
+      Ct[jb * CTS + ul] = c;
     }
     lds_barrier();                                        // tile complete; the slab in LDS is free again
     if constexpr (XR) {
@@ -867,7 +863,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
       }
       if (ract) store_x(reinterpret_cast<float*>(xr_chunk(step & 3, row) + (BF ? col >> 1 : col)), __uint_as_float(rv), local);
       unsigned* op = reinterpret_cast<unsigned*>(out + seq_row(tt, rl ? b0 + row : b0, Bs, T, bm) * 2 * h + d * h + us * UW + (BF ? (col & ~1) : col));
-      if (oact) *op = ov;
+      if (oact && !(TSG_FWD_ABL & 4)) *op = ov;
     } else {
       const int row = tid / UW, col = tid % UW;
       if constexpr (BF) {
@@ -878,12 +874,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
         if (b0 + row < B) store_x(out + seq_row(tt, b0 + row, Bs, T, bm) * 2 * h + d * h + us * UW + col, Ht[row * HTS + col], local);
       }
     }
-    if (live) {
-      const size_t s = (((size_t)tt * 2 + d) * Bs + b) * h + u;
+    {
+      // R tile = 16 rows x (UW units x 4 gates) as stored, Cs tile = 16 rows x UW floats: 16-byte pieces, rows of whole lines
       // (R / Cs as non-temporal stores: 3.70 -> 3.31 us per step stand-alone in the bf16 storage mode at [128, 128, 512], nothing in the train
       // step, and 3.70 -> 4.1 us with fp32 storage at T = 256: not used -- profiles/r4/lstm_fwd_nontemporal_stores_ab_v1.txt)
-      Cs[s] = c;
-      st4(R + s * 4, make_float4(gi, gf, gg, go));
+      constexpr int RPR = UW / EW, CPR = UW / 4;             // 16-byte pieces per row of the R tile / of the Cs tile
+      const int rrow = tid / RPR, rpart = tid % RPR;
+      if (rrow < 16 && b0 + rrow < B && !(TSG_FWD_ABL & 1)) {
+        const size_t srow_ = (((size_t)tt * 2 + d) * Bs + b0 + rrow) * h + us * UW;
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned*>(R + srow_ * 4) + 4 * rpart) = *reinterpret_cast<const u32x4*>(Rt + rrow * RTS + 4 * rpart);
+      }
+      const int crow = tid / CPR, cpart = tid % CPR;
+      if (crow < 16 && b0 + crow < B && !(TSG_FWD_ABL & 1))
+        *reinterpret_cast<f32x4*>(Cs + (((size_t)tt * 2 + d) * Bs + b0 + crow) * h + us * UW + 4 * cpart) = *reinterpret_cast<const f32x4*>(Ct + crow * CTS + 4 * cpart);
     }
 #ifdef TSG_LSTM_TIMING
     if (step > 0) TSG_TICK(3)                                // gates, stores issued, workgroup met
@@ -1499,12 +1502,13 @@ static bool xr_wanted(int B, bool bf) {
   return B >= 96 || (bf && B <= 32);
 }
 extern "C" int tsg_lstm_set_ring(int mode) { g_xr.store(mode < 0 ? -1 : (mode != 0), std::memory_order_relaxed); return 0; }
-// 64-unit workgroups on half the CUs (lstm_fwd_persist_w64_kernel: bf16 storage, h = 512, ring workspace): -1 automatic (>= 96 rows), 0 never, 1 whenever possible
+// 64-unit workgroups (lstm_fwd_persist_w64_kernel: bf16 storage, h = 512, ring workspace): -1 automatic (more than 128 rows: one launch where the
+// 32-unit kernel needs two), 0 never, 1 whenever possible
 static std::atomic<int> g_w64{-2};
 static bool w64_wanted(int B) {
   int v = g_w64.load(std::memory_order_relaxed);
   if (v == -2) { const char* e = getenv("TSG_LSTM_W64"); v = e ? (atoi(e) != 0) : -1; g_w64.store(v, std::memory_order_relaxed); }
-  return v >= 0 ? v != 0 : B >= 96;
+  return v >= 0 ? v != 0 : B > 128;      // (up to 128 rows the 32-unit kernel with staged streams is faster: 2.19 vs 2.6 us per step)
 }
 extern "C" int tsg_lstm_set_wide(int mode) { g_w64.store(mode < 0 ? -1 : (mode != 0), std::memory_order_relaxed); return 0; }
 
@@ -1571,7 +1575,7 @@ static int lstm_fwd_impl(const void* Gx, const void* bias, const void* Whh, void
     const bool xr = need > 0 && ws_bytes >= need && xr_wanted(B, bf);
     const int NW = ((nw_env == 4 || (nw_env == 0 && B <= 32)) && h == 512 && (split || (bf && xr))) ? 4 : 8;
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
-    const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 33 + 4);
+    const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 36 + 16 * (132 + 136 + 36) + 4);     // slab, h tile, Gx / R / Cs tiles (fp32, 32 units: the largest)
     static_assert(kSlabFloats >= 16 * (kPersistMaxH + 8), "slab region holds the fp32 slab too");
     typedef void (*Launch)(int, size_t, hipStream_t, const void*, const void*, const void*, void*, void*, void*, void*, int, int, int, int, int, int, size_t, int);
     Launch go = nullptr;

@@ -280,7 +280,7 @@ def test_exchange_ring_forward_equals_out_polling(shape, dt, bm, request):
             assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("B,T", [(128, 24), (96, 16), (100, 12), (256, 8), (300, 6)])
+@pytest.mark.parametrize("B,T", [(128, 24), (96, 16), (100, 12), (256, 8), (300, 6), (200, 10)])
 @pytest.mark.parametrize("bm", [0, 1])
 def test_wide_workgroup_forward_equals_the_32_unit_kernel(B, T, bm, request):
     """lstm_fwd_persist_w64_kernel (round 5: bf16 storage, h = 512, 64-unit workgroups -- two A-tiles of W_hh per wave, 8 workgroups per exchange
