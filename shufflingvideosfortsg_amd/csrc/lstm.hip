@@ -1118,6 +1118,9 @@ static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
 // the write-through traffic: 14.1 us per step).  Consumers are never more than one step apart, so a slot's previous
 // generation has been read by everyone before its next one is written.
 // ---------------------------------------------------------------------------------------------
+#ifndef TSG_BWD_ABL
+#define TSG_BWD_ABL 0              // timing builds only: 1 no dG stores, 2 no operand loads, 4 no c_{t-1} load
+#endif
 constexpr int kDLS = 128 + 8;                    // own-dG tile row stride (floats), = 8 mod 64
 constexpr int kDLB = 64 + 8;                     // split-precision mode: row stride (dwords) of each bf16 plane of that tile
 constexpr int kDlFloats = 2 * 16 * kDLB;         // LDS dwords of the dG tile region (>= 16 * kDLS)
@@ -1210,14 +1213,14 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
     const bool has_prev = (d == 0) ? (tt > 0) : (tt < T - 1);
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float cc = 0.f, cpv = 0.f, dov = 0.f;
-    if (live) {
+    if (live && !(TSG_BWD_ABL & 2)) {
       // (requested here, in front of the poll.  With these operands L2-resident the step measures 3.8 instead of 4.6 us, but
       // requesting them one step ahead, after the previous poll -- what the forward kernel does with its input gates --
       // measured 4.8-5.6 us in every variant tried)
       const size_t sidx = (((size_t)tt * 2 + d) * Bs + b) * h + u;
       g4 = ld4s(R + sidx * 4);
       cc = ld1s(Cs + sidx);
-      if (has_prev) cpv = ld1s(Cs + (((size_t)tp * 2 + d) * Bs + b) * h + u);
+      if (has_prev && !(TSG_BWD_ABL & 4)) cpv = ld1s(Cs + (((size_t)tp * 2 + d) * Bs + b) * h + u);
       dov = ld1s(dOut + seq_row(tt, b, Bs, T, bm) * 2 * h + d * h + u);
       if (step == 0 && dHn) dov += dHn[((size_t)d * Bs + b) * h + u];
     }
@@ -1268,7 +1271,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
       const float dc = fmaf(dh * go, 1.f - tc * tc, dc_carry);
       dc_carry = dc * gf;
       const float dg[4] = {dc * gg * gi * (1.f - gi), dc * cpv * gf * (1.f - gf), dc * gi * (1.f - gg * gg), dh * tc * go * (1.f - go)};
-      if (live) {
+      if (live && !(TSG_BWD_ABL & 1)) {
         GT* g = dG + (seq_row(tt, b, Bs, T, bm) * 2 + d) * K + u;
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) st1s(g + gate * h, dg[gate]);
