@@ -422,6 +422,20 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+#ifndef TSG_FWD_NT
+#define TSG_FWD_NT 0                 // A/B builds: 1 non-temporal Gx loads, 2 non-temporal R / Cs stores in the forward kernel
+#endif
+template <bool NT> __device__ __forceinline__ u32x4 ld_u4(const u32x4* p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
+template <bool NT> __device__ __forceinline__ void st_u4(u32x4* p, u32x4 v) { if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+// LDS-DMA of one 16-byte piece per lane (asm: hipcc neither counts it nor drains it in front of LDS reads).  lds_addr: wave-uniform LDS byte
+// address of lane 0's piece; the hardware adds 16 bytes per lane.  M0 is the compiler's: saved and restored inside the statement.
+template <bool NT = false> __device__ __forceinline__ void dma16(const void* src, unsigned lds_addr) {
+  unsigned keep;
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
+}
 // The launch's error word, read inside the poll loops (every 32nd retry).  Load and wait in ONE asm statement: as a compiler-
 // visible load its destination register stayed "pending" for the waitcnt pass across the loop, which then put a
 // conservative s_waitcnt vmcnt(0) in front of the first MFMA that reused the register -- a wait for the loads requested
@@ -642,7 +656,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
 #define TSG_FWD_ABL 0            // timing-only ablations of the streams: 1 no R / Cs stores, 2 no Gx loads, 4 no `out` store
 #endif
   auto load_gx = [&](int t) {
-    if (gact && !(TSG_FWD_ABL & 2)) gq = *reinterpret_cast<const u32x4*>(Gx + (seq_row(t, b0 + grow, Bs, T, bm) * 2 + d) * 4 * h + ggate * h + us * UW + gpart * 4 * EW);
+    if (gact && !(TSG_FWD_ABL & 2)) gq = ld_u4<(TSG_FWD_NT & 1) != 0>(reinterpret_cast<const u32x4*>(Gx + (seq_row(t, b0 + grow, Bs, T, bm) * 2 + d) * 4 * h + ggate * h + us * UW + gpart * 4 * EW));
   };
   load_gx(d == 0 ? 0 : T - 1);
   for (int step = 0; step < T; ++step) {
@@ -882,11 +896,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
       const int rrow = tid / RPR, rpart = tid % RPR;
       if (rrow < 16 && b0 + rrow < B && !(TSG_FWD_ABL & 1)) {
         const size_t srow_ = (((size_t)tt * 2 + d) * Bs + b0 + rrow) * h + us * UW;
-        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned*>(R + srow_ * 4) + 4 * rpart) = *reinterpret_cast<const u32x4*>(Rt + rrow * RTS + 4 * rpart);
+        st_u4<(TSG_FWD_NT & 2) != 0>(reinterpret_cast<u32x4*>(reinterpret_cast<unsigned*>(R + srow_ * 4) + 4 * rpart), *reinterpret_cast<const u32x4*>(Rt + rrow * RTS + 4 * rpart));
       }
       const int crow = tid / CPR, cpart = tid % CPR;
       if (crow < 16 && b0 + crow < B && !(TSG_FWD_ABL & 1))
-        *reinterpret_cast<f32x4*>(Cs + (((size_t)tt * 2 + d) * Bs + b0 + crow) * h + us * UW + 4 * cpart) = *reinterpret_cast<const f32x4*>(Ct + crow * CTS + 4 * cpart);
+        st_u4<(TSG_FWD_NT & 2) != 0>(reinterpret_cast<u32x4*>(Cs + (((size_t)tt * 2 + d) * Bs + b0 + crow) * h + us * UW + 4 * cpart), *reinterpret_cast<const u32x4*>(Ct + crow * CTS + 4 * cpart));
     }
 #ifdef TSG_LSTM_TIMING
     if (step > 0) TSG_TICK(3)                                // gates, stores issued, workgroup met
@@ -1118,14 +1132,22 @@ static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
 // the write-through traffic: 14.1 us per step).  Consumers are never more than one step apart, so a slot's previous
 // generation has been read by everyone before its next one is written.
 // ---------------------------------------------------------------------------------------------
+#ifndef TSG_BWD_AHEAD_POS
+#define TSG_BWD_AHEAD_POS 1          // where the next step's operand tiles are requested: 0 behind the poll's barrier, 1 behind the dG tile barrier
+#endif
 #ifndef TSG_BWD_ABL
-#define TSG_BWD_ABL 0              // timing builds only: 1 no dG stores, 2 no operand loads, 4 no c_{t-1} load
+#define TSG_BWD_ABL 0              // timing builds only: 1 no dG stores, 2 no operand streams
 #endif
 constexpr int kDLS = 128 + 8;                    // own-dG tile row stride (floats), = 8 mod 64
 constexpr int kDLB = 64 + 8;                     // split-precision mode: row stride (dwords) of each bf16 plane of that tile
 constexpr int kDlFloats = 2 * 16 * kDLB;         // LDS dwords of the dG tile region (>= 16 * kDLS)
 constexpr int kPLS = kPersistMaxH + 8;           // partial-dh gather row stride
 constexpr int kQLS = 36;                         // polled partial sums row stride
+#ifndef TSG_BWD_AHEAD
+#define TSG_BWD_AHEAD 1
+#endif
+constexpr int kObAhead = TSG_BWD_AHEAD, kObBufs = kObAhead + 1;   // steps of look-ahead of the backward's operand tiles; LDS buffers
+constexpr int kObDw = 3072;                      // dwords of one buffer of the backward's streamed operand tiles (fp32: 8 + 2 + 2 KiB)
 
 // MODE as in the forward kernel: 0 fp32, 1 split precision (TSG_F32S), 2 = bf16 storage of R, dOut and dG with one bf16 MFMA per
 // k block (TSG_BF16; the partial-dh ring, Cs, dHn, dbias stay fp32).
@@ -1142,6 +1164,8 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
   unsigned* Dlo = Dhi + 16 * kDLB;
   float* Pl = Dl + kDlFloats;                     // [16][kPLS]  partial dh of all h units, gathered for whole-line stores
   float* Ql = Pl + 16 * kPLS;                     // [4][16][kQLS] sums of the polled blocks per producer group
+  unsigned* Ob = reinterpret_cast<unsigned*>(Ql + 4 * 16 * kQLS);    // [2][kObDw] the streamed operands of a step (R | c_(t-1) | dOut tiles), by LDS-DMA
+  const unsigned ob_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)Ob;
   __shared__ unsigned s_fail;                     // raised by a wave whose bounded wait expired (static: see the forward kernel)
   if (threadIdx.x == 0) s_fail = 0u;
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
@@ -1203,6 +1227,54 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
 #ifdef TSG_LSTM_TIMING
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tm0 = 0, tm1 = 0;
 #endif
+  // The streamed operands of a step -- R (four gates), c_(t-1), dOut of the workgroup's 16 x 32 tile -- are moved by LDS-DMA, 16-byte pieces of
+  // whole lines, ONE STEP AHEAD: requested behind the poll of the step before into the other half of `Ob`, landed by the time the next poll's
+  // s_waitcnt vmcnt(0) returns (the operations of a wave retire in order), read from LDS by the (row, unit) threads behind that poll's barrier.
+  // Until round 5 they were per-thread loads in front of the poll, which then waited for them: 0.6-0.76 us of a 3.1-3.8 us step
+  // (profiles/r5/lstm_bwd_streams_ablation_v1.txt); as register loads a step ahead hipcc put the wait for them at the loop's end (a loop-carried
+  // register copy, a bf16 conversion): in front of the next poll again.  c_t itself is the c_(t-1) of the step before.
+#ifndef TSG_BWD_NT
+#define TSG_BWD_NT 1                 // non-temporal operand DMAs (0: A/B builds).  Train step 12.36 -> 12.27 ms (f32s), 7.34 -> 7.20 (bf16 storage); without the hint
+#endif                               // 12.5 / 7.36: the streamed lines then stay in the L2s the exchange rings live in (profiles/r5/lstm_bwd_operand_dma_v1.txt)
+  constexpr bool ONT = TSG_BWD_NT != 0;
+  constexpr int kObR = BF ? 4096 : 8192, kObC = kObR;                 // byte offsets inside a buffer: R tile | c_(t-1) tile (2 KiB) | dOut tile
+  auto request = [&](int s1) {
+    if (TSG_BWD_ABL & 2) return;
+    const int fs1 = T - 1 - s1, tt1 = d == 0 ? fs1 : T - 1 - fs1;
+    const bool hp1 = (d == 0) ? (tt1 > 0) : (tt1 < T - 1);
+    const int tp1 = hp1 ? (d == 0 ? tt1 - 1 : tt1 + 1) : tt1;
+    const unsigned base = ob_lds + (unsigned)((s1 % kObBufs) * kObDw * 4);
+    auto rowc = [&](int r) { const int bb = b0 + r; return bb < B ? bb : B - 1; };       // rows beyond B re-read the last one (never used)
+    if constexpr (BF) {
+      if (wv < 4) {                                           // R: 256 pieces = (row, 2 units)
+        const int p = tid;
+        dma16<ONT>(R + ((((size_t)tt1 * 2 + d) * Bs + rowc(p >> 4)) * h + us * 32 + 2 * (p & 15)) * 4, __builtin_amdgcn_readfirstlane(base + 1024u * wv));
+      } else if (wv < 6) {                                    // c_(t-1): 128 pieces = (row, 4 units)
+        const int p = tid - 256;
+        dma16<ONT>(Cs + (((size_t)tp1 * 2 + d) * Bs + rowc(p >> 3)) * h + us * 32 + 4 * (p & 7), __builtin_amdgcn_readfirstlane(base + kObC + 1024u * (wv - 4)));
+      } else if (wv == 6) {                                   // dOut: 64 pieces = (row, 8 units)
+        const int p = tid - 384;
+        dma16<ONT>(dOut + seq_row(tt1, rowc(p >> 2), Bs, T, bm) * 2 * h + d * h + us * 32 + 8 * (p & 3), __builtin_amdgcn_readfirstlane(base + kObC + 2048u));
+      }
+    } else {
+      dma16<ONT>(R + ((((size_t)tt1 * 2 + d) * Bs + rowc(tid >> 5)) * h + us * 32 + (tid & 31)) * 4, __builtin_amdgcn_readfirstlane(base + 1024u * wv));   // R: piece = (row, unit)
+      if (wv < 2) {
+        const int p = tid;
+        dma16<ONT>(Cs + (((size_t)tp1 * 2 + d) * Bs + rowc(p >> 3)) * h + us * 32 + 4 * (p & 7), __builtin_amdgcn_readfirstlane(base + kObC + 1024u * wv));
+      } else if (wv < 4) {
+        const int p = tid - 128;
+        dma16<ONT>(dOut + seq_row(tt1, rowc(p >> 3), Bs, T, bm) * 2 * h + d * h + us * 32 + 4 * (p & 7), __builtin_amdgcn_readfirstlane(base + kObC + 2048u + 1024u * (wv - 2)));
+      }
+    }
+  };
+  float cc, dhn0 = 0.f;
+  {
+    const int tt0 = d == 0 ? T - 1 : 0;
+    cc = ld1s(Cs + (((size_t)tt0 * 2 + d) * Bs + (live ? b : B - 1)) * h + u);
+    if (dHn && live) dhn0 = dHn[((size_t)d * Bs + b) * h + u];
+    request(0);
+    if (kObAhead > 1 && T > 1) request(1);
+  }
   for (int step = 0; step < T; ++step) {
 #ifdef TSG_LSTM_TIMING
     tm0 = __builtin_amdgcn_s_memtime();
@@ -1211,19 +1283,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
     const int tt = d == 0 ? fs : T - 1 - fs;                // time index handled now
     const int tp = d == 0 ? tt - 1 : tt + 1;                // forward-earlier neighbour (c_{t-1})
     const bool has_prev = (d == 0) ? (tt > 0) : (tt < T - 1);
-    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float cc = 0.f, cpv = 0.f, dov = 0.f;
-    if (live && !(TSG_BWD_ABL & 2)) {
-      // (requested here, in front of the poll.  With these operands L2-resident the step measures 3.8 instead of 4.6 us, but
-      // requesting them one step ahead, after the previous poll -- what the forward kernel does with its input gates --
-      // measured 4.8-5.6 us in every variant tried)
-      const size_t sidx = (((size_t)tt * 2 + d) * Bs + b) * h + u;
-      g4 = ld4s(R + sidx * 4);
-      cc = ld1s(Cs + sidx);
-      if (has_prev && !(TSG_BWD_ABL & 4)) cpv = ld1s(Cs + (((size_t)tp * 2 + d) * Bs + b) * h + u);
-      dov = ld1s(dOut + seq_row(tt, b, Bs, T, bm) * 2 * h + d * h + u);
-      if (step == 0 && dHn) dov += dHn[((size_t)d * Bs + b) * h + u];
-    }
+    if (step == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); }     // the first step's operand tiles have landed (later steps: the poll's wait)
     float rec = 0.f;
     if (step > 0) {
       // poll the nus blocks addressed to this workgroup in slot (step-1)%4: thread = (producer group pg, row pr, 4 units pc);
@@ -1264,12 +1324,31 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) rec += Ql[(g * 16 + row) * kQLS + ul];
     }
+    if (TSG_BWD_AHEAD_POS == 0 && step + kObAhead < T) request(step + kObAhead);
+    float4 g4;
+    float cpv, dov;
+    {
+      const unsigned* ob = Ob + (step % kObBufs) * kObDw;
+      if constexpr (BF) {
+        const uint2 r2 = *reinterpret_cast<const uint2*>(ob + (row * 32 + ul) * 2);
+        g4 = make_float4(bf16_lo(r2.x), bf16_hi(r2.x), bf16_lo(r2.y), bf16_hi(r2.y));
+        const unsigned w2 = ob[kObC / 4 + 512 + (row * 32 + ul) / 2];
+        dov = (ul & 1) ? bf16_hi(w2) : bf16_lo(w2);
+      } else {
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(ob + tid * 4);
+        g4 = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        dov = __uint_as_float(ob[kObC / 4 + 512 + row * 32 + ul]);
+      }
+      cpv = has_prev ? __uint_as_float(ob[kObC / 4 + row * 32 + ul]) : 0.f;
+      if (step == 0) dov += dhn0;                            // (loaded in front of the loop: a load inside it, even on a path taken once, makes hipcc drain vmcnt -- the DMAs -- at the join)
+    }
     {
       const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
       const float tc = tanh_f(cc);
       const float dh = dov + rec;
       const float dc = fmaf(dh * go, 1.f - tc * tc, dc_carry);
       dc_carry = dc * gf;
+      cc = cpv;                                              // c_t of the next step is this step's c_(t-1): one stream less
       const float dg[4] = {dc * gg * gi * (1.f - gi), dc * cpv * gf * (1.f - gf), dc * gi * (1.f - gg * gg), dh * tc * go * (1.f - go)};
       if (live && !(TSG_BWD_ABL & 1)) {
         GT* g = dG + (seq_row(tt, b, Bs, T, bm) * 2 + d) * K + u;
@@ -1293,6 +1372,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
     if (step > 0) TSG_TICK(1)                                // reduce + cell backward + dG / Dl stores issued
     if (step + 1 < T) {
       lds_barrier();                                       // the dG tile is complete (and Ql is free again)
+      if (TSG_BWD_AHEAD_POS == 1 && step + kObAhead < T) request(step + kObAhead);
       if (step > 0) TSG_TICK(4)                              // (timing builds: the wait at this barrier)
       f32x4 acc[TW];
 #pragma unroll
@@ -1664,7 +1744,7 @@ extern "C" long long tsg_lstm_bwd_ws_bytes(int B, int T, int h) {
   return kSyncBytes + 4LL * 2 * bslices * nus * nus * 512 * (long long)sizeof(float);
 }
 
-static constexpr size_t kBwd2Lds = sizeof(float) * ((size_t)kDlFloats + 16 * kPLS + 4 * 16 * kQLS + 4);
+static constexpr size_t kBwd2Lds = sizeof(float) * ((size_t)kDlFloats + 16 * kPLS + 4 * 16 * kQLS + kObBufs * kObDw + 4);
 static_assert(kDlFloats >= 16 * kDLS, "dG tile region holds the fp32 tile too");
 static int bwd_persist_capacity() { return persist_capacity(2, lstm_bwd_persist2_kernel<4, 0>, kThreads, kBwd2Lds, 1); }
 
