@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
       dc_carry = dc * gf;
       cc = cpv;                                              // c_t of the next step is this step's c_(t-1): one stream less
       const float dg[4] = {dc * gg * gi * (1.f - gi), dc * cpv * gf * (1.f - gf), dc * gi * (1.f - gg * gg), dh * tc * go * (1.f - go)};
-      if (live && !(TSG_BWD_ABL & 1)) {
+      if (!BF && live && !(TSG_BWD_ABL & 1)) {               // (bf16 storage: the tile goes out as 16-byte pieces behind the barrier below)
         GT* g = dG + (seq_row(tt, b, Bs, T, bm) * 2 + d) * K + u;
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) st1s(g + gate * h, dg[gate]);
@@ -1370,8 +1370,16 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
       }
     }
     if (step > 0) TSG_TICK(1)                                // reduce + cell backward + dG / Dl stores issued
+    lds_barrier();                                         // the dG tile is complete (and Ql is free again)
+    if constexpr (BF) {
+      // bf16 storage: the hi plane IS the dG tile as stored -- 16 rows x 4 gates x 64 bytes = 256 pieces of 16 bytes, one store for half the threads
+      // instead of four 2-byte stores from each (0.12-0.19 us per step, profiles/r5/lstm_bwd_streams_ablation_v1.txt)
+      const int prow = tid >> 4, pgate = (tid >> 2) & 3, ppart = tid & 3;
+      if (tid < 256 && b0 + prow < B && !(TSG_BWD_ABL & 1))
+        __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(Dhi + prow * kDLB + pgate * 16 + ppart * 4),
+                                    reinterpret_cast<u32x4*>(dG + (seq_row(tt, b0 + prow, Bs, T, bm) * 2 + d) * K + pgate * h + us * 32 + ppart * 8));
+    }
     if (step + 1 < T) {
-      lds_barrier();                                       // the dG tile is complete (and Ql is free again)
       if (TSG_BWD_AHEAD_POS == 1 && step + kObAhead < T) request(step + kObAhead);
       if (step > 0) TSG_TICK(4)                              // (timing builds: the wait at this barrier)
       f32x4 acc[TW];
