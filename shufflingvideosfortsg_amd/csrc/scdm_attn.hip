@@ -74,9 +74,9 @@ __device__ __forceinline__ int wave_id() {    // wave-uniform (SGPR) wave index 
 // 160+ VGPRs and spills).  (Calibration, tools/ubench: v_rcp_f32 ~10 cyc, v_fma_f32 ~2.8 cyc per
 // wave-instruction; v_pk_fma_f32 costs two v_fma_f32, and sharing one rcp between two elements
 // (1/x0 = x1/(x0 x1)) buys nothing, so the plain fma-rcp-fma triple is the floor: ~15.6 cyc.)
-template <int NP, int R, int G = (R == 1) ? 4 : 2>     // G = words per scheduling group (~16 triples of VALU work at G R = 4)
+template <int NP, int R, int G = (R == 1) ? 4 : 2, int NA = NP>     // G = words per scheduling group (~16 triples of VALU work at G R = 4); NA >= NP: slots of `acc`
 __device__ __forceinline__ void scdm_chunk_step(const float (&Ea)[R][4], const float* __restrict__ esp, int HP,
-                                                const float (&w2)[4], float (&acc)[R][NP]) {
+                                                const float (&w2)[4], float (&acc)[R][NA]) {
   static_assert(NP % G == 0, "word groups");
   float4 cur[G], nxt[G];
 #pragma unroll
@@ -689,7 +689,7 @@ __device__ __forceinline__ k1_f32x16 k1_mfma8(k1_u32x2 a, k1_u32x2 b, k1_f32x16 
 
 // ST = bf16_t (dtype TSG_BF16): a, s, V, gr, C are bf16 in HBM; the rows are kept as raw 8-byte pieces until the score loop consumes them,
 // VW is exact in bf16 so its lo plane (and the third MFMA of every k step) drops out, r / out are one 2-byte element per lane.
-template <int NP, bool GATE, int CT, int PW, typename ST>
+template <int NP, bool GATE, int CT, int PW, typename ST, int XW = 0>
 __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
     const ST* __restrict__ a, const ST* __restrict__ s, const float* __restrict__ w,
     const ST* __restrict__ V, ST* __restrict__ C, float* __restrict__ P,
@@ -699,8 +699,13 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
   constexpr int SUB = 8;                             // rows per sub-tile
   constexpr int RPW = SUB / PW;                      // rows per producer wave and sub-tile (one after the other)
   constexpr int PP = 36;
-  constexpr bool K8 = NP > 16 && NP <= 24;           // words 16 .. 23 as ONE 32x32x8 k step (2-register operands) instead of a 32x32x16
+  // XW > 0 (fp32 storage, N = 24 + XW <= 26 -- the ActivityNet configs' N = 25): words 0 .. 23 on the matrix pipe as for N <= 24, the XW words beyond
+  // them as fp32 FMAs on the accumulator (P[row][24 + x] from LDS times one resident VW register per tile and word): the consumer's strip stays
+  // within the 128 VGPRs of the 8 + 8 wave layout (a second 16-word k step does not: hi + lo of 32 words = 64 registers per wave)
+  static_assert(XW == 0 || (NP == 28 && PW == 8 && XW <= 2), "XW: the 8 + 8 layout at N = 25, 26");
+  constexpr bool K8 = (NP > 16 && NP <= 24) || XW > 0; // words 16 .. 23 as ONE 32x32x8 k step (2-register operands) instead of a 32x32x16
   constexpr int KS = NP > 16 && !K8 ? 2 : 1;         // full 16-word k steps
+  constexpr int NS = XW > 0 ? 26 : NP;               // word slots the score loop walks (bf16 storage at N = 25: 26 instead of 28 slots measured no faster, 80 us)
   constexpr int CC = 8 * CT / PW;                    // 32-column tiles per consumer wave (Ds / PW columns)
   const int HP = roundup256(H);
   extern __shared__ __align__(16) float lds[];
@@ -782,7 +787,7 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
         const float4 e = exp2x4(cvt4(q[c]));
         Ea[0][0] = e.x; Ea[0][1] = e.y; Ea[0][2] = e.z; Ea[0][3] = e.w;
         q[c] = ldraw4(nrow + 256 * c);
-        if (!TSG_SKIP(1)) scdm_chunk_step<NP, 1, 2>(Ea, Es + k, HP, w2, acc);
+        if (!TSG_SKIP(1)) scdm_chunk_step<NS, 1, 2, NP>(Ea, Es + k, HP, w2, acc);     // (XW: 26 of the 28 slots are scored, the others stay 0 and are masked below)
         __builtin_amdgcn_sched_barrier(0);
       }
       // land the next row ahead of the P stores (vmcnt counts loads and stores together, in order)
@@ -860,6 +865,13 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
         vh8[ct] = (k1_u32x2){h0, h1}; vl8[ct] = (k1_u32x2){l0, l1};
       }
     }
+    float vx[CC][XW > 0 ? XW : 1];
+    if constexpr (XW > 0) {
+#pragma unroll
+      for (int ct = 0; ct < CC; ++ct)
+#pragma unroll
+        for (int x = 0; x < XW; ++x) vx[ct][x] = ld1(Vb + (size_t)(24 + x) * Ds + 32 * ct);
+    }
     const unsigned lane_off = (unsigned)(4 * hh) * (unsigned)Ds + (unsigned)(col0 + jl);
     const unsigned lane_col = (unsigned)(col0 + jl);
     float rr[CC][4];
@@ -898,6 +910,13 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
         const float e[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
         k1_split8(e, ph[ks], pl[ks]);
       }
+      float px[XW > 0 ? XW : 1][4];
+      if constexpr (XW > 0) {
+#pragma unroll
+        for (int x = 0; x < XW; ++x)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) px[x][i] = Pcur[(i + 4 * hh) * PP + 24 + x];
+      }
       if (K8) {
         float4 x = *reinterpret_cast<const float4*>(Pcur + (jl & 7) * PP + 16 + 4 * hh);
         if (jl >= 8) x = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -925,6 +944,10 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float v = o[i];
+          if constexpr (XW > 0) {
+#pragma unroll
+            for (int x = 0; x < XW; ++x) v = fmaf(px[x][i], vx[ct][x], v);
+          }
           if (GATE) v = rr[ct][i] * fast_rcp(1.f + fast_exp2(fmaf(v, -kLog2e, gb[ct])));
           if (t0 + i + 4 * hh < T) st1(dst + (size_t)i * Ds + lane_off, v);
         }
@@ -2031,6 +2054,17 @@ int launch_fwd_ws(const ST* a, const ST* s, const float* w, const ST* V, ST* C, 
   constexpr bool kCanPw8 = NP > 8 && (NP <= 24 || (storage_is_bf16<ST>::value && NP <= 28));
   const bool pw8 = kCanPw8 && pw_env != 4;
   void (*kern)(const ST*, const ST*, const float*, const ST*, ST*, float*, const ST*, const float*, int, int, int, int, int, int, int, int);
+  if constexpr (NP == 28 && !storage_is_bf16<ST>::value) {
+    // N = 25, 26 in fp32 storage: 8 + 8 waves with the words beyond 24 on the VALU (round-4 review item 3a); N = 27, 28: 4 + 4
+    if ((N == 25 || N == 26) && pw_env != 4) {
+      if (N == 25) kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 8, ST, 1> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 8, ST, 1> : scdm_fwd_ws_kernel<NP, GATE, 1, 8, ST, 1>;
+      else kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 8, ST, 2> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 8, ST, 2> : scdm_fwd_ws_kernel<NP, GATE, 1, 8, ST, 2>;
+      hipError_t e = allow_lds(kern, lds);
+      if (e != hipSuccess) return set_error((int)e, "scdm_attn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+      hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(1024), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
+      return check_launch("scdm_attn_fwd");
+    }
+  }
   if constexpr (kCanPw8) {
     if (pw8) kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 8, ST> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 8, ST> : scdm_fwd_ws_kernel<NP, GATE, 1, 8, ST>;
     else kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 4, ST> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 4, ST> : scdm_fwd_ws_kernel<NP, GATE, 1, 4, ST>;
