@@ -356,6 +356,12 @@ int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, long long ldw,
  * transposed copy of the weight per call.  M % 256 == 0, N % 256 == 0, K % 32 == 0, kseg % 32 == 0 (ABI revision 5).                 */
 int tsg_gemm_f32s_nn(const void* x, long long ldx, const void* w0, const void* w1, int kseg, long long ldw, const void* bias,
                      void* y, long long ldy, int M, int N, int K, void* stream);
+/* y[M,N] += x[M,K] w[K,N] (ABI revision 6): tsg_gemm_f32s_nn with a read-add-store epilogue.  The second consumer of an activation adds its
+ * input gradient dX = dY W onto the first consumer's (reference: the recalibration block reads the BiLSTM output twice -- W_a's input and the
+ * gate's r, VideoEncoder.py:52-59 / attention.py:104-121 -- and the final clip features feed both heads, SpanGroundMatchDisc.py:80-96): no
+ * elementwise add kernel over the [B, T, D] gradient.  Same shape rules as tsg_gemm_f32s_nn; no bias.                                        */
+int tsg_gemm_f32s_nn_acc(const void* x, long long ldx, const void* w0, const void* w1, int kseg, long long ldw,
+                         void* y, long long ldy, int M, int N, int K, void* stream);
 
 /* ---- The same projections in the bf16 STORAGE mode (ABI revision 6; csrc/gemm_bf16.hip): y [M,N] = x [M,K] . w [N,K]^T (+ bias [N], fp32 or
  * NULL); x and w are bf16 matrices (row strides ldx / ldw in elements, multiples of 8; w as an nn.Linear stores its weight), fp32 accumulation,

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "tsg_gemm_f32s": [_P] * 4 + [_I] * 3 + [_P],
     "tsg_gemm_f32s_ld": [_P, c_longlong, _P, c_longlong, _P, _P, c_longlong, _I, _I, _I, _P],
     "tsg_gemm_f32s_nn": [_P, c_longlong, _P, _P, _I, c_longlong, _P, _P, c_longlong, _I, _I, _I, _P],
+    "tsg_gemm_f32s_nn_acc": [_P, c_longlong, _P, _P, _I, c_longlong, _P, c_longlong, _I, _I, _I, _P],
     "tsg_head_gemm_ws_bytes": [_I, _I, _I],
     "tsg_match_head_gemm": [_P, c_longlong, _P, c_longlong, _P, _P, _P, _P, _P, _P, c_longlong, _I, _I, _I, _I, _I, _P],
     "tsg_boundary_head_gemm": [_P, c_longlong, _P, _P, c_longlong] + [_P] * 10 + [c_longlong, _I, _I, _I, _I, _P],

@@ -113,6 +113,7 @@ __device__ __forceinline__ int acc_row(const TilePos& p, int i, int r) { return 
 // ---- epilogue: plain store ------------------------------------------------------------------------------------------------------
 struct EpiStore {
   const float* bias; float* Y; long long ldy;
+  int accumulate = 0;                              // 1: Y += acc (+ bias): a second gradient contribution lands on the first one's buffer, no add kernel
   static constexpr bool kUsesLds = false;
   template <int MI>
   __device__ __forceinline__ void run(const g_f32x16 (&acc)[MI][2], const TilePos& p, float* /*lds*/) const {
@@ -123,8 +124,16 @@ struct EpiStore {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         float* yp = Y + (size_t)(p.m0 + p.wm + 32 * i + 4 * p.kg) * ldy + col;
+        if (accumulate) {
+          float prev[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r] + bv;
+          for (int r = 0; r < 16; ++r) prev[r] = yp[(size_t)((r & 3) + 8 * (r >> 2)) * ldy];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * ldy] = prev[r] + (acc[i][j][r] + bv);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r] + bv;
+        }
       }
     }
   }
@@ -481,9 +490,8 @@ extern "C" int tsg_gemm_f32s_ld(const void* x, long long ldx, const void* w, lon
 
 // y[M,N] = x[M,K] w[K,N] (+ bias): the right operand contraction-major, optionally as two ROW segments (w0: rows < kseg, w1: the rest;
 // kseg = K and w1 = NULL for one matrix) -- the input gradient dX = dY W of a Linear with its weight as it is stored.
-extern "C" int tsg_gemm_f32s_nn(const void* x, long long ldx, const void* w0, const void* w1, int kseg, long long ldw, const void* bias,
-                                void* y, long long ldy, int M, int N, int K, void* stream) {
-  const char* fn = "tsg_gemm_f32s_nn";
+static int gemm_nn_impl(const char* fn, const void* x, long long ldx, const void* w0, const void* w1, int kseg, long long ldw, const void* bias,
+                        void* y, long long ldy, int M, int N, int K, int accumulate, void* stream) {
   for (const void* p : {x, w0, (const void*)y}) {
     if (!p) return set_error(TSG_E_NULL, "%s: NULL pointer argument", fn);
     if (!aligned16(p)) return set_error(TSG_E_ALIGN, "%s: pointer %p is not 16-byte aligned", fn, p);
@@ -493,9 +501,22 @@ extern "C" int tsg_gemm_f32s_nn(const void* x, long long ldx, const void* w0, co
   if (kseg <= 0 || kseg > K || kseg % kBK || (kseg < K && (!w1 || !aligned16(w1))))
     return set_error(TSG_E_SHAPE, "%s: kseg=%d must be a multiple of 32 in (0, K] and w1 given when kseg < K", fn, kseg);
   if (ldx < K || ldw < N || ldy < N || ldx % 4 || ldw % 4) return set_error(TSG_E_ALIGN, "%s: leading dimensions ldx=%lld ldw=%lld ldy=%lld", fn, ldx, ldw, ldy);
-  const EpiStore epi{(const float*)bias, (float*)y, ldy};
+  const EpiStore epi{(const float*)bias, (float*)y, ldy, accumulate};
   return launch_gemm<256, EpiStore, true>(fn, (const float*)x, ldx, (const float*)w0, (const float*)(w1 ? w1 : w0), kseg, ldw, epi, M, N, K,
                                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tsg_gemm_f32s_nn(const void* x, long long ldx, const void* w0, const void* w1, int kseg, long long ldw, const void* bias,
+                                void* y, long long ldy, int M, int N, int K, void* stream) {
+  return gemm_nn_impl("tsg_gemm_f32s_nn", x, ldx, w0, w1, kseg, ldw, bias, y, ldy, M, N, K, 0, stream);
+}
+
+// y[M,N] += x[M,K] w[K,N]: the same kernel with a read-add-store epilogue.  A tensor with two consumers gets two input gradients; the second
+// consumer's dX = dY W lands on the first one's buffer instead of in a tensor of its own that autograd then adds (a 3 x 64 MB elementwise
+// kernel per [128, 128, 1024] activation: 30 us each, four per GMD step).
+extern "C" int tsg_gemm_f32s_nn_acc(const void* x, long long ldx, const void* w0, const void* w1, int kseg, long long ldw,
+                                    void* y, long long ldy, int M, int N, int K, void* stream) {
+  return gemm_nn_impl("tsg_gemm_f32s_nn_acc", x, ldx, w0, w1, kseg, ldw, nullptr, y, ldy, M, N, K, 1, stream);
 }
 
 extern "C" long long tsg_head_gemm_ws_bytes(int M, int N, int heads) {

@@ -456,6 +456,25 @@ def gemm_f32s_nn(x: torch.Tensor, w: torch.Tensor, w1: torch.Tensor = None) -> t
     return y
 
 
+def gemm_f32s_nn_acc(x: torch.Tensor, w: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """y [M,N] += x [M,K] @ w [K,N] in the split-precision arithmetic (tsg_gemm_f32s_nn_acc): the input gradient dX = dY W of a Linear added onto a
+    gradient buffer that another consumer of the same activation has already written -- no add kernel.  Returns y."""
+    require_device(x, w, y)
+    x = _f32c(x)
+    M, K = x.shape
+    N = w.shape[1]
+    if (w.dtype != torch.float32 or w.shape[0] != K or w.stride(1) != 1 or w.stride(0) % 4 or w.data_ptr() % 16
+            or y.dtype != torch.float32 or y.shape != (M, N) or not y.is_contiguous()):
+        raise ValueError(f"gemm_f32s_nn_acc: x{tuple(x.shape)} w{tuple(w.shape)} y{tuple(y.shape)}")
+    _call("tsg_gemm_f32s_nn_acc", x, ptr(x), K, ptr(w), None, K, w.stride(0), ptr(y), N, M, N, K)
+    return y
+
+
+def gemm_f32s_nn_ok(M: int, N: int, K: int) -> bool:
+    """Shapes tsg_gemm_f32s_nn / _nn_acc take (include/tsg_hip.h)."""
+    return _OWN_GEMM and M % 256 == 0 and N % 256 == 0 and K % 32 == 0
+
+
 def _mm(a: torch.Tensor, b: torch.Tensor, mode=_AUTO) -> torch.Tensor:
     """fp32 [M,K] @ [K,N] -> fp32 in the GEMM precision ``mode`` (default: the configured one): rocBLAS / hipBLASLt, or -- "f32s", whole 256-tiles -- the
     hand-written split-on-load GEMM (the right operand is taken as [N,K] contiguous: a weight's `.t()` view as it is, a [K,N]
@@ -612,6 +631,71 @@ class _ScdmGate(torch.autograd.Function):
 def scdm_gate(a, s, w, VW, gbias, r):
     """SCDM attention fused with the recalibration gate (see include/tsg_hip.h, K1g)."""
     return _ScdmGate.apply(a, s, w.reshape(-1), VW, gbias, r)
+
+
+class _ScdmGateProj(torch.autograd.Function):
+    """The recalibration block's tail on ONE autograd node (f32s mode): a = x W_a^T, out = x * sigmoid(P(a, s) @ VW + gbias) -- the BiLSTM output x
+    is both the attention's clip operand (through W_a) and the gate's r (reference VideoEncoder.py:52-59, attention.py:104-121).  As two nodes
+    (``linear`` + ``scdm_gate``) autograd adds their two gradients of x with an elementwise kernel over [B, T, D] (30 us at [128, 128, 1024], twice
+    per GMD step); here the K1g backward writes dr and the input-gradient GEMM of W_a adds da W_a onto that buffer in its epilogue
+    (tsg_gemm_f32s_nn_acc).  Same kernels, same arithmetic: the sum is the same single fp32 addition per element."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, x, wa, s, w, VW, gbias):
+        require_device(x, wa, s, w, VW, gbias)
+        x, wa, s, w, VW, gbias = _f32c(x), _f32c(wa), _f32c(s), _f32p(w), _f32c(VW), _f32p(gbias)
+        B, T, Dv = x.shape
+        H = wa.shape[0]
+        _, N, Ds = VW.shape
+        if wa.shape[1] != Dv or s.shape != (B, N, H) or w.numel() != H or Ds != Dv or gbias.numel() != Ds:
+            raise ValueError(f"scdm_gate_proj: shape mismatch x{tuple(x.shape)} W_a{tuple(wa.shape)} s{tuple(s.shape)} VW{tuple(VW.shape)}")
+        a = gemm_f32s(x.view(B * T, Dv), wa).view(B, T, H)
+        out = torch.empty(B, T, Ds, device=x.device, dtype=torch.float32)
+        P = torch.empty(B, T, N, device=x.device, dtype=torch.float32)
+        _call("tsg_scdm_gate_fwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(x), ptr(out), ptr(P), B, T, N, H, Ds, TSG_F32S)
+        ctx.save_for_backward(x, wa, a, s, w, VW, gbias, P)
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dout):
+        x, wa, a, s, w, VW, gbias, P = ctx.saved_tensors
+        dout = _f32c(dout)
+        B, T, Dv = x.shape
+        H = wa.shape[0]
+        _, N, Ds = VW.shape
+        da = torch.empty_like(a); ds = torch.empty_like(s); dw = torch.empty_like(w)
+        dVW = torch.empty_like(VW); dgb = torch.empty_like(gbias); dx = torch.empty_like(x)
+        nb = int(load().tsg_scdm_bwd_ws_bytes(B, T, N, H, Ds, 1))
+        ws = torch.empty(nb // 4 + 4, device=x.device, dtype=torch.float32)
+        _gate_before()
+        _call("tsg_scdm_gate_bwd", a, ptr(a), ptr(s), ptr(w), ptr(VW), ptr(gbias), ptr(x), ptr(P), ptr(dout),
+              ptr(da), ptr(ds), ptr(dw), ptr(dVW), ptr(dgb), ptr(dx), ptr(ws), nb, B, T, N, H, Ds, TSG_F32S)      # dx <- dr
+        da2, x2 = da.view(B * T, H), x.view(B * T, Dv)
+        dwa = None
+        if ctx.needs_input_grad[1]:
+            dwa = wgrad_f32s(da2, x2)[0] if _WGRAD_KERNEL and wgrad_f32s_ok(B * T, H, Dv) else da2.t() @ x2
+        if ctx.needs_input_grad[0]:
+            gemm_f32s_nn_acc(da2, wa, dx.view(B * T, Dv))                                                           # dx += da W_a
+        else:
+            dx = None
+        return dx, dwa, ds, dw.view_as(w), dVW, dgb
+
+
+def scdm_gate_proj_ok(x: torch.Tensor, wa: torch.Tensor, VW: torch.Tensor) -> bool:
+    """The one-node form applies: f32s mode on the GPU, fp32 tensors, whole GEMM tiles, the gate as wide as the clip features."""
+    if not (_GEMM_DTYPE == "f32s" and x.is_cuda and x.dtype == torch.float32 and not bf16_storage() and x.dim() == 3 and not torch.is_autocast_enabled()):
+        return False
+    if os.environ.get("TSG_SHARED_GRAD", "1") == "0":
+        return False
+    M, Dv, H = x.shape[0] * x.shape[1], x.shape[2], wa.shape[0]
+    return VW.shape[-1] == Dv and gemm_f32s_ok(M, H, Dv) and gemm_f32s_nn_ok(M, Dv, H) and M >= 2048
+
+
+def scdm_gate_proj(x, wa, s, w, VW, gbias):
+    """out = x * sigmoid(softmax_n(w . tanh(W_s s_n + W_a x_t + b)) @ VW + gbias) with the clip projection inside the node (``_ScdmGateProj``)."""
+    return _ScdmGateProj.apply(x, wa, s, w.reshape(-1), VW, gbias)
 
 
 _k3_ws = {}        # (device, stream, B, T, Hm) -> uint8 workspace of the one-launch K3 backward; its ticket counters are zero between calls

@@ -59,6 +59,11 @@ class rnn_recalibration_layer(nn.Module):
             # fused tail: sent_linear(P @ words) = P @ (words W_l^T) + b_l, so the Linear runs on the N word rows
             # instead of the T clip rows and bias / sigmoid / gate are the attention kernel's epilogue
             VW = TF.linear(word_feat, self.sent_linear.weight)
+            if TF.scdm_gate_proj_ok(rnn_output, att.W_a.weight, VW):
+                # W_a's projection inside the gate's autograd node: the two gradients of rnn_output (through W_a, and as the gate's r) are summed
+                # by the input-gradient GEMM's epilogue, not by an elementwise kernel
+                s = TF.linear(word_feat, att.W_s.weight, att.W_a.bias)
+                return TF.scdm_gate_proj(rnn_output, att.W_a.weight, s, att.w.weight, VW, self.sent_linear.bias)
             a, s = att.projections(rnn_output, word_feat)
             return TF.scdm_gate(a, s, att.w.weight, VW, self.sent_linear.bias, rnn_output)
         # un-fused tail (another attention class, or a word width sent_linear was not built for)

@@ -298,3 +298,37 @@ def test_scdm_bwd_exchange_is_reproducible(B, gate):
     from shufflingvideosfortsg_amd import _lib
     lib = _lib.load()
     assert _k1_bwd_exchange_run(lib, B, gate, 80, dirty_every=16) == 80
+
+
+@pytest.mark.parametrize("shape", [(16, 128, 20, 1024), (8, 256, 25, 512)])
+def test_scdm_gate_proj_one_node_equals_two_nodes(shape):
+    """Round 5: the recalibration block's tail as ONE autograd node (``TF.scdm_gate_proj``: W_a's projection inside the gate's node, the second
+    gradient of the clip features added by the input-gradient GEMM's epilogue, tsg_gemm_f32s_nn_acc) against the two-node form (``linear`` +
+    ``scdm_gate``, gradients of x summed by autograd): same kernels and the same single fp32 addition per element -- outputs and every gradient
+    bit-equal (the two that the K1g backward forms with float atomics: to rounding)."""
+    from shufflingvideosfortsg_amd import engine, functional as TF
+    B, T, N, D = shape
+    g = torch.Generator().manual_seed(B + T + N)
+    x0 = torch.randn(B, T, D, generator=g).cuda(); words = torch.randn(B, N, D, generator=g).cuda()
+    wa0 = (torch.randn(D, D, generator=g) / D ** 0.5).cuda(); ws0 = (torch.randn(D, D, generator=g) / D ** 0.5).cuda(); ba = torch.randn(D, generator=g).cuda() * 0.1
+    w0 = (torch.randn(1, D, generator=g) / D ** 0.5).cuda(); wl0 = (torch.randn(D, D, generator=g) / D ** 0.5).cuda(); bl0 = torch.randn(D, generator=g).cuda() * 0.1
+    dout = torch.randn(B, T, D, generator=g).cuda()
+    res = []
+    with engine.precision("f32s"):
+        for one in (True, False):
+            x, wa, w, wl, bl, wsn = (t.clone().requires_grad_(True) for t in (x0, wa0, w0, wl0, bl0, ws0))
+            VW = TF.linear(words, wl)
+            s = TF.linear(words, wsn, ba)
+            if one:
+                assert TF.scdm_gate_proj_ok(x, wa, VW)
+                out = TF.scdm_gate_proj(x, wa, s, w, VW, bl)
+            else:
+                out = TF.scdm_gate(TF.linear(x, wa, None), s, w, VW, bl, x)
+            out.backward(dout)
+            res.append((out.detach(), x.grad, wa.grad, w.grad, wl.grad, bl.grad, wsn.grad))
+    TF.check_kernel_errors()
+    for a, b, name in zip(res[0], res[1], ("out", "dx", "dW_a", "dw", "dW_l", "db_l", "dW_s")):
+        if name in ("dw", "db_l"):       # float atomics across workgroups inside the K1g backward: equal to rounding, not to the bit, in either form
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+        else:
+            assert torch.equal(a, b), f"{name}: one-node and two-node forms differ (max {float((a - b).abs().max()):.3e})"
