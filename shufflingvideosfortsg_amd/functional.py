@@ -456,17 +456,21 @@ def gemm_f32s_nn(x: torch.Tensor, w: torch.Tensor, w1: torch.Tensor = None) -> t
     return y
 
 
-def gemm_f32s_nn_acc(x: torch.Tensor, w: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-    """y [M,N] += x [M,K] @ w [K,N] in the split-precision arithmetic (tsg_gemm_f32s_nn_acc): the input gradient dX = dY W of a Linear added onto a
-    gradient buffer that another consumer of the same activation has already written -- no add kernel.  Returns y."""
-    require_device(x, w, y)
+def gemm_f32s_nn_acc(x: torch.Tensor, w: torch.Tensor, y: torch.Tensor, w1: torch.Tensor = None) -> torch.Tensor:
+    """y [M,N] += x [M,K] @ [w ; w1] [K,N] in the split-precision arithmetic (tsg_gemm_f32s_nn_acc): the input gradient dX = dY W of a Linear added
+    onto a gradient buffer that another consumer of the same activation has already written -- no add kernel.  w (and w1: the contraction
+    rows behind w's, same row stride) may be column slices of wider row-major parameters.  Returns y."""
+    require_device(x, w, y, w1)
     x = _f32c(x)
     M, K = x.shape
-    N = w.shape[1]
-    if (w.dtype != torch.float32 or w.shape[0] != K or w.stride(1) != 1 or w.stride(0) % 4 or w.data_ptr() % 16
-            or y.dtype != torch.float32 or y.shape != (M, N) or not y.is_contiguous()):
+    k0, N = w.shape
+    k1 = w1.shape[0] if w1 is not None else 0
+    for t in (w, w1):
+        if t is not None and (t.dtype != torch.float32 or t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16 or t.shape[1] != N or t.stride(0) != w.stride(0)):
+            raise ValueError("gemm_f32s_nn_acc: the right operand must be fp32 row-major (or a column slice of such a matrix), 16-byte aligned rows")
+    if k0 + k1 != K or y.dtype != torch.float32 or y.shape != (M, N) or not y.is_contiguous():
         raise ValueError(f"gemm_f32s_nn_acc: x{tuple(x.shape)} w{tuple(w.shape)} y{tuple(y.shape)}")
-    _call("tsg_gemm_f32s_nn_acc", x, ptr(x), K, ptr(w), None, K, w.stride(0), ptr(y), N, M, N, K)
+    _call("tsg_gemm_f32s_nn_acc", x, ptr(x), K, ptr(w), ptr(w1) if w1 is not None else None, k0, w.stride(0), ptr(y), N, M, N, K)
     return y
 
 
@@ -687,7 +691,7 @@ def scdm_gate_proj_ok(x: torch.Tensor, wa: torch.Tensor, VW: torch.Tensor) -> bo
     """The one-node form applies: f32s mode on the GPU, fp32 tensors, whole GEMM tiles, the gate as wide as the clip features."""
     if not (_GEMM_DTYPE == "f32s" and x.is_cuda and x.dtype == torch.float32 and not bf16_storage() and x.dim() == 3 and not torch.is_autocast_enabled()):
         return False
-    if os.environ.get("TSG_SHARED_GRAD", "1") == "0":
+    if not _SHARED_GRAD:
         return False
     M, Dv, H = x.shape[0] * x.shape[1], x.shape[2], wa.shape[0]
     return VW.shape[-1] == Dv and gemm_f32s_ok(M, H, Dv) and gemm_f32s_nn_ok(M, Dv, H) and M >= 2048
@@ -995,6 +999,111 @@ def head_gemm_ok(M: int, N: int, K: int, T: int, head_width: int) -> bool:
             and 0 < T <= 8192 and M % T == 0 and M <= (1 << 22))
 
 
+class GradSink:
+    """The gradient of ONE activation with several consumers (the final clip features of GMD: matching head, boundary head on the leading rows,
+    temporal-order discriminator -- SpanGroundMatchDisc.py:80-96), summed inside the consumers' own kernels: the first consumer to run its
+    backward leaves its input gradient here, the later ones ADD theirs in the epilogue of their input-gradient GEMM (tsg_gemm_f32s_nn_acc), all
+    of them return None for the activation, and ``_ShareGrad.backward`` hands the sum upstream.  As separate gradients autograd summed them with
+    elementwise kernels (and a zero-filled full-size buffer + copy for the row slice): 85 us of a 12.2 ms step."""
+    __slots__ = ("tensor", "buf")
+
+    def __init__(self, tensor):
+        self.tensor, self.buf = tensor, None
+
+    def rows(self, x):
+        """Row range of ``x`` (the shared activation or a contiguous block of its leading-axis rows) inside the shared tensor."""
+        t = self.tensor
+        row_bytes = t.stride(0) * t.element_size()
+        r0 = (x.data_ptr() - t.data_ptr()) // row_bytes
+        return r0, r0 + x.shape[0]
+
+    def take(self, dx):
+        """First contribution, full size: the sink adopts the tensor."""
+        self.buf = dx
+
+    def full(self):
+        """The [rows, D] buffer for an accumulating contribution (zero-filled if nobody has written yet)."""
+        if self.buf is None:
+            self.buf = torch.zeros_like(self.tensor)
+        return self.buf
+
+
+_ACTIVE_SINK = None
+_SHARED_GRAD = os.environ.get("TSG_SHARED_GRAD", "1") != "0"      # 0: autograd sums the gradients of shared activations itself (A/B)
+
+
+class _ShareGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sink):
+        ctx.sink = sink
+        ctx.set_materialize_grads(False)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf = ctx.sink.buf
+        ctx.sink.buf = ctx.sink.tensor = None
+        if buf is None:
+            return g, None
+        return (buf if g is None else buf + g), None
+
+
+class shared_grad:
+    """``with shared_grad(x) as xs:`` -- consumers called on ``xs`` (or on a block of its leading-axis rows) inside the block that know about sinks
+    (match_head_params, boundary_head_params, moment_pool) sum their input gradients in place (``GradSink``).  Outside the f32s GPU training path
+    the context is a no-op and yields ``x`` itself."""
+
+    def __init__(self, x):
+        ok = (_SHARED_GRAD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous() and x.requires_grad
+              and torch.is_grad_enabled() and _GEMM_DTYPE == "f32s" and not bf16_storage() and not torch.is_autocast_enabled())
+        self.x, self.sink = x, None
+        if ok:
+            self.sink = GradSink(None)
+            self.x = _ShareGrad.apply(x, self.sink)
+            self.sink.tensor = self.x
+
+    def __enter__(self):
+        global _ACTIVE_SINK
+        self.prev, _ACTIVE_SINK = _ACTIVE_SINK, self.sink
+        return self.x
+
+    def __exit__(self, *exc):
+        global _ACTIVE_SINK
+        _ACTIVE_SINK = self.prev
+        return False
+
+
+def _sink_for(x):
+    """The active sink if ``x`` is its tensor or a contiguous block of its rows (same trailing shape), else None."""
+    a = _ACTIVE_SINK
+    if a is None or a.tensor is None or not torch.is_grad_enabled() or not x.requires_grad:
+        return None
+    t = a.tensor
+    if x.dtype != t.dtype or x.dim() != t.dim() or x.shape[1:] != t.shape[1:] or not x.is_contiguous() or x.device != t.device:
+        return None
+    row_bytes = t.stride(0) * t.element_size()
+    off = x.data_ptr() - t.data_ptr()
+    if off < 0 or off % row_bytes or off // row_bytes + x.shape[0] > t.shape[0]:
+        return None
+    return a
+
+
+def _sink_add_dx(sink, x, dy2, w, w1=None):
+    """sink[rows of x] += dy2 @ [w ; w1]  ([M, N] @ [N, Dv]); the first full-size contribution is taken as it comes.  True when done here."""
+    M, Dv = dy2.shape[0], w.shape[1]
+    N = dy2.shape[1]
+    if not gemm_f32s_nn_ok(M, Dv, N):
+        return False
+    r0, r1 = sink.rows(x)
+    whole = r0 == 0 and r1 == sink.tensor.shape[0]
+    if sink.buf is None and whole and w1 is None:
+        sink.take(gemm_f32s_nn(dy2, w).view(sink.tensor.shape))
+        return True
+    buf = sink.full()
+    gemm_f32s_nn_acc(dy2, w, buf[r0:r1].view(M, Dv), w1)
+    return True
+
+
 def _dx_f32s(dy2: torch.Tensor, w_rows: torch.Tensor) -> torch.Tensor:
     """dX [M,K] = dY [M,N] @ W [N,K] in the f32s arithmetic: the own GEMM with the (small) weight transposed once where its tile
     constraints hold, else the generic split-precision product."""
@@ -1144,8 +1253,9 @@ class _MatchHeadFull(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, x, q, W1, b1, w2, b2, act):
+    def forward(ctx, x, q, W1, b1, w2, b2, act, sink=None):
         require_device(x, q, W1, b1, w2, b2)
+        ctx.sink, ctx.x_in = sink, (x if sink is not None else None)
         x = _f32c(x)
         B, T, Dv = x.shape
         H = W1.shape[0]
@@ -1177,7 +1287,12 @@ class _MatchHeadFull(torch.autograd.Function):
         dcs = torch.empty_like(cs); dw2 = torch.empty_like(w2); db2 = torch.empty(1, device=y.device, dtype=torch.float32)
         _call("tsg_match_head_bwd", y, ptr(y), ptr(cs), ptr(w2), ptr(dl), ptr(dy), ptr(dcs), ptr(dw2), ptr(db2), B, T, H, ctx.act, TSG_F32)
         dy2, x2 = dy.view(B * T, H), x.view(B * T, Dv)
-        dx = _dx_f32s(dy2, W1[:, :Dv]).view(B, T, Dv) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.sink is not None and _sink_add_dx(ctx.sink, ctx.x_in, dy2, W1[:, :Dv]):
+                pass                                                     # summed in the shared activation's sink: None for autograd
+            else:
+                dx = _dx_f32s(dy2, W1[:, :Dv]).view(B, T, Dv)
         dq = dcs @ W1[:, Dv:] if ctx.needs_input_grad[1] else None
         dW1 = None
         if ctx.needs_input_grad[2]:
@@ -1185,12 +1300,12 @@ class _MatchHeadFull(torch.autograd.Function):
             _dw_f32s(dy2, x2, out=dW1[:, :Dv])
             dW1[:, Dv:] = dcs.t() @ q
         db1 = dcs.sum(0) if ctx.needs_input_grad[3] else None
-        return dx, dq, dW1, db1, dw2.view(ctx.shapes[0]), db2.view(ctx.shapes[1]), None
+        return dx, dq, dW1, db1, dw2.view(ctx.shapes[0]), db2.view(ctx.shapes[1]), None, None
 
 
 def match_head_params(x, q, W1, b1, w2, b2, activation="relu"):
     """Matching head from its parameters (tsg_match_head_gemm; see _MatchHeadFull)."""
-    return _MatchHeadFull.apply(x, q, W1, b1, w2, b2, _ACTS[activation])
+    return _MatchHeadFull.apply(x, q, W1, b1, w2, b2, _ACTS[activation], _sink_for(x))
 
 
 class _BoundaryHeadFull(torch.autograd.Function):
@@ -1202,8 +1317,9 @@ class _BoundaryHeadFull(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, x, sent, Ws, bs, We, be, w2s, b2s, w2e, b2e, gate, mask):
+    def forward(ctx, x, sent, Ws, bs, We, be, w2s, b2s, w2e, b2e, gate, mask, sink=None):
         require_device(x, sent, Ws, bs, We, be, w2s, b2s, w2e, b2e, gate, mask)
+        ctx.sink, ctx.x_in = sink, (x if sink is not None else None)
         x = _f32c(x)
         B, T, Dv = x.shape
         Hm, J = Ws.shape[0], 2 * Ws.shape[0]
@@ -1257,7 +1373,10 @@ class _BoundaryHeadFull(torch.autograd.Function):
         ws_, we_ = Ws[:, :Dv], We[:, :Dv]
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _dx_f32s(dy2, torch.cat([ws_, we_], 0)).view(B, T, Dv)
+            if ctx.sink is not None and _sink_add_dx(ctx.sink, ctx.x_in, dy2, ws_, we_):
+                pass                                                     # added onto the shared activation's gradient rows: None for autograd
+            else:
+                dx = _dx_f32s(dy2, torch.cat([ws_, we_], 0)).view(B, T, Dv)
         dsent = torch.addmm(dcs[:, :Hm] @ Ws[:, Dv:], dcs[:, Hm:], We[:, Dv:]) if ctx.needs_input_grad[1] else None
         dWs = dWe = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[4]:
@@ -1268,12 +1387,12 @@ class _BoundaryHeadFull(torch.autograd.Function):
             dWs, dWe = dW[0], dW[1]
         db1, dw2, db2 = db1p.sum(0), dw2p.sum(0), db2p.sum(0)
         s2s, s2e = ctx.shapes
-        return (dx, dsent, dWs, db1[:Hm], dWe, db1[Hm:], dw2[:Hm].view(s2s), db2[0:1], dw2[Hm:].view(s2e), db2[1:2], dgate, None)
+        return (dx, dsent, dWs, db1[:Hm], dWe, db1[Hm:], dw2[:Hm].view(s2s), db2[0:1], dw2[Hm:].view(s2e), db2[1:2], dgate, None, None)
 
 
 def boundary_head_params(x, sent, Ws, bs, We, be, w2s, b2s, w2e, b2e, gate=None, mask=None):
     """Boundary head from its parameters (tsg_boundary_head_gemm; see _BoundaryHeadFull)."""
-    return _BoundaryHeadFull.apply(x, sent, Ws, bs, We, be, w2s, b2s, w2e, b2e, gate, mask)
+    return _BoundaryHeadFull.apply(x, sent, Ws, bs, We, be, w2s, b2s, w2e, b2e, gate, mask, _sink_for(x))
 
 
 def boundary_head_gemm(x, w_start, w_end, cs, b1, w2, b2, gate=None, mask=None):
@@ -1389,8 +1508,9 @@ class _MomentPool(torch.autograd.Function):
     mode), masks float [B,T] x 3 -> (target, fore, back) means, fp32 [B,D] each (views of one [B,3,D] buffer)."""
 
     @staticmethod
-    def forward(ctx, feat, m_target, m_fore, m_back):
+    def forward(ctx, feat, m_target, m_fore, m_back, sink=None):
         require_device(feat, m_target, m_fore, m_back)
+        ctx.sink, ctx.x_in = sink, (feat if sink is not None else None)
         bf = feat.dtype == _BF
         feat = _act(feat, bf)
         ms = tuple(_f32p(m) for m in (m_target, m_fore, m_back))
@@ -1414,12 +1534,20 @@ class _MomentPool(torch.autograd.Function):
         dpooled = _f32p(dpooled)
         dfeat = torch.empty(B, T, D, device=dpooled.device, dtype=_BF if ctx.dt == TSG_BF16 else torch.float32)
         _call("tsg_moment_pool_bwd", dpooled, ptr(dpooled), ptr(ms[0]), ptr(ms[1]), ptr(ms[2]), ptr(dfeat), B, T, D, ctx.dt)
-        return dfeat, None, None, None
+        sink = ctx.sink
+        if sink is not None and sink.tensor is not None and dfeat.dtype == torch.float32:
+            r0, r1 = sink.rows(ctx.x_in)
+            if sink.buf is None and r0 == 0 and r1 == sink.tensor.shape[0]:
+                sink.take(dfeat)                                         # the first consumer to run (it is created last): the sink adopts its gradient
+            else:
+                sink.full()[r0:r1].add_(dfeat)
+            return None, None, None, None, None
+        return dfeat, None, None, None, None
 
 
 def moment_pool(feat, m_target, m_fore, m_back):
     """-> (target, fore, back) [B,D]: masked means of feat over the three ranges (include/tsg_hip.h: tsg_moment_pool_fwd)."""
-    return _MomentPool.apply(feat, m_target, m_fore, m_back)
+    return _MomentPool.apply(feat, m_target, m_fore, m_back, _sink_for(feat))
 
 
 class _GmdLosses(torch.autograd.Function):

@@ -6,6 +6,7 @@ straight into the boundary kernel (K3), the gated concat is never built."""
 import torch
 import torch.nn as nn
 
+from .. import functional as TF
 from ..data import adjacent_cat
 from .components import (CrossModalInteraction, SentenceEncoder, SpanPredictor, TemporalOrderDiscriminator,
                          VideoEncoder)
@@ -51,19 +52,22 @@ class GMD(nn.Module):
         # (every op in it is per-sample): half as many sequential LSTM steps, twice the rows per launch
         B = ori_video_feat.size(0)
         both = self.video_encoder(adjacent_cat(ori_video_feat, pseudo_video_feat), torch.cat([word_feat, word_feat], 0))
-        ori_frame_feat, pseudo_frame_feat = both[:B], both[B:]
-        # the matching gate and the temporal-order discriminator are per-sample too: both streams in one pass
-        cat2 = lambda a, b: None if a is None or b is None else adjacent_cat(a, b)     # (a view when the batch put them back to back)
-        vmask2 = cat2(ori_video_mask, pseudo_video_mask)
-        if vmask2 is not None or (ori_video_mask is None and pseudo_video_mask is None):
-            match2, _ = self.csmm(both, torch.cat([sent_embed, sent_embed], 0), vmask2)
-            ori_match, pseudo_match = match2[:B], match2[B:]
-        else:
-            ori_match, _ = self.csmm(ori_frame_feat, sent_embed, ori_video_mask)
-            pseudo_match, _ = self.csmm(pseudo_frame_feat, sent_embed, pseudo_video_mask)
-        span_prob = self._span(ori_frame_feat, word_feat, sent_embed, ori_match, ori_video_mask)
-        disc2 = self.tod(both, adjacent_cat(ori_temporal_mask, pseudo_temporal_mask),
-                         adjacent_cat(ori_fore_mask, pseudo_fore_mask), adjacent_cat(ori_back_mask, pseudo_back_mask))
+        # the clip features feed three consumers (matching head, boundary head on the first B rows, temporal-order discriminator): their input
+        # gradients are summed inside their own kernels (TF.shared_grad / GradSink), not by autograd's add kernels
+        with TF.shared_grad(both) as both:
+            ori_frame_feat, pseudo_frame_feat = both[:B], both[B:]
+            # the matching gate and the temporal-order discriminator are per-sample too: both streams in one pass
+            cat2 = lambda a, b: None if a is None or b is None else adjacent_cat(a, b)     # (a view when the batch put them back to back)
+            vmask2 = cat2(ori_video_mask, pseudo_video_mask)
+            if vmask2 is not None or (ori_video_mask is None and pseudo_video_mask is None):
+                match2, _ = self.csmm(both, torch.cat([sent_embed, sent_embed], 0), vmask2)
+                ori_match, pseudo_match = match2[:B], match2[B:]
+            else:
+                ori_match, _ = self.csmm(ori_frame_feat, sent_embed, ori_video_mask)
+                pseudo_match, _ = self.csmm(pseudo_frame_feat, sent_embed, pseudo_video_mask)
+            span_prob = self._span(ori_frame_feat, word_feat, sent_embed, ori_match, ori_video_mask)
+            disc2 = self.tod(both, adjacent_cat(ori_temporal_mask, pseudo_temporal_mask),
+                             adjacent_cat(ori_fore_mask, pseudo_fore_mask), adjacent_cat(ori_back_mask, pseudo_back_mask))
         return span_prob, ori_match, pseudo_match, disc2[:B], disc2[B:]
 
     def eval_forward(self, video_feat, query_feat, video_mask=None, sent_mask=None):

@@ -376,3 +376,47 @@ def test_graphed_train_step_matches_eager():
     for a, b in zip(got, eager):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (got, eager)
     assert abs(got[3] - eager[3]) <= 1e-4 * max(1.0, abs(eager[3]))
+
+
+def test_shared_gradient_sinks_match_autograd_sums(request):
+    """Round 5: activations with several consumers (the BiLSTM output inside a recalibration block; the final clip features: matching head,
+    boundary head on the first B rows, temporal-order discriminator) get their gradient summed inside the consumers' kernels
+    (TF.scdm_gate_proj, TF.shared_grad / GradSink, tsg_gemm_f32s_nn_acc) instead of by autograd's add kernels.  One GMD train step at
+    B = 16 pairs, T = 128, N = 20, d = 1024 in the f32s mode, both ways: same loss, every parameter
+    gradient equal to fp32 summation-order rounding; and the sink path is really the one taken."""
+    from shufflingvideosfortsg_amd import data, engine, functional as TF
+    engine.set_precision("f32s")
+    request.addfinalizer(lambda: engine.set_precision(None))
+    params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, dropout=0.0, video_len=128, sent_len=20)
+    d = data.synthetic_batch(16, 128, 20, seed=11, pair=True, device="cuda")
+    res = []
+    took = {"n": 0}
+    add0 = TF._sink_add_dx
+
+    def counting(*a, **k):
+        ok = add0(*a, **k)
+        took["n"] += int(ok)
+        return ok
+    for on in (True, False):
+        torch.manual_seed(0)
+        model = engine.build_model("gmd", params).cuda().train()
+        model.tod.dropout.p = 0.0
+        old = TF._SHARED_GRAD
+        TF._SHARED_GRAD = on
+        TF._sink_add_dx = counting if on else add0
+        try:
+            loss, _, _ = engine.gmd_step(model, d, params)
+            loss.backward()
+        finally:
+            TF._SHARED_GRAD = old
+            TF._sink_add_dx = add0
+        res.append((float(loss), {k: p.grad.clone() for k, p in model.named_parameters()}))
+    TF.check_kernel_errors()
+    assert took["n"] == 2, took                     # matching head + boundary head summed into the sink the discriminator's pooling opened
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[1][0])          # (the forward is untouched; the loss kernel's float atomics order its last bit)
+    gmax = max(float(g.abs().max()) for g in res[1][1].values())
+    for k in res[0][1]:
+        a, b = res[0][1][k].double(), res[1][1][k].double()
+        # norm-wise per parameter (some gradients are ~1e-14 at the default initialisation: their elements are summation-order noise)
+        err, ref = float((a - b).norm()), float(b.norm())
+        assert err <= 2e-4 * ref + 1e-7 * gmax * b.numel() ** 0.5, f"{k}: |a - b| = {err:.3e} against |b| = {ref:.3e}"
