@@ -42,7 +42,8 @@ extern "C" {
                            4: tsg_boundary_score_bwd_ws (K3 backward in one launch); tsg_gemm_f32s
                            5: tsg_scdm_bwd_mode / tsg_scdm_bwd_fused_ok (path selection as a call and a predicate instead of an
                               environment variable and an error code); per-device error words
-                           6: tsg_lstm_fwd_ws (the persistent LSTM forward's exchange ring in a caller-owned workspace) */
+                           6: tsg_lstm_fwd_ws (the persistent LSTM forward's exchange ring in a caller-owned workspace), tsg_gemm_bf16, tsg_adam_step,
+                              tsg_gemm_f32s_nn_acc, tsg_lstm_set_ring / _wide, tsg_wgrad_set_stream_k */
 #define TSG_F32 0
 #define TSG_BF16 1   /* bf16 storage of the activations, fp32 arithmetic (see Conventions)                               */
 #define TSG_F32S 2   /* fp32 storage; matrix products as split-precision bf16 MFMAs (x = hi + lo; hi*hi + hi*lo + lo*hi,
