@@ -176,6 +176,34 @@ def test_persistent_lstm_hand_offs_keep_their_scope_bits(kernels):
         assert ew, f"{k}: no error-word poll of the form `load sc1 ; s_waitcnt vmcnt(0)` inside the poll loops"
 
 
+def test_lstm_backward_operand_streams_are_dma_and_nobody_waits_for_them_inside_the_step(kernels):
+    """csrc/lstm.hip, round 5 (BiLSTM backward, networks/RNN.py:26-48 through autograd): the streamed operands of the NEXT step (R, c_(t-1), dOut
+    tiles) are requested by non-temporal LDS-DMA -- no destination registers -- one step ahead, and retired by the next poll's own vmcnt(0).
+    What made three register-prefetch builds SLOWER than loads in front of the poll was a compiler-placed s_waitcnt vmcnt in front of a
+    loop-carried copy at the end of the step (profiles/r5/lstm_bwd_operand_dma_v1.txt).  In the shipped code object: every backward kernel
+    requests by `global_load_lds_dwordx4 ... nt`, and between the last request of the step loop and the write-through partial-dh stores
+    behind it there is no s_waitcnt that mentions vmcnt."""
+    names = [k for k in kernels if "lstm_bwd_persist2_kernel" in k]
+    assert len(names) >= 12, names
+    for k in names:
+        ins = kernels[k]
+        dma = [i for i, t in enumerate(ins) if t.startswith("global_load_lds_dwordx4")]
+        assert len(dma) >= 4, f"{k}: {len(dma)} LDS-DMA requests (prologue + step loop expected)"
+        assert all(re.search(r"\bnt\b", ins[i]) for i in dma), f"{k}: an operand DMA without the non-temporal hint"
+        first_poll = next(i for i, t in enumerate(ins) if re.match(r"global_load_dwordx4 ", t) and re.search(r"\bsc1\b", t))
+        # the partial-dh stores of the step: the first 16-byte write-through stores behind the poll; the loop's requests sit between the two
+        # (the prologue's requests are laid out elsewhere: in front of the poll or behind the loop)
+        stores = [i for i in range(first_poll, len(ins)) if re.match(r"global_store_dwordx4 ", ins[i]) and re.search(r"\bsc1\b", ins[i])]
+        assert stores, f"{k}: no partial-dh stores behind the poll"
+        in_loop = [i for i in dma if first_poll < i < stores[0]]
+        assert in_loop, f"{k}: no request between the poll and the partial-dh stores"
+        between = ins[in_loop[-1] + 1:stores[0]]
+        bad = [t for t in between if t.startswith("s_waitcnt") and "vmcnt" in t]
+        assert not bad, f"{k}: the step waits for its own operand requests ({bad[0]}) in front of the partial-dh stores"
+        assert not any(re.match(r"global_load_(dword|dwordx2|dwordx4|ushort|short_d16) v", t) and " nt" in t for t in between), \
+            f"{k}: a streamed REGISTER load inside the step"
+
+
 def test_k4_last_arrival_finalisation_is_a_release(kernels):
     """csrc/losses.hip (grounding/loss.py:6-51 as train.py:142-165 combines them): every workgroup adds its loss terms with float atomics,
     then `__threadfence()` and a ticket; the last arriver reads the sums.  On gfx950 the fence must be the full release -- buffer_wbl2 +
