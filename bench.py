@@ -686,8 +686,9 @@ def main():
                 "ceiling_note": ("fp32 / f32s arithmetic: one v_rcp_f32 + 2 v_fma_f32 per (t,n,k) element = 14.5-16 cycles per 64 elements on "
                                  "1024 SIMDs -> 40-44 us of VALU issue per 128-pair launch = an upper bound of 0.64-0.70 of the 8 TB/s "
                                  "roofline for this arithmetic; with the ~15 us ramp of a single wave of 256 workgroups the kernel's own "
-                                 "ceiling is 0.50-0.52 (DESIGN.md section 4, K1g).  bf16 storage: the score loop is packed f16 (two Newton "
-                                 "steps instead of v_rcp_f32: 8 packed instructions per element pair), half the bytes at half the loop time")
+                                 "ceiling is 0.50-0.52 (DESIGN.md section 4, K1g).  bf16 storage: the SAME fp32 score loop on half the bytes -- the launch "
+                                 "takes the same time, so its fraction of the HBM roofline halves (a packed-f16 loop measured no faster: gfx950 "
+                                 "has no packed reciprocal; profiles/r4/k1g_fwd_packed_f16_experiment_v1.txt)")
                 if gate else None}
         what = "fwd-only" if a.fwd_only else "fwd+bwd"
         wl = (f"{a.model}_forward: fwd+losses under no_grad, " if a.fwd_only else
