@@ -161,6 +161,92 @@ __global__ __launch_bounds__(kMhThreads) void match_head_bwd_kernel(const ST* __
   if (lane == 0) atomicAdd(db2, sb);
 }
 
+// backward, round 5: COLUMN-SLICED workgroups.  The kernel above ends every workgroup (pair, 32 clips) with 2 H float atomics -- 512 workgroups x 2048
+// at [128, 128, 1024]: a million atomics on 132 K addresses, 512 deep on each dw2 column; it measured 75 us for a 128 MB pass (1.7 TB/s), its own
+// batching experiment already said "bound by its fold + atomics tail".  Here a workgroup owns 128 hidden columns of a GROUP OF WHOLE PAIRS: a half
+// wave handles one clip row (32 lanes x 4 columns = 512 contiguous bytes, fp32), dcs[b, cols] is complete inside the workgroup (plain stores, no
+// atomics), dw2 costs 128 atomics per workgroup (32-64 deep per column instead of 512), db2 one per column-0 workgroup.
+constexpr int kMcCols = 128;             // hidden columns per workgroup
+template <int ACT, typename ST>
+__global__ __launch_bounds__(kMhThreads) void match_head_bwd_cols_kernel(const ST* __restrict__ y, const float* __restrict__ cs,
+                                                                         const float* __restrict__ w2, const float* __restrict__ dl,
+                                                                         ST* __restrict__ dy, float* __restrict__ dcs,
+                                                                         float* __restrict__ dw2, float* __restrict__ db2,
+                                                                         int B, int T, int H, int ipg) {
+  __shared__ float4 fold[2 * kMhWaves][32];                        // [half wave][4 columns of a lane]
+  __shared__ float gsum[2 * kMhWaves];
+  const int lane = threadIdx.x & 63, wv = mh_wave_id();
+  const int hw = 2 * wv + (lane >> 5), l32 = lane & 31;            // half wave 0..15 = row slot; lane of the half wave = 4 columns
+  const int nslices = H / kMcCols;
+  const int slice = blockIdx.x % nslices, grp = blockIdx.x / nslices;
+  const int col = slice * kMcCols + 4 * l32;
+  const float4 w = *reinterpret_cast<const float4*>(w2 + col);
+  const float ww[4] = {w.x, w.y, w.z, w.w};
+  float4 sw = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sb = 0.f;
+  constexpr int RS = 2 * kMhWaves;                                 // 16 rows per pass
+  constexpr int NB = 4;                                            // rows per half wave requested together
+  for (int b = grp * ipg; b < B && b < (grp + 1) * ipg; ++b) {
+    const float4 c = *reinterpret_cast<const float4*>(cs + (size_t)b * H + col);
+    const float cc[4] = {c.x, c.y, c.z, c.w};
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t0 = hw; t0 < T; t0 += RS * NB) {
+      float4 v[NB];
+      float g[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int t = t0 + RS * i;
+        const bool ok = t < T;
+        const size_t r = (size_t)b * T + (ok ? t : 0);
+        g[i] = ok ? dl[r] : 0.f;
+        v[i] = ld4(y + r * H + col);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int t = t0 + RS * i;
+        if (t < T) {
+          const size_t r = (size_t)b * T + t;
+          const float z[4] = {v[i].x + cc[0], v[i].y + cc[1], v[i].z + cc[2], v[i].w + cc[3]};
+          float d[4], a[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { a[k] = act_f<ACT>(z[k]); d[k] = g[i] * ww[k] * act_d<ACT>(z[k], a[k]); }
+          st4(dy + r * H + col, make_float4(d[0], d[1], d[2], d[3]));
+          sc.x += d[0]; sc.y += d[1]; sc.z += d[2]; sc.w += d[3];
+          sw.x += g[i] * a[0]; sw.y += g[i] * a[1]; sw.z += g[i] * a[2]; sw.w += g[i] * a[3];
+          sb += g[i];
+        }
+      }
+    }
+    // dcs[b, cols]: the 16 row slots meet in LDS, in slot order (run-to-run identical); complete here -- a plain store
+    __syncthreads();
+    fold[hw][l32] = sc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float4 s4 = fold[0][threadIdx.x];
+#pragma unroll
+      for (int u = 1; u < RS; ++u) { const float4 q = fold[u][threadIdx.x]; s4.x += q.x; s4.y += q.y; s4.z += q.z; s4.w += q.w; }
+      *reinterpret_cast<float4*>(dcs + (size_t)b * H + slice * kMcCols + 4 * threadIdx.x) = s4;
+    }
+  }
+  __syncthreads();
+  fold[hw][l32] = sw;
+  if (l32 == 0) gsum[hw] = sb;                                      // every lane of a half wave carries the same row gradients
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float4 s4 = fold[0][threadIdx.x];
+#pragma unroll
+    for (int u = 1; u < RS; ++u) { const float4 q = fold[u][threadIdx.x]; s4.x += q.x; s4.y += q.y; s4.z += q.z; s4.w += q.w; }
+    float* o = dw2 + slice * kMcCols + 4 * threadIdx.x;
+    atomicAdd(o, s4.x); atomicAdd(o + 1, s4.y); atomicAdd(o + 2, s4.z); atomicAdd(o + 3, s4.w);
+  }
+  if (slice == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < RS; ++u) s += gsum[u];
+    atomicAdd(db2, s);
+  }
+}
+
 int mh_check(const char* fn, int B, int T, int H, int act, int dtype) {
   if (dtype != TSG_F32 && dtype != TSG_BF16)
     return set_error(TSG_E_DTYPE, "%s: dtype %d not supported (TSG_F32, or TSG_BF16 = y / dy stored as bf16)", fn, dtype);
@@ -209,8 +295,31 @@ extern "C" int tsg_match_head_bwd(const void* y, const void* cs, const void* w2,
   int rc = mh_check(fn, B, T, H, activation, dtype);
   if (rc) return rc;
   auto st = static_cast<hipStream_t>(stream);
-  hipError_t e = zero3_async(dcs, sizeof(float) * (size_t)B * H, dw2, sizeof(float) * H, db2, sizeof(float), st);     // one node, not three
+  static const bool cols_off = getenv("TSG_MH_BWD_COLS") && atoi(getenv("TSG_MH_BWD_COLS")) == 0;     // A/B: the (pair, 32 clips) kernel
+  const bool cols = !cols_off && H % kMcCols == 0 && (long long)B * T >= 2048;
+  // one zero-fill node, not three (the column-sliced kernel writes dcs whole: only the two atomic targets are zeroed)
+  hipError_t e = cols ? zero3_async(dw2, sizeof(float) * H, db2, sizeof(float), nullptr, 0, st)
+                      : zero3_async(dcs, sizeof(float) * (size_t)B * H, dw2, sizeof(float) * H, db2, sizeof(float), st);
   if (e != hipSuccess) return set_error((int)e, "%s: memset: %s", fn, hipGetErrorString(e));
+  if (cols) {
+    const int nslices = H / kMcCols;
+    int groups = 512 / nslices;                                      // ~512 workgroups
+    if (groups > B) groups = B;
+    if (groups < 1) groups = 1;
+    const int ipg = cdiv(B, groups);
+    const int grid2 = nslices * cdiv(B, ipg);
+    if (dtype == TSG_BF16) {
+      using S = bf16_t;
+      auto k = activation == 0 ? match_head_bwd_cols_kernel<0, S> : activation == 1 ? match_head_bwd_cols_kernel<1, S> : match_head_bwd_cols_kernel<2, S>;
+      hipLaunchKernelGGL(k, dim3(grid2), dim3(kMhThreads), 0, st, (const S*)y, (const float*)cs, (const float*)w2,
+                         (const float*)dlogits, (S*)dy, (float*)dcs, (float*)dw2, (float*)db2, B, T, H, ipg);
+    } else {
+      auto k = activation == 0 ? match_head_bwd_cols_kernel<0, float> : activation == 1 ? match_head_bwd_cols_kernel<1, float> : match_head_bwd_cols_kernel<2, float>;
+      hipLaunchKernelGGL(k, dim3(grid2), dim3(kMhThreads), 0, st, (const float*)y, (const float*)cs, (const float*)w2,
+                         (const float*)dlogits, (float*)dy, (float*)dcs, (float*)dw2, (float*)db2, B, T, H, ipg);
+    }
+    return check_launch(fn);
+  }
   const int grid = B * cdiv(T, kMhRows);
   if (dtype == TSG_BF16) {
     using S = bf16_t;
