@@ -348,24 +348,18 @@ constexpr int kSpinLimit = 1 << 22;
 constexpr int kSlabV = 16 * (kPersistMaxH / 4) / kThreads;   // float4 of the 16-row slab per thread (4 at h = 512)
 constexpr unsigned kSentinel = 0x7fa5c3e1u;     // a signalling-NaN bit pattern: never the value of h = o * tanh(c)
 
-#ifndef TSG_ST_BITS
-#define TSG_ST_BITS "sc1"        // write-through to memory (agent scope)
-#endif
-#ifndef TSG_LD_BITS
-#define TSG_LD_BITS "sc1"        // agent scope: the per-CU L1 is bypassed
-#endif
 __device__ __forceinline__ f32x4 load_sc1_x4(const float* p) {
   f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off " TSG_LD_BITS : "=v"(v) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
 __device__ __forceinline__ void store_sc1(float* p, float v) {
-  asm volatile("global_store_dword %0, %1, off " TSG_ST_BITS : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 load_sc1_u4(const float* p) {           // integer typed: the sentinel is a NaN pattern
   u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off " TSG_LD_BITS : "=v"(v) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
 // a wave-uniform pointer the compiler may hold in VGPRs (its divergence analysis is conservative): forced into an SGPR pair
@@ -376,14 +370,14 @@ __device__ __forceinline__ const unsigned* uniform_ptr(const unsigned* p) {
 }
 __device__ __forceinline__ u32x4 load_sc1_u4_s(const unsigned* sbase, unsigned voff) {   // scalar base + 32-bit lane offset (bytes): one VGPR per address
   u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, %2 " TSG_LD_BITS : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
   return v;
 }
 __device__ __forceinline__ void store_sc1_u4(float* p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off " TSG_ST_BITS : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_sc1_u(float* p, unsigned v) {
-  asm volatile("global_store_dword %0, %1, off " TSG_ST_BITS : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 
 // Exchange stores.  Each XCD has its own L2, and an agent-scope (sc1) load is served by the L2 of the XCD it is issued on
@@ -396,11 +390,11 @@ __device__ __forceinline__ void store_sc1_u(float* p, unsigned v) {
 // the per-XCD share; correctness never depends on that.
 __device__ __forceinline__ void store_x(float* p, float v, bool local) {
   if (local) asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
-  else asm volatile("global_store_dword %0, %1, off " TSG_ST_BITS : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_x_u4(float* p, u32x4 v, bool local) {
   if (local) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, off " TSG_ST_BITS : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ int xcd_major_index() {          // position of this workgroup when the grid is ordered by (XCD, arrival)
   const int g = gridDim.x, x = blockIdx.x & 7, s = blockIdx.x >> 3;
@@ -422,11 +416,6 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-#ifndef TSG_FWD_NT
-#define TSG_FWD_NT 0                 // A/B builds: 1 non-temporal Gx loads, 2 non-temporal R / Cs stores in the forward kernel
-#endif
-template <bool NT> __device__ __forceinline__ u32x4 ld_u4(const u32x4* p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
-template <bool NT> __device__ __forceinline__ void st_u4(u32x4* p, u32x4 v) { if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v; }
 // LDS-DMA of one 16-byte piece per lane (asm: hipcc neither counts it nor drains it in front of LDS reads).  lds_addr: wave-uniform LDS byte
 // address of lane 0's piece; the hardware adds 16 bytes per lane.  M0 is the compiler's: saved and restored inside the statement.
 template <bool NT = false> __device__ __forceinline__ void dma16(const void* src, unsigned lds_addr) {
@@ -656,7 +645,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
 #define TSG_FWD_ABL 0            // timing-only ablations of the streams: 1 no R / Cs stores, 2 no Gx loads, 4 no `out` store
 #endif
   auto load_gx = [&](int t) {
-    if (gact && !(TSG_FWD_ABL & 2)) gq = ld_u4<(TSG_FWD_NT & 1) != 0>(reinterpret_cast<const u32x4*>(Gx + (seq_row(t, b0 + grow, Bs, T, bm) * 2 + d) * 4 * h + ggate * h + us * UW + gpart * 4 * EW));
+    if (gact && !(TSG_FWD_ABL & 2)) gq = *reinterpret_cast<const u32x4*>(Gx + (seq_row(t, b0 + grow, Bs, T, bm) * 2 + d) * 4 * h + ggate * h + us * UW + gpart * 4 * EW);
   };
   load_gx(d == 0 ? 0 : T - 1);
   for (int step = 0; step < T; ++step) {
@@ -722,9 +711,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
             if (pend) raw |= 1u << i;
           }
           raw &= pending;
-#ifdef TSG_DEBUG_SENTINEL
-          if (raw) __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
           if (!raw) break;
           // the error word (a memory round trip) is looked at on every 32nd retry only; a wave that gives up also raises the
           // workgroup's LDS flag, which is what the other waves check after the barrier below
@@ -890,17 +876,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
     }
     {
       // R tile = 16 rows x (UW units x 4 gates) as stored, Cs tile = 16 rows x UW floats: 16-byte pieces, rows of whole lines
-      // (R / Cs as non-temporal stores: 3.70 -> 3.31 us per step stand-alone in the bf16 storage mode at [128, 128, 512], nothing in the train
-      // step, and 3.70 -> 4.1 us with fp32 storage at T = 256: not used -- profiles/r4/lstm_fwd_nontemporal_stores_ab_v1.txt)
+      // (R / Cs as non-temporal stores, Gx as a non-temporal load: nothing in the train step in rounds 4 and 5 -- profiles/r4/lstm_fwd_nontemporal_stores_ab_v1.txt,
+      // profiles/r5/lstm_bwd_operand_dma_v1.txt (4) -- not used)
       constexpr int RPR = UW / EW, CPR = UW / 4;             // 16-byte pieces per row of the R tile / of the Cs tile
       const int rrow = tid / RPR, rpart = tid % RPR;
       if (rrow < 16 && b0 + rrow < B && !(TSG_FWD_ABL & 1)) {
         const size_t srow_ = (((size_t)tt * 2 + d) * Bs + b0 + rrow) * h + us * UW;
-        st_u4<(TSG_FWD_NT & 2) != 0>(reinterpret_cast<u32x4*>(reinterpret_cast<unsigned*>(R + srow_ * 4) + 4 * rpart), *reinterpret_cast<const u32x4*>(Rt + rrow * RTS + 4 * rpart));
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned*>(R + srow_ * 4) + 4 * rpart) = *reinterpret_cast<const u32x4*>(Rt + rrow * RTS + 4 * rpart);
       }
       const int crow = tid / CPR, cpart = tid % CPR;
       if (crow < 16 && b0 + crow < B && !(TSG_FWD_ABL & 1))
-        st_u4<(TSG_FWD_NT & 2) != 0>(reinterpret_cast<u32x4*>(Cs + (((size_t)tt * 2 + d) * Bs + b0 + crow) * h + us * UW + 4 * cpart), *reinterpret_cast<const u32x4*>(Ct + crow * CTS + 4 * cpart));
+        *reinterpret_cast<u32x4*>(Cs + (((size_t)tt * 2 + d) * Bs + b0 + crow) * h + us * UW + 4 * cpart) = *reinterpret_cast<const u32x4*>(Ct + crow * CTS + 4 * cpart);
     }
 #ifdef TSG_LSTM_TIMING
     if (step > 0) TSG_TICK(3)                                // gates, stores issued, workgroup met
@@ -1132,9 +1118,6 @@ static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
 // the write-through traffic: 14.1 us per step).  Consumers are never more than one step apart, so a slot's previous
 // generation has been read by everyone before its next one is written.
 // ---------------------------------------------------------------------------------------------
-#ifndef TSG_BWD_AHEAD_POS
-#define TSG_BWD_AHEAD_POS 1          // where the next step's operand tiles are requested: 0 behind the poll's barrier, 1 behind the dG tile barrier
-#endif
 #ifndef TSG_BWD_ABL
 #define TSG_BWD_ABL 0              // timing builds only: 1 no dG stores, 2 no operand streams
 #endif
@@ -1143,10 +1126,8 @@ constexpr int kDLB = 64 + 8;                     // split-precision mode: row st
 constexpr int kDlFloats = 2 * 16 * kDLB;         // LDS dwords of the dG tile region (>= 16 * kDLS)
 constexpr int kPLS = kPersistMaxH + 8;           // partial-dh gather row stride
 constexpr int kQLS = 36;                         // polled partial sums row stride
-#ifndef TSG_BWD_AHEAD
-#define TSG_BWD_AHEAD 1
-#endif
-constexpr int kObAhead = TSG_BWD_AHEAD, kObBufs = kObAhead + 1;   // steps of look-ahead of the backward's operand tiles; LDS buffers
+constexpr int kObBufs = 2;                       // LDS buffers of the backward's streamed operand tiles: this step's and the next one's (a second step of
+                                                 // look-ahead measured no gain: profiles/r5/lstm_bwd_operand_dma_v1.txt (3))
 constexpr int kObDw = 3072;                      // dwords of one buffer of the backward's streamed operand tiles (fp32: 8 + 2 + 2 KiB)
 
 // MODE as in the forward kernel: 0 fp32, 1 split precision (TSG_F32S), 2 = bf16 storage of R, dOut and dG with one bf16 MFMA per
@@ -1233,10 +1214,9 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
   // Until round 5 they were per-thread loads in front of the poll, which then waited for them: 0.6-0.76 us of a 3.1-3.8 us step
   // (profiles/r5/lstm_bwd_streams_ablation_v1.txt); as register loads a step ahead hipcc put the wait for them at the loop's end (a loop-carried
   // register copy, a bf16 conversion): in front of the next poll again.  c_t itself is the c_(t-1) of the step before.
-#ifndef TSG_BWD_NT
-#define TSG_BWD_NT 1                 // non-temporal operand DMAs (0: A/B builds).  Train step 12.36 -> 12.27 ms (f32s), 7.34 -> 7.20 (bf16 storage); without the hint
-#endif                               // 12.5 / 7.36: the streamed lines then stay in the L2s the exchange rings live in (profiles/r5/lstm_bwd_operand_dma_v1.txt)
-  constexpr bool ONT = TSG_BWD_NT != 0;
+  // non-temporal: train step 12.36 -> 12.27 ms (f32s), 7.34 -> 7.20 (bf16 storage); without the hint 12.5 / 7.36 -- the streamed lines then stay in the
+  // L2s the exchange rings live in (profiles/r5/lstm_bwd_operand_dma_v1.txt (5))
+  constexpr bool ONT = true;
   constexpr int kObR = BF ? 4096 : 8192, kObC = kObR;                 // byte offsets inside a buffer: R tile | c_(t-1) tile (2 KiB) | dOut tile
   auto request = [&](int s1) {
     if (TSG_BWD_ABL & 2) return;
@@ -1273,7 +1253,6 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
     cc = ld1s(Cs + (((size_t)tt0 * 2 + d) * Bs + (live ? b : B - 1)) * h + u);
     if (dHn && live) dhn0 = dHn[((size_t)d * Bs + b) * h + u];
     request(0);
-    if (kObAhead > 1 && T > 1) request(1);
   }
   for (int step = 0; step < T; ++step) {
 #ifdef TSG_LSTM_TIMING
@@ -1324,7 +1303,6 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) rec += Ql[(g * 16 + row) * kQLS + ul];
     }
-    if (TSG_BWD_AHEAD_POS == 0 && step + kObAhead < T) request(step + kObAhead);
     float4 g4;
     float cpv, dov;
     {
@@ -1380,7 +1358,7 @@ __global__ __launch_bounds__(kThreads) void lstm_bwd_persist2_kernel(
                                     reinterpret_cast<u32x4*>(dG + (seq_row(tt, b0 + prow, Bs, T, bm) * 2 + d) * K + pgate * h + us * 32 + ppart * 8));
     }
     if (step + 1 < T) {
-      if (TSG_BWD_AHEAD_POS == 1 && step + kObAhead < T) request(step + kObAhead);
+      if (step + 1 < T) request(step + 1);                 // the next step's operand tiles (behind the poll's barrier measured the same or 0.1 us slower)
       if (step > 0) TSG_TICK(4)                              // (timing builds: the wait at this barrier)
       f32x4 acc[TW];
 #pragma unroll

@@ -1375,14 +1375,8 @@ __global__ __launch_bounds__(kColThreads) void scdm_bwd_cols_kernel(
 //   end         row splits folded through LDS in fixed order; ds, dVW stored; dw, dbias: one atomic per column.
 // ------------------------------------------------------------------------------------------
 constexpr int kFusedThreads = 512, kFusedWaves = kFusedThreads / kWave;
-#ifndef TSG_FUSED_SUB
-#define TSG_FUSED_SUB 32
-#endif
-#ifndef TSG_FUSED_PF
-#define TSG_FUSED_PF 4
-#endif
-constexpr int kFusedSub = TSG_FUSED_SUB;       // rows per dP folding round
-constexpr int kFusedPF = TSG_FUSED_PF;         // rows in flight per wave
+constexpr int kFusedSub = 32;       // rows per dP folding round
+constexpr int kFusedPF = 4;         // rows in flight per wave
 constexpr unsigned kXchSpinLimit = 1u << 22;   // bounded wait on the neighbours (~seconds); expiry sets the error sink
 template <int NP> constexpr int fused_cpl() { return NP <= 20 ? 2 : 1; }
 
