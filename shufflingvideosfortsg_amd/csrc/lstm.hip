@@ -552,8 +552,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
   // touches the tiles with 16 rows x 4 units per wave instruction, which on the natural strides is a 16-way bank conflict.
   constexpr int EW = BF ? 2 : 1;                           // elements per dword of the sequence tensors
   constexpr int GTS = 4 * UW / EW + 4, RTS = 4 * UW / EW + 8, CTS = UW + 4;
+  // fp32 storage: the Gx tile of the NEXT step arrives by non-temporal LDS-DMA (no registers held over the step) into the other one of two
+  // UNPADDED [16][4 UW] images; the DMA writes LDS lane-linearly, so the bank swizzle is applied to the piece each lane FETCHES: slot p of row r
+  // holds piece p ^ (r & 15), and the gate phase reads dword 4 ((k UW/4 + at) ^ jb) + ku of row jb -- 16 rows x 4 units on 64 distinct banks.
+  // (against the piece held in four registers over the step: 3.70 -> 3.63 us per step at [128, 128, 512] f32s, 2.91 -> 2.80 at 64 rows, the f32s kernel
+  //  without scratch; bf16 storage keeps the register piece -- its Gx stream costs 0.06 us: profiles/r5/lstm_fwd_gx_dma_ab_v1.txt)
+  constexpr bool GXD = !BF && UW >= 16;
+  constexpr int GTW = GXD ? 2 * 16 * 4 * UW : 16 * GTS;      // dwords of the Gx tile region
   unsigned* Gt = reinterpret_cast<unsigned*>(Ht + 16 * 36 + (16 * HTS > 16 * 36 ? 16 * HTS - 16 * 36 : 0));   // [16][GTS] input gates of the step, as stored
-  unsigned* Rt = Gt + 16 * GTS;                            // [16][RTS] activated gates (i,f,g,o per unit), as stored
+  unsigned* Rt = Gt + GTW;                                 // [16][RTS] activated gates (i,f,g,o per unit), as stored
   float* Ct = reinterpret_cast<float*>(Rt + 16 * RTS);     // [16][CTS] cell states
   // raised by a wave whose bounded wait expired.  A static __shared__ variable: through a pointer derived from the dynamic
   // LDS block the compiler lost the address space and read the flag with a FLAT load, whose vmcnt(0) wait behind the barrier
@@ -647,7 +654,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
   auto load_gx = [&](int t) {
     if (gact && !(TSG_FWD_ABL & 2)) gq = *reinterpret_cast<const u32x4*>(Gx + (seq_row(t, b0 + grow, Bs, T, bm) * 2 + d) * 4 * h + ggate * h + us * UW + gpart * 4 * EW);
   };
-  load_gx(d == 0 ? 0 : T - 1);
+  const unsigned gt_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)Gt;
+  auto request_gx = [&](int t, int buf) {                    // (GXD) thread = slot tid % UW of row tid / UW of the image
+    if (TSG_FWD_ABL & 2) return;
+    const int r = tid / UW, pi = (tid % UW) ^ (r & 15), br = b0 + r < B ? b0 + r : B - 1;      // rows beyond B re-read the last one (never used)
+    dma16<true>(Gx + (seq_row(t, br, Bs, T, bm) * 2 + d) * 4 * h + (pi / (UW / 4)) * h + us * UW + 4 * (pi % (UW / 4)),
+                __builtin_amdgcn_readfirstlane(gt_lds + (unsigned)(buf * 16 * 4 * UW * 4) + 1024u * (unsigned)wv));
+  };
+  if constexpr (GXD) request_gx(d == 0 ? 0 : T - 1, 0); else load_gx(d == 0 ? 0 : T - 1);
   for (int step = 0; step < T; ++step) {
 #ifdef TSG_LSTM_TIMING
     tm0 = __builtin_amdgcn_s_memtime();
@@ -660,10 +674,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
     // The piece is taken over (to LDS) right AFTER the poll (whose wait has covered it), never at the loop head, where the wait for
     // it would also wait for the stores of the step before.
     auto prefetch_gx = [&]() {
-      if (tid < 64 * PPG) *reinterpret_cast<u32x4*>(Gt + grow * GTS + ggate * (UW / EW) + 4 * gpart) = gq;
-      if (step + 1 < T) load_gx(d == 0 ? step + 1 : T - 2 - step);
+      if constexpr (GXD) {
+        if (step + 1 < T) request_gx(d == 0 ? step + 1 : T - 2 - step, (step + 1) & 1);      // retired by the NEXT poll's vmcnt(0), read behind its barrier
+      } else {
+        if (tid < 64 * PPG) *reinterpret_cast<u32x4*>(Gt + grow * GTS + ggate * (UW / EW) + 4 * gpart) = gq;
+        if (step + 1 < T) load_gx(d == 0 ? step + 1 : T - 2 - step);
+      }
     };
-    if (step == 0) { prefetch_gx(); lds_barrier(); }
+    if (step == 0) {
+      if constexpr (GXD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first tile has landed
+      prefetch_gx();
+      lds_barrier();
+    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (step > 0) {
       f32x4 v[SV];
@@ -829,6 +851,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if constexpr (BF) { const unsigned w2 = Gt[jb * GTS + k * (UW / 2) + (ul >> 1)]; gx[k] = ((ul & 1) ? bf16_hi(w2) : bf16_lo(w2)) + bi[k]; }
+        else if constexpr (GXD) gx[k] = __uint_as_float(Gt[(step & 1) * 16 * 4 * UW + jb * 4 * UW + 4 * ((k * (UW / 4) + at) ^ jb) + ku]) + bi[k];
         else gx[k] = __uint_as_float(Gt[jb * GTS + k * UW + ul]) + bi[k];
       }
       const float gi = sigmoid_f(acc[0] + gx[0]), gf = sigmoid_f(acc[1] + gx[1]);
@@ -1644,7 +1667,7 @@ static int lstm_fwd_impl(const void* Gx, const void* bias, const void* Whh, void
     const bool xr = need > 0 && ws_bytes >= need && xr_wanted(B, bf);
     const int NW = ((nw_env == 4 || (nw_env == 0 && B <= 32)) && h == 512 && (split || (bf && xr))) ? 4 : 8;
     const int HLS = kPersistMaxH + 8;                      // fixed: the prefetch above may read (never use) columns up to kPersistMaxH
-    const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 36 + 16 * (132 + 136 + 36) + 4);     // slab, h tile, Gx / R / Cs tiles (fp32, 32 units: the largest)
+    const size_t plds = sizeof(float) * ((size_t)kSlabFloats + 16 * 36 + 2 * 16 * 128 + 16 * (136 + 36) + 4);     // slab, h tile, Gx / R / Cs tiles (fp32, 32 units: the largest)
     static_assert(kSlabFloats >= 16 * (kPersistMaxH + 8), "slab region holds the fp32 slab too");
     typedef void (*Launch)(int, size_t, hipStream_t, const void*, const void*, const void*, void*, void*, void*, void*, int, int, int, int, int, int, size_t, int);
     Launch go = nullptr;
