@@ -386,6 +386,12 @@ int tsg_gemm_bf16(const void* x, long long ldx, const void* w, long long ldw, co
 int tsg_adam_step(int n, const void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                   const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
                   void* state, const void* skip, void* stream);
+/* The same update, additionally rewriting a bf16 shadow of every parameter that has one (shadow: n pointers, entries may be NULL; NULL = none):
+ * shadow[i][e] = rne_bf16(params[i][e]) after the update -- the operand the bf16 storage mode's GEMMs read, so the per-step casts of the weights
+ * (`w.to(torch.bfloat16)` once per Linear and LSTM layer) disappear.  A skipped update leaves the shadows untouched (ABI revision 6).       */
+int tsg_adam_step_shadow(int n, const void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                         void* const* shadow, const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay,
+                         double grad_scale, void* state, const void* skip, void* stream);
 
 /* ---- the heads as the EPILOGUE of their own first-Linear GEMM (ABI revision 5; round-3 review: SURVEY 8f #2 "split-W Linear + ReLU
  * + dot epilogue").  Same f32s arithmetic and tiling as tsg_gemm_f32s (row tiles of 256 / 128 / 64 so that a narrow head still

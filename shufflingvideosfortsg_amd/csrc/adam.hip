@@ -21,6 +21,7 @@ constexpr int kAdamMaxTensors = 64;               // per launch: the tables trav
 constexpr int kAdamChunk = 8192;                  // elements per workgroup (256 threads x 8 float4)
 struct AdamTable {
   float* p[kAdamMaxTensors]; const float* g[kAdamMaxTensors]; float* m[kAdamMaxTensors]; float* v[kAdamMaxTensors];
+  unsigned short* pb[kAdamMaxTensors];             // bf16 shadow of p (the bf16 storage mode's GEMM operand), or NULL: rewritten with every update
   unsigned first_chunk[kAdamMaxTensors + 1];      // prefix of chunks per tensor
   unsigned numel[kAdamMaxTensors];
   int n;
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tb, float lr,
     }
     const unsigned base = (blockIdx.x - tb.first_chunk[lo]) * (unsigned)kAdamChunk, n = tb.numel[lo];
     float* __restrict__ p = tb.p[lo]; const float* __restrict__ g = tb.g[lo]; float* __restrict__ m = tb.m[lo]; float* __restrict__ v = tb.v[lo];
+    unsigned short* __restrict__ pb = tb.pb[lo];
     const float t = *step + 1.f;
     // 1 - b^t = -expm1(t log b): formed as 1 - exp(..) the fp32 difference loses three digits at b2 = 0.999, t = 1 (1 - 0.999 = 1e-3 from
     // two numbers known to 6e-8).  log b and 1 - b arrive from the host, formed in DOUBLE from the double hyper-parameters as torch forms them
@@ -52,7 +54,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tb, float lr,
       vv = fmaf(b2, vv, omb2 * gg * gg);
       pp -= step_size * mm / fmaf(sqrtf(vv), rs2, eps);
     };
-    const bool al16 = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
+    const bool al16 = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15u) == 0 &&
+                      (reinterpret_cast<uintptr_t>(pb) & 7u) == 0;
     if (al16 && base + kAdamChunk <= n) {                                // a whole chunk of 16-byte aligned tensors (views into a flat gradient buffer need not be)
 #pragma unroll
       for (int i = 0; i < kAdamChunk / 1024; ++i) {
@@ -61,12 +64,14 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tb, float lr,
         const float4 gq = *reinterpret_cast<const float4*>(g + e);
         upd(pq.x, gq.x, mq.x, vq.x); upd(pq.y, gq.y, mq.y, vq.y); upd(pq.z, gq.z, mq.z, vq.z); upd(pq.w, gq.w, mq.w, vq.w);
         *reinterpret_cast<float4*>(p + e) = pq; *reinterpret_cast<float4*>(m + e) = mq; *reinterpret_cast<float4*>(v + e) = vq;
+        if (pb) *reinterpret_cast<uint2*>(pb + e) = make_uint2(pack_bf16x2(pq.x, pq.y), pack_bf16x2(pq.z, pq.w));     // (16-byte aligned tensors: 8-byte aligned here)
       }
     } else {
       for (unsigned e = base + threadIdx.x; e < n && e < base + kAdamChunk; e += 256u) {
         float pp = p[e], mm = m[e], vv = v[e];
         upd(pp, g[e], mm, vv);
         p[e] = pp; m[e] = mm; v[e] = vv;
+        if (pb) pb[e] = (unsigned short)(pack_bf16x2(pp, 0.f) & 0xffffu);
       }
     }
   }
@@ -90,10 +95,9 @@ using namespace tsg;
 // numel[i] elements each (< 2^31).  state: device buffer of 2 words {float step count, unsigned ticket (zero between calls)} owned by the caller
 // (zero-initialised once).  skip: device float or NULL.  More than 64 tensors run as consecutive launches that read the same step count; the
 // LAST launch advances it.
-extern "C" int tsg_adam_step(int n, const void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
-                             const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
-                             void* state, const void* skip, void* stream) {
-  const char* fn = "tsg_adam_step";
+static int adam_impl(const char* fn, int n, const void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                     void* const* shadow, const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
+                     void* state, const void* skip, void* stream) {
   if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !state) return set_error(TSG_E_NULL, "%s: NULL argument or n=%d", fn, n);
   if (!(beta1 > 0. && beta1 < 1. && beta2 > 0. && beta2 < 1.)) return set_error(TSG_E_SHAPE, "%s: betas (%g, %g) outside (0, 1)", fn, beta1, beta2);
   for (int i = 0; i < n; ++i) {
@@ -110,6 +114,7 @@ extern "C" int tsg_adam_step(int n, const void* const* params, const void* const
     unsigned chunks = 0;
     for (int i = 0; i < cnt; ++i) {
       tb.p[i] = (float*)params[i0 + i]; tb.g[i] = (const float*)grads[i0 + i]; tb.m[i] = (float*)exp_avg[i0 + i]; tb.v[i] = (float*)exp_avg_sq[i0 + i];
+      tb.pb[i] = shadow ? (unsigned short*)shadow[i0 + i] : nullptr;
       tb.numel[i] = (unsigned)numel[i0 + i];
       tb.first_chunk[i] = chunks;
       chunks += (unsigned)((numel[i0 + i] + kAdamChunk - 1) / kAdamChunk);
@@ -120,4 +125,22 @@ extern "C" int tsg_adam_step(int n, const void* const* params, const void* const
                        (float*)state, (const float*)skip, (unsigned*)state + 1, i0 + cnt >= n ? 1 : 0);
   }
   return check_launch(fn);
+}
+
+extern "C" int tsg_adam_step(int n, const void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                             const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
+                             void* state, const void* skip, void* stream) {
+  return adam_impl("tsg_adam_step", n, params, grads, exp_avg, exp_avg_sq, nullptr, numel, lr, beta1, beta2, eps, weight_decay, grad_scale, state, skip, stream);
+}
+
+// The same update that also rewrites a bf16 SHADOW of every parameter that has one (shadow[i] may be NULL; bf16 = rne of the updated fp32 value, what
+// `.to(torch.bfloat16)` gives): the bf16 storage mode's GEMMs read the shadows, so the per-step fp32 -> bf16 casts of the weights (eleven launches,
+// 0.11 ms of a 7 ms step) disappear.  A skipped update leaves the shadows as they are (they match the untouched parameters).
+extern "C" int tsg_adam_step_shadow(int n, const void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                                    void* const* shadow, const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                    double grad_scale, void* state, const void* skip, void* stream) {
+  if (shadow)
+    for (int i = 0; i < n; ++i)
+      if (shadow[i] && (reinterpret_cast<uintptr_t>(shadow[i]) & 1u)) return set_error(TSG_E_ALIGN, "tsg_adam_step_shadow: shadow %d is not 2-byte aligned", i);
+  return adam_impl("tsg_adam_step_shadow", n, params, grads, exp_avg, exp_avg_sq, shadow, numel, lr, beta1, beta2, eps, weight_decay, grad_scale, state, skip, stream);
 }

@@ -151,9 +151,17 @@ class TsgAdam(torch.optim.Optimizer):
             numel = (ctypes.c_longlong * n)(*[p.numel() for p in ps])
             b1, b2 = group["betas"]
             skip = self.found_inf
-            rc = lib.tsg_adam_step(n, arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]), arr([self.state[p]["exp_avg_sq"] for p in ps]),
-                                   numel, float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                   float(self.grad_scale), ptr(words), ptr(skip) if skip is not None else None, TF.stream_of(ps[0]))
+            # bf16 shadows of the parameters the bf16 storage mode has used as GEMM operands (functional.weight_bf16): rewritten by the same kernel
+            shadows = [TF.shadow_of(p) for p in ps]
+            if any(sh is not None for sh in shadows):
+                sh_arr = (ctypes.c_void_p * n)(*[sh.data_ptr() if sh is not None else None for sh in shadows])
+                rc = lib.tsg_adam_step_shadow(n, arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]), arr([self.state[p]["exp_avg_sq"] for p in ps]),
+                                              sh_arr, numel, float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                              float(self.grad_scale), ptr(words), ptr(skip) if skip is not None else None, TF.stream_of(ps[0]))
+            else:
+                rc = lib.tsg_adam_step(n, arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]), arr([self.state[p]["exp_avg_sq"] for p in ps]),
+                                       numel, float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                       float(self.grad_scale), ptr(words), ptr(skip) if skip is not None else None, TF.stream_of(ps[0]))
             TF.check(rc, "tsg_adam_step")
         return loss
 

@@ -517,6 +517,36 @@ def _bfc(t: torch.Tensor) -> torch.Tensor:
     return t.to(_BF).contiguous()
 
 
+_SHADOWS = os.environ.get("TSG_BF16_SHADOW", "1") != "0"       # 0: cast the fp32 parameters to bf16 at every use (A/B)
+
+
+def weight_bf16(w: torch.Tensor) -> torch.Tensor:
+    """The bf16 operand of an fp32 parameter in the bf16 storage mode.  For a leaf parameter the rounded copy is kept as a SHADOW on the parameter
+    object and rewritten by the optimizer's own kernel with every update (engine.TsgAdam -> tsg_adam_step_shadow), so a training step does not
+    cast its weights at all (eleven cast launches, 0.11 ms of the 7 ms GMD step).  The shadow is trusted while the parameter's version counter is
+    the one it was made at: TsgAdam updates through raw pointers (no version bump, and it rewrites the shadow); every other in-place change
+    (load_state_dict, an optimizer that is not TsgAdam, manual edits) bumps the version and the shadow is re-made here."""
+    wd = w.detach()
+    if not (_SHADOWS and w.is_leaf and w.requires_grad and w.dtype == torch.float32 and w.is_cuda and w.is_contiguous()):
+        return wd.to(_BF)
+    sh = getattr(w, "_tsg_shadow", None)
+    if sh is None or sh.shape != w.shape or sh.device != w.device:
+        sh = wd.to(_BF)
+        w._tsg_shadow, w._tsg_shadow_version = sh, w._version
+    elif w._tsg_shadow_version != w._version:
+        sh.copy_(wd)
+        w._tsg_shadow_version = w._version
+    return sh
+
+
+def shadow_of(p: torch.Tensor):
+    """The parameter's live bf16 shadow (``weight_bf16``) or None -- what the optimizer passes to tsg_adam_step_shadow."""
+    sh = getattr(p, "_tsg_shadow", None)
+    if sh is None or not _SHADOWS or getattr(p, "_tsg_shadow_version", None) != p._version or sh.shape != p.shape or sh.device != p.device:
+        return None
+    return sh
+
+
 def _f32p(t: torch.Tensor) -> torch.Tensor:
     """fp32 contiguous: parameters and the small [B,T] / [B,J] side inputs the kernels keep in fp32 in every mode."""
     return t.float().contiguous()
@@ -1731,7 +1761,7 @@ class _LinearBf16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         x2 = _bfc(x).view(-1, x.shape[-1])
-        wb = w.detach().to(_BF)
+        wb = weight_bf16(w)
         y = _mm_bf16_nt(x2, wb, b)
         ctx.save_for_backward(x2, wb)
         ctx.has_bias, ctx.xshape = b is not None, x.shape
@@ -1927,14 +1957,14 @@ class _BiLSTMLayerBf16(torch.autograd.Function):
     prologue, fp32 cell state, fp32 Cs); W_ih / W_hh / bias gradients leave their GEMMs / the kernel in fp32.  Batch-major."""
 
     @staticmethod
-    def forward(ctx, x, W_ih, bias, W_hh):
+    def forward(ctx, x, W_ih, bias, W_hh, W_ih_bf16=None):
         require_device(x, W_ih, bias, W_hh)
         x, bias, W_hh = _bfc(x), _f32p(bias), _f32p(W_hh)
         B, T, I = x.shape
         h = W_hh.shape[2]
         if W_ih.shape != (8 * h, I) or W_hh.shape != (2, 4 * h, h) or bias.numel() != 8 * h:
             raise ValueError(f"bilstm: shape mismatch x{tuple(x.shape)} W_ih{tuple(W_ih.shape)} W_hh{tuple(W_hh.shape)}")
-        Wb = W_ih.detach().to(_BF)                                        # [8h, I]
+        Wb = W_ih_bf16 if (W_ih_bf16 is not None and W_ih_bf16.shape == W_ih.shape and W_ih_bf16.dtype == _BF) else weight_bf16(W_ih)     # [8h, I]
         Gx = _mm_bf16_nt(x.view(B * T, I), Wb)                            # bf16 [B*T, 8h]; the bias is added inside the kernel
         out = torch.empty(B, T, 2 * h, device=x.device, dtype=_BF)
         R = torch.empty(T, 2, B, h, 4, device=x.device, dtype=_BF)
@@ -1973,7 +2003,7 @@ class _BiLSTMLayerBf16(torch.autograd.Function):
             # h rows are read straight from `out` (row r -+ 1 of the same sequence, zero at its ends) -- no shifted copy, no fp32
             dW_ih, dW_hh = wgrad_bf16_out2(dGf, x.view(TB, I), out.view(TB, 2 * h), N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h,
                                            shift=1, period=T)            # the two parameter-shaped tensors: no slicing copies
-            return dx, dW_ih.view(8 * h, I), dbias, dW_hh
+            return dx, dW_ih.view(8 * h, I), dbias, dW_hh, None
         dW_ih = torch.mm(dGf.t(), x.view(TB, I), out_dtype=torch.float32)           # [8h, I], both directions
         # dW_hh[d] = sum_t dG_t[d]^T h_{t-1}[d] (h_{t+1} for the reverse direction): the partner rows as ONE shifted bf16 copy of
         # `out` (zero at the sequence ends), then a GEMM per direction on strided column views (no cat, no fp32 operands)
@@ -1983,10 +2013,10 @@ class _BiLSTMLayerBf16(torch.autograd.Function):
         g2, hp2 = dG.view(TB, 2, 4 * h), hp.view(TB, 2 * h)
         dW_hh = torch.stack([torch.mm(g2[:, 0].t(), hp2[:, :h], out_dtype=torch.float32),
                              torch.mm(g2[:, 1].t(), hp2[:, h:], out_dtype=torch.float32)])
-        return dx, dW_ih, dbias, dW_hh
+        return dx, dW_ih, dbias, dW_hh, None
 
 
-def bilstm_layer(x, W_ih, bias, W_hh, batch_major=False, bias2=None):
+def bilstm_layer(x, W_ih, bias, W_hh, batch_major=False, bias2=None, W_ih_bf16=None):
     """x [T,B,I] (or [B,T,I] with batch_major) -> (out in the same layout, Cs [T,2,B,h] cell states, not differentiable).
     ``bias2``: a second bias vector (nn.LSTM keeps b_ih and b_hh apart); the layer uses bias + bias2.
     bf16 storage mode: bf16 in and out through the TSG_BF16 recurrence kernels where they exist (T > 1, h in 128..512 step 128,
@@ -1996,7 +2026,7 @@ def bilstm_layer(x, W_ih, bias, W_hh, batch_major=False, bias2=None):
         if bias2 is not None:
             bias = bias + bias2
         if batch_major and lstm_bf16_ok(T, h):
-            return _BiLSTMLayerBf16.apply(x, W_ih, bias, W_hh)
+            return _BiLSTMLayerBf16.apply(x, W_ih, bias, W_hh, W_ih_bf16)       # (W_ih_bf16: the joined parameters' live bf16 shadow, or None)
         # the fp32-storage layer in the f32s arithmetic: the mode is an ARGUMENT (saved in ctx for the backward), not a flip of the global
         out, Cs = _BiLSTMLayer.apply(x.float(), W_ih, bias, W_hh, batch_major, "f32s")
         return out.to(_BF), Cs

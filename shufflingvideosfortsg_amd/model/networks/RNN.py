@@ -63,6 +63,7 @@ class BiLSTM(nn.Module):
         self.backend = os.environ.get("TSG_LSTM", "hip")
         self._join = os.environ.get("TSG_LSTM_JOIN", "1") != "0"      # A/B switch: 0 = torch.cat / torch.stack every call
         self._fused = {}                          # (layer, part) -> buffer holding the forward and the reverse parameter back to back
+        self._shadow = {}                         # layer -> bf16 buffer holding the two weight_ih shadows back to back (bf16 storage mode)
 
     def _joined(self, k, part, stack=False):
         """[forward; reverse] parameter ``part`` of layer k as ONE tensor.  The two nn.Parameters keep their identity, names and
@@ -86,6 +87,27 @@ class BiLSTM(nn.Module):
             self._fused[(k, part)] = base
         return _Joined.apply(pf, pr, base, stack)
 
+    def _joined_bf16(self, k):
+        """bf16 storage mode: the joined [forward; reverse] ``weight_ih`` of layer k as bf16 WITHOUT a cast -- one bf16 buffer whose halves are the two
+        parameters' shadows (functional.weight_bf16 / shadow_of), which the optimizer's kernel rewrites with every update
+        (tsg_adam_step_shadow).  None when it cannot be kept (a graph capture in progress while it would have to be (re)made)."""
+        L = self.lstm
+        pf, pr = getattr(L, f"weight_ih_l{k}"), getattr(L, f"weight_ih_l{k}_reverse")
+        if not (TF._SHADOWS and pf.is_cuda and pf.requires_grad and pr.requires_grad and pf.dtype == torch.float32):
+            return None
+        n = pf.numel()
+        sb = self._shadow.get(k)
+        sf, sr = TF.shadow_of(pf), TF.shadow_of(pr)
+        if sb is None or sf is None or sr is None or sf.data_ptr() != sb.data_ptr() or sr.data_ptr() != sb.data_ptr() + 2 * n or sb.device != pf.device:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            with torch.no_grad():
+                sb = torch.cat([pf.detach().reshape(-1), pr.detach().reshape(-1)]).to(torch.bfloat16)
+            pf._tsg_shadow, pf._tsg_shadow_version = sb[:n].view(pf.shape), pf._version
+            pr._tsg_shadow, pr._tsg_shadow_version = sb[n:].view(pr.shape), pr._version
+            self._shadow[k] = sb
+        return sb.view(2 * pf.shape[0], *pf.shape[1:])
+
     def _hip_forward(self, x, states=True):
         L, p = self.lstm, self.lstm.dropout
         bm = os.environ.get("TSG_LSTM_LAYOUT", "bm") != "tm"   # default: batch-major throughout, the kernels index [B,T,..]
@@ -93,7 +115,8 @@ class BiLSTM(nn.Module):
         for k in range(self.num_layers):
             W_ih = self._joined(k, "weight_ih")                              # [8h, I]   (forward rows, then reverse)
             W_hh = self._joined(k, "weight_hh", stack=True)                  # [2, 4h, h]
-            out, Cs = TF.bilstm_layer(inp, W_ih, self._joined(k, "bias_ih"), W_hh, batch_major=bm, bias2=self._joined(k, "bias_hh"))
+            wb16 = self._joined_bf16(k) if TF.bf16_storage() and inp.is_cuda else None
+            out, Cs = TF.bilstm_layer(inp, W_ih, self._joined(k, "bias_ih"), W_hh, batch_major=bm, bias2=self._joined(k, "bias_hh"), W_ih_bf16=wb16)
             h = self.hidden_size
             if states is True:
                 hn += [out[:, -1, :h], out[:, 0, h:]] if bm else [out[-1, :, :h], out[0, :, h:]]

@@ -99,3 +99,41 @@ def test_engine_optimizer_step_uses_the_own_adam_and_skips_on_the_device():
     assert torch.equal(m.weight.detach(), w0)
     engine.optimizer_step(opt, loss)
     assert not torch.equal(m.weight.detach(), w0)
+
+
+def test_tsg_adam_keeps_bf16_shadows_of_the_parameters():
+    """Round 5: the bf16 storage mode reads bf16 SHADOWS of the fp32 parameters (functional.weight_bf16); the optimizer's kernel rewrites them with
+    every update (tsg_adam_step_shadow), so a training step casts no weight.  After every update the shadow is, bit for bit, the parameter
+    rounded to bf16; a skipped update leaves it alone; a change of the parameter behind the optimizer's back (load_state_dict / copy_) is
+    noticed through the version counter and the shadow is re-made at its next use; parameters without a shadow are updated as before."""
+    from shufflingvideosfortsg_amd import functional as TF
+    from shufflingvideosfortsg_amd.engine import TsgAdam
+    a, b, g = _models(3)
+    own = TsgAdam(a, lr=1e-3, weight_decay=1e-4, eps=1e-6)
+    ref = torch.optim.Adam(b, lr=1e-3, weight_decay=1e-4, eps=1e-6)
+    shadowed = a[::2]                                      # every second tensor has been used as a bf16 operand (all size classes; both launches)
+    for p in shadowed:
+        sh = TF.weight_bf16(p)
+        assert sh.dtype == torch.bfloat16 and TF.shadow_of(p) is sh and torch.equal(sh, p.detach().to(torch.bfloat16))
+    ptrs = [TF.weight_bf16(p).data_ptr() for p in shadowed]
+    for it in range(4):
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, generator=g).cuda()
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        if it == 2:
+            own.found_inf = torch.ones((), device="cuda")  # a skipped update: parameters AND shadows stay
+            keep = [TF.shadow_of(p).clone() for p in shadowed]
+            own.step(); own.found_inf = None
+            for p, k in zip(shadowed, keep):
+                assert torch.equal(TF.shadow_of(p), k)
+            continue
+        own.step(); ref.step()
+        for p in shadowed:
+            assert torch.equal(TF.shadow_of(p), p.detach().to(torch.bfloat16)), f"shadow of a {tuple(p.shape)} tensor after update {it}"
+    for pa, pb in zip(a, b):
+        torch.testing.assert_close(pa.data, pb.data, rtol=2e-6, atol=1e-7)
+    assert [TF.weight_bf16(p).data_ptr() for p in shadowed] == ptrs          # the same buffers all along: no cast, no reallocation
+    with torch.no_grad():
+        shadowed[3].copy_(torch.full_like(shadowed[3], 0.333))               # behind the optimizer's back: the version counter moves
+    assert TF.shadow_of(shadowed[3]) is None
+    assert torch.equal(TF.weight_bf16(shadowed[3]), shadowed[3].detach().to(torch.bfloat16)) and TF.shadow_of(shadowed[3]) is not None
