@@ -1894,12 +1894,20 @@ class _BiLSTMLayer(torch.autograd.Function):
         # row r -+ B of `out` (time-major) or row r -+ 1 of the same sequence (batch-major), zero at the sequence ends
         shift, period = (1, T) if bm else (B, 0)
         x2, o2 = x.view(TB, I), out.view(TB, 2 * h)
-        if ctx.own and T > 1 and wgrad_f32s_ok(TB, 4 * h, I, h) and gemm_f32s_ok(TB, I, 8 * h):
+        dx_gemm = gemm_f32s_ok(TB, I, 8 * h)
+        dx_split = not dx_gemm and _LSTM_SPLITK and wgrad_f32s_ok(8 * h, TB, I)      # few rows, long contraction (the sentence encoder: 1280 rows, K = 4096)
+        if ctx.own and T > 1 and wgrad_f32s_ok(TB, 4 * h, I, h) and (dx_gemm or dx_split or not ctx.needs_input_grad[0]):
             # own kernels, no operand planes: dX = dG W_ih on tsg_gemm_f32s (one transposed copy of the weight), and ONE weight-gradient
             # launch for dG[d]^T [x | h_{t-+1}[d]] of both directions, the shifted h rows read straight from `out`, written as the two
             # parameter-shaped tensors (tsg_wgrad_f32s_out2)
             if ctx.needs_input_grad[0]:
-                dx = gemm_f32s(dGf, transposed(W_ih)).view(x.shape)
+                if dx_gemm:
+                    dx = gemm_f32s(dGf, transposed(W_ih)).view(x.shape)
+                else:
+                    # [1280 x 4096] . [4096 x 1024]: 20 output tiles cannot fill the chip, and the GEMM kernel has no split over K.  The
+                    # weight-gradient kernel does (row ranges + a reduce pass) and takes both operands contraction-major: dX = (dG^T)^T W_ih
+                    # with one transposed copy of dG (20 MB).  (Until round 5: bf16 planes + an 8-chunk library bmm + a sum: 71 + 12 + 36 us.)
+                    dx = wgrad_f32s(transposed(dGf), W_ih)[0].view(x.shape)
             dW_ih, dW_hh = wgrad_f32s_out2(dGf, x2, o2, N=4 * h, K1=h, a_group_stride=4 * h, b1_group_stride=h, shift=shift, period=period)
             return dx, dW_ih.view(8 * h, I), dbias, dW_hh, None, None, (dbias if ctx.two_biases else None)
         if T == 1:
