@@ -622,8 +622,9 @@ class _ScdmGate(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, a, s, w, VW, gbias, r):
+    def forward(ctx, a, s, w, VW, gbias, r, sink=None):
         require_device(a, s, w, VW, gbias, r)
+        ctx.sink, ctx.r_in = sink, (r if sink is not None else None)
         bf = r.dtype == _BF                                    # bf16 storage: a, s, VW, r, out (and their gradients) as bf16
         a, s, w, VW, gbias, r = _act(a, bf), _act(s, bf), _f32p(w), _act(VW, bf), _f32p(gbias), _act(r, bf)
         B, T, H = a.shape
@@ -659,12 +660,15 @@ class _ScdmGate(torch.autograd.Function):
             _call("tsg_scdm_gate_bwd", af, ptr(af), ptr(sf), ptr(w), ptr(vf), ptr(gbias), ptr(rf), ptr(P), ptr(gf),
                   ptr(daf), ptr(dsf), ptr(dw), ptr(dvf), ptr(dgb), ptr(drf), ptr(ws), nb, B, T, N, H, Ds, TSG_F32)
             da, ds, dVW, dr = daf.to(_BF), dsf.to(_BF), dvf.to(_BF), drf.to(_BF)
-        return da, ds, dw, dVW, dgb, dr
+        if ctx.sink is not None and ctx.sink.tensor is not None and dr.dtype == ctx.sink.tensor.dtype:
+            _sink_add(ctx.sink, ctx.r_in, dr)                  # r is a shared activation (the BiLSTM output: also W_a's input): its gradient meets the other there
+            dr = None
+        return da, ds, dw, dVW, dgb, dr, None
 
 
 def scdm_gate(a, s, w, VW, gbias, r):
     """SCDM attention fused with the recalibration gate (see include/tsg_hip.h, K1g)."""
-    return _ScdmGate.apply(a, s, w.reshape(-1), VW, gbias, r)
+    return _ScdmGate.apply(a, s, w.reshape(-1), VW, gbias, r, _sink_for(r))
 
 
 class _ScdmGateProj(torch.autograd.Function):
@@ -1084,8 +1088,9 @@ class shared_grad:
     the context is a no-op and yields ``x`` itself."""
 
     def __init__(self, x):
-        ok = (_SHARED_GRAD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous() and x.requires_grad
-              and torch.is_grad_enabled() and _GEMM_DTYPE == "f32s" and not bf16_storage() and not torch.is_autocast_enabled())
+        mode_ok = (x.dtype == torch.float32 and _GEMM_DTYPE == "f32s" and not bf16_storage()) or (x.dtype == _BF and bf16_storage())
+        ok = (_SHARED_GRAD and x.is_cuda and mode_ok and x.dim() == 3 and x.is_contiguous() and x.requires_grad
+              and torch.is_grad_enabled() and not torch.is_autocast_enabled())
         self.x, self.sink = x, None
         if ok:
             self.sink = GradSink(None)
@@ -1132,6 +1137,26 @@ def _sink_add_dx(sink, x, dy2, w, w1=None):
     buf = sink.full()
     gemm_f32s_nn_acc(dy2, w, buf[r0:r1].view(M, Dv), w1)
     return True
+
+
+def _sink_add_dx_bf16(sink, x, dy2, wb):
+    """bf16 storage mode: sink[rows of x] += dy2 [M,N] @ wb [N,K] -- the first full-size contribution is taken as it comes, later ones are added in the
+    GEMM (beta = 1: one rounding of gradient + fp32 accumulator instead of a bf16 add kernel over the [B, T, D] tensor)."""
+    M, K = dy2.shape[0], wb.shape[1]
+    r0, r1 = sink.rows(x)
+    if sink.buf is None and r0 == 0 and r1 == sink.tensor.shape[0]:
+        sink.take(_mm_bf16_nn(dy2, wb).view(sink.tensor.shape))
+    else:
+        sink.full()[r0:r1].view(M, K).addmm_(dy2, wb)
+
+
+def _sink_add(sink, x, g):
+    """sink[rows of x] += g (a gradient that a kernel has already produced in full, e.g. K1g's dr): adopted when it is the first and covers the tensor."""
+    r0, r1 = sink.rows(x)
+    if sink.buf is None and r0 == 0 and r1 == sink.tensor.shape[0] and g.dtype == sink.tensor.dtype and g.is_contiguous():
+        sink.take(g)
+    else:
+        sink.full()[r0:r1].add_(g)
 
 
 def _dx_f32s(dy2: torch.Tensor, w_rows: torch.Tensor) -> torch.Tensor:
@@ -1565,7 +1590,7 @@ class _MomentPool(torch.autograd.Function):
         dfeat = torch.empty(B, T, D, device=dpooled.device, dtype=_BF if ctx.dt == TSG_BF16 else torch.float32)
         _call("tsg_moment_pool_bwd", dpooled, ptr(dpooled), ptr(ms[0]), ptr(ms[1]), ptr(ms[2]), ptr(dfeat), B, T, D, ctx.dt)
         sink = ctx.sink
-        if sink is not None and sink.tensor is not None and dfeat.dtype == torch.float32:
+        if sink is not None and sink.tensor is not None and dfeat.dtype == sink.tensor.dtype:
             r0, r1 = sink.rows(ctx.x_in)
             if sink.buf is None and r0 == 0 and r1 == sink.tensor.shape[0]:
                 sink.take(dfeat)                                         # the first consumer to run (it is created last): the sink adopts its gradient
@@ -1759,7 +1784,8 @@ class _LinearBf16(torch.autograd.Function):
     reduction in fp32 (the master gradient is never rounded to bf16)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, sink=None):
+        ctx.sink, ctx.x_in = sink, (x if sink is not None else None)
         x2 = _bfc(x).view(-1, x.shape[-1])
         wb = weight_bf16(w)
         y = _mm_bf16_nt(x2, wb, b)
@@ -1771,7 +1797,12 @@ class _LinearBf16(torch.autograd.Function):
     def backward(ctx, dy):
         x2, wb = ctx.saved_tensors
         dy2 = _bfc(dy).view(-1, wb.shape[0])
-        dx = _mm_bf16_nn(dy2, wb).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.sink is not None and ctx.sink.tensor is not None:
+                _sink_add_dx_bf16(ctx.sink, ctx.x_in, dy2, wb)          # summed in the shared activation's sink: None for autograd
+            else:
+                dx = _mm_bf16_nn(dy2, wb).view(ctx.xshape)
         dw = None
         if ctx.needs_input_grad[1]:
             M, (N, K) = x2.shape[0], wb.shape
@@ -1780,7 +1811,7 @@ class _LinearBf16(torch.autograd.Function):
             else:
                 dw = torch.mm(dy2.t(), x2, out_dtype=torch.float32)
         db = _colsum(dy2) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def linear(x, w, b=None):
@@ -1788,7 +1819,7 @@ def linear(x, w, b=None):
     attention.py:104-106, the matching head's and the boundary head's first Linear) run as split-precision GEMMs; in the bf16
     storage mode every projection of the path is a bf16 GEMM with bf16 output (``_LinearBf16``)."""
     if bf16_storage() and x.is_cuda:
-        return _LinearBf16.apply(x, w, b)
+        return _LinearBf16.apply(x, w, b, _sink_for(x) if x.dtype == _BF else None)
     if x.dtype == _BF and w.dtype != _BF:                    # a bf16 activation met outside the storage mode's context
         return torch.nn.functional.linear(x.float(), w, b)
     rows = x.numel() // max(x.shape[-1], 1)

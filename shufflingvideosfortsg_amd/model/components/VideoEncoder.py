@@ -64,8 +64,11 @@ class rnn_recalibration_layer(nn.Module):
                 # by the input-gradient GEMM's epilogue, not by an elementwise kernel
                 s = TF.linear(word_feat, att.W_s.weight, att.W_a.bias)
                 return TF.scdm_gate_proj(rnn_output, att.W_a.weight, s, att.w.weight, VW, self.sent_linear.bias)
-            a, s = att.projections(rnn_output, word_feat)
-            return TF.scdm_gate(a, s, att.w.weight, VW, self.sent_linear.bias, rnn_output)
+            # (other modes: the BiLSTM output is W_a's input and the gate's r -- its two gradients meet in a sink where the consumers know about
+            #  sinks (bf16 storage: K1g leaves dr there, W_a's input-gradient GEMM adds onto it); elsewhere the context is a no-op)
+            with TF.shared_grad(rnn_output) as xs:
+                a, s = att.projections(xs, word_feat)
+                return TF.scdm_gate(a, s, att.w.weight, VW, self.sent_linear.bias, xs)
         # un-fused tail (another attention class, or a word width sent_linear was not built for)
         acts = {'sigmoid': torch.sigmoid, 'relu': torch.relu, 'tanh': torch.tanh}
         channel_attn = self.sent_linear(self.attention(rnn_output, word_feat))
