@@ -78,3 +78,37 @@ def test_sink_with_a_consumer_that_never_runs_and_with_only_the_row_block():
             if use == ("boundary",):
                 assert float(res[0][B2 // 2:].abs().max()) == 0.0          # the rows nobody touched are exact zeros
     assert TF._ACTIVE_SINK is None                                          # the context restored the previous state
+
+
+@pytest.mark.parametrize("order", [("lin", "rows", "pool"), ("pool", "lin", "rows"), ("rows", "pool", "lin")])
+def test_sinks_in_the_bf16_storage_mode(order):
+    """bf16 storage: the consumers are ``linear`` (input-gradient GEMM with beta = 1 onto the sink), a ``linear`` on the leading rows and ``moment_pool``;
+    the sums agree with autograd's bf16 additions to bf16 rounding (the sink rounds ONCE per contribution, from the fp32 accumulator)."""
+    from shufflingvideosfortsg_amd import engine, functional as TF
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(B2, T, D, generator=g).cuda()
+    W = (torch.randn(H, D, generator=g) * D ** -0.5).cuda().requires_grad_(True); W2 = (torch.randn(HM, D, generator=g) * D ** -0.5).cuda().requires_grad_(True)
+    ms = [(torch.rand(B2, T, generator=g) > 0.5).float().cuda() for _ in range(3)]
+    res = []
+    with engine.precision("bf16"):
+        for on in (True, False):
+            old, TF._SHARED_GRAD = TF._SHARED_GRAD, on
+            try:
+                x = x0.to(torch.bfloat16).requires_grad_(True)
+                terms = []
+                with TF.shared_grad(x) as xs:
+                    assert (xs is not x) == on
+                    for name in order:
+                        if name == "lin":
+                            terms.append(TF.linear(xs, W).float().square().mean())
+                        elif name == "rows":
+                            terms.append(TF.linear(xs[:B2 // 2], W2).float().sum() * 1e-3)
+                        else:
+                            a, b, c = TF.moment_pool(xs, *ms)
+                            terms.append((a * b).mean() + c.square().mean())
+                sum(terms).backward()
+                res.append(x.grad.float().clone())
+            finally:
+                TF._SHARED_GRAD = old
+    err = float((res[0] - res[1]).norm() / res[1].norm())
+    assert err <= 1e-2, err
