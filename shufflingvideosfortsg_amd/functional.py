@@ -530,19 +530,20 @@ def weight_bf16(w: torch.Tensor) -> torch.Tensor:
     if not (_SHADOWS and w.is_leaf and w.requires_grad and w.dtype == torch.float32 and w.is_cuda and w.is_contiguous()):
         return wd.to(_BF)
     sh = getattr(w, "_tsg_shadow", None)
+    key = (w._version, w.data_ptr())                       # in-place edits bump the version; a re-pointed ``.data`` (``.to()``, a joined buffer) moves the address
     if sh is None or sh.shape != w.shape or sh.device != w.device:
         sh = wd.to(_BF)
-        w._tsg_shadow, w._tsg_shadow_version = sh, w._version
-    elif w._tsg_shadow_version != w._version:
+        w._tsg_shadow, w._tsg_shadow_version = sh, key
+    elif w._tsg_shadow_version != key:
         sh.copy_(wd)
-        w._tsg_shadow_version = w._version
+        w._tsg_shadow_version = key
     return sh
 
 
 def shadow_of(p: torch.Tensor):
     """The parameter's live bf16 shadow (``weight_bf16``) or None -- what the optimizer passes to tsg_adam_step_shadow."""
     sh = getattr(p, "_tsg_shadow", None)
-    if sh is None or not _SHADOWS or getattr(p, "_tsg_shadow_version", None) != p._version or sh.shape != p.shape or sh.device != p.device:
+    if sh is None or not _SHADOWS or getattr(p, "_tsg_shadow_version", None) != (p._version, p.data_ptr()) or sh.shape != p.shape or sh.device != p.device:
         return None
     return sh
 
@@ -1062,7 +1063,7 @@ class GradSink:
         return self.buf
 
 
-_ACTIVE_SINK = None
+_ACTIVE_SINK = None                # (module state, like the precision mode: one training thread per process -- one process per GPU)
 _SHARED_GRAD = os.environ.get("TSG_SHARED_GRAD", "1") != "0"      # 0: autograd sums the gradients of shared activations itself (A/B)
 
 

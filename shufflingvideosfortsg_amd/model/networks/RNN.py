@@ -103,8 +103,8 @@ class BiLSTM(nn.Module):
                 return None
             with torch.no_grad():
                 sb = torch.cat([pf.detach().reshape(-1), pr.detach().reshape(-1)]).to(torch.bfloat16)
-            pf._tsg_shadow, pf._tsg_shadow_version = sb[:n].view(pf.shape), pf._version
-            pr._tsg_shadow, pr._tsg_shadow_version = sb[n:].view(pr.shape), pr._version
+            pf._tsg_shadow, pf._tsg_shadow_version = sb[:n].view(pf.shape), (pf._version, pf.data_ptr())
+            pr._tsg_shadow, pr._tsg_shadow_version = sb[n:].view(pr.shape), (pr._version, pr.data_ptr())
             self._shadow[k] = sb
         return sb.view(2 * pf.shape[0], *pf.shape[1:])
 
