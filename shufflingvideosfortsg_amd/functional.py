@@ -1128,7 +1128,7 @@ def _sink_add_dx(sink, x, dy2, w, w1=None):
     """sink[rows of x] += dy2 @ [w ; w1]  ([M, N] @ [N, Dv]); the first full-size contribution is taken as it comes.  True when done here."""
     M, Dv = dy2.shape[0], w.shape[1]
     N = dy2.shape[1]
-    if not gemm_f32s_nn_ok(M, Dv, N):
+    if sink.tensor is None or not gemm_f32s_nn_ok(M, Dv, N):      # (a second backward through a retained graph: the sink is spent -- ordinary gradients)
         return False
     r0, r1 = sink.rows(x)
     whole = r0 == 0 and r1 == sink.tensor.shape[0]
