@@ -308,10 +308,11 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
 
 def pmc_traffic(kernel, B, T, N, d, launch_B=None, dtype="f32"):
     """(HBM bytes per launch, source file) from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes;
-    profiles/r4 first, then r3, r2, r1) -- a citation of a profile of the same kernel and shape, not something this run observed:
+    profiles/r5 first, then r4, r3, r2, r1) -- a citation of a profile of the same kernel and shape, not something this run observed:
     the JSON says so in `traffic_source`.  (None, None) when no pass exists for this shape and storage dtype."""
     launch_B = launch_B or B
-    for rnd, fname in (("r4", "k1_pmc_traffic_bf16.json" if dtype == "bf16" else "k1_pmc_traffic.json"),
+    for rnd, fname in (("r5", "k1_pmc_traffic_bf16.json" if dtype == "bf16" else "k1_pmc_traffic.json"),
+                       ("r4", "k1_pmc_traffic_bf16.json" if dtype == "bf16" else "k1_pmc_traffic.json"),
                        ("r3", "k1_pmc_traffic_bf16.json" if dtype == "bf16" else "k1_pmc_traffic.json"), ("r2", "k1_pmc_traffic.json"),
                        ("r1", "k1_pmc_traffic.json")):
         rel = os.path.join("profiles", rnd, fname)
