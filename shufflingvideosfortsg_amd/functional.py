@@ -941,6 +941,8 @@ def mha_graph_rng(device):
     """Create (outside any capture) the device-resident (seed, offset) state the in-kernel attention dropout uses while a HIP
     graph is being captured / replayed on ``device``."""
     device = _cuda_device(device)
+    if device not in _graph_keys:
+        _graph_keys[device] = [torch.zeros(kKeySlots, 2, dtype=torch.int32, device=device), 0]       # key slots of the captured dropout calls (see _graph_key_slot)
     if device not in _mha_rng_state:
         seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
         _mha_rng_state[device] = torch.tensor([seed, int(torch.randint(0, 2 ** 40, (1,)).item())], dtype=torch.int64, device=device)
@@ -1502,6 +1504,31 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 _OWN_DROPOUT = os.environ.get("TSG_DROPOUT", "own") != "torch"          # A/B switch: "torch" = F.dropout (byte mask written and re-read)
 
 
+_graph_keys = {}       # device -> [persistent int32 [kKeySlots, 2] buffer, next slot]
+
+
+def _graph_key_slot(device):
+    """Two key words for ONE captured dropout call, in memory that does not belong to the graph's pool.  Round 5: as ``torch.empty(2)`` inside the
+    capture the keys of the three dropouts of a GMD step shared their 512-byte pool blocks with a gradient allocated later in the same graph
+    (``word_embed.bias.grad``, 1200 bytes = the three blocks), and in back-to-back replays of the two graphs of ``GraphedTrainStep`` the key words
+    showed up INSIDE that gradient -- once in ~100 replays as a NaN pattern, which then stuck in the parameter (bench.py --dtype bf16 --steps 400:
+    non-finite; with a host synchronisation between the graphs, or with keys that do not share blocks, 400 steps stay finite).  The slots are
+    created outside the capture (``mha_graph_rng``), each captured call takes the next one, a slot is never reused by another call site of the
+    same graph."""
+    dev = _cuda_device(device)
+    st = _graph_keys.get(dev)
+    if st is None:
+        raise RuntimeError("dropout under graph capture needs functional.mha_graph_rng(device) called before the capture (engine.GraphedTrainStep does)")
+    buf, nxt = st
+    if nxt >= buf.shape[0]:
+        raise RuntimeError(f"more than {buf.shape[0]} dropout calls captured on {dev}: raise functional.kKeySlots")
+    st[1] = nxt + 1
+    return buf[nxt]
+
+
+kKeySlots = 4096
+
+
 class _Dropout(torch.autograd.Function):
     """Dropout without a stored mask (tsg_dropout): the backward is the same launch on the gradient, the mask regenerated from the keys."""
 
@@ -1513,7 +1540,7 @@ class _Dropout(torch.autograd.Function):
         ctx.dt = TSG_BF16 if x.dtype == _BF else TSG_F32
         ctx.p, ctx.seed, ctx.offset = p, seed, offset
         if rng is not None:                                          # under graph capture: (seed, offset) in device memory, keys kept for the backward
-            keys = torch.empty(2, dtype=torch.int32, device=x.device)
+            keys = _graph_key_slot(x.device)
             _call("tsg_dropout", x, ptr(x), ptr(y), x.numel(), p, 0, 0, ptr(rng), ptr(keys), 1, ctx.dt)
             ctx.save_for_backward(keys)
         else:

@@ -420,3 +420,33 @@ def test_shared_gradient_sinks_match_autograd_sums(request):
         # norm-wise per parameter (some gradients are ~1e-14 at the default initialisation: their elements are summation-order noise)
         err, ref = float((a - b).norm()), float(b.norm())
         assert err <= 2e-4 * ref + 1e-7 * gmax * b.numel() ** 0.5, f"{k}: |a - b| = {err:.3e} against |b| = {ref:.3e}"
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32s"])
+def test_graphed_train_step_long_replay_stays_finite(mode):
+    """Round 5 regression: 250 back-to-back replays of the two graphs of engine.GraphedTrainStep at the benchmark shape WITH dropout.  The key words
+    of the captured dropout calls used to be ``torch.empty(2)`` tensors of the graph's pool; they shared their pool blocks with a gradient
+    allocated later in the same graph, and once in ~100 replays a key word with a NaN bit pattern ended up in that gradient, was applied by
+    Adam and stuck (bench.py --dtype bf16 --steps 400: non-finite).  The keys now live outside the pool (functional._graph_key_slot): the loss,
+    every parameter and every gradient stay finite, and nothing looks like a stray key word (|g| < 1e3)."""
+    from shufflingvideosfortsg_amd import data, engine, functional as TF
+    params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, video_len=128, sent_len=20)
+    assert params["dropout"] > 0
+    torch.manual_seed(0)
+    model = engine.build_model("gmd", params).cuda().train()
+    opt = engine.make_optimizer(model, params, capturable=True)
+    batch = data.synthetic_batch(64, 128, 20, seed=1234, pair=True, device="cuda")
+    engine.set_precision(mode)
+    try:
+        g = engine.GraphedTrainStep(model, opt, lambda m, b: engine.gmd_step(m, b, params)[0], batch, warmup=3)
+        for _ in range(250):
+            loss = g()
+        torch.cuda.synchronize()
+        TF.check_kernel_errors()
+        assert bool(torch.isfinite(loss)), float(loss)
+        for k, p in model.named_parameters():
+            assert bool(torch.isfinite(p).all()), f"parameter {k} is not finite after 250 replays"
+            if p.grad is not None:
+                assert bool(torch.isfinite(p.grad).all()) and float(p.grad.float().abs().max()) < 1e3, f"gradient of {k}: {float(p.grad.float().abs().max())}"
+    finally:
+        engine.set_precision(None)
