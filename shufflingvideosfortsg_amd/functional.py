@@ -941,8 +941,11 @@ def mha_graph_rng(device):
     """Create (outside any capture) the device-resident (seed, offset) state the in-kernel attention dropout uses while a HIP
     graph is being captured / replayed on ``device``."""
     device = _cuda_device(device)
-    if device not in _graph_keys:
-        _graph_keys[device] = [torch.zeros(kKeySlots, 2, dtype=torch.int32, device=device), 0]       # key slots of the captured dropout calls (see _graph_key_slot)
+    st = _graph_keys.get(device)
+    if st is None or st[0].shape[0] - st[1] < 256:           # (re)filled here, outside any capture: a capture could only allocate from its own pool
+        _graph_keys[device] = [torch.zeros(kKeySlots, 2, dtype=torch.int32, device=device), 0]       # key slots of the captured dropout calls (see
+        _graph_key_buffers.append(_graph_keys[device][0])                                             # _graph_key_slot); a replaced buffer stays alive for
+                                                                                                      # the graphs captured on it (they replay its addresses)
     if device not in _mha_rng_state:
         seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
         _mha_rng_state[device] = torch.tensor([seed, int(torch.randint(0, 2 ** 40, (1,)).item())], dtype=torch.int64, device=device)
@@ -1505,6 +1508,7 @@ _OWN_DROPOUT = os.environ.get("TSG_DROPOUT", "own") != "torch"          # A/B sw
 
 
 _graph_keys = {}       # device -> [persistent int32 [kKeySlots, 2] buffer, next slot]
+_graph_key_buffers = []   # every key buffer ever created: never freed
 
 
 def _graph_key_slot(device):
