@@ -37,13 +37,14 @@
 extern "C" {
 #endif
 
-#define TSG_VERSION 6   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points
+#define TSG_VERSION 7   /* 2: K1 backward takes (ws, ws_bytes); input pipeline / span decode entry points
                            3: tsg_error_word (device-side expiry report); dtype TSG_BF16 (bf16 storage) in K1 / K1g / K2 / K3 / LSTM
                            4: tsg_boundary_score_bwd_ws (K3 backward in one launch); tsg_gemm_f32s
                            5: tsg_scdm_bwd_mode / tsg_scdm_bwd_fused_ok (path selection as a call and a predicate instead of an
                               environment variable and an error code); per-device error words
                            6: tsg_lstm_fwd_ws (the persistent LSTM forward's exchange ring in a caller-owned workspace), tsg_gemm_bf16, tsg_adam_step,
-                              tsg_gemm_f32s_nn_acc, tsg_lstm_set_ring / _wide, tsg_wgrad_set_stream_k */
+                              tsg_gemm_f32s_nn_acc, tsg_lstm_set_ring / _wide, tsg_wgrad_set_stream_k
+                           7: tsg_time_next_launch / tsg_timed_launch_us (one launch bracketed by its own event pair) */
 #define TSG_F32 0
 #define TSG_BF16 1   /* bf16 storage of the activations, fp32 arithmetic (see Conventions)                               */
 #define TSG_F32S 2   /* fp32 storage; matrix products as split-precision bf16 MFMAs (x = hi + lo; hi*hi + hi*lo + lo*hi,
@@ -58,6 +59,15 @@ extern "C" {
 
 int         tsg_version(void);
 const char* tsg_last_error(void);
+
+/* Measurement hook (bench.py's roofline line; never used by the product path).  tsg_time_next_launch(slot) arms the calling
+ * thread: the NEXT launch of tsg_scdm_attn_fwd / tsg_scdm_gate_fwd (dtype TSG_F32S or TSG_BF16) or tsg_scdm_attn_bwd / tsg_scdm_gate_bwd
+ * (their fused kernel) made by this thread is issued with hipExtLaunchKernel and the library-owned event pair of `slot`
+ * (0 <= slot < 1024), which brackets that kernel alone -- the duration rocprofv3's kernel trace reports, without the dispatch gap an
+ * event pair recorded around the call adds.  tsg_timed_launch_us(slot, &us) waits for the launch and returns its duration in
+ * microseconds; TSG_E_SHAPE for a slot out of range or never used.  tsg_time_next_launch(-1) disarms.  Not valid while a stream capture is open.                        */
+int tsg_time_next_launch(int slot);
+int tsg_timed_launch_us(int slot, float* us);
 
 /* ---- K1: SCDM additive cross-attention (SCDM_Attention.forward, networks/attention.py:109-121)
  * inputs are the PROJECTED tensors: a = W_a(video)+b [B,T,H], s = W_s(sent) [B,N,H], w [H] (the

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "tsg_scdm_bwd_mode": [_I],
     "tsg_scdm_bwd_fused_ok": [_I] * 5,
     "tsg_error_sink": [_P],
+    "tsg_time_next_launch": [c_int], "tsg_timed_launch_us": [c_int, _P],
     "tsg_error_word": [_P],
     "tsg_scdm_gate_fwd": [_P] * 8 + [_I] * 6 + [_P],
     "tsg_scdm_gate_bwd": [_P] * 15 + [c_longlong] + [_I] * 6 + [_P],
@@ -117,8 +118,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)            # AttributeError here = header / library mismatch
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, c_int)
-    if lib.tsg_version() != 6:
-        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 6 expected by the Python host code")
+    if lib.tsg_version() != 7:
+        raise TsgLibraryError(f"libtsg_hip.so version {lib.tsg_version()} != 7 expected by the Python host code")
     _lib = lib
     return lib
 

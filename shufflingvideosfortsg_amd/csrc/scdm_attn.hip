@@ -102,6 +102,46 @@ __device__ __forceinline__ void scdm_chunk_step(const float (&Ea)[R][4], const f
   }
 }
 
+// The same chunk step with ONE reciprocal per lane and word instead of four (round 6): the lane's four k elements share a denominator,
+//     sum_c w_c / d_c = [ (w0 d1 + w1 d0) d2 d3 + (w2 d3 + w3 d2) d0 d1 ] / (d0 d1 d2 d3)
+// -- 14 full-rate VALU instructions + 1 quarter-rate v_rcp_f32 per 4 elements instead of 8 + 4 (tools/ubench: v_rcp_f32 ~9.4 cycles, an FMA ~2.55).
+// Range: the caller passes Ea' = exp(2a) 2^-13 and Es' = exp(2s) 2^-13, so d'_c = clamp01(Ea' Es' + u) = u (1 + x) saturated at 1 (u = kQU = 2^-26; the
+// clamp is the FMA's output modifier and costs nothing): u <= d' <= 1, the product of four stays above 2^-104, an overflowing Ea' Es' lands on 1 and NaN is
+// impossible.  Saturation sets tanh = 1 - 2^-25 where x >= 2^26 (fp32 rounds the true value to 1 there: half an ulp).  w2 carries -2 w u.
+constexpr int kK1PRows = 64;             // scdm_fwd_ws_kernel: P rows kept in LDS (the largest tile)
+constexpr int kK1TrHalf = 4 * 32 + 32;   // ... its consumers' transpose block: [2 halves][4 rows][32 columns], the halves 32 banks apart
+constexpr int kK1TrWave = 2 * kK1TrHalf; // floats per consumer wave
+constexpr float kQU = 0x1p-26f;          // u
+constexpr float kQHalfExp = 13.f;        // Ea', Es' = exp2(.. - kQHalfExp) each
+__device__ __forceinline__ float fma_sat(float a, float b, float c) { return __builtin_amdgcn_fmed3f(fmaf(a, b, c), 0.f, 1.f); }
+template <int NP, int G, int NA>
+__device__ __forceinline__ void scdm_chunk_step_q(const float (&Ea)[4], const float* __restrict__ esp, int HP,
+                                                  const float (&w2)[4], float (&acc)[NA]) {
+  static_assert(NP % G == 0, "word groups");
+  float4 cur[G], nxt[G];
+#pragma unroll
+  for (int u = 0; u < G; ++u) cur[u] = *reinterpret_cast<const float4*>(esp + u * HP);
+#pragma unroll
+  for (int n0 = 0; n0 < NP; n0 += G) {
+    if (n0 + G < NP) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) nxt[u] = *reinterpret_cast<const float4*>(esp + (n0 + G + u) * HP);
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const float d0 = fma_sat(Ea[0], cur[u].x, kQU), d1 = fma_sat(Ea[1], cur[u].y, kQU);
+      const float d2 = fma_sat(Ea[2], cur[u].z, kQU), d3 = fma_sat(Ea[3], cur[u].w, kQU);
+      const float n01 = fmaf(w2[1], d0, w2[0] * d1), p01 = d0 * d1;
+      const float n23 = fmaf(w2[3], d2, w2[2] * d3), p23 = d2 * d3;
+      const float num = fmaf(n23, p01, n01 * p23);
+      acc[n0 + u] = fmaf(num, fast_rcp(p01 * p23), acc[n0 + u]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < G; ++u) cur[u] = nxt[u];
+  }
+}
+
 // Sum NP per-lane partials over the 64 lanes with the gfx950 swap instructions: v_permlane32_swap
 // folds the two wave halves of TWO values at once, v_permlane16_swap the two 16-lane rows of each
 // half, then 4 DPP steps finish inside a row.  NP values -> NP/4 registers; afterwards register j,
@@ -139,6 +179,10 @@ __device__ __forceinline__ float4 exp2x4(float4 v) {     // exp(2 v), v clamped 
   return make_float4(fast_exp2(clampf(v.x, -kClamp, kClamp) * k2Log2e), fast_exp2(clampf(v.y, -kClamp, kClamp) * k2Log2e),
                      fast_exp2(clampf(v.z, -kClamp, kClamp) * k2Log2e), fast_exp2(clampf(v.w, -kClamp, kClamp) * k2Log2e));
 }
+
+// exp(2 v) 2^-13 for scdm_chunk_step_q (lower clamp -39: the scaled value stays a normal number)
+__device__ __forceinline__ float exp2q(float v) { return fast_exp2(fmaf(clampf(v, -kClamp + 1.f, kClamp), k2Log2e, -kQHalfExp)); }
+__device__ __forceinline__ float4 exp2x4q(float4 v) { return make_float4(exp2q(v.x), exp2q(v.y), exp2q(v.z), exp2q(v.w)); }
 
 // Forward kernel.  Workgroup = (batch item b, TT consecutive clips), 8 waves.  The TT rows are
 // processed as TT/SUB sub-tiles of SUB = 8R rows (R rows per wave): scores+softmax of sub-tile i+1
@@ -681,6 +725,9 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_mm_kernel(
 #ifndef TSG_WS_PRIO_C
 #define TSG_WS_PRIO_C 0
 #endif
+#ifndef TSG_WS_PRIO_P1
+#define TSG_WS_PRIO_P1 3                                  // the producer whose turn it is
+#endif
 typedef short k1_s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned k1_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ k1_f32x16 k1_mfma8(k1_u32x2 a, k1_u32x2 b, k1_f32x16 c) {      // 32x32x8: k = 4 (lane / 32) + j
@@ -689,6 +736,22 @@ __device__ __forceinline__ k1_f32x16 k1_mfma8(k1_u32x2 a, k1_u32x2 b, k1_f32x16 
 
 // ST = bf16_t (dtype TSG_BF16): a, s, V, gr, C are bf16 in HBM; the rows are kept as raw 8-byte pieces until the score loop consumes them,
 // VW is exact in bf16 so its lo plane (and the third MFMA of every k step) drops out, r / out are one 2-byte element per lane.
+#ifdef TSG_K1_TICKS       // developer builds: per-wave shader-clock sums of the phases of scdm_fwd_ws_kernel (tools/k1_ticks.py reads them back)
+__device__ unsigned long long g_k1_ticks[256 * 16 * 8];
+#define K1_TICK(i) { const unsigned long long tnow_ = __builtin_amdgcn_s_memtime(); tph_[i] += tnow_ - tlast_; tlast_ = tnow_; }
+#define K1_TICK_DECL unsigned long long tph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
+#define K1_TICK_DUMP if (blockIdx.x < 256 && lane == 0) { tph_[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); /* HW_ID */ for (int i_ = 0; i_ < 8; ++i_) g_k1_ticks[(blockIdx.x * 16 + wv) * 8 + i_] = tph_[i_]; }
+#else
+#define K1_TICK(i)
+#define K1_TICK_DECL
+#define K1_TICK_DUMP
+#endif
+// s_setprio TSG_WS_PRIO_P + (hi ? 1 : 0) for a wave-uniform hi
+#define TSG_STR2(x) #x
+#define TSG_STR(x) TSG_STR2(x)
+__device__ __forceinline__ void k1_prio_turn(int hi) {
+  asm volatile("s_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio " TSG_STR(TSG_WS_PRIO_P) "\n\ts_branch 2f\n1:\n\ts_setprio " TSG_STR(TSG_WS_PRIO_P1) "\n2:" :: "s"(hi) : "scc");
+}
 template <int NP, bool GATE, int CT, int PW, typename ST, int XW = 0>
 __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
     const ST* __restrict__ a, const ST* __restrict__ s, const float* __restrict__ w,
@@ -707,20 +770,28 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
   constexpr int KS = NP > 16 && !K8 ? 2 : 1;         // full 16-word k steps
   constexpr int NS = XW > 0 ? 26 : NP;               // word slots the score loop walks (bf16 storage at N = 25: 26 instead of 28 slots measured no faster, 80 us)
   constexpr int CC = 8 * CT / PW;                    // 32-column tiles per consumer wave (Ds / PW columns)
+#ifdef TSG_K1_TRIPLE
+  constexpr bool QS = false;                         // (A/B builds: the round-3 fma-rcp-fma triple per element)
+#else
+  constexpr bool QS = true;                          // score loop with one reciprocal per four k elements (scdm_chunk_step_q)
+#endif
   const int HP = roundup256(H);
   extern __shared__ __align__(16) float lds[];
   float* Es = lds;                       // [NP][HP]
   float* Wl = lds + NP * HP;             // [HP]   -2*w
-  float* Pl = Wl + HP;                   // [2][SUB][PP]
+  float* Pl = Wl + HP;                   // [kK1PRows][PP]: the P rows of the whole tile (TT <= 64)
+  unsigned* sync = reinterpret_cast<unsigned*>(Pl + kK1PRows * PP);     // [0 .. 7] rows scored per sub-tile, [8] the next row to hand out
+  float* Tr = reinterpret_cast<float*>(sync + 16);                     // [PW][kK1TrWave]: the consumers' 8 x 32 transpose blocks
 
   const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+  K1_TICK_DECL
   const int jl = lane & 31, hh = lane >> 5;
   const int bid = xcd_remap(blockIdx.x, gridDim.x, tiles);
   const int b = bid / tiles, tile = bid % tiles;
   const int t_tile = tile * TT;
   constexpr bool BF = storage_is_bf16<ST>::value;
   const ST* ab = a + (size_t)b * T * H;
-  const int nsub = TT / SUB;
+  const int rows_valid = min(TT, T - t_tile);            // rows of this tile that exist
 
   // ---- prologue (all waves): Es = exp(2 s[b]), -2w, zeroed P tiles
   const ST* sb = s + (size_t)b * N * H;
@@ -739,7 +810,7 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
       const int idx = base + u * NT;
       if (idx < total4) {
         const int n = idx / hp4, k = (idx % hp4) * 4;
-        float4 e = exp2x4(v[u]);
+        float4 e = QS ? exp2x4q(v[u]) : exp2x4(v[u]);
         if (v[u].x == -1e30f) e = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(Es + n * HP + k) = e;
       }
@@ -748,15 +819,21 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
   for (int k = tid * 4; k < HP; k += 4 * NT) {
     float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < H) wq = *reinterpret_cast<const float4*>(w + k);
-    *reinterpret_cast<float4*>(Wl + k) = make_float4(-2.f * wq.x, -2.f * wq.y, -2.f * wq.z, -2.f * wq.w);
+    const float ws = QS ? -2.f * kQU : -2.f;
+    *reinterpret_cast<float4*>(Wl + k) = make_float4(ws * wq.x, ws * wq.y, ws * wq.z, ws * wq.w);
   }
-  for (int i = tid; i < 2 * SUB * PP; i += NT) Pl[i] = 0.f;
+  for (int i = tid; i < kK1PRows * PP; i += NT) Pl[i] = 0.f;
+  if (tid < 16) sync[tid] = tid == 8 ? PW : 0;             // (rows 0 .. PW - 1 are the producers' first rows)
 
   if (wv < PW) {
-    // =================================== producer: rows t0 + RPW wv .. =====================================================
-    __builtin_amdgcn_s_setprio(TSG_WS_PRIO_P);             // the score loop is the critical path of the CU
-    // The wave's current row lives in CT float4; chunk c of the row it scores NEXT (its next row of this sub-tile, or its first of
-    // the next one) is requested into slot c as soon as the score loop has consumed it, unconditionally (clamped address).
+    // =================================== producer: one row at a time, handed out by an LDS counter =========================
+    // (round 6: no workgroup barrier in the tile loop.  With one barrier per sub-tile every sub-tile cost the time of its SLOWEST wave: of the two
+    // producers of a SIMD the older one wins the issue arbitration and scored a row in 7.7 k ticks, the other in 11 k, and the low-priority consumers
+    // finished last of all -- each wave waited 15..35 % of its life at the barrier (tools/k1_ticks.py).  Now a producer takes the next unscored row
+    // when it is done with one, the P rows of the whole tile stay in LDS, and the consumers wait for a sub-tile's row count.)
+    __builtin_amdgcn_s_setprio(TSG_WS_PRIO_P);
+    // The wave's current row lives in CT float4; chunk c of the row it scores NEXT is requested into slot c as soon as the score loop
+    // has consumed it, unconditionally (clamped address): the next row is claimed before the current one is scored.
     typedef typename Raw4T<ST>::type Raw4;
     Raw4 q[CT];
     auto row_ptr = [&](int t) { return ab + (size_t)(t < T ? t : T - 1) * H + lane * 4; };
@@ -768,30 +845,44 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
       }
     };
     {
-      const ST* row = row_ptr(t_tile + RPW * wv);
+      const ST* row = row_ptr(t_tile + wv);
 #pragma unroll
       for (int c = 0; c < CT; ++c) q[c] = ldraw4(row + c * 256);
     }
     land();
     lds_barrier();
-    auto score_row = [&](float* Pcur, int tl, int t, const ST* nrow) {
+    K1_TICK(0)                                             // 0: prologue
+    const int turn = (wv >> 2) & 1;                        // which of the SIMD's two producers this wave is
+    auto score_row = [&](float* Prow, int t, const ST* nrow) {
       float acc[1][NP];
 #pragma unroll
       for (int n = 0; n < NP; ++n) acc[0][n] = 0.f;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const int k = 256 * c + lane * 4;
+#ifndef TSG_K1_NO_PRIO_SWAP
+        // The SIMD's arbiter serves its OLDEST wave first: of the two producers of a SIMD the first-launched one scored a row in 7.7 k ticks, the other in
+        // 11 k, and the sub-tile waited for the slower (tools/k1_ticks.py).  They take turns at the higher priority, chunk by chunk, and finish together.
+        // (s_setprio takes an immediate.  The choice is a branch INSIDE one asm statement: a compiler-visible branch in the chunk loop cost 245 spilled
+        // registers, the loop instantiated once per parity 7 -- their reloads wait behind the next row's requests)
+        if constexpr (PW == 8 && CT >= 2) k1_prio_turn((turn ^ c) & 1);
+#endif
         const float4 wq = *reinterpret_cast<const float4*>(Wl + k);
         const float w2[4] = {wq.x, wq.y, wq.z, wq.w};
         float Ea[1][4];
-        const float4 e = exp2x4(cvt4(q[c]));
+        const float4 e = QS ? exp2x4q(cvt4(q[c])) : exp2x4(cvt4(q[c]));
         Ea[0][0] = e.x; Ea[0][1] = e.y; Ea[0][2] = e.z; Ea[0][3] = e.w;
         q[c] = ldraw4(nrow + 256 * c);
-        if (!TSG_SKIP(1)) scdm_chunk_step<NS, 1, 2, NP>(Ea, Es + k, HP, w2, acc);     // (XW: 26 of the 28 slots are scored, the others stay 0 and are masked below)
+        if (!TSG_SKIP(1)) {                                                            // (XW: 26 of the 28 slots are scored, the others stay 0 and are masked below)
+          if constexpr (QS) scdm_chunk_step_q<NS, 2, NP>(Ea[0], Es + k, HP, w2, acc[0]);
+          else scdm_chunk_step<NS, 1, 2, NP>(Ea, Es + k, HP, w2, acc);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
+      K1_TICK(1)                                           // 1: score loop
       // land the next row ahead of the P stores (vmcnt counts loads and stores together, in order)
       land();
+      K1_TICK(2)                                           // 2: wait for the next row
       float z[NP / 4];
       wave_transpose_sum<NP>(acc[0], z);
       const int qd = lane >> 4;
@@ -815,23 +906,28 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
         for (int j = 0; j < NP / 4; ++j) {
           const int n = 4 * j + nq;
           const float pv = z[j] * inv;
-          Pcur[tl * PP + n] = pv;
-          if (n < N && t < T) P[((size_t)b * T + t) * N + n] = pv;
+          Prow[n] = pv;
+          if (n < N) P[((size_t)b * T + t) * N + n] = pv;
         }
       }
     };
+    int row = wv;
 #pragma unroll 1
-    for (int st = 0; st < nsub; ++st) {
-      const int t0 = t_tile + st * SUB + RPW * wv;
-      float* Pcur = Pl + (st & 1) * SUB * PP;
-#pragma unroll
-      for (int r = 0; r < RPW; ++r)
-        score_row(Pcur, RPW * wv + r, t0 + r, row_ptr(r + 1 < RPW ? t0 + r + 1 : t0 + SUB));
-      lds_barrier();                                       // hand-over #st: the sub-tile's P rows are in LDS
+    while (row < rows_valid) {
+      unsigned claim = 0;
+      if (lane == 0) claim = __hip_atomic_fetch_add(sync + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int nxt = __builtin_amdgcn_readfirstlane((int)claim);
+      K1_TICK(4)                                           // 4: claiming the next row
+      score_row(Pl + row * PP, t_tile + row, row_ptr(t_tile + nxt));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // the P row is in LDS before its sub-tile's count moves
+      if (lane == 0) __hip_atomic_fetch_add(sync + (row >> 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      K1_TICK(3)                                           // 3: reduction, softmax, P stores, hand-over
+      row = nxt;
     }
+    K1_TICK_DUMP
   } else {
-    // =================================== consumer: phase 2 of the sub-tile handed over last ================================
-    if (TSG_WS_PRIO_C) __builtin_amdgcn_s_setprio(TSG_WS_PRIO_C);
+    // =================================== consumer: phase 2 of every sub-tile whose rows have all been scored ==============
+    __builtin_amdgcn_s_setprio(TSG_WS_PRIO_C);
     const int col0 = (wv - PW) * 32 * CC;
     lds_barrier();                                         // (prologue barrier first: the producers do not wait for the VW loads below)
     const ST* Vb = V + (size_t)b * N * Ds + col0 + jl;
@@ -872,33 +968,44 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
 #pragma unroll
         for (int x = 0; x < XW; ++x) vx[ct][x] = ld1(Vb + (size_t)(24 + x) * Ds + 32 * ct);
     }
-    const unsigned lane_off = (unsigned)(4 * hh) * (unsigned)Ds + (unsigned)(col0 + jl);
-    const unsigned lane_col = (unsigned)(col0 + jl);
-    float rr[CC][4];
+    // Epilogue layout (round 6): the accumulator gives a lane 4 consecutive ROWS of one column (dword loads / stores: 16 + 16 instructions per wave and
+    // sub-tile, and the store issue was worth 6 us of the launch).  Each 8 x 32 tile goes through a per-wave LDS block instead and comes back as 4 consecutive
+    // COLUMNS of one row per lane: one 16-byte r load and one 16-byte store per tile -- 8 rows x 128 bytes per instruction.
+    float* trw = Tr + (wv - PW) * kK1TrWave;
+    const int wr_off = hh * kK1TrHalf + jl;                // write: row i + 4 hh at [hh][i][jl] (the halves 32 banks apart: conflict-free)
+    const int em = lane & 3, eq = (lane >> 2) & 7;         // read back: row em + 4 hh, columns 4 eq .. 4 eq + 3
+    const int rd_off = hh * kK1TrHalf + em * 32 + 4 * eq;
+    const int erow = em + 4 * hh;
+    typedef typename Raw4T<ST>::type Raw4;
+    Raw4 rr[CC];
     auto load_rr = [&](int t0) {
+      const ST* base = gr + ((size_t)b * T + min(t0 + erow, T - 1)) * Ds + col0 + 4 * eq;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int u = min(t0 + i, T - 1);
-        const ST* base = gr + ((size_t)b * T + u) * Ds;
-        const unsigned off = u + 4 < T ? lane_off : lane_col;
-#pragma unroll
-        for (int ct = 0; ct < CC; ++ct) rr[ct][i] = ld1(base + 32 * ct + off);
-      }
+      for (int ct = 0; ct < CC; ++ct) rr[ct] = ldraw4(base + 32 * ct);
     };
     if (GATE) load_rr(t_tile);
+    K1_TICK(0)                                             // 0: prologue + VW gathers
 #pragma unroll 1
-    for (int st = 0; st < nsub; ++st) {
+    for (int st = 0; st * SUB < rows_valid; ++st) {
       const int t0 = t_tile + st * SUB;
-      const float* Pcur = Pl + (st & 1) * SUB * PP;
-      lds_barrier();                                       // hand-over #st
+      const float* Pcur = Pl + st * SUB * PP;
+      {                                                    // hand-over #st: all rows of the sub-tile have been scored
+        const unsigned need = (unsigned)min(SUB, rows_valid - st * SUB);
+        while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(sync + st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
+          __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      }
+      K1_TICK(1)                                           // 1: waiting for the producers
       // land the r rows HERE (requested a whole score loop ago), before any of this sub-tile's stores is issued: a wait placed after
       // them would be vmcnt(0) (the stores sit under row predicates, the compiler cannot count them) and drain the store queue
       if (GATE) {
 #pragma unroll
-        for (int ct = 0; ct < CC; ++ct)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(rr[ct][i]));
+        for (int ct = 0; ct < CC; ++ct) {
+          if constexpr (BF) asm volatile("" : "+v"(rr[ct].x), "+v"(rr[ct].y));
+          else asm volatile("" : "+v"(rr[ct].x), "+v"(rr[ct].y), "+v"(rr[ct].z), "+v"(rr[ct].w));
+        }
       }
+      K1_TICK(2)                                           // 2: wait for the r rows
       if (TSG_SKIP(4)) continue;
       k1_u32x4 ph[KS], pl[KS];
       k1_u32x2 ph8, pl8;
@@ -940,7 +1047,6 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
           if constexpr (!BF) o = k1_mfma8(ph8, vl8[ct], o);
           o = k1_mfma8(pl8, vh8[ct], o);
         }
-        ST* dst = C + ((size_t)b * T + t0) * Ds + 32 * ct;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float v = o[i];
@@ -948,12 +1054,22 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
 #pragma unroll
             for (int x = 0; x < XW; ++x) v = fmaf(px[x][i], vx[ct][x], v);
           }
-          if (GATE) v = rr[ct][i] * fast_rcp(1.f + fast_exp2(fmaf(v, -kLog2e, gb[ct])));
-          if (t0 + i + 4 * hh < T) st1(dst + (size_t)i * Ds + lane_off, v);
+          if (GATE) v = fmaf(v, -kLog2e, gb[ct]);          // (the bias rides in the sigmoid's exponent, applied while the lane still owns ONE column)
+          trw[wr_off + 32 * i] = v;
         }
+        float4 e = *reinterpret_cast<const float4*>(trw + rd_off);
+        if (GATE) {
+          const float4 g = cvt4(rr[ct]);
+          e = make_float4(g.x * fast_rcp(1.f + fast_exp2(e.x)), g.y * fast_rcp(1.f + fast_exp2(e.y)),
+                          g.z * fast_rcp(1.f + fast_exp2(e.z)), g.w * fast_rcp(1.f + fast_exp2(e.w)));
+        }
+        if (t0 + erow < T) st4(C + ((size_t)b * T + t0 + erow) * Ds + col0 + 32 * ct + 4 * eq, e);
       }
+      K1_TICK(3)                                           // 3: phase 2 + stores issued
       if (GATE) load_rr(t0 + SUB);                         // the next sub-tile's r rows: a whole score loop of cover
+      K1_TICK(4)                                           // 4: r requests issued
     }
+    K1_TICK_DUMP
   }
 }
 
@@ -2005,7 +2121,7 @@ int launch_fwd(const ST* a, const ST* s, const float* w, const ST* V, ST* C, flo
   auto kern = scdm_fwd_kernel<NP, R, GATE, ST>;
   hipError_t e = allow_lds(kern, lds);
   if (e != hipSuccess) return set_error((int)e, "scdm_attn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
-  hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(kFwdThreads), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
+  launch_timed(kern, dim3(B * tiles), dim3(kFwdThreads), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
   return check_launch("scdm_attn_fwd");
 }
 
@@ -2023,9 +2139,9 @@ int launch_fwd_mm(const float* a, const float* s, const float* w, const float* V
   int TT = 64;                               // rows per workgroup: as many as still give every CU a workgroup (as launch_fwd)
   while (TT > 8 && (long)B * cdiv(T, TT) < 256) TT >>= 1;
   static const int tt_env = [] { const char* e = getenv("TSG_K1_TT"); return e ? atoi(e) : 0; }();
-  if (tt_env >= 8 && tt_env % 8 == 0) TT = tt_env;
+  if (tt_env >= 8 && tt_env % 8 == 0 && tt_env <= kK1PRows) TT = tt_env;
   const int tiles = cdiv(T, TT);
-  const size_t lds = sizeof(float) * ((size_t)(NP + 1) * roundup256(H) + (size_t)2 * 8 * 36);
+  const size_t lds = sizeof(float) * ((size_t)(NP + 1) * roundup256(H) + (size_t)kK1PRows * 36 + 16 + 8 * kK1TrWave);
   if (lds > (size_t)kLdsBytes) return -1000;
   static const bool mm_only = [] { const char* e = getenv("TSG_K1_FWD"); return e && e[0] == 'm'; }();   // A/B: time-shared roles
   if (mm_only) {
@@ -2055,7 +2171,7 @@ int launch_fwd_ws(const ST* a, const ST* s, const float* w, const ST* V, ST* C, 
       else kern = Ds == 1024 ? scdm_fwd_ws_kernel<NP, GATE, 4, 8, ST, 2> : Ds == 512 ? scdm_fwd_ws_kernel<NP, GATE, 2, 8, ST, 2> : scdm_fwd_ws_kernel<NP, GATE, 1, 8, ST, 2>;
       hipError_t e = allow_lds(kern, lds);
       if (e != hipSuccess) return set_error((int)e, "scdm_attn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
-      hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(1024), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
+      launch_timed(kern, dim3(B * tiles), dim3(1024), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
       return check_launch("scdm_attn_fwd");
     }
   }
@@ -2067,7 +2183,7 @@ int launch_fwd_ws(const ST* a, const ST* s, const float* w, const ST* V, ST* C, 
   }
   hipError_t e = allow_lds(kern, lds);
   if (e != hipSuccess) return set_error((int)e, "scdm_attn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
-  hipLaunchKernelGGL(kern, dim3(B * tiles), dim3(pw8 ? 1024 : 512), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
+  launch_timed(kern, dim3(B * tiles), dim3(pw8 ? 1024 : 512), lds, st, a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, ablate_mask());
   return check_launch("scdm_attn_fwd");
 }
 
@@ -2081,9 +2197,9 @@ int launch_fwd_ws_bf16(const bf16_t* a, const bf16_t* s, const float* w, const b
   int TT = 64;
   while (TT > 8 && (long)B * cdiv(T, TT) < 256) TT >>= 1;
   static const int tt_env = [] { const char* e = getenv("TSG_K1_TT"); return e ? atoi(e) : 0; }();
-  if (tt_env >= 8 && tt_env % 8 == 0) TT = tt_env;
+  if (tt_env >= 8 && tt_env % 8 == 0 && tt_env <= kK1PRows) TT = tt_env;
   const int tiles = cdiv(T, TT);
-  const size_t lds = sizeof(float) * ((size_t)(NP + 1) * roundup256(H) + (size_t)2 * 8 * 36);
+  const size_t lds = sizeof(float) * ((size_t)(NP + 1) * roundup256(H) + (size_t)kK1PRows * 36 + 16 + 8 * kK1TrWave);
   if (lds > (size_t)kLdsBytes) return -1000;
   return launch_fwd_ws<NP, GATE, bf16_t>(a, s, w, V, C, P, gr, gbias, B, T, N, H, Ds, TT, tiles, lds, st);
 }
@@ -2169,7 +2285,7 @@ int launch_bwd(const ST* a, const ST* s, const float* w, const ST* V, const floa
     auto kern = mrow ? scdm_bwd_fused_kernel<NP, GATE, true, ST> : scdm_bwd_fused_kernel<NP, GATE, false, ST>;
     hipError_t e = allow_lds(kern, pl.lds);
     if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute(%zu): %s", fn, pl.lds, hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kFusedThreads), pl.lds, st, a, s, w, V, P, dC, gr, gbias, da, ds, dw, dV, dbias, dr,
+    launch_timed(kern, dim3(pl.grid), dim3(kFusedThreads), pl.lds, st, a, s, w, V, P, dC, gr, gbias, da, ds, dw, dV, dbias, dr,
                        xch, cnt, error_sink(), B, T, N, H, Ds, pl.parts, pl.SP, ablate_mask());
     return check_launch(fn);
   }
@@ -2347,3 +2463,9 @@ extern "C" int tsg_scdm_gate_bwd(const void* a, const void* s, const void* w, co
                                                    (float*)dVW, (const float*)r, (const float*)gbias,
                                                    (float*)dgbias, (float*)dr, ws, ws_bytes, B, T, N, H, Ds, st)));
 }
+
+#ifdef TSG_K1_TICKS
+extern "C" int tsg_debug_k1_ticks(unsigned long long* host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(tsg::g_k1_ticks), sizeof(unsigned long long) * 256 * 16 * 8);
+}
+#endif

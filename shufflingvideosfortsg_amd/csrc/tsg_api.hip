@@ -12,6 +12,10 @@ thread_local char g_err[512] = "";
 std::atomic<unsigned*> g_error_sink{nullptr};
 std::atomic<unsigned*> g_error_word[64];       // one device word PER DEVICE (ABI revision 5; ADVICE r3: with one global word a launch on
                                                 // device 0 reported into device 1's memory after a second device had registered)
+constexpr int kTimeSlots = 1024;
+struct EventPair { hipEvent_t start = nullptr, stop = nullptr; bool used = false; };
+EventPair g_time_slots[kTimeSlots];               // (created on first use; one measuring thread per process)
+thread_local int g_armed_slot = -1;
 int current_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
@@ -21,6 +25,17 @@ int current_device() {
 
 ErrSink error_sink() {
   return ErrSink{g_error_sink.load(std::memory_order_relaxed), g_error_word[current_device()].load(std::memory_order_relaxed)};
+}
+
+bool take_launch_events(hipEvent_t* start, hipEvent_t* stop) {
+  const int slot = g_armed_slot;
+  if (slot < 0) return false;
+  g_armed_slot = -1;
+  EventPair& p = g_time_slots[slot];
+  if (!p.start && (hipEventCreate(&p.start) != hipSuccess || hipEventCreate(&p.stop) != hipSuccess)) return false;
+  p.used = true;
+  *start = p.start; *stop = p.stop;
+  return true;
 }
 
 hipError_t ensure_lds(const void* kernel, size_t bytes) {
@@ -77,3 +92,21 @@ extern "C" int tsg_error_word(void* p) {
 }
 extern "C" int tsg_version(void) { return TSG_VERSION; }
 extern "C" const char* tsg_last_error(void) { return tsg::g_err; }
+extern "C" int tsg_time_next_launch(int slot) {
+  if (slot == -1) { tsg::g_armed_slot = -1; return 0; }      // disarm
+  if (slot < 0 || slot >= tsg::kTimeSlots) return tsg::set_error(TSG_E_SHAPE, "tsg_time_next_launch: slot %d outside [0, %d)", slot, tsg::kTimeSlots);
+  tsg::g_armed_slot = slot;
+  tsg::g_time_slots[slot].used = false;
+  return 0;
+}
+extern "C" int tsg_timed_launch_us(int slot, float* us) {
+  if (!us) return tsg::set_error(TSG_E_NULL, "tsg_timed_launch_us: us is NULL");
+  if (slot < 0 || slot >= tsg::kTimeSlots || !tsg::g_time_slots[slot].used)
+    return tsg::set_error(TSG_E_SHAPE, "tsg_timed_launch_us: slot %d was not used by a launch", slot);
+  hipError_t e = hipEventSynchronize(tsg::g_time_slots[slot].stop);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, tsg::g_time_slots[slot].start, tsg::g_time_slots[slot].stop);
+  if (e != hipSuccess) return tsg::set_error((int)e, "tsg_timed_launch_us: %s", hipGetErrorString(e));
+  *us = ms * 1e3f;
+  return 0;
+}

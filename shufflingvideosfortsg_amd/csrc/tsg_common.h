@@ -1,6 +1,7 @@
 // Shared host/device helpers for libtsg_hip.so (gfx950 only; wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -36,9 +37,19 @@ hipError_t ensure_lds(const void* kernel, size_t bytes);
 template <typename K>
 inline hipError_t allow_lds(K kernel, size_t bytes) { return ensure_lds(reinterpret_cast<const void*>(kernel), bytes); }
 int device_cu_count();                           // CUs of the current device (cached per device)
+// tsg_time_next_launch: true (once) when the calling thread armed a slot; the slot's event pair then brackets the launch
+bool take_launch_events(hipEvent_t* start, hipEvent_t* stop);
 
 // ---- device side -------------------------------------------------------------------------
 #if defined(__HIPCC__)
+
+// Launch `kern`; when the thread armed tsg_time_next_launch, with that slot's events around this kernel alone.
+template <typename K, typename... A>
+inline void launch_timed(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
+  hipEvent_t e0, e1;
+  if (take_launch_events(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0, e1, 0, args...);
+  else hipLaunchKernelGGL(kern, grid, block, lds, st, args...);
+}
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

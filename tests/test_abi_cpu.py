@@ -29,7 +29,7 @@ def test_exports_match_header(lib):
     assert want == _lib.exported_symbols(), "ctypes signature table and header disagree"
     for name in want:
         assert hasattr(lib, name), f"{name} declared in tsg_hip.h but not exported by libtsg_hip.so"
-    assert lib.tsg_version() == 6
+    assert lib.tsg_version() == 7
 
 
 def test_argument_errors_without_gpu(lib):
@@ -94,3 +94,14 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("test oracle", ""), f"{f} mentions the oracle"
+
+
+def test_timing_hook_argument_errors(lib):
+    """tsg_time_next_launch / tsg_timed_launch_us (ABI 7): slot range and never-used slots are argument errors; -1 disarms."""
+    us = ctypes.c_float(-1.0)
+    assert lib.tsg_time_next_launch(4096) == -2 and b"slot" in lib.tsg_last_error()
+    assert lib.tsg_time_next_launch(-1) == 0
+    assert lib.tsg_timed_launch_us(7, ctypes.byref(us)) == -2          # no launch used slot 7
+    assert lib.tsg_timed_launch_us(7, None) == -1
+    assert lib.tsg_time_next_launch(7) == 0 and lib.tsg_time_next_launch(-1) == 0
+    assert lib.tsg_timed_launch_us(7, ctypes.byref(us)) == -2          # armed and disarmed without a launch

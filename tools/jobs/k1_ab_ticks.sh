@@ -1,0 +1,14 @@
+#!/bin/bash
+# K1g forward: stand-alone timing of the tree's library vs variants, then ticks of instrumented builds.  usage: k1_ab_ticks.sh OUT "variants" "tick libs"
+O=gpurun_out/$1; mkdir -p $O
+for rep in 1 2; do
+  echo "== tree" >> $O/k1.txt; python tools/k1_variants.py 128 200 2>&1 | grep "^f32s\|^bf16" >> $O/k1.txt
+  for v in $2; do
+    echo "== $v" >> $O/k1.txt; TSG_HIP_LIB=tools/_ablate/$v.so python tools/k1_variants.py 128 200 2>&1 | grep "^f32s\|^bf16" >> $O/k1.txt
+  done
+done
+for v in $3; do
+  echo "=== $v gate=1" >> $O/k1.txt
+  TSG_HIP_LIB=tools/_ablate/$v.so python tools/k1_ticks.py 128 1 2 2>&1 | grep -v amdgpu.ids | head -34 >> $O/k1.txt
+done
+cat $O/k1.txt
