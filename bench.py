@@ -456,6 +456,7 @@ def main():
         gc.disable()                                      # no cyclic-GC pauses of the host inside a timed region
         if use_dist:
             dist.barrier()
+        engine.skipped_updates(reset=True)                # (synchronises: reads the device counter)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
@@ -470,6 +471,11 @@ def main():
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        # updates the guard skipped inside this region (non-finite loss / gradient, expired bounded wait -- on ANY rank: the flag is reduced with
+        # the gradients): steps that did not update are not training steps, so a region that skipped reports no throughput (round-5 review)
+        timed.skipped = engine.skipped_updates()
+        if timed.skipped:
+            raise SystemExit(f"{timed.skipped} optimizer update(s) were skipped by the step guard inside a timed region of {n} steps: no throughput reported")
         return dt, t_enq, last
 
     if a.graph_only:
@@ -483,6 +489,7 @@ def main():
         functional.check_lstm_errors()
         out = {"graph_replay": {"value": round(Bglobal * a.steps / dt4, 2), "unit": "pairs/s", "ms_per_step": round(dt4 / a.steps * 1e3, 3),
                                 "host_enqueue_ms_per_step": round(enq4 / a.steps * 1e3, 3), "finite": bool(torch.isfinite(loss4)),
+                                "skipped_updates": timed.skipped,
                                 "note": "same step and mode replayed from two HIP graphs (forward+losses+backward | guarded Adam), gradient "
                                         "exchange eager between them (engine.GraphedTrainStep); measured in a child process"}}
         os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
@@ -497,6 +504,7 @@ def main():
     # operand-split launches, whose barrier packets would cost milliseconds per step (rocprof has their times)
     functional.kernel_timer.enable(only=None if a.time_all else ("tsg_scdm", "tsg_boundary", "tsg_mha", "tsg_match_head", "tsg_moment_pool"))
     dt, t_enq, loss = timed(step, a.steps)                # t_enq: host time to enqueue the K steps (== dt when the host is the limit)
+    skipped_main = timed.skipped
     functional.kernel_timer.disable()
     ms_ = torch.cuda.memory_stats()
     log(f"timed {a.steps} steps in {dt:.3f} s (host enqueue {t_enq:.3f} s); device allocs {ms_.get('num_device_alloc')} frees {ms_.get('num_device_free')} "
@@ -546,6 +554,7 @@ def main():
     # what --gpus N > 1 runs by default.  A rank that cannot capture reports it and ALL ranks skip the leg (agreed by an
     # all-reduce) -- a half-captured world would deadlock in the exchange.
     graph_inproc = None
+    graph_replay_bf16 = None
     enq_ranks = [round(t_enq / a.steps * 1e3, 3)]
     if use_dist:
         t = torch.zeros(world, device=dev, dtype=torch.float64)
@@ -586,7 +595,7 @@ def main():
                 dist.all_reduce(t)
                 genq = [round(float(v), 3) for v in t.tolist()]
             graph_inproc = {"value": round(Bglobal * a.steps / dtg, 2), "unit": "pairs/s", "ms_per_step": round(dtg / a.steps * 1e3, 3),
-                            "host_enqueue_ms_per_step_by_rank": genq, "finite": bool(torch.isfinite(lossg)),
+                            "host_enqueue_ms_per_step_by_rank": genq, "finite": bool(torch.isfinite(lossg)), "skipped_updates": timed.skipped,
                             "note": "same step, mode and batch replayed from two HIP graphs in this process on every rank "
                                     "(forward+losses+backward | guarded Adam), RCCL gradient exchange eager between them"}
             log(f"graph replay (in process): {graph_inproc['ms_per_step']} ms/step")
@@ -612,6 +621,9 @@ def main():
                 return {"error": f"{type(e).__name__}: {e}"[:300]}
         graph_replay = graph_child(a.dtype)
         log(f"graph replay: {graph_replay}")
+        if a.dtype != "bf16" and not a.no_alt:            # BASELINE config 2's own dtype, as its own graph-replayed line (round-5 review item 3)
+            graph_replay_bf16 = graph_child("bf16")
+            log(f"graph replay, bf16 storage: {graph_replay_bf16}")
 
     if rank == 0:
         kt = functional.kernel_timer.summary()          # (name, dims) -> (mean us, launches, median us)
@@ -714,7 +726,13 @@ def main():
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "value_mode": value_mode + (": the same full step replayed from two HIP graphs per rank (engine.GraphedTrainStep)"
                                            if value_mode == "graph_replay" else ": one Python-enqueued step per iteration"),
-               "eager": eager, "graph_replay_in_process": graph_inproc,
+               "eager": eager, "graph_replay_in_process": graph_inproc, "skipped_updates": skipped_main,
+               # the same step in the two other arithmetic modes, as top-level fields (round-5 review items 3 and 7): strict fp32 (rocBLAS fp32
+               # GEMMs, every kernel fp32) and bf16 storage (BASELINE config 2's dtype) -- the better of its eager and graph-replayed legs
+               "value_f32": next((m["value"] for m in alt if m["dtype"] == "f32"), None),
+               "value_bf16": max([m["value"] for m in alt if m["dtype"] == "bf16"] +
+                                 ([graph_replay_bf16["value"]] if graph_replay_bf16 and graph_replay_bf16.get("finite") else []), default=None),
+               "graph_replay_bf16": graph_replay_bf16,
                "config": {"workload": wl + f"{bdesc},T_clip={a.T},T_word={a.N},d={a.d}, i3d width 1024, GloVe 300"
                                       + ("" if a.predictor == "mlp" else f", boundary head {a.predictor}")
                                       + ("" if a.dtype == "f32" else "; " + NOTES[a.dtype]),

@@ -44,7 +44,7 @@ extern "C" {
                               environment variable and an error code); per-device error words
                            6: tsg_lstm_fwd_ws (the persistent LSTM forward's exchange ring in a caller-owned workspace), tsg_gemm_bf16, tsg_adam_step,
                               tsg_gemm_f32s_nn_acc, tsg_lstm_set_ring / _wide, tsg_wgrad_set_stream_k
-                           7: tsg_time_next_launch / tsg_timed_launch_us (one launch bracketed by its own event pair) */
+                           7: tsg_time_next_launch / tsg_timed_launch_us (one launch bracketed by its own event pair), tsg_grads_nonfinite */
 #define TSG_F32 0
 #define TSG_BF16 1   /* bf16 storage of the activations, fp32 arithmetic (see Conventions)                               */
 #define TSG_F32S 2   /* fp32 storage; matrix products as split-precision bf16 MFMAs (x = hi + lo; hi*hi + hi*lo + lo*hi,
@@ -402,6 +402,12 @@ int tsg_adam_step(int n, const void* const* params, const void* const* grads, vo
 int tsg_adam_step_shadow(int n, const void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                          void* const* shadow, const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay,
                          double grad_scale, void* state, const void* skip, void* stream);
+
+/* The gradient part of the optimizer guard (ABI revision 7): *flag (device float, caller-owned, not cleared by the call) = 1 when any element of
+ * the n fp32 gradient tensors is a NaN or an infinity.  engine.TsgAdam launches it in front of a guarded update with flag = the update's `skip`
+ * input, so a step whose backward produced non-finite gradients (an overflow; the NaN the K1 backward writes when its exchange wait expires)
+ * never reaches the parameters or the moments, also under graph replay.                                                                  */
+int tsg_grads_nonfinite(int n, const void* const* grads, const long long* numel, void* flag, void* stream);
 
 /* ---- the heads as the EPILOGUE of their own first-Linear GEMM (ABI revision 5; round-3 review: SURVEY 8f #2 "split-W Linear + ReLU
  * + dot epilogue").  Same f32s arithmetic and tiling as tsg_gemm_f32s (row tiles of 256 / 128 / 64 so that a narrow head still

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "tsg_lstm_set_wide": [_I],
     "tsg_wgrad_set_stream_k": [_I],
     "tsg_adam_step": [_I, _P, _P, _P, _P, _P] + [ctypes.c_double] * 6 + [_P, _P, _P],
+    "tsg_grads_nonfinite": [_I, _P, _P, _P, _P],
     "tsg_adam_step_shadow": [_I, _P, _P, _P, _P, _P, _P] + [ctypes.c_double] * 6 + [_P, _P, _P],
     "tsg_gemm_bf16": [_P, c_longlong, _P, c_longlong, _P, _P, c_longlong, _I, _I, _I, _I, _P],
     "tsg_match_head_fwd": [_P] * 5 + [_I] * 5 + [_P],

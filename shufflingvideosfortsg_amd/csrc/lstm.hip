@@ -23,6 +23,9 @@
 // workgroup and step -- and the step time was dominated by address-translation misses.)
 // Saved for backward (caller-owned): R [T][2][B][h][4] activated gates, Cs [T][2][B][h] cell states.
 #include "tsg_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 #include <cstdlib>
 
 namespace tsg {
@@ -1498,26 +1501,30 @@ static int l2_exchange() {        // TSG_LSTM_L2X=0: always write-through exchan
 extern "C" int tsg_lstm_set_l2_exchange(int on) { g_l2x.store(on != 0, std::memory_order_relaxed); return 0; }
 
 // Workgroups of a persistent kernel that can be co-resident: ONE per CU is counted (margin against over-reporting), cached
-// per (device, kernel slot).  0 = the kernel cannot run persistently here.
-static constexpr int kMaxDev = 16;
+// per (device, kernel INSTANTIATION) -- the instantiations differ in LDS and register footprint, so an occupancy answer is never shared
+// between them (a slot number used to stand for several kernels).  0 = the kernel cannot run persistently here.
+// (`slot` is the callers' old cache index: unused.)
 template <class K>
-static int persist_capacity(int slot, K kern, int threads, size_t lds, int per_cu) {
-  static std::atomic<int> cache[kMaxDev][4];
-  static std::once_flag once;
-  std::call_once(once, [] { for (auto& d : cache) for (auto& c : d) c.store(-1); });
+static int persist_capacity(int /*slot*/, K kern, int threads, size_t lds, int per_cu) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> cache;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 0;
-  // the LDS attribute is per (device, INSTANTIATION): a slot serves several instantiations (hidden size x arithmetic), so it is
-  // requested for the one being launched on every call (a table hit after the first), not only when the slot's cache is filled
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+  // the LDS attribute is per (device, instantiation): requested on every call (a table hit after the first)
   hipError_t e1 = allow_lds(kern, lds);
   if (e1 != hipSuccess) return 0;
-  int cap = cache[dev][slot].load(std::memory_order_relaxed);
-  if (cap >= 0) return cap;
+  const auto key = std::make_pair(dev, reinterpret_cast<const void*>(kern));
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+  }
   int cus = 0, per = 0;
-  if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, threads, lds);
-  cap = (e1 == hipSuccess && per >= per_cu) ? cus * per_cu : 0;
-  cache[dev][slot].store(cap, std::memory_order_relaxed);
+  const int cap = (e1 == hipSuccess && per >= per_cu) ? cus * per_cu : 0;
+  std::lock_guard<std::mutex> lock(mu);
+  cache[key] = cap;
   return cap;
 }
 // Rows per launch when the B rows of a layer need more workgroups than fit: balanced chunks of whole 16-row slices, each

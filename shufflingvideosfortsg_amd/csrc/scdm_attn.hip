@@ -773,7 +773,8 @@ __global__ __launch_bounds__(128 * PW) void scdm_fwd_ws_kernel(
 #ifdef TSG_K1_TRIPLE
   constexpr bool QS = false;                         // (A/B builds: the round-3 fma-rcp-fma triple per element)
 #else
-  constexpr bool QS = true;                          // score loop with one reciprocal per four k elements (scdm_chunk_step_q)
+  constexpr bool QS = NP <= 24;                      // score loop with one reciprocal per four k elements (scdm_chunk_step_q); 28 word slots: its six
+                                                     // extra live registers spill (4-6 reloads per row: 310 vs 304 us at [128,512,25,1024]) -- the triple there
 #endif
   const int HP = roundup256(H);
   extern __shared__ __align__(16) float lds[];

@@ -88,6 +88,15 @@ class FlatGradAllReduce:
         self._gated_wanted = bool(gated)
         self.gated = self._gated_wanted and self.overlap
         self._hooked = False
+        # Parameters that receive no gradient (an unused branch, a frozen head): their bucket would never "complete" and it and ALL later
+        # buckets would wait for finish().  After the first exchanged step the ranks agree on the set of parameters that had
+        # a gradient on NO rank (one MAX all-reduce of a byte mask); from then on those count as ready at the start of every step.
+        self._unused = None        # ids of the parameters assumed to stay without a gradient (None = not learnt yet)
+        self._late_grad = False    # a gradient arrived for such a parameter after its bucket had left: this step's update is skipped
+        self._gate_calls = 0       # after_persistent() calls of the current backward
+        self._gate_seen_prev = True
+        self.flushed_in_finish = 0 # buckets (beyond the last one) that finish() had to launch in the last step: lost overlap
+        self._warned_flush = False
         # RCCL averages inside the reduction (no extra pass over the buffer); gloo has no AVG: sum, then one division
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
@@ -98,12 +107,21 @@ class FlatGradAllReduce:
         if broadcast and self.world > 1:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0, group=self.group)
+            from . import functional as TF                 # written through .data: the parameters' version counters did not move
+            TF.invalidate_shadows(module)
 
     # -- per-step protocol ----------------------------------------------------------------
     def zero_grad(self):
         for p in self.params:
             p.grad = None
         self._ready = [0] * len(self.buckets)
+        if self._unused:
+            for b, (_, _, params) in enumerate(self.buckets):
+                self._ready[b] = sum(1 for p in params if id(p) in self._unused)
+        self._late_grad = False
+        # gated mode launches from after_persistent() only: a backward without a persistent kernel (TSG_LSTM_PERSIST=0, a non-HIP LSTM)
+        # would exchange everything in finish().  If the previous backward made no gate call, the hooks launch as in the ungated mode.
+        self._gate_seen_prev, self._gate_calls = (self._gate_calls > 0 or self._next == 0), 0
         self._launched = [False] * len(self.buckets)
         self._next = 0
         self._handles = []
@@ -138,8 +156,14 @@ class FlatGradAllReduce:
     def _hook(self, p):
         if not self.overlap:
             return
-        self._ready[self._bucket_of[id(p)]] += 1
-        if not self.gated:
+        b = self._bucket_of[id(p)]
+        if self._unused and id(p) in self._unused:         # assumed unused, and here is its gradient
+            self._unused.discard(id(p))                    # (counted as ready already)
+            if self._launched[b]:                          # its bucket has left without it: the exchanged mean misses this rank's part --
+                self._late_grad = True                     # the guard slot makes EVERY rank skip this update; from the next step on the
+            return                                         # parameter is waited for again
+        self._ready[b] += 1
+        if not self.gated or not self._gate_seen_prev:
             self._advance()
 
     def set_overlap(self, on: bool, gated: Optional[bool] = None):
@@ -162,6 +186,7 @@ class FlatGradAllReduce:
 
     def after_persistent(self):
         """A persistent kernel has just been enqueued: collectives launched now start when it has finished."""
+        self._gate_calls += 1
         if self.gated:
             self._advance()
 
@@ -183,9 +208,23 @@ class FlatGradAllReduce:
         1-element tensor, non-zero = skip the update), reduced across the ranks with the gradients (see ``guard``)."""
         if not self.active:
             return
+        if self._late_grad:
+            guard = torch.ones(1, device=self.flat.device, dtype=self.flat.dtype)
         self._set_guard(guard)
         if self.overlap:
+            self.flushed_in_finish = max(0, len(self.buckets) - self._next - 1)     # (the last bucket completes with the backward itself)
+            if self.flushed_in_finish and self._unused is not None and not self._warned_flush:
+                import warnings
+                warnings.warn(f"FlatGradAllReduce: {self.flushed_in_finish + 1} of {len(self.buckets)} buckets were still waiting when the backward "
+                              "ended (a parameter without a gradient in front of them, or no persistent kernel to gate on): their exchange did not overlap")
+                self._warned_flush = True
+            learn = self._unused is None and self.world > 1
+            if learn:                                      # first exchanged step: which parameters had a gradient on no rank at all?
+                mask = torch.tensor([0 if p.grad is None else 1 for p in self.params], device=self.flat.device, dtype=torch.int32)
             self._advance(flush=True)                      # what the hooks / gates have not launched yet, in index order
+            if learn:
+                dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+                self._unused = {id(p) for p, m in zip(self.params, mask.tolist()) if m == 0}
             # the buckets are already in flight: the guard slot goes in a collective of its own (4 bytes)
             self._handles.append(dist.all_reduce(self.flat[self._numel:], op=self._op, group=self.group, async_op=True))
         else:

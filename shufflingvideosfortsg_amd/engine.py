@@ -113,13 +113,17 @@ class TsgAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True, capturable=True))
         self.found_inf = None          # device float (non-zero = skip this update): the protocol of torch's fused optimizers (GradScaler)
         self.grad_scale = 1.0
-        self._state_words = {}         # device -> [update count (float), ticket]
+        self._state_words = {}         # (device, param group index) -> [update count (float), ticket]
         self._tables = {}
 
-    def _words(self, dev):
-        w = self._state_words.get(dev)
+    def _words(self, dev, gi=0):
+        """The update count of param group ``gi`` on ``dev``: the kernel advances it once per call, so every group keeps its own (with one
+        word per device the count rose once per GROUP and later groups were bias-corrected at t + 1).  A parameter whose first gradient arrives late
+        still starts at its group's t against zero moments -- torch keeps a count per parameter; the reference's optimizer has one group and every
+        parameter receives a gradient in every step."""
+        w = self._state_words.get((dev, gi))
         if w is None:
-            w = self._state_words[dev] = torch.zeros(2, device=dev, dtype=torch.float32)
+            w = self._state_words[(dev, gi)] = torch.zeros(2, device=dev, dtype=torch.float32)
         return w
 
     @torch.no_grad()
@@ -129,12 +133,18 @@ class TsgAdam(torch.optim.Optimizer):
         from ._lib import load, ptr
         loss = closure() if closure is not None else None
         lib = load()
-        for group in self.param_groups:
+        if self.found_inf is not None:                     # a guarded update also looks at the gradients themselves: a NaN or an infinity
+            gs = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None and p.grad.is_contiguous()]   # in ANY group skips them all
+            if gs:
+                TF.check(lib.tsg_grads_nonfinite(len(gs), (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs]),
+                                                 (ctypes.c_longlong * len(gs))(*[g.numel() for g in gs]), ptr(self.found_inf),
+                                                 TF.stream_of(gs[0])), "tsg_grads_nonfinite")
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
             dev = ps[0].device
-            words = self._words(dev)
+            words = self._words(dev, gi)
             for p in ps:
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.device == dev):
                     raise ValueError("TsgAdam: fp32 contiguous CUDA parameters on one device only")
@@ -163,6 +173,8 @@ class TsgAdam(torch.optim.Optimizer):
                                        numel, float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                                        float(self.grad_scale), ptr(words), ptr(skip) if skip is not None else None, TF.stream_of(ps[0]))
             TF.check(rc, "tsg_adam_step")
+            for p in ps:                                   # the kernel wrote p (and its shadow) through raw pointers: version counters follow
+                TF.restamp_shadow(p)
         return loss
 
 
@@ -207,13 +219,40 @@ def optimizer_step(opt, loss, dp=None, guard=None):
     if dp is not None and getattr(dp, "active", False) and dp.guard is not None:
         bad = torch.maximum(bad, (dp.guard != 0).to(torch.float32))
     if fused:
-        opt.found_inf = bad.reshape(())
+        flag = bad.reshape(())
+        opt.found_inf = flag
         try:
-            opt.step()
+            opt.step()                                     # (TsgAdam also ORs "a gradient is NaN / inf" into the flag: tsg_grads_nonfinite)
         finally:
             opt.found_inf = None
+        _skip_counter(flag.device).add_((flag != 0).to(torch.float32))     # on the device: part of the captured update under graph replay
     elif float(bad.item()) == 0.0:                         # host-side optimizers (CPU tests, non-fused GPU optimizers), with or without a
         opt.step()                                         # gradient exchange: the same rule, the flag read on the host (one sync)
+    else:
+        _skip_counter(bad.device).add_(1.0)
+
+
+_SKIPPED = {}              # device -> float32 [] count of optimizer updates the guard has skipped
+
+
+def _skip_counter(device):
+    c = _SKIPPED.get(device)
+    if c is None:
+        c = _SKIPPED[device] = torch.zeros((), device=device, dtype=torch.float32)
+    return c
+
+
+def skipped_updates(device=None, reset: bool = False) -> int:
+    """How many updates ``optimizer_step`` has skipped on ``device`` (default: every device) since the start / the last reset: a
+    non-finite loss, an expired bounded wait, a NaN / inf gradient, or -- with a gradient exchange -- any of these on ANY rank.  A
+    throughput measured over steps that did not update is not a training throughput: bench.py prints the count and refuses a run
+    whose timed region skipped.  Synchronises (reads the device counters)."""
+    devs = [d for d in _SKIPPED if device is None or d == torch.device(device)]
+    n = int(sum(float(_SKIPPED[d]) for d in devs))
+    if reset:
+        for d in devs:
+            _SKIPPED[d].zero_()
+    return n
 
 
 class GraphedTrainStep:

@@ -541,8 +541,11 @@ def weight_bf16(w: torch.Tensor) -> torch.Tensor:
     """The bf16 operand of an fp32 parameter in the bf16 storage mode.  For a leaf parameter the rounded copy is kept as a SHADOW on the parameter
     object and rewritten by the optimizer's own kernel with every update (engine.TsgAdam -> tsg_adam_step_shadow), so a training step does not
     cast its weights at all (eleven cast launches, 0.11 ms of the 7 ms GMD step).  The shadow is trusted while the parameter's version counter is
-    the one it was made at: TsgAdam updates through raw pointers (no version bump, and it rewrites the shadow); every other in-place change
-    (load_state_dict, an optimizer that is not TsgAdam, manual edits) bumps the version and the shadow is re-made here."""
+    the one it was made at: TsgAdam rewrites the shadow in its own kernel and re-stamps it (``restamp_shadow``); every other in-place change made
+    THROUGH THE PARAMETER (``load_state_dict``, ``p.copy_()`` / ``p.mul_()`` under ``no_grad``, an optimizer that is not TsgAdam) bumps the version
+    and the shadow is re-made here.  NOT seen: writes through ``p.data`` (``p.data.copy_()``, ``dist.broadcast(p.data)``, EMA weight swaps) or
+    through raw pointers -- ``.data`` carries its own version counter -- so code that edits parameters that way calls
+    ``invalidate_shadows(module)`` afterwards (dp.FlatGradAllReduce does, after its initial broadcast)."""
     wd = w.detach()
     if not (_SHADOWS and w.is_leaf and w.requires_grad and w.dtype == torch.float32 and w.is_cuda and w.is_contiguous()):
         return wd.to(_BF)
@@ -555,6 +558,30 @@ def weight_bf16(w: torch.Tensor) -> torch.Tensor:
         sh.copy_(wd)
         w._tsg_shadow_version = key
     return sh
+
+
+def invalidate_shadows(module_or_params) -> int:
+    """Drop the bf16 shadows of a module's (or an iterable's) parameters: the next bf16-storage forward re-makes them from the fp32 masters.
+    Call it after editing parameters through ``p.data`` or raw pointers (see ``weight_bf16``); returns the number of shadows dropped."""
+    ps = module_or_params.parameters() if hasattr(module_or_params, "parameters") else module_or_params
+    n = 0
+    for p in ps:
+        if getattr(p, "_tsg_shadow", None) is not None:
+            p._tsg_shadow = None
+            p._tsg_shadow_version = None
+            n += 1
+    return n
+
+
+def restamp_shadow(p: torch.Tensor) -> None:
+    """The optimizer has rewritten ``p`` AND its shadow in one kernel through raw pointers: bump both version counters -- a backward that runs
+    after the step on a graph that saved the old weights then fails autograd's saved-tensor check, as it does with torch's own in-place
+    optimizers, instead of silently using the new weights -- and mark the shadow as current for the new version."""
+    p._bump_version()
+    sh = getattr(p, "_tsg_shadow", None)
+    if sh is not None:
+        sh._bump_version()
+        p._tsg_shadow_version = (p._version, p.data_ptr())
 
 
 def shadow_of(p: torch.Tensor):

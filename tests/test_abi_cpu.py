@@ -105,3 +105,14 @@ def test_timing_hook_argument_errors(lib):
     assert lib.tsg_timed_launch_us(7, None) == -1
     assert lib.tsg_time_next_launch(7) == 0 and lib.tsg_time_next_launch(-1) == 0
     assert lib.tsg_timed_launch_us(7, ctypes.byref(us)) == -2          # armed and disarmed without a launch
+
+
+def test_grads_nonfinite_argument_errors(lib):
+    buf = (ctypes.c_float * 64)()
+    p = (ctypes.addressof(buf) + 15) & ~15
+    one = (ctypes.c_void_p * 1)(p); cnt = (ctypes.c_longlong * 1)(8)
+    assert lib.tsg_grads_nonfinite(0, one, cnt, p, None) == -1
+    assert lib.tsg_grads_nonfinite(1, one, cnt, None, None) == -1
+    assert lib.tsg_grads_nonfinite(1, (ctypes.c_void_p * 1)(None), cnt, p, None) == -1
+    assert lib.tsg_grads_nonfinite(1, one, (ctypes.c_longlong * 1)(0), p, None) == -2
+    assert lib.tsg_grads_nonfinite(1, (ctypes.c_void_p * 1)(p + 2), cnt, p, None) == -3

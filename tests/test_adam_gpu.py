@@ -137,3 +137,93 @@ def test_tsg_adam_keeps_bf16_shadows_of_the_parameters():
         shadowed[3].copy_(torch.full_like(shadowed[3], 0.333))               # behind the optimizer's back: the version counter moves
     assert TF.shadow_of(shadowed[3]) is None
     assert torch.equal(TF.weight_bf16(shadowed[3]), shadowed[3].detach().to(torch.bfloat16)) and TF.shadow_of(shadowed[3]) is not None
+
+
+def test_shadow_goes_stale_through_dot_data_and_invalidate_shadows_drops_it():
+    """a write through ``p.data`` does not move ``p._version`` (``.data`` has its own counter), so the shadow check cannot see it --
+    that is the documented limit; ``functional.invalidate_shadows`` is the remedy (dp.FlatGradAllReduce calls it after its broadcast)."""
+    from shufflingvideosfortsg_amd import functional as TF
+    lin = torch.nn.Linear(64, 32).cuda()
+    sh = TF.weight_bf16(lin.weight)
+    lin.weight.data.mul_(2.0)                              # behind the version counter
+    assert TF.shadow_of(lin.weight) is sh and not torch.equal(sh, lin.weight.detach().to(torch.bfloat16))      # stale, undetected
+    assert TF.invalidate_shadows(lin) == 1 and TF.shadow_of(lin.weight) is None
+    assert torch.equal(TF.weight_bf16(lin.weight), lin.weight.detach().to(torch.bfloat16))
+    assert TF.invalidate_shadows([lin.bias]) == 0          # parameters that never had a shadow
+
+
+def test_tsg_adam_bumps_versions_so_a_late_backward_fails_loudly():
+    """The update and the shadow rewrite go through raw pointers; TsgAdam bumps the version counters afterwards, so a backward through a graph
+    that SAVED the old weight (or its shadow) raises autograd's in-place error instead of silently using the new values -- torch's own
+    optimizers behave the same way -- and the shadow stays current (no re-cast at the next use)."""
+    from shufflingvideosfortsg_amd import functional as TF
+    from shufflingvideosfortsg_amd.engine import TsgAdam
+    w = torch.nn.Parameter(torch.randn(32, 16, device="cuda"))
+    opt = TsgAdam([w], lr=1e-2)
+    sh = TF.weight_bf16(w)
+    x = torch.randn(4, 16, device="cuda", requires_grad=True)
+    y = x @ w.t()                                          # saves w for the backward
+    v0 = w._version
+    w.grad = torch.randn_like(w)
+    opt.step()
+    assert w._version > v0 and TF.shadow_of(w) is sh and torch.equal(sh, w.detach().to(torch.bfloat16))
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        y.sum().backward()
+
+
+def test_tsg_adam_param_groups_keep_their_own_update_count():
+    """two param groups on one device used to share (and both advance) one update count; each group's bias correction now sees its own t."""
+    from shufflingvideosfortsg_amd.engine import TsgAdam
+    g = torch.Generator().manual_seed(5)
+    ps = [torch.randn(300, generator=g).cuda(), torch.randn(17, 9, generator=g).cuda(), torch.randn(4096, generator=g).cuda()]
+    a = [torch.nn.Parameter(p.clone()) for p in ps]
+    b = [torch.nn.Parameter(p.clone()) for p in ps]
+    mk = lambda cls, q: cls([dict(params=q[:2], lr=1e-3), dict(params=q[2:], lr=3e-3, betas=(0.8, 0.99))], eps=1e-6, weight_decay=1e-4)
+    own, ref = mk(TsgAdam, a), mk(torch.optim.Adam, b)
+    for it in range(5):
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, generator=g).cuda()
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        own.step(); ref.step()
+    assert float(own.state[a[0]]["step"]) == 5.0 and float(own.state[a[2]]["step"]) == 5.0
+    for pa, pb in zip(a, b):
+        torch.testing.assert_close(pa.data, pb.data, rtol=3e-6, atol=1e-7)
+
+
+def test_guarded_update_skips_on_non_finite_gradients():
+    """the guard looked at the loss and the error words only.  tsg_grads_nonfinite puts the gradients themselves into the skip flag: one
+    NaN or infinity anywhere (first, last, odd-sized and unaligned tensors; the second launch's table) and nothing moves; finite gradients pass."""
+    import ctypes
+    from shufflingvideosfortsg_amd import _lib
+    from shufflingvideosfortsg_amd.engine import TsgAdam
+    lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
+    a, _, g = _models(7)
+
+    def flag_of(grads):
+        n = len(grads); f = torch.zeros((), device="cuda")
+        rc = lib.tsg_grads_nonfinite(n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in grads]), (ctypes.c_longlong * n)(*[t.numel() for t in grads]), f.data_ptr(), st)
+        assert rc == 0, lib.tsg_last_error()
+        return float(f)
+    grads = [torch.randn(p.shape, generator=g).cuda() for p in a]
+    flat = torch.randn(5000, generator=g).cuda()
+    grads.append(flat[1:4098])                             # 4-byte aligned only (a view into a flat buffer)
+    assert flag_of(grads) == 0.0
+    for which, pos, val in ((0, 0, float("nan")), (4, 8192, float("inf")), (6, -1, float("-inf")), (len(a) - 1, 100, float("nan")), (len(grads) - 1, 4096, float("inf"))):
+        keep = grads[which].reshape(-1)[pos].clone()
+        grads[which].reshape(-1)[pos] = val
+        assert flag_of(grads) == 1.0, (which, pos, val)
+        grads[which].reshape(-1)[pos] = keep
+    assert flag_of(grads) == 0.0
+    own = TsgAdam(a, lr=1e-3)
+    for p, gr in zip(a, grads):
+        p.grad = gr.clone()
+    own.step()
+    before = [p.detach().clone() for p in a]
+    a[70].grad.reshape(-1)[3] = float("nan")               # a tensor of the second launch
+    own.found_inf = torch.zeros((), device="cuda")         # a guarded update whose other inputs (loss, error words) are clean
+    own.step()
+    torch.cuda.synchronize()
+    assert float(own.found_inf) == 1.0 and float(own.state[a[0]]["step"]) == 1.0
+    own.found_inf = None
+    for p, q in zip(a, before):
+        assert torch.equal(p.data, q)

@@ -205,3 +205,60 @@ def test_world4_unequal_gradient_presence_and_reduced_guard(protocol, bucket_mb,
         # the guard: set on one rank -> seen by ALL ranks, and ALL of them skip the update (replicas stay identical)
         assert (flag != 0.0) == (poison_rank is not None), (rank, flag)
         assert moved == (poison_rank is None), (rank, moved)
+
+
+def _unused_worker(rank, world, port, out):
+    """Three steps with tiny buckets: (1) the ranks learn that `unused` never gets a gradient; (2) its bucket -- the FIRST in the buffer, the
+    parameter being the last registered -- no longer holds the others back: nothing is left for finish(); (3) rank 0 alone suddenly uses it:
+    the late gradient sets the guard on EVERY rank (its bucket had left), and the parameter is waited for again afterwards."""
+    import warnings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7)
+    model = Tiny()
+    dp = FlatGradAllReduce(model, bucket_mb=0.0002, overlap=True)
+    local = shard_batch(_batch(), rank, world)
+    rec = {}
+    with warnings.catch_warnings(record=True) as wlog:
+        warnings.simplefilter("always")
+        dp.zero_grad(); _loss(model, local).backward(); dp.finish()
+        rec["flushed1"], rec["unused_learnt"] = dp.flushed_in_finish, len(dp._unused)
+        g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+        dp.zero_grad(); _loss(model, local).backward()
+        rec["next_before_finish2"], rec["buckets"] = dp._next, len(dp.buckets)
+        dp.finish()
+        rec["flushed2"] = dp.flushed_in_finish
+        rec["same_grads"] = all(torch.allclose(g1[k], p.grad) for k, p in model.named_parameters())
+        dp.zero_grad()
+        batch3 = dict(local)
+        if rank == 0:                          # on the INPUT side: its gradient is the last of the backward, long after its bucket (the first) has left
+            v = local["video"]
+            batch3["video"] = v + torch.cat([model.unused(v[..., :3]), torch.zeros_like(v[..., 3:])], -1)
+        _loss(model, batch3).backward(); dp.finish()
+        rec["guard3"] = float(dp.guard[0])
+        dp.zero_grad(); _loss(model, local).backward(); dp.finish()
+        rec["guard4"], rec["flushed4"] = float(dp.guard[0]), dp.flushed_in_finish
+    rec["warned"] = sum("buckets were still waiting" in str(w.message) for w in wlog)
+    out.put((rank, rec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unused_parameters_do_not_hold_the_buckets_back():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_unused_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    recs = dict(q.get() for _ in range(2))
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    for rank in (0, 1):
+        r = recs[rank]
+        assert r["flushed1"] > 0 and r["unused_learnt"] == 2, r            # step 1: everything waited behind `unused` (weight + bias)
+        assert r["flushed2"] == 0 and r["next_before_finish2"] >= r["buckets"] - 1 and r["same_grads"], r
+        assert r["guard3"] != 0.0, r                                       # rank 0's late gradient: every rank skips the update
+        assert r["guard4"] == 0.0, r
+    assert recs[1]["flushed4"] == 0 and recs[0]["flushed4"] > 0            # rank 0 waits for the parameter again (it has no gradient now)
