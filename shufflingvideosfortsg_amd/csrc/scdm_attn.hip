@@ -2313,6 +2313,9 @@ int check_common(const char* fn, std::initializer_list<const void*> ptrs, int B,
   if (B <= 0 || T <= 0 || N <= 0 || H <= 0 || Ds <= 0)
     return set_error(TSG_E_SHAPE, "%s: non-positive dimension B=%d T=%d N=%d H=%d Ds=%d", fn, B, T, N, H, Ds);
   if (N > 32) return set_error(TSG_E_SHAPE, "%s: N=%d > 32 words not supported", fn, N);
+  // the kernels keep B * tiles in an int grid and B * T rows in 32-bit row arithmetic (found by the host sanitizer build: the workspace plan of
+  // B = T = 2^30 overflowed a long long)
+  if ((long long)B * T >= (1LL << 31)) return set_error(TSG_E_SHAPE, "%s: B * T = %lld rows (limit 2^31 - 1)", fn, (long long)B * T);
   if (H % 4 || Ds % 4) return set_error(TSG_E_ALIGN, "%s: H=%d and Ds=%d must be multiples of 4", fn, H, Ds);
   return 0;
 }
@@ -2364,7 +2367,7 @@ extern "C" int tsg_scdm_attn_fwd(const void* a, const void* s, const void* w, co
 }
 
 extern "C" long long tsg_scdm_bwd_ws_bytes(int B, int T, int N, int H, int Ds, int gate) {
-  if (B <= 0 || T <= 0 || N <= 0 || N > 32 || H <= 0 || Ds <= 0) return 0;
+  if (B <= 0 || T <= 0 || N <= 0 || N > 32 || H <= 0 || Ds <= 0 || (long long)B * T >= (1LL << 31)) return 0;     // (shapes the entry points reject)
   const int np = roundup(N, 4);
   const long long split = split_ws_bytes(B, T, N, Ds, gate != 0);
   long long fused = 0;

@@ -577,10 +577,10 @@ def restamp_shadow(p: torch.Tensor) -> None:
     """The optimizer has rewritten ``p`` AND its shadow in one kernel through raw pointers: bump both version counters -- a backward that runs
     after the step on a graph that saved the old weights then fails autograd's saved-tensor check, as it does with torch's own in-place
     optimizers, instead of silently using the new weights -- and mark the shadow as current for the new version."""
-    p._bump_version()
+    torch.autograd.graph.increment_version(p)
     sh = getattr(p, "_tsg_shadow", None)
     if sh is not None:
-        sh._bump_version()
+        torch.autograd.graph.increment_version(sh)
         p._tsg_shadow_version = (p._version, p.data_ptr())
 
 

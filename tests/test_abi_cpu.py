@@ -33,43 +33,26 @@ def test_exports_match_header(lib):
 
 
 def test_argument_errors_without_gpu(lib):
-    from shufflingvideosfortsg_amd._lib import TSG_F32
-    buf = (ctypes.c_float * 64)()
-    p = ctypes.addressof(buf)
-    p = (p + 15) & ~15
-    # NULL pointer
-    assert lib.tsg_scdm_attn_fwd(None, p, p, p, p, p, 1, 1, 1, 4, 4, TSG_F32, None) == -1
-    assert b"NULL" in lib.tsg_last_error()
-    # bad shapes / dtype / alignment
-    assert lib.tsg_scdm_attn_fwd(p, p, p, p, p, p, 1, 1, 33, 4, 4, TSG_F32, None) == -2      # N > 32
-    assert lib.tsg_scdm_attn_fwd(p, p, p, p, p, p, 1, 1, 1, 6, 4, TSG_F32, None) == -3       # H % 4
-    assert lib.tsg_scdm_attn_fwd(p, p, p, p, p, p, 1, 1, 1, 4, 4, 7, None) == -4             # dtype
-    assert lib.tsg_scdm_attn_fwd(p + 4, p, p, p, p, p, 1, 1, 1, 4, 4, TSG_F32, None) == -3   # misaligned
-    assert lib.tsg_mha_fwd(p, p, p, p, None, None, p, 1, 4, 4, 8, 8, 3, 1.0, 0, 0.0, 0, 0, TSG_F32, None) == -2  # 8 % 3
-    assert lib.tsg_mha_fwd(p, p, p, p, None, None, p, 1, 4, 4, 8, 8, 2, 1.0, 0, 1.0, 0, 0, TSG_F32, None) == -2  # dropout probability outside [0,1)
-    assert lib.tsg_boundary_score_fwd(p, p, p, p, p, None, None, p, p, 1, 4, 3, TSG_F32, None) == -2             # 2*Hm % 4
-    assert lib.tsg_mha_bwd(p, p, p, p, p, p, p, p, p, p, 1, 4, 4, 8, 8, 2, 1.0, 0, 0.0, 0, 0, 7, None) == -4     # dtype (TSG_F32 / TSG_F32S only)
-    # dtype TSG_BF16 (bf16 storage, ABI revision 3): accepted where the header says so, shapes it does not take are TSG_E_SHAPE (-2)
-    from shufflingvideosfortsg_amd._lib import TSG_BF16
-    assert lib.tsg_mha_fwd(p, p, p, p, p, None, p, 1, 4, 4, 64, 64, 2, 1.0, 0, 0.0, 0, 0, TSG_BF16, None) == -2      # A_sum asked for
-    assert lib.tsg_mha_fwd(p, p, p, p, None, None, p, 1, 4, 4, 40, 40, 2, 1.0, 0, 0.0, 0, 0, TSG_BF16, None) == -2   # head width 20
-    assert lib.tsg_mha_bwd(p, p, p, p, p, p, p, p, p, p, 1, 4, 4, 512, 512, 2, 1.0, 0, 0.0, 0, 0, TSG_BF16, None) == -2   # head width 256
-    assert lib.tsg_lstm_fwd_bias(p, None, p, p, p, p, p, 4, 16, 100, TSG_BF16, 1, None) == -2                      # h = 100: no persistent kernel
-    assert lib.tsg_lstm_fwd_bias(p, None, p, p, p, p, None, 4, 16, 128, TSG_BF16, 1, None) == -2                   # no sync workspace
-    assert lib.tsg_lstm_bwd_ws_layout(p, p, p, p, None, p, p, None, 0, None, 4, 16, 128, TSG_BF16, 1, None) == -2  # no ring workspace
-    assert lib.tsg_match_head_fwd(p, p, p, p, p, 1, 4, 8, 0, 7, None) == -4                                        # dtype (new argument)
-    assert lib.tsg_boundary_score_fwd(p, p, p, p, p, None, None, p, p, 1, 4, 4, 7, None) == -4
-    assert lib.tsg_error_word(None) == 0 and lib.tsg_error_sink(None) == 0                                         # un-registering is allowed
-    assert lib.tsg_wgrad_bf16(p, 256, 0, p, 100, 128, None, 0, 0, 0, 0, 0, p, 128, 0, None, 0, 64, 256, 1, None) == -2    # ldb0 < K0
-    # the weight-gradient GEMM: host-side plan and argument checks (no launch)
-    assert lib.tsg_wgrad_f32s_ws_bytes(16384, 1024, 1024, 0, 1) == 8 * 4 * 1024 * 1024      # 32 tiles -> 8 row ranges of partial tiles
-    assert lib.tsg_wgrad_f32s_ws_bytes(16384, 2048, 1024, 512, 2) == 4 * 4 * 2 * 2048 * 1536  # the LSTM shape: 192 tiles -> 4 ranges
-    assert lib.tsg_wgrad_f32s_ws_bytes(32, 256, 128, 0, 1) == 0                               # one chunk: no partials
-    assert lib.tsg_wgrad_f32s_ws_bytes(48, 256, 128, 0, 1) == -1                              # M % 32
-    assert lib.tsg_wgrad_f32s_ws_bytes(64, 128, 128, 0, 1) == -1                              # N % 256
-    assert lib.tsg_wgrad_f32s(p, 256, 0, p, 128, 128, None, 0, 0, 0, 0, 0, p, 128, 0, None, 0, 64, 256, 3, None) == -2   # groups
-    assert lib.tsg_wgrad_f32s(p, 256, 0, p, 100, 128, None, 0, 0, 0, 0, 0, p, 128, 0, None, 0, 64, 256, 1, None) == -2   # ldb0 < K0
-    assert lib.tsg_wgrad_f32s(None, 256, 0, p, 128, 128, None, 0, 0, 0, 0, 0, p, 128, 0, None, 0, 64, 256, 1, None) == -1  # NULL
+    """Argument errors, workspace planners and range checks of every entry point family, on paths that return before a launch (the
+    call list lives in tests/abi_host_driver.py: the sanitizer build below runs the same list)."""
+    import abi_host_driver
+    assert abi_host_driver.run_checks(lib) > 2000
+
+
+def test_host_layer_under_address_and_ub_sanitizers():
+    """SURVEY 5 / round-5 review item 8: the host layer of the C ABI (argument checks, tsg_*_ws_bytes planners, check_head / tile / range
+    arithmetic) built WITHOUT device code under AddressSanitizer + UndefinedBehaviorSanitizer (build.build_sanitized) and driven with the
+    same call list in a python that has the ASAN runtime preloaded -- incl. the ADVICE-r4 regression input (fused heads at
+    M in (2^22, 2^23]).  The first run of this build found a signed overflow in tsg_scdm_bwd_ws_bytes (B T >= 2^31: now rejected).
+    CPU only: nothing is launched, no GPU is touched."""
+    import subprocess
+    import sys
+    from shufflingvideosfortsg_amd import build
+    san = build.build_sanitized()
+    env = dict(os.environ, LD_PRELOAD=build.asan_runtime(), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abi_host_driver.py"), san], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "host-side calls clean" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
 
 
 def test_no_cpu_fallback():
@@ -94,25 +77,3 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("test oracle", ""), f"{f} mentions the oracle"
-
-
-def test_timing_hook_argument_errors(lib):
-    """tsg_time_next_launch / tsg_timed_launch_us (ABI 7): slot range and never-used slots are argument errors; -1 disarms."""
-    us = ctypes.c_float(-1.0)
-    assert lib.tsg_time_next_launch(4096) == -2 and b"slot" in lib.tsg_last_error()
-    assert lib.tsg_time_next_launch(-1) == 0
-    assert lib.tsg_timed_launch_us(7, ctypes.byref(us)) == -2          # no launch used slot 7
-    assert lib.tsg_timed_launch_us(7, None) == -1
-    assert lib.tsg_time_next_launch(7) == 0 and lib.tsg_time_next_launch(-1) == 0
-    assert lib.tsg_timed_launch_us(7, ctypes.byref(us)) == -2          # armed and disarmed without a launch
-
-
-def test_grads_nonfinite_argument_errors(lib):
-    buf = (ctypes.c_float * 64)()
-    p = (ctypes.addressof(buf) + 15) & ~15
-    one = (ctypes.c_void_p * 1)(p); cnt = (ctypes.c_longlong * 1)(8)
-    assert lib.tsg_grads_nonfinite(0, one, cnt, p, None) == -1
-    assert lib.tsg_grads_nonfinite(1, one, cnt, None, None) == -1
-    assert lib.tsg_grads_nonfinite(1, (ctypes.c_void_p * 1)(None), cnt, p, None) == -1
-    assert lib.tsg_grads_nonfinite(1, one, (ctypes.c_longlong * 1)(0), p, None) == -2
-    assert lib.tsg_grads_nonfinite(1, (ctypes.c_void_p * 1)(p + 2), cnt, p, None) == -3
