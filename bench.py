@@ -604,9 +604,11 @@ def main():
             log(f"graph replay (in process) skipped: {graph_inproc['error']}")
 
     graph_replay = None
-    if not a.fwd_only and not a.no_alt and world == 1 and not (graph_inproc and "value" in graph_inproc):
-        # fallback when the in-process graph leg above did not produce a number: the same measurement in a CHILD process started
-        # from this one (a fresh capture state; a failure there cannot take this result down).  One GPU only: the child shares it.
+    if not a.fwd_only and not a.no_alt and world == 1:
+        # the same measurement in a CHILD process started from this one (a fresh capture state; a failure there cannot take this result
+        # down).  One GPU only: the child shares it.  (a) fallback for `value` when the in-process graph leg above did not produce a number;
+        # (b) ALWAYS for the bf16 storage mode -- BASELINE config 2's own dtype -- as its own graph-replayed line next to `value`
+        # (round-5 review item 3): eager, that mode is bound by the host's enqueue time, not by the GPU.
         import subprocess
 
         def graph_child(dtype):
@@ -619,12 +621,12 @@ def main():
                 return json.loads(lines[-1])["graph_replay"] if lines else {"error": f"child exit code {r.returncode}: {r.stderr[-300:]}"}
             except Exception as e:                                # noqa: BLE001
                 return {"error": f"{type(e).__name__}: {e}"[:300]}
-        graph_replay = graph_child(a.dtype)
-        log(f"graph replay: {graph_replay}")
-        if a.dtype != "bf16" and not a.no_alt:            # BASELINE config 2's own dtype, as its own graph-replayed line (round-5 review item 3)
+        if not (graph_inproc and "value" in graph_inproc):
+            graph_replay = graph_child(a.dtype)
+            log(f"graph replay: {graph_replay}")
+        if a.dtype != "bf16":
             graph_replay_bf16 = graph_child("bf16")
             log(f"graph replay, bf16 storage: {graph_replay_bf16}")
-
     if rank == 0:
         kt = functional.kernel_timer.summary()          # (name, dims) -> (mean us, launches, median us)
         ks = functional.kernel_timer.kernel_summary()   # the K1 launches bracketed by their OWN event pair (tsg_time_next_launch)

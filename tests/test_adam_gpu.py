@@ -208,7 +208,7 @@ def test_guarded_update_skips_on_non_finite_gradients():
     flat = torch.randn(5000, generator=g).cuda()
     grads.append(flat[1:4098])                             # 4-byte aligned only (a view into a flat buffer)
     assert flag_of(grads) == 0.0
-    for which, pos, val in ((0, 0, float("nan")), (4, 8192, float("inf")), (6, -1, float("-inf")), (len(a) - 1, 100, float("nan")), (len(grads) - 1, 4096, float("inf"))):
+    for which, pos, val in ((0, 0, float("nan")), (4, 8191, float("inf")), (6, -1, float("-inf")), (len(a) - 1, 100, float("nan")), (len(grads) - 1, 4096, float("inf"))):
         keep = grads[which].reshape(-1)[pos].clone()
         grads[which].reshape(-1)[pos] = val
         assert flag_of(grads) == 1.0, (which, pos, val)
