@@ -28,6 +28,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -308,13 +309,12 @@ def micro_kernels(B, T, N, d, heads=8, iters=30):
 
 def pmc_traffic(kernel, B, T, N, d, launch_B=None, dtype="f32"):
     """(HBM bytes per launch, source file) from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes;
-    profiles/r5 first, then r4, r3, r2, r1) -- a citation of a profile of the same kernel and shape, not something this run observed:
+    the newest round's first) -- a citation of a profile of the same kernel and shape, not something this run observed:
     the JSON says so in `traffic_source`.  (None, None) when no pass exists for this shape and storage dtype."""
     launch_B = launch_B or B
-    for rnd, fname in (("r5", "k1_pmc_traffic_bf16.json" if dtype == "bf16" else "k1_pmc_traffic.json"),
-                       ("r4", "k1_pmc_traffic_bf16.json" if dtype == "bf16" else "k1_pmc_traffic.json"),
-                       ("r3", "k1_pmc_traffic_bf16.json" if dtype == "bf16" else "k1_pmc_traffic.json"), ("r2", "k1_pmc_traffic.json"),
-                       ("r1", "k1_pmc_traffic.json")):
+    fname = "k1_pmc_traffic_bf16.json" if dtype == "bf16" else "k1_pmc_traffic.json"
+    rounds = sorted((d_ for d_ in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+", d_)), key=lambda d_: -int(d_[1:]))
+    for rnd in rounds:                                    # the newest committed pass of this shape and storage dtype
         rel = os.path.join("profiles", rnd, fname)
         try:
             with open(os.path.join(ROOT, rel)) as f:
@@ -522,7 +522,8 @@ def main():
              "bf16g": "library GEMM operands bf16, fp32 accumulate, fp32 storage; HIP kernels, recurrent state, softmax, losses, "
                       "optimizer f32; deviates ~1e-3 from the fp32 reference",
              "f32s": "LSTM GEMMs, LSTM recurrence products and the large projections as split-precision bf16 MFMA products "
-                     "(hi*hi+hi*lo+lo*hi, fp32 accumulate: fp32-GEMM-level error, passes the fp32 parity suite); everything else f32"}
+                     "(hi*hi+hi*lo+lo*hi, fp32 accumulate: <= 2e-5 x scale against float64 -- 2^-16 product error, ~100x a true fp32 GEMM's rounding; passes the 1e-4 "
+                     "output tolerance of the parity suite); everything else f32"}
     alt = []
     gdt_main = gdt
     for mode in ([] if a.no_alt else [m for m in MODES if m != a.dtype]):
@@ -706,12 +707,12 @@ def main():
                 "timing": k1.get("timing", "HIP event pair recorded around the call on the launch stream"),
                 "around_call_mean_us": k1.get("around_call_mean_us"),
                 # round-3 review: state the kernel's own ceiling instead of chasing the last 10 %
-                "ceiling_note": ("fp32 / f32s arithmetic: one v_rcp_f32 + 2 v_fma_f32 per (t,n,k) element = 14.5-16 cycles per 64 elements on "
-                                 "1024 SIMDs -> 40-44 us of VALU issue per 128-pair launch = an upper bound of 0.64-0.70 of the 8 TB/s "
-                                 "roofline for this arithmetic; with the ~15 us ramp of a single wave of 256 workgroups the kernel's own "
-                                 "ceiling is 0.50-0.52 (DESIGN.md section 4, K1g).  bf16 storage: the SAME fp32 score loop on half the bytes -- the launch "
-                                 "takes the same time, so its fraction of the HBM roofline halves (a packed-f16 loop measured no faster: gfx950 "
-                                 "has no packed reciprocal; profiles/r4/k1g_fwd_packed_f16_experiment_v1.txt)")
+                "ceiling_note": ("clock-bound, not issue- or bandwidth-bound (DESIGN.md section 4.1): PMC traffic is 1.02 x algorithmic; on one box the same "
+                                 "launch takes 62 us on random operands and 53 us on all-zero operands, and the in-kernel clock reads 1.6-1.7 GHz of the "
+                                 "nominal 2.4 (profiles/r6/k1g_fwd_power_bound_probe_v1.txt): the VALU-dense score loop (3.75 VALU instructions and 4 LDS "
+                                 "bytes per (t,n,k) element, one v_rcp_f32 per four elements) makes the chip hold its clock down, so instruction savings "
+                                 "return as a lower clock.  bf16 storage: the SAME fp32 score loop on half the bytes -- the launch takes the same time, "
+                                 "so its fraction of the HBM roofline halves")
                 if gate else None}
         what = "fwd-only" if a.fwd_only else "fwd+bwd"
         wl = (f"{a.model}_forward: fwd+losses under no_grad, " if a.fwd_only else

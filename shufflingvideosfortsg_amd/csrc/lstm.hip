@@ -929,7 +929,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void lstm_fwd_persist_ker
 // forward, persistent, bf16 storage, 64-UNIT workgroups on HALF the CUs (round 5; h = 512, >= 96 rows).
 // What paces the forward step at the full chip is not the work between its barriers but the all-gather of the 16-row h slab through
 // one XCD's L2 -- every workgroup of a group polls the whole slab, two groups share an L2 -- and the clock of a fully busy chip
-// ("Round 5": only the poll phase differs between 64 and 128 rows; with bf16 storage the MFMA phase halves and the
+// (HISTORY.md, old section 5, "Round 5": only the poll phase differs between 64 and 128 rows; with bf16 storage the MFMA phase halves and the
 // waiting grows by the same amount).  With bf16 storage W_hh is one plane: a wave can hold TWO A-tiles (8 units x 4 gates x h = 128 VGPRs), a
 // workgroup 64 units, a group 8 workgroups -- half the slab readers per L2 and half the CUs idle -- for twice the MFMA and gate work per
 // wave, which the waiting absorbs: a timing-only emulation (the 64-row grid with every wave's MFMAs and gates doubled:
@@ -1130,7 +1130,7 @@ static int lstm_check(const char* fn, int B, int T, int h, int dtype) {
 // ---------------------------------------------------------------------------------------------
 // backward, PERSISTENT (the default when the caller provides the ring workspace): exchange dh, not dG.
 // (A first version mirrored the forward literally -- consumers polling the sentinel-marked 4h-wide dG slab, 128 KiB per
-// workgroup and step -- and measured 17.9 us per step against 14.9 for the launch-per-step kernels; see DESIGN.md.)
+// workgroup and step -- and measured 17.9 us per step against 14.9 for the launch-per-step kernels; see HISTORY.md.)
 // Workgroup = (direction, 32 units, 16 batch rows) as in the forward.  Its OWN gate gradients of the step before
 // (16 rows x 128 gate columns, in LDS) are the B operand, its 128 x h slice of W_hh (registers, 128 VGPRs at h = 512)
 // the A operand of  partial_dh[16 rows][ALL h units] = dG_own W_hh[own gate rows, :]  -- no operand has to be fetched.

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(kFwdThreads) void scdm_fwd_mm_kernel(
 // forward, split-precision variant with ROLE-SPECIALISED waves (dtype TSG_F32S, the default for H = Ds = 256 CT).
 //
 // In the kernel above every wave alternates between the score loop (VALU issue) and phase 2 (r loads, MFMAs, out stores), and the
-// barrier between them keeps the 8 waves of the CU in the same phase: the ablation shows the two phases
+// barrier between them keeps the 8 waves of the CU in the same phase: the ablation (HISTORY.md, K1g round 3) shows the two phases
 // adding up (34 us + 15 us) instead of overlapping.  Here the roles are split across waves instead of across time:
 //   waves 0..PW-1     producers: scores + softmax of 8/PW rows each (one after the other) per 8-row sub-tile, nothing else;
 //   waves PW..2PW-1   consumers: phase 2 of the PREVIOUS sub-tile -- all 8 rows x Ds/PW columns each on the matrix pipe, the r loads,

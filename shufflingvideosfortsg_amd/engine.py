@@ -71,7 +71,7 @@ def set_precision(gemm_dtype=None):
 class precision:
     """Context manager for the arithmetic mode of the path; the previous mode is RESTORED on exit (round-3 review: it used to set a
     process global and return a null context, so the mode leaked past the block).  ``None`` / fp32 = strict fp32 (parity mode);
-    ``"f32s"`` = split-precision bf16 MFMA products, fp32 storage (the headline mode: fp32-level error); ``"bf16"`` = bf16 STORAGE
+    ``"f32s"`` = split-precision bf16 MFMA products, fp32 storage (the headline mode; error <= 2e-5 x scale against float64 -- 2^-16 products, ~100x a true fp32 GEMM's rounding, within the 1e-4 output tolerance); ``"bf16"`` = bf16 STORAGE
     mode (BASELINE configs 2 / 4): activations and their gradients live in HBM as bf16, the hand-written kernels run with dtype
     TSG_BF16 (fp32 arithmetic inside), the GEMMs are plain bf16 MFMA GEMMs, parameters / weight gradients / optimizer state stay
     fp32 -- no autocast involved; ``torch.bfloat16`` = the older operands-only mode: every library GEMM (nn.Linear projections via

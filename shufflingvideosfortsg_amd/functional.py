@@ -201,7 +201,7 @@ def _call(name: str, like: torch.Tensor, *args) -> None:
 # Library-GEMM precision of the adjacent glue (the LSTM's input / weight-gradient GEMMs): None = fp32 rocBLAS
 # (parity mode, default); torch.bfloat16 = bf16 operands with fp32 accumulation (BASELINE configs 2-4);
 # "f32s" = split precision: both operands as bf16 (hi, lo) planes (tsg_split_bf16x3), ONE bf16 MFMA GEMM over the
-# 3x longer contraction with fp32 accumulate = hi·hi + hi·lo + lo·hi, fp32-GEMM-level error at 2-3x its speed.
+# 3x longer contraction with fp32 accumulate = hi·hi + hi·lo + lo·hi, error <= 2e-5 x scale against float64 (2^-16 products: ~100x a true fp32 GEMM's rounding) at 2-3x its speed.
 # "bf16" (the string) = bf16 STORAGE mode (BASELINE configs 2 / 4): every activation and activation
 # gradient of the path lives in HBM as bf16 -- the hand-written kernels take dtype TSG_BF16 (half the bytes; fp32
 # arithmetic, softmax, cell state and accumulation inside), the GEMMs are plain bf16 MFMA GEMMs with fp32 accumulation
@@ -1906,7 +1906,7 @@ def linear(x, w, b=None):
 
 def linear_hip(x, w, b=None):
     """torch.nn.functional.linear on the hand-written fp32 MFMA GEMM (include/tsg_hip.h: tsg_linear_fwd).  Opt-in: rocBLAS
-    is ~18 % faster at the path's shapes, so the modules keep F.linear."""
+    is ~18 % faster at the path's shapes (HISTORY.md, old section 4 "Projection GEMMs"), so the modules keep F.linear."""
     return _LinearHip.apply(x, w, b)
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer probe: inside ONE captured HIP graph, every workgroup reads a small buffer X (kernel 1), one workgroup overwrites X (kernel 2), every
 workgroup reads X again (kernel 3).  Does kernel 3 ever see kernel 1's contents when the graph is replayed back to back (no host synchronisation)?
-(Round 5: the key words of captured dropout launches showed up inside a gradient that reused their pool blocks -- DESIGN.md status (11).)"""
+(Round 5: the key words of captured dropout launches showed up inside a gradient that reused their pool blocks -- HISTORY.md, round-5 status (11).)"""
 import torch
 dev = "cuda"
 N = 1 << 22
