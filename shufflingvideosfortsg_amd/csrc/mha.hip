@@ -1272,10 +1272,13 @@ __device__ __forceinline__ void gather_frag(const ET* __restrict__ rows, int ld,
 }
 
 // (A) dK, dV.  grid = B * H * ceil(Tk / 128); wave w owns keys kb + 32 w .. +31.
-template <int DT, bool DROP, typename ET>
+// WDS (round 6; one key block, Tk <= the head width): the dS tile this kernel forms anyway is also WRITTEN -- dS[b][q][head's columns: key] -- into
+// the dQ buffer (a [Tq x Tk] block per head fits the head's [Tq x 32 DT] columns), and dQ = dS K becomes a small product over it
+// (mha_bwd_dq_from_ds_kernel) instead of a second kernel that re-reads Q, K, V, dO and forms S, P, dP, dS again.
+template <int DT, bool DROP, typename ET, bool WDS = false>
 __global__ __launch_bounds__(256) void mha_bwd_split_dkv_kernel(
     const ET* __restrict__ Q, const ET* __restrict__ K, const ET* __restrict__ V, const ET* __restrict__ dO,
-    const float* __restrict__ LSE, const float* __restrict__ delta, ET* __restrict__ dK, ET* __restrict__ dV,
+    const float* __restrict__ LSE, const float* __restrict__ delta, ET* __restrict__ dK, ET* __restrict__ dV, ET* __restrict__ dS,
     int B, int Tq, int Tk, int dk, int H, float inv_scale, int causal, DropCfg dc) {
   drop_resolve(dc);
 #ifdef TSG_K2_TIMING
@@ -1358,6 +1361,16 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dkv_kernel(
       pm[r] = p * mk;
       ds[r] = p * (dp[r] * mk - dlv[r]) * inv_scale;
     }
+    if constexpr (WDS) {                                                 // (kb = 0; keys beyond Tk carry p = 0: zeros are stored and contracted)
+      if (32 * wv + jl < 32 * DT) {
+        ET* dsb = dS + (size_t)b * Tq * dk + hd * 32 * DT + 32 * wv + jl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int q = q0 + rho(r, hh);
+          if (q < Tq) st1(dsb + (size_t)q * dk, ds[r]);
+        }
+      }
+    }
     K2_TICK(3)
     // dV[key][c] += sum_q P[q][key] dO[q][c];  dK[key][c] += sum_q dS[q][key] Q[q][c]   (A = the registers above, B = transposed planes)
 #pragma unroll
@@ -1401,6 +1414,78 @@ __global__ __launch_bounds__(256) void mha_bwd_split_dkv_kernel(
   if (blockIdx.x == 0 && lane == 0)
     for (int i = 0; i < 8; ++i) dK[wv * 8 + i] = (float)tph[i];
 #endif
+}
+
+// (B') dQ = dS K from the dS the WDS kernel left in the dQ buffer, IN PLACE: grid = B * H * ceil(Tq / 128); wave w owns queries qb + 32 w .. +31,
+// reads its 32 dS rows (the head's columns) into A-operand fragments before anything is stored, streams the head's K rows through LDS as
+// transposed bf16 planes (32 keys per tile) and writes its 32 dQ rows over the dS rows it read.  2 DT x DT x 3 MFMAs per tile and wave; no S, no
+// softmax, no dP; reads dS + K, writes dQ.
+template <int DT, typename ET>
+__global__ __launch_bounds__(256) void mha_bwd_dq_from_ds_kernel(const ET* __restrict__ K, ET* __restrict__ dQ, int B, int Tq, int Tk, int dk, int H) {
+  using SK = SplitTile<DT, true, false, ET>;                             // transposed planes only
+  extern __shared__ __align__(16) unsigned lds_u[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hh = lane >> 5;
+  const int qblocks = (Tq + 127) / 128;
+  const int b = blockIdx.x / (H * qblocks), hd = (blockIdx.x / qblocks) % H, qb = (blockIdx.x % qblocks) * 128;
+  SK tk(K + (size_t)b * Tk * dk + hd * 32 * DT, dk);
+  tk.request(0, Tk);
+  ET* dQb = dQ + (size_t)b * Tq * dk + hd * 32 * DT;
+  u32x4v sh[2 * DT], sl[2 * DT];
+  own_rows<DT>(static_cast<const ET*>(dQb), dk, qb, Tq, sh, sl);          // dS[q][keys 16 ks + 8 hh .. +7], q = qb + 32 wv + jl
+  f32x16 dqt[DT];
+#pragma unroll
+  for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqt[ct][r] = 0.f;
+  tk.stage(lds_u);
+  __syncthreads();
+  const int ntiles = (Tk + 31) / 32;                                     // <= DT (host-checked: Tk <= 32 DT)
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {                                         // (unrolled: 2 t + s selects among the register-resident dS fragments)
+    if (t < ntiles) {                                                    // workgroup-uniform
+      const int buf = t & 1;
+      tk.request(min(32 * t + 32, 32 * (ntiles - 1)), Tk);
+      const unsigned* Th = lds_u + buf * SK::kDwords;                    // [channel][32 keys as 16 dwords (+4)], hi plane; lo plane kCol dwords on
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ct = 0; ct < DT; ++ct) {
+          const unsigned* pk = Th + (32 * ct + jl) * SK::PT + 8 * s + 4 * hh;      // keys 16 s + 8 hh .. +7 of the tile, channel 32 ct + jl
+          const u32x4v bh = *reinterpret_cast<const u32x4v*>(pk), bl = *reinterpret_cast<const u32x4v*>(pk + SK::kCol);
+          dqt[ct] = mfma3(sh[2 * t + s], sl[2 * t + s], bh, bl, dqt[ct]);
+        }
+      tk.stage(lds_u + (buf ^ 1) * SK::kDwords);
+      __syncthreads();
+    }
+  }
+  // accumulators: rows = queries rho(r, hh) of this wave, column = channel 32 ct + jl: 128-byte row segments
+#pragma unroll
+  for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = qb + 32 * wv + rho(r, hh);
+      if (q < Tq) st1(dQb + (size_t)q * dk + 32 * ct + jl, dqt[ct][r]);
+    }
+}
+
+// delta[b][h][q] = <dO[b,q,head], O[b,q,head]> for either storage type (one wave per (b, q) row)
+template <typename ET>
+__global__ __launch_bounds__(256) void mha_bwd_delta_t_kernel(const ET* __restrict__ O, const ET* __restrict__ dO, float* __restrict__ delta,
+                                                              int B, int Tq, int dv, int H) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wv;
+  if (row >= (long)B * Tq) return;
+  const int b = (int)(row / Tq), q = (int)(row % Tq), dvh = dv / H;
+  const ET* o = O + (size_t)row * dv; const ET* g = dO + (size_t)row * dv;
+  for (int hd = 0; hd < H; ++hd) {
+    float acc = 0.f;
+    for (int c = lane * 4; c < dvh; c += 256) {
+      const float4 x = ld4(o + hd * dvh + c), y = ld4(g + hd * dvh + c);
+      acc = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, acc))));
+    }
+    acc = wave_allsum(acc);
+    if (lane == 0) delta[((size_t)b * H + hd) * Tq + q] = acc;
+  }
 }
 
 // (B) dQ.  grid = B * H * ceil(Tq / 128); wave w owns queries qb + 32 w .. +31.
@@ -2131,6 +2216,25 @@ int launch_bwd_split(const char* fn, const ET* Q, const ET* K, const ET* V, cons
     return check_launch(fn);
   }
   const size_t lds_a = sizeof(unsigned) * (size_t)(2 * 2 * ST::kDwords) + sizeof(float) * 128;
+  // one key block no wider than the head (self-attention over T <= 128 clips at head width 128: the north-star shape): dS is written once and
+  // dQ = dS K is a small product over it -- Q, K, V, dO are read ONCE (round-5 review item 6).  TSG_K2_BWD=pair keeps the two full kernels (A/B timing).
+  static const bool pair_only = [] { const char* e = getenv("TSG_K2_BWD"); return e && e[0] == 'p'; }();
+  if (Tk <= 128 && Tk <= 32 * DT && !pair_only) {
+    using SKT = SplitTile<DT, true, false, ET>;
+    const size_t lds_q = sizeof(unsigned) * (size_t)(2 * SKT::kDwords);
+    auto kd = mha_bwd_delta_t_kernel<ET>;
+    auto kw = mha_bwd_split_dkv_kernel<DT, DROP, ET, true>;
+    auto kx = mha_bwd_dq_from_ds_kernel<DT, ET>;
+    hipError_t e = allow_lds(kw, lds_a);
+    if (e == hipSuccess) e = allow_lds(kx, lds_q);
+    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+    hipLaunchKernelGGL(kd, dim3(cdiv(B * Tq, 4)), dim3(256), 0, st, O, dO, delta, B, Tq, dk, H);
+    hipLaunchKernelGGL(kw, dim3(B * H), dim3(256), lds_a, st, Q, K, V, dO, lse, (const float*)delta, dK, dV, dQ, B, Tq, Tk, dk, H, inv_scale, causal, dc);
+    int rc = check_launch(fn);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kx, dim3(B * H * cdiv(Tq, 128)), dim3(256), lds_q, st, K, dQ, B, Tq, Tk, dk, H);
+    return check_launch(fn);
+  }
   size_t lds_b = sizeof(unsigned) * (size_t)(2 * (ST::kDwords + SV::kDwords));
   const size_t out_b = sizeof(float) * 4 * 32 * (32 * DT + 4);
   if (out_b > lds_b) lds_b = out_b;
@@ -2143,7 +2247,7 @@ int launch_bwd_split(const char* fn, const ET* Q, const ET* K, const ET* V, cons
   hipLaunchKernelGGL(kq, dim3(B * H * cdiv(Tq, 128)), dim3(256), lds_b, st, Q, K, V, dO, lse, O, delta, dQ, B, Tq, Tk, dk, H, inv_scale, causal, dc);
   int rc = check_launch(fn);
   if (rc) return rc;
-  hipLaunchKernelGGL(ka, dim3(B * H * cdiv(Tk, 128)), dim3(256), lds_a, st, Q, K, V, dO, lse, (const float*)delta, dK, dV, B, Tq, Tk, dk, H, inv_scale, causal, dc);
+  hipLaunchKernelGGL(ka, dim3(B * H * cdiv(Tk, 128)), dim3(256), lds_a, st, Q, K, V, dO, lse, (const float*)delta, dK, dV, (ET*)nullptr, B, Tq, Tk, dk, H, inv_scale, causal, dc);
   return check_launch(fn);
 }
 
