@@ -213,7 +213,7 @@ class FlatGradAllReduce:
         self._set_guard(guard)
         if self.overlap:
             self.flushed_in_finish = max(0, len(self.buckets) - self._next - 1)     # (the last bucket completes with the backward itself)
-            if self.flushed_in_finish and self._unused is not None and not self._warned_flush:
+            if 2 * self.flushed_in_finish >= len(self.buckets) > 1 and self._unused is not None and not self._warned_flush:   # (a gated backward leaves the tail after its last gate: by design)
                 import warnings
                 warnings.warn(f"FlatGradAllReduce: {self.flushed_in_finish + 1} of {len(self.buckets)} buckets were still waiting when the backward "
                               "ended (a parameter without a gradient in front of them, or no persistent kernel to gate on): their exchange did not overlap")

@@ -306,7 +306,9 @@ class GraphedTrainStep:
         if dp is not None and dp.active:
             dp.adopt(self.grads, self.guard)                # gather + exchange once: .grad now points into the flat buffer
             torch.cuda.synchronize()                        # the exchange has finished before the second capture begins
-        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=side, capture_error_mode="thread_local"):
+        # graph B (a handful of tiny flag tensors) gets a pool of its OWN: nothing it allocates can land in a block graph A still reads or writes
+        # (the round-5 stale read involved blocks shared inside a pool; its cause is not established, so no sharing that is not needed)
+        with torch.cuda.graph(self.graph_b, stream=side, capture_error_mode="thread_local"):
             optimizer_step(opt, self.loss, dp=dp, guard=self.guard)   # reads the REDUCED flag (dp.guard: static memory of the flat buffer)
 
     def _zero(self):

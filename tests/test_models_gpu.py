@@ -450,3 +450,44 @@ def test_graphed_train_step_long_replay_stays_finite(mode):
                 assert bool(torch.isfinite(p.grad).all()) and float(p.grad.float().abs().max()) < 1e3, f"gradient of {k}: {float(p.grad.float().abs().max())}"
     finally:
         engine.set_precision(None)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32s"])
+def test_graph_replay_gradients_match_the_eager_step(mode):
+    """the stale-read defect of round 5 mostly produced FINITE garbage, which the finite / |g| < 1e3 checks above cannot see.  With dropout
+    off and lr = 0 the parameters never move, so EVERY replay of graph A must reproduce the gradients of an eager step on the same batch -- up to the
+    order of the float atomics a few sums use (dw of K1, dgbias of K1g, the loss accumulators) -- and a stray word anywhere in any gradient shows up
+    as an O(1) relative error.  120 back-to-back replays at the benchmark shape, every gradient checked norm-wise and element-wise after each tenth."""
+    from shufflingvideosfortsg_amd import data, engine, functional as TF
+    params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, video_len=128, sent_len=20)
+    params["dropout"] = 0.0
+    params["lr"] = 0.0
+    torch.manual_seed(0)
+    model = engine.build_model("gmd", params).cuda().train()
+    batch = data.synthetic_batch(64, 128, 20, seed=1234, pair=True, device="cuda")
+    engine.set_precision(mode)
+    try:
+        step = lambda m, b: engine.gmd_step(m, b, params)[0]
+        model.zero_grad(set_to_none=True)
+        step(model, batch).backward()
+        torch.cuda.synchronize()
+        ref = {k: p.grad.detach().float().clone() for k, p in model.named_parameters() if p.grad is not None}
+        model.zero_grad(set_to_none=True)
+        opt = engine.make_optimizer(model, params, capturable=True)
+        g = engine.GraphedTrainStep(model, opt, step, batch, warmup=3)
+        rtol = 2e-2 if mode == "bf16" else 2e-4          # (bf16 storage: dgbias / dw sums of bf16-rounded terms move with the atomics' order)
+        for it in range(120):
+            g()
+            if it % 10 == 9:
+                torch.cuda.synchronize()
+                TF.check_kernel_errors()
+                for k, p in model.named_parameters():
+                    if k not in ref:
+                        continue
+                    a, b = p.grad.detach().float(), ref[k]
+                    scale = float(b.abs().max())
+                    err = float((a - b).abs().max())
+                    assert err <= rtol * scale + 1e-7, f"replay {it}: gradient of {k} deviates from the eager step by {err:.3e} (max |g| = {scale:.3e})"
+        assert engine.skipped_updates() == 0
+    finally:
+        engine.set_precision(None)
