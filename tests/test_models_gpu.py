@@ -464,6 +464,9 @@ def test_graph_replay_gradients_match_the_eager_step(mode):
     params["lr"] = 0.0
     torch.manual_seed(0)
     model = engine.build_model("gmd", params).cuda().train()
+    for m_ in model.modules():
+        if isinstance(m_, torch.nn.Dropout):
+            m_.p = 0.0                                   # (the discriminator's dropout is not governed by params["dropout"])
     batch = data.synthetic_batch(64, 128, 20, seed=1234, pair=True, device="cuda")
     engine.set_precision(mode)
     try:
@@ -475,7 +478,7 @@ def test_graph_replay_gradients_match_the_eager_step(mode):
         model.zero_grad(set_to_none=True)
         opt = engine.make_optimizer(model, params, capturable=True)
         g = engine.GraphedTrainStep(model, opt, step, batch, warmup=3)
-        rtol = 2e-2 if mode == "bf16" else 2e-4          # (bf16 storage: dgbias / dw sums of bf16-rounded terms move with the atomics' order)
+        rtol = 2e-5                                      # measured (tools/graph_grad_probe.py, 40 replays, both modes): <= 8e-7 of the parameter's max |g|
         for it in range(120):
             g()
             if it % 10 == 9:
