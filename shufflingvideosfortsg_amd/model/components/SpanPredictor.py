@@ -105,8 +105,9 @@ class Self_Attention_predictor(nn.Module):
         x = crossmodal_feat
         if self.position_encoding:
             x = x + positional_encodings_like(x)
-        s = self.start_fc(self.start_selfattn(x, x, x)).squeeze(dim=2)
-        e = self.end_fc(self.end_selfattn(x, x, x)).squeeze(dim=2)
+        # (bf16 storage mode: the attention output is bf16; the [D -> 1] logits, their mask and the softmax over T are fp32 like every output the losses read)
+        s = self.start_fc(self.start_selfattn(x, x, x).to(self.start_fc.weight.dtype)).squeeze(dim=2)
+        e = self.end_fc(self.end_selfattn(x, x, x).to(self.end_fc.weight.dtype)).squeeze(dim=2)
         if v_mask is not None:
             s, e = mask_logits(s, v_mask), mask_logits(e, v_mask)
         return torch.softmax(s, dim=1), torch.softmax(e, dim=1)

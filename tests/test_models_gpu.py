@@ -326,6 +326,40 @@ def test_baseline_with_self_attention_predictor_trains():
     assert torch.equal(o1, o2)
 
 
+@pytest.mark.parametrize("mode", ["f32s", "bf16"])
+def test_gmd_with_self_attention_predictor_steps_in_every_mode(mode):
+    """The GMD step with `predictor='self_attn'` (K2 as the boundary head) at the north-star shape in the f32s and the bf16 storage modes -- the bf16
+    one used to fail in the head's [D -> 1] Linear (a bf16 attention output met fp32 weights; bench.py --predictor self_attn lost its whole line to
+    it).  Finite loss and gradients, probabilities that sum to one, and the two modes agree on the boundary scores within the bf16 tolerance.
+    T = 128 keys at head width 128: the backward is the dS-once pair (mha_bwd_dq_from_ds_kernel)."""
+    from shufflingvideosfortsg_amd import data, engine
+    params = engine.default_params(video_rnn_hiddendim=512, sent_rnn_hiddendim=512, video_len=128, sent_len=20, predictor="self_attn", dropout=0.0)
+    torch.manual_seed(0)
+    model = engine.build_model("gmd", params).cuda().train()
+    for m_ in model.modules():
+        if isinstance(m_, torch.nn.Dropout):
+            m_.p = 0.0
+    batch = data.synthetic_batch(8, 128, 20, seed=5, pair=True, device="cuda")
+    outs = {}
+    for md in ("f32s", mode):
+        b = dict(batch)
+        if md == "bf16":
+            b["video"] = batch["video"].to(torch.bfloat16); b["pseudo_video"] = batch["pseudo_video"].to(torch.bfloat16)
+        model.zero_grad(set_to_none=True)
+        with engine.precision(md):
+            loss, _, span = engine.gmd_step(model, b, params)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss), md
+        assert span["start"].dtype == torch.float32
+        torch.testing.assert_close(span["start"].sum(1), torch.ones(8, device="cuda"), atol=1e-4, rtol=1e-4)
+        for k, p in model.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), (md, k)
+        outs[md] = span["start"].detach().float().clone()
+    if mode == "bf16":
+        torch.testing.assert_close(outs["bf16"], outs["f32s"], atol=1e-2, rtol=5e-2)
+
+
 def test_graphed_train_step_matches_eager():
     """engine.GraphedTrainStep: the GMD train step captured into HIP graphs (C-ABI kernels, their zero-fill nodes, autograd, the
     fused Adam with device-side step counters) and replayed reproduces the eager steps' loss trajectory (dropout off: no RNG),
