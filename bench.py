@@ -112,6 +112,7 @@ if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
     if _a.gpus > 1:
         sys.exit(spawn_ranks(_a))
 
+import shufflingvideosfortsg_amd          # noqa: E402,F401  (before torch touches the GPU: _runtime_env sets what the ROCm runtime must see at its start)
 import torch                              # noqa: E402
 import torch.distributed as dist          # noqa: E402
 

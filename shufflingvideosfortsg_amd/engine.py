@@ -255,6 +255,10 @@ def skipped_updates(device=None, reset: bool = False) -> int:
     return n
 
 
+import os as _os
+_GRAPH_PROBE = _os.environ.get("TSG_GRAPH_PROBE", "")     # developer probe of the replay defect: 'ab' / 'ba' host syncs, 'skipb'
+
+
 class GraphedTrainStep:
     """One training step as two HIP graphs: A = forward + losses + backward, B = the (guarded) Adam update, with the
     gradient exchange of ``dp`` (FlatGradAllReduce; may be inactive) run eagerly between them.  The step's ~390 kernel
@@ -270,6 +274,11 @@ class GraphedTrainStep:
 
     def __init__(self, model, opt, step_fn, batch, dp=None, warmup=3):
         from . import functional as TF
+        from . import _runtime_env
+        if not _runtime_env.graph_replay_safe() and _os.environ.get("TSG_GRAPH_UNSAFE") != "1":
+            raise RuntimeError("GraphedTrainStep: the ROCm runtime's graph packet capture is on (DEBUG_CLR_GRAPH_PACKET_CAPTURE must be 0 BEFORE the first "
+                               "GPU call of the process; import shufflingvideosfortsg_amd before touching the GPU, or export it): replayed graphs can "
+                               "read stale data from reused pool blocks (shufflingvideosfortsg_amd/_runtime_env.py).  TSG_GRAPH_UNSAFE=1 overrides.")
         self.model, self.opt, self.dp, self.batch = model, opt, dp, batch
         if dp is not None and dp.overlap:
             raise ValueError("GraphedTrainStep: the gradient exchange must run after the backward (FlatGradAllReduce(overlap=False))")
@@ -291,6 +300,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         TF.check_lstm_errors()
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        if _os.environ.get("TSG_GRAPH_DOT"):               # developer probe: hipGraphDebugDotPrint of graph A after the capture
+            self.graph_a.enable_debug_mode()
         self._zero()
         # capture on the warm-up stream: autograd's AccumulateGrad nodes were created there, and a capture on another stream
         # would record cross-stream event nodes into the graph (a forked graph: hipGraphLaunch then enqueues node by node)
@@ -303,6 +314,8 @@ class GraphedTrainStep:
             self.loss.backward()
             self.guard = step_guard(self.loss)              # this rank's skip flag: the last node of graph A (after the backward)
         self.grads = [p.grad for p in self.params]          # the graph's static gradient tensors (None: no gradient)
+        if _os.environ.get("TSG_GRAPH_DOT"):
+            self.graph_a.debug_dump(_os.environ["TSG_GRAPH_DOT"])
         if dp is not None and dp.active:
             dp.adopt(self.grads, self.guard)                # gather + exchange once: .grad now points into the flat buffer
             torch.cuda.synchronize()                        # the exchange has finished before the second capture begins
@@ -323,10 +336,16 @@ class GraphedTrainStep:
         expired wait of an EARLIER replay surfaces (its update was already skipped on the device)."""
         from . import functional as TF
         TF.check_kernel_errors()
+        mode = _GRAPH_PROBE
         self.graph_a.replay()
+        if "ab" in mode:
+            torch.cuda.current_stream().synchronize()
         if self.dp is not None and self.dp.active:
             self.dp.exchange_static(self.grads, self.guard)
-        self.graph_b.replay()
+        if "skipb" not in mode:
+            self.graph_b.replay()
+        if "ba" in mode:
+            torch.cuda.current_stream().synchronize()
         return self.loss
 
 

@@ -3,11 +3,12 @@ import sys
 
 import numpy as np
 import pytest
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import shufflingvideosfortsg_amd  # noqa: E402,F401  (before torch touches the GPU: _runtime_env)
+import torch  # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # The CPU oracle's recurrences are thousands of small ops; with torch's default of one thread per hardware thread (128 on the GPU box) every
 # one of them pays a 128-way fork / join: the 2-layer BiLSTM at [3, 512, 1024] takes 52.9 s with 128 threads, 1.2 s with 8
