@@ -2,7 +2,7 @@
 """Host-side checks of the C ABI that need no GPU: argument errors, workspace planners, tile / range arithmetic.  Two users:
   * tests/test_abi_cpu.py calls ``run_checks(lib)`` on the product library;
   * the same file, run as a script with a library path, is the driver of the host SANITIZER build: an AddressSanitizer +
-    UndefinedBehaviorSanitizer build of the host layer without device code (``python -m shufflingvideosfortsg_amd.build --sanitize``),
+    UndefinedBehaviorSanitizer build of the host layer without device code (``python tools/build_host_sanitized.py``),
     loaded into a python that has the ASAN runtime preloaded.  It imports neither torch nor the package (an uninstrumented torch under a
     preloaded ASAN runtime is slow and noisy): the ctypes signature table is read out of _lib.py with a placeholder in torch's place.
 Every call here returns before a kernel launch.  Never run on a GPU box."""

@@ -41,15 +41,16 @@ def test_argument_errors_without_gpu(lib):
 
 def test_host_layer_under_address_and_ub_sanitizers():
     """SURVEY 5 / round-5 review item 8: the host layer of the C ABI (argument checks, tsg_*_ws_bytes planners, check_head / tile / range
-    arithmetic) built WITHOUT device code under AddressSanitizer + UndefinedBehaviorSanitizer (build.build_sanitized) and driven with the
+    arithmetic) built WITHOUT device code under AddressSanitizer + UndefinedBehaviorSanitizer (tools/build_host_sanitized.py) and driven with the
     same call list in a python that has the ASAN runtime preloaded -- incl. the ADVICE-r4 regression input (fused heads at
     M in (2^22, 2^23]).  The first run of this build found a signed overflow in tsg_scdm_bwd_ws_bytes (B T >= 2^31: now rejected).
     CPU only: nothing is launched, no GPU is touched."""
     import subprocess
     import sys
-    from shufflingvideosfortsg_amd import build
-    san = build.build_sanitized()
-    env = dict(os.environ, LD_PRELOAD=build.asan_runtime(), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_host_sanitized as san_build            # (CPU-only tool: listed in .gpurunignore, absent on a GPU box -- this test never runs there)
+    san = san_build.build_sanitized()
+    env = dict(os.environ, LD_PRELOAD=san_build.asan_runtime(), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abi_host_driver.py"), san], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "host-side calls clean" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
