@@ -503,6 +503,7 @@ def test_graph_replay_gradients_match_the_eager_step(mode):
             m_.p = 0.0                                   # (the discriminator's dropout is not governed by params["dropout"])
     batch = data.synthetic_batch(64, 128, 20, seed=1234, pair=True, device="cuda")
     engine.set_precision(mode)
+    engine.skipped_updates(reset=True)                   # (earlier tests of the process skip updates on purpose)
     try:
         step = lambda m, b: engine.gmd_step(m, b, params)[0]
         model.zero_grad(set_to_none=True)
