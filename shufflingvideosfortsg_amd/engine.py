@@ -300,8 +300,6 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         TF.check_lstm_errors()
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        if _os.environ.get("TSG_GRAPH_DOT"):               # developer probe: hipGraphDebugDotPrint of graph A after the capture
-            self.graph_a.enable_debug_mode()
         self._zero()
         # capture on the warm-up stream: autograd's AccumulateGrad nodes were created there, and a capture on another stream
         # would record cross-stream event nodes into the graph (a forked graph: hipGraphLaunch then enqueues node by node)
@@ -314,8 +312,6 @@ class GraphedTrainStep:
             self.loss.backward()
             self.guard = step_guard(self.loss)              # this rank's skip flag: the last node of graph A (after the backward)
         self.grads = [p.grad for p in self.params]          # the graph's static gradient tensors (None: no gradient)
-        if _os.environ.get("TSG_GRAPH_DOT"):
-            self.graph_a.debug_dump(_os.environ["TSG_GRAPH_DOT"])
         if dp is not None and dp.active:
             dp.adopt(self.grads, self.guard)                # gather + exchange once: .grad now points into the flat buffer
             torch.cuda.synchronize()                        # the exchange has finished before the second capture begins
