@@ -144,3 +144,16 @@ def test_pair_batch_halves_are_adjacent_and_cat_is_a_view():
     c = data.adjacent_cat(g[:2], g[2:])                                     # needs a gradient: torch.cat (autograd splits it back)
     c.sum().backward()
     assert torch.equal(g.grad, torch.ones(4, 4))
+
+
+def test_runtime_env_is_set_before_hip_starts():
+    """Importing the package sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (the ROCm runtime's graph packet capture lets replayed graphs read stale data from
+    reused pool blocks: _runtime_env.py); an explicit other value is respected and reported as unsafe, which GraphedTrainStep refuses."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import shufflingvideosfortsg_amd as P; "
+            "print(os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'), P._runtime_env.graph_replay_safe())" % root)
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.split() == ["0", "True"]
+    assert subprocess.run([sys.executable, "-c", code], env=dict(env, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1"), capture_output=True, text=True).stdout.split() == ["1", "False"]
