@@ -256,6 +256,10 @@ __global__ __launch_bounds__(kGT) void gemm_nt_f32s_kernel(const float* __restri
   constexpr int kBuf = 2 * kPlaneX + 2 * kPlaneW;
   extern __shared__ __align__(16) unsigned lds[];                   // [2 buffers][X hi | X lo | W hi | W lo]
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // The SIMD's arbiter serves its OLDER wave first (cdna_hip_programming.md T5, static form; seen in K1g this round as 7.7 k vs 11 k ticks per row): the
+  // second-dispatched half of an 8-wave workgroup gets priority 1 once, so the two waves of a SIMD advance together -- 1-2.5 % at the step's shapes
+  // (profiles/r6/gemm_young_half_priority_ab_v1.txt)
+  if (wv >= 4) __builtin_amdgcn_s_setprio(1);
   const int wm = (wv >> 2) * (TM / 2), wn = (wv & 3) * 64;
   const int jl = lane & 31, kg = lane >> 5;
   const int ntiles = (M / TM) * tiles_n;

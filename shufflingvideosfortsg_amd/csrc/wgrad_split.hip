@@ -432,6 +432,7 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_split_kernel(const WgradAr
   const int v = xcd_major(blockIdx.x, gridDim.x);
   const long chunks = a.M / BM;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wn = wv / WK, wk = wv % WK;
+  if (__builtin_amdgcn_readfirstlane(wv) >= 4) __builtin_amdgcn_s_setprio(1);     // static priority for the younger wave of each SIMD (see gemm_f32s.hip)
   f32x16 acc[2][2];
   // The workgroup's piece of the flattened (tile, chunk) space.  stream-K: [v * ipw, (v + 1) * ipw) = at most kMaxContrib - 1 tile segments;
   // split scheme: ONE segment, row range `split` of tile v % tps (possibly empty: its partial tile is still written, as zeros).
