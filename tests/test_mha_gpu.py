@@ -196,6 +196,8 @@ def test_attention_dropout_under_graph_capture():
     (1, 70, 70, 448, 2, True, 0.0),       # head width 224, causal, ragged
     (1, 70, 45, 384, 2, True, 0.1),       # head width 192, ragged, causal needs Tq == Tk -> see below
     (2, 100, 20, 1280, 8, False, 0.0),    # head width 160, one key tile (wide backward with an idle key group)
+    (1, 300, 100, 256, 2, False, 0.1),    # one ragged key block no wider than the head, three query blocks, dropout: dS written once, dQ = dS K (round 6)
+    (2, 40, 96, 768, 8, False, 0.0),      # the same path at head width 96 (three key tiles of the head's three)
 ])
 def test_mha_split_precision(B, Tq, Tk, d, h, causal, p):
     """dtype TSG_F32S (the 'f32s' GEMM mode): the attention products as bf16 hi/lo products on the MFMA -- one forward kernel with an
