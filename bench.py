@@ -719,6 +719,9 @@ def main():
                                  "return as a lower clock.  bf16 storage: the SAME fp32 score loop on half the bytes -- the launch takes the same time, "
                                  "so its fraction of the HBM roofline halves")
                 if gate else None}
+        # one line per run in the log, so that a regression of the roofline kernel is visible from round to round (round-5 review)
+        log(f"roofline kernel {roof['kernel']}: {roof['mean_launch_us']} us per {k1B}-pair launch in the step (its own event pair; "
+            f"{roof.get('around_call_mean_us')} us around the call) = {roof['frac']} of {HBM_PEAK_GBS / 1e3:.0f} TB/s")
         what = "fwd-only" if a.fwd_only else "fwd+bwd"
         wl = (f"{a.model}_forward: fwd+losses under no_grad, " if a.fwd_only else
               f"{a.model}_train_step: fwd+losses+bwd+grad-allreduce+Adam, ")
